@@ -1,0 +1,299 @@
+/*
+ * slr_oracle.c -- CPU restatement of the SLR-SFS frame-synthesis hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker for the HIP kernels in
+ * slr-sfs_amd/csrc/.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product path (slr_sfs_amd.*) never calls
+ * into it and raises when the HIP library is missing.
+ *
+ * Parity status: PINNED.  Every function below is checked (tests/test_oracle_golden.py)
+ * against the .npz fixtures under tests/golden/, produced by tools/make_golden.py from the
+ * reference itself run in the build container:
+ *   - euler_integration: the unmodified reference Python function
+ *     (models/projection/euler_integration_manipulator.py:7-56) executed on CPU;
+ *   - splat kernels: the reference's own kernel text (models/softsplat.py:12-326),
+ *     expanded by the reference's cupy_kernel() (:328-381) and executed on the host,
+ *     one "thread" running the whole grid-stride loop (sequential, deterministic order);
+ *   - FunctionSoftsplat modes / _FunctionMaximumWarpNormsplat: the reference Python
+ *     wrappers (:665-690, :576-624) around those kernels.
+ *
+ * Every function cites the reference lines it restates.  All tensors fp32, NCHW,
+ * contiguous.  Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (see Makefile);
+ * -ffp-contract=off keeps "in * w" a single rounding, as in the reference kernels.
+ *
+ * Defined behaviour where the reference has none: a non-finite or |.| >= 2^30 target
+ * coordinate drops all four corners (the reference casts it to int, which is UB in C
+ * and saturates on CUDA, where the corners also end up out of bounds).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ euler */
+
+/* One Euler step for one pixel; restates euler_integration_manipulator.py:37-46.
+ * (px,py) is the current (always in-bounds) coordinate, inv the sticky invalid flag. */
+static inline void euler_step(const float *mx, const float *my, int H, int W,
+                              float ox, float oy, float *px, float *py, int *inv)
+{
+    /* :37-38  gather at round-half-even of the current coordinate, then add */
+    long ix = (long)rintf(*px);
+    long iy = (long)rintf(*py);
+    float nx = *px + mx[iy * (long)W + ix];
+    float ny = *py + my[iy * (long)W + ix];
+    /* :39-42  strict comparisons against W-1 / H-1 / 0; sticky OR.
+     * Non-finite coordinates are made invalid (reference: undefined). */
+    int oob = (nx > (float)(W - 1)) || (nx < 0.0f) || (ny > (float)(H - 1)) || (ny < 0.0f)
+              || !(nx == nx) || !(ny == ny);
+    *inv |= oob;
+    /* :45-46  invalid pixels are reset to their origin */
+    if (*inv) { nx = ox; ny = oy; }
+    *px = nx; *py = ny;
+}
+
+/* euler_integration(motion, n) -> (disp[2,H,W], visible[H,W])
+ * euler_integration_manipulator.py:7-56 (return_all_frames=False branch). */
+ORACLE_API void oracle_euler_integrate(const float *motion, int H, int W, int nsteps,
+                                       float *disp, float *visible)
+{
+    const float *mx = motion, *my = motion + (size_t)H * W;
+    const float big = (float)(H > W ? H : W) + 1.0f;          /* :55 */
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float ox = (float)x, oy = (float)y, px = ox, py = oy;
+            int inv = 0;
+            for (int s = 0; s < nsteps; ++s) euler_step(mx, my, H, W, ox, oy, &px, &py, &inv);
+            size_t i = (size_t)y * W + x;
+            /* :33-34 n==0 -> zeros / ones falls out of the same formula */
+            disp[i]                 = inv ? big : px - ox;    /* :53,55 */
+            disp[(size_t)H * W + i] = inv ? big : py - oy;
+            visible[i]              = inv ? 0.0f : 1.0f;      /* :54 */
+        }
+}
+
+/* All frames 0..nmax in one pass: disp_all[t] == euler_integration(motion, t)[0],
+ * vis_all[t] == ...[1].  The reference's own return_all_frames=True branch is broken
+ * (euler_integration_manipulator.py:31,50); this is the equivalent of calling :7-56
+ * once per t, which is what forward_flow does (animating_softmax_splating.py:847-848). */
+ORACLE_API void oracle_euler_integrate_all(const float *motion, int H, int W, int nmax,
+                                           float *disp_all, float *vis_all)
+{
+    const float *mx = motion, *my = motion + (size_t)H * W;
+    const float big = (float)(H > W ? H : W) + 1.0f;
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float ox = (float)x, oy = (float)y, px = ox, py = oy;
+            int inv = 0;
+            size_t i = (size_t)y * W + x;
+            for (int t = 0; t <= nmax; ++t) {
+                if (t > 0) euler_step(mx, my, H, W, ox, oy, &px, &py, &inv);
+                disp_all[(size_t)t * 2 * HW + i]      = inv ? big : px - ox;
+                disp_all[(size_t)t * 2 * HW + HW + i] = inv ? big : py - oy;
+                vis_all[(size_t)t * HW + i]           = inv ? 0.0f : 1.0f;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------ splat */
+
+typedef struct {
+    int ok;            /* target coordinate representable */
+    int x0, y0;        /* north-west corner */
+    float w[4];        /* NW, NE, SW, SE */
+} corners_t;
+
+/* softsplat.py:169-184 -- target coordinate, four corners, bilinear weights */
+static inline corners_t corners(float fx, float fy, int x, int y)
+{
+    corners_t c;
+    float X = (float)x + fx;
+    float Y = (float)y + fy;
+    c.ok = (fabsf(X) < 1073741824.0f) && (fabsf(Y) < 1073741824.0f);   /* false for NaN/inf */
+    if (!c.ok) { c.x0 = c.y0 = 0; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0.0f; return c; }
+    c.x0 = (int)floorf(X);
+    c.y0 = (int)floorf(Y);
+    float x1 = (float)(c.x0 + 1), y1 = (float)(c.y0 + 1), x0f = (float)c.x0, y0f = (float)c.y0;
+    c.w[0] = (x1 - X) * (y1 - Y);        /* NW :181 */
+    c.w[1] = (X - x0f) * (y1 - Y);       /* NE :182 */
+    c.w[2] = (x1 - X) * (Y - y0f);       /* SW :183 */
+    c.w[3] = (X - x0f) * (Y - y0f);      /* SE :184 */
+    return c;
+}
+
+static inline int inb(int cx, int cy, int H, int W) { return (cx >= 0) & (cx < W) & (cy >= 0) & (cy < H); }
+
+/* _FunctionSoftsplat.forward + kernel_Softsplat_updateOutput
+ * softsplat.py:157-202, 390-424.  out is zeroed here (:404).  Accumulation order is the
+ * element-index order of the reference loop (n, c, y, x; corners NW, NE, SW, SE).
+ * Planes are independent, so they are spread over OpenMP threads without changing
+ * any plane's summation order. */
+ORACLE_API void oracle_softsplat_forward(const float *in, const float *flow, float *out,
+                                         int N, int C, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+    memset(out, 0, sizeof(float) * (size_t)N * C * HW);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int nc = 0; nc < N * C; ++nc) {
+        int n = nc / C;
+        const float *ip = in + (size_t)nc * HW;
+        float *op = out + (size_t)nc * HW;
+        const float *fx = flow + (size_t)n * 2 * HW, *fy = fx + HW;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)y * W + x;
+                corners_t c = corners(fx[i], fy[i], x, y);
+                if (!c.ok) continue;
+                float v = ip[i];
+                if (inb(c.x0,     c.y0,     H, W)) op[(size_t)c.y0 * W + c.x0]           += v * c.w[0];
+                if (inb(c.x0 + 1, c.y0,     H, W)) op[(size_t)c.y0 * W + c.x0 + 1]       += v * c.w[1];
+                if (inb(c.x0,     c.y0 + 1, H, W)) op[(size_t)(c.y0 + 1) * W + c.x0]     += v * c.w[2];
+                if (inb(c.x0 + 1, c.y0 + 1, H, W)) op[(size_t)(c.y0 + 1) * W + c.x0 + 1] += v * c.w[3];
+            }
+    }
+}
+
+/* kernel_Softsplat_updateGradInput  softsplat.py:204-255 (gather; sum order NW,NE,SW,SE) */
+ORACLE_API void oracle_softsplat_grad_input(const float *flow, const float *gout, float *gin,
+                                            int N, int C, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int nc = 0; nc < N * C; ++nc) {
+        int n = nc / C;
+        const float *gp = gout + (size_t)nc * HW;
+        float *op = gin + (size_t)nc * HW;
+        const float *fx = flow + (size_t)n * 2 * HW, *fy = fx + HW;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)y * W + x;
+                corners_t c = corners(fx[i], fy[i], x, y);
+                float g = 0.0f;
+                if (c.ok) {
+                    if (inb(c.x0,     c.y0,     H, W)) g += gp[(size_t)c.y0 * W + c.x0]           * c.w[0];
+                    if (inb(c.x0 + 1, c.y0,     H, W)) g += gp[(size_t)c.y0 * W + c.x0 + 1]       * c.w[1];
+                    if (inb(c.x0,     c.y0 + 1, H, W)) g += gp[(size_t)(c.y0 + 1) * W + c.x0]     * c.w[2];
+                    if (inb(c.x0 + 1, c.y0 + 1, H, W)) g += gp[(size_t)(c.y0 + 1) * W + c.x0 + 1] * c.w[3];
+                }
+                op[i] = g;
+            }
+    }
+}
+
+/* kernel_Softsplat_updateGradFlow  softsplat.py:257-326
+ * gflow[n,k,y,x] = sum_c in[c] * gout[c,corner] * d w_corner / d flow_k, accumulated in
+ * channel order, corners NW,NE,SW,SE inside each channel, ((in*gout)*dw) association. */
+ORACLE_API void oracle_softsplat_grad_flow(const float *in, const float *flow, const float *gout,
+                                           float *gflow, int N, int C, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+    for (int nk = 0; nk < N * 2; ++nk) {
+        int n = nk / 2, k = nk % 2;
+        const float *fx = flow + (size_t)n * 2 * HW, *fy = fx + HW;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)y * W + x;
+                float X = (float)x + fx[i], Y = (float)y + fy[i];
+                float g = 0.0f;
+                if ((fabsf(X) < 1073741824.0f) && (fabsf(Y) < 1073741824.0f)) {
+                    int x0 = (int)floorf(X), y0 = (int)floorf(Y);
+                    float dw[4];
+                    if (k == 0) {                                       /* :289-293 */
+                        dw[0] = (-1.0f) * ((float)(y0 + 1) - Y);
+                        dw[1] = (+1.0f) * ((float)(y0 + 1) - Y);
+                        dw[2] = (-1.0f) * (Y - (float)y0);
+                        dw[3] = (+1.0f) * (Y - (float)y0);
+                    } else {                                            /* :295-299 */
+                        dw[0] = ((float)(x0 + 1) - X) * (-1.0f);
+                        dw[1] = (X - (float)x0) * (-1.0f);
+                        dw[2] = ((float)(x0 + 1) - X) * (+1.0f);
+                        dw[3] = (X - (float)x0) * (+1.0f);
+                    }
+                    int b0 = inb(x0, y0, H, W), b1 = inb(x0 + 1, y0, H, W),
+                        b2 = inb(x0, y0 + 1, H, W), b3 = inb(x0 + 1, y0 + 1, H, W);
+                    for (int c = 0; c < C; ++c) {                       /* :303-321 */
+                        float v = in[((size_t)n * C + c) * HW + i];
+                        const float *gp = gout + ((size_t)n * C + c) * HW;
+                        if (b0) g += v * gp[(size_t)y0 * W + x0]           * dw[0];
+                        if (b1) g += v * gp[(size_t)y0 * W + x0 + 1]       * dw[1];
+                        if (b2) g += v * gp[(size_t)(y0 + 1) * W + x0]     * dw[2];
+                        if (b3) g += v * gp[(size_t)(y0 + 1) * W + x0 + 1] * dw[3];
+                    }
+                }
+                gflow[((size_t)n * 2 + k) * HW + i] = g;
+            }
+    }
+}
+
+/* kernel_Maximumsplat_updateOutput  softsplat.py:12-82
+ * out[corner] = fmaxf(out[corner], in * w) -- out is IN/OUT: the caller initialises it
+ * (zeros for _FunctionMaximumsplat :497, -1000 for _FunctionMaximumWarpNormsplat :590). */
+ORACLE_API void oracle_maxsplat_forward(const float *in, const float *flow, float *out,
+                                        int N, int C, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int nc = 0; nc < N * C; ++nc) {
+        int n = nc / C;
+        const float *ip = in + (size_t)nc * HW;
+        float *op = out + (size_t)nc * HW;
+        const float *fx = flow + (size_t)n * 2 * HW, *fy = fx + HW;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)y * W + x;
+                corners_t c = corners(fx[i], fy[i], x, y);
+                if (!c.ok) continue;
+                float v = ip[i];
+                for (int k = 0; k < 4; ++k) {
+                    int cx = c.x0 + (k & 1), cy = c.y0 + (k >> 1);
+                    if (inb(cx, cy, H, W)) {
+                        float *p = &op[(size_t)cy * W + cx];
+                        *p = fmaxf(v * c.w[k], *p);
+                    }
+                }
+            }
+    }
+}
+
+/* kernel_Inversesplat_updateOutput  softsplat.py:84-155
+ * out[src] = fmaxf over in-bounds corners of maxwarp[corner], and of out[src] itself
+ * (out is IN/OUT: _FunctionMaximumWarpNormsplat seeds it with input.clone(), :606). */
+ORACLE_API void oracle_inversesplat(const float *maxwarp, const float *flow, float *out,
+                                    int N, int C, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int nc = 0; nc < N * C; ++nc) {
+        int n = nc / C;
+        const float *mp = maxwarp + (size_t)nc * HW;
+        float *op = out + (size_t)nc * HW;
+        const float *fx = flow + (size_t)n * 2 * HW, *fy = fx + HW;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)y * W + x;
+                corners_t c = corners(fx[i], fy[i], x, y);
+                if (!c.ok) continue;
+                float m = op[i];
+                for (int k = 0; k < 4; ++k) {
+                    int cx = c.x0 + (k & 1), cy = c.y0 + (k >> 1);
+                    if (inb(cx, cy, H, W)) m = fmaxf(mp[(size_t)cy * W + cx], m);
+                }
+                op[i] = m;
+            }
+    }
+}
+
+/* ------------------------------------------------------- thread control */
+#ifdef _OPENMP
+#include <omp.h>
+ORACLE_API void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+ORACLE_API int  oracle_max_threads(void)  { return omp_get_max_threads(); }
+#else
+ORACLE_API void oracle_set_threads(int n) { (void)n; }
+ORACLE_API int  oracle_max_threads(void)  { return 1; }
+#endif

@@ -1,0 +1,94 @@
+"""Pin the CPU oracle (oracle/) against fixtures generated from the reference itself
+(tools/make_golden.py).  Euler integration must be bit-exact; the splat family is compared
+at 1e-5 (the fixtures come from a sequential execution of the reference kernel text in the
+same element order, so the observed difference is 0 -- the slack only covers libm exp)."""
+import numpy as np
+import pytest
+
+
+def _load(golden_dir, name):
+    return np.load(f"{golden_dir}/{name}.npz")
+
+
+def test_euler_bit_exact(oracle, golden_dir):
+    g = _load(golden_dir, "euler")
+    for i in range(int(g["count"])):
+        d, v = oracle.euler_integration(g[f"c{i}_motion"], int(g[f"c{i}_n"]))
+        tag = str(g[f"c{i}_tag"])
+        assert np.array_equal(d, g[f"c{i}_disp"]), tag
+        assert np.array_equal(v, g[f"c{i}_vis"]), tag
+
+
+def test_euler_all_frames_equals_per_frame(oracle, golden_dir):
+    g = _load(golden_dir, "euler")
+    by_motion = {}
+    for i in range(int(g["count"])):
+        by_motion.setdefault(g[f"c{i}_motion"].tobytes(), []).append(i)
+    for idxs in by_motion.values():
+        m = g[f"c{idxs[0]}_motion"]
+        dall, vall = oracle.euler_integration_all(m, 60)
+        for i in idxs:
+            n = int(g[f"c{i}_n"])
+            assert np.array_equal(dall[n], g[f"c{i}_disp"][0]), str(g[f"c{i}_tag"])
+            assert np.array_equal(vall[n], g[f"c{i}_vis"][0])
+
+
+def test_euler_module_batch(oracle, golden_dir):
+    g = _load(golden_dir, "euler")
+    m, dest = g["module_motion"], g["module_dest"]
+    for b in range(m.shape[0]):
+        d, v = oracle.euler_integration(m[b:b + 1], int(dest[b]))
+        assert np.array_equal(d[0], g["module_disp"][b])
+        assert np.array_equal(v[0], g["module_vis"][b])
+
+
+def test_splat_summation_forward_backward(oracle, golden_dir):
+    g = _load(golden_dir, "splat_sum")
+    for i in range(int(g["count"])):
+        tag = str(g[f"c{i}_tag"])
+        x, fl, go = g[f"c{i}_in"], g[f"c{i}_flow"], g[f"c{i}_gout"]
+        out = oracle.softsplat_forward(x, fl)
+        np.testing.assert_allclose(out, g[f"c{i}_out"], rtol=0, atol=1e-6, err_msg=tag)
+        gin, gfl = oracle.softsplat_backward(x, fl, go)
+        np.testing.assert_allclose(gin, g[f"c{i}_gin"], rtol=0, atol=1e-6, err_msg=tag)
+        np.testing.assert_allclose(gfl, g[f"c{i}_gflow"], rtol=1e-6, atol=1e-5, err_msg=tag)
+
+
+def test_function_softsplat_modes(oracle, golden_dir):
+    g = _load(golden_dir, "splat_modes")
+    for i in range(int(g["count"])):
+        tag = str(g[f"c{i}_tag"])
+        out = oracle.function_softsplat(g[f"c{i}_in"], g[f"c{i}_flow"], g[f"c{i}_metric"], str(g[f"c{i}_mode"]))
+        np.testing.assert_allclose(out, g[f"c{i}_out"], rtol=1e-5, atol=1e-5, err_msg=tag)
+    out = oracle.function_softsplat(g["module_in"], g["module_flow"], np.ones_like(g["module_in"][:, :1]), "summation")
+    np.testing.assert_allclose(out, g["module_out"], rtol=0, atol=1e-6)
+
+
+def test_max_splat_family(oracle, golden_dir):
+    g = _load(golden_dir, "splat_max")
+    for i in range(int(g["count"])):
+        tag = str(g[f"c{i}_tag"])
+        mx = oracle.maxsplat_forward(g[f"c{i}_in"], g[f"c{i}_flow"])
+        assert np.array_equal(mx, g[f"c{i}_max"]), tag
+        wn = oracle.maximum_warp_norm_splat(g[f"c{i}_in"], g[f"c{i}_flow"])
+        assert np.array_equal(wn, g[f"c{i}_warpnorm"]), tag
+
+
+@pytest.mark.parametrize("t", [0, 1, 30, 59])
+def test_forward_flow_decoder_input(oracle, golden_dir, t):
+    """a6: the tensor the reference forward_flow feeds its decoder (baseline and SLR v1)."""
+    g = _load(golden_dir, "pipeline_a6")
+    N = int(g["N"])
+    gen = oracle.synth_baseline(g["fs"], g["Z"], g["motion"], t, N)
+    np.testing.assert_allclose(gen, g[f"baseline_t{t}_gen_fs"], rtol=1e-5, atol=2e-6)
+    a = g["alpha_out"]
+    abg = (1.0 / (1.0 + np.exp(-a[:, 0:1]))).astype(np.float32)
+    for tag, a0 in (("v1", True), ("v1noa0", False)):
+        if f"{tag}_t{t}_gen_fs" not in g:
+            continue
+        gen, afl, _ = oracle.synth_v1(g["fs"], g["Z"], a[:, 1:2], abg, g["motion"], t, N, use_alpha0=a0)
+        np.testing.assert_allclose(gen, g[f"{tag}_t{t}_gen_fs"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(np.concatenate([gen, afl], 1), g[f"{tag}_t{t}_dec_alpha_in"],
+                                   rtol=1e-5, atol=5e-6)
+        # holes are exact zeros: the partial-conv decoder masks on x != 0 (architectures.py:369)
+        assert np.array_equal(gen == 0, g[f"{tag}_t{t}_gen_fs"] == 0)

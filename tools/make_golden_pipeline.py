@@ -1,0 +1,120 @@
+"""P1 fixtures: the tensor the reference's own ``forward_flow`` hands to its decoder(s).
+
+Runs the UNMODIFIED reference methods
+  AnimatingSoftmaxSplating.forward_flow        (models/animating_softmax_splating.py:777-981)
+  AnimatingSoftmaxSplatingJoint.forward_flow   (models/animating_softmax_splating_2layers_alpha_seperate.py:843-1108)
+as unbound functions on a stand-in ``self`` that carries the reference's parsed options
+(options/train_options.py, canonical flag sets of train_animating_scripts/*.sh), the reference's
+``softsplat.ModuleSoftsplat('summation')`` and recording stubs in place of the decoders (and a
+fixed random map in place of the alpha encoder).  What is recorded is the decoder INPUT --
+i.e. everything between the encoder output and the decoder: Euler step counts, alpha, exp
+weighting, channel packing, two-direction accumulation and normalisation.
+
+Called from tools/make_golden.py (needs /root/reference; only numbers are committed).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+
+def _stub(name, **kw):
+    m = types.ModuleType(name)
+    m.__dict__.update(kw)
+    sys.modules[name] = m
+    return m
+
+
+class _Recorder(torch.nn.Module):
+    def __init__(self, out_ch):
+        super().__init__()
+        self.out_ch = out_ch
+        self.seen = []
+
+    def forward(self, x):
+        self.seen.append(x.detach().clone())
+        return x.new_zeros(x.shape[0], self.out_ch, x.shape[2], x.shape[3])
+
+
+class _Fixed(torch.nn.Module):
+    def __init__(self, value):
+        super().__init__()
+        self.value = value
+
+    def forward(self, x):
+        return self.value
+
+
+def _plain(t):
+    return t.detach().as_subclass(torch.Tensor).numpy().astype(np.float32)
+
+
+def capture_pipeline(ss, eim, out_dir, rng, cudalike):
+    for n in ("cv2", "av", "lz4framed"):
+        _stub(n)
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms")
+    tv.models = _stub("torchvision.models", vgg19=None)
+    tv.utils = _stub("torchvision.utils")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    import models.animating_softmax_splating as A
+    import models.animating_softmax_splating_2layers_alpha_seperate as B
+    # both model files did `from ...euler_integration_manipulator import euler_integration`;
+    # the function object is the reference's own, its module global torch is the CPU proxy.
+    from options.train_options import ArgumentParser
+
+    W, N = 20, 60
+    base = ("--model_type softmax_splating --refine_model_type resnet_256W8UpDown64_de_resnet_pconv2_nonorm "
+            "--pconv pconv_pbn_woresbias --norm_G sync:spectral_batch --train_Z --use_softmax_splatter "
+            "--losses 1.0_l1 --W %d" % W)
+    v1 = base.replace("softmax_splating ", "softmax_splating_2layers_alpha_seperate ") + \
+        (" --bg_refine_model_type resnet_256W8UpDown64BG_nonorm "
+         "--alpha_refine_model_type resnet_256W8UpDown64Layers_de_resnet_pconv2_nonorm "
+         "--out_channel 65 --ngf 64 --train_bg --train_alpha --use_alpha0_as_blending_weight")
+    opt_base, _ = ArgumentParser().parse(base)
+    opt_v1, _ = ArgumentParser().parse(v1)
+    opt_v1_noa0, _ = ArgumentParser().parse(v1.replace(" --use_alpha0_as_blending_weight", ""))
+
+    y, x = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.5 * np.sin(2 * np.pi * (2 * x / W + y / W) + 0.3)
+    v = 1.5 * np.cos(2 * np.pi * (x / W - 1.5 * y / W) + 1.1)
+    m = (x >= 0.35 * W).astype(np.float32)
+    motion = np.stack([u * m, v * m])[None].astype(np.float32)
+    fs = rng.standard_normal((1, 64, W, W)).astype(np.float32)
+    Z = (rng.standard_normal((1, 1, W, W)) * 3).astype(np.float32)
+    img = rng.uniform(-1, 1, (1, 3, W, W)).astype(np.float32)
+    alpha_out = rng.standard_normal((1, 2, W, W)).astype(np.float32)      # [bg logit, fluid logit]
+    bg = rng.standard_normal((1, 3, W, W)).astype(np.float32)
+
+    g = {"fs": fs, "Z": Z, "motion": motion, "img": img, "alpha_out": alpha_out, "bg": bg,
+         "N": np.int32(N), "ts": np.array([0, 1, 30, 59], np.int32)}
+
+    for t in (0, 1, 30, 59):
+        batch = {"features": [(cudalike(fs), cudalike(Z))], "images": [cudalike(img)],
+                 "motions": [cudalike(motion)], "index": torch.tensor([[0, t, N - 1]])}
+        # ---- baseline
+        rec = _Recorder(3)
+        me = types.SimpleNamespace(opt=opt_base, softsplater=ss.ModuleSoftsplat("summation"), projector=rec)
+        pred = A.AnimatingSoftmaxSplating.forward_flow(me, batch)
+        assert pred["PredImg"].shape == (1, 3, W, W)
+        g[f"baseline_t{t}_gen_fs"] = _plain(rec.seen[0])
+        # ---- v1 with / without use_alpha0_as_blending_weight
+        for tag, opt in (("v1", opt_v1), ("v1noa0", opt_v1_noa0)):
+            if tag == "v1noa0" and t not in (1, 30):
+                continue
+            rec_p, rec_a = _Recorder(3), _Recorder(1)
+            me = types.SimpleNamespace(opt=opt, softsplater=ss.ModuleSoftsplat("summation"),
+                                       projector=rec_p, net_alpha_decoder=rec_a,
+                                       net_alpha_encoder=_Fixed(cudalike(alpha_out)))
+            b = dict(batch)
+            b["BGImg"] = [cudalike(bg)]
+            pred = B.AnimatingSoftmaxSplatingJoint.forward_flow(me, b)
+            g[f"{tag}_t{t}_gen_fs"] = _plain(rec_p.seen[0])
+            g[f"{tag}_t{t}_dec_alpha_in"] = _plain(rec_a.seen[0])          # cat[gen_fs, alpha_fluid]
+            # with zero decoder outputs: fluid=tanh(0)=0, alpha=sigmoid(0)=.5 -> exercises compositing
+            g[f"{tag}_t{t}_PredImg"] = _plain(pred["PredImg"])
+            g[f"{tag}_t{t}_CompositeFluidAlpha"] = _plain(pred["CompositeFluidAlpha"])
+    np.savez_compressed(os.path.join(out_dir, "pipeline_a6.npz"), **g)
