@@ -1,0 +1,153 @@
+/*
+ * slr_splat.h -- C ABI of libslrsplat.so: MI355X (gfx950) kernels for the SLR-SFS
+ * frame-synthesis hot path (Euler-integrated feature warping + softmax splatting).
+ *
+ * The reference has no FFI for this path: models/softsplat.py hands raw data_ptr()s to
+ * cupy-JIT-compiled CUDA kernels (softsplat.py:408-416) and euler_integration is a Python
+ * loop of torch ops (models/projection/euler_integration_manipulator.py:36-55).  Each entry
+ * point below names the reference code it replaces (file:line under the reference root).
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every tensor is fp32, NCHW, contiguous, resident in device (HBM) memory -- the same
+ *     contract the reference asserts (softsplat.py:397-402);
+ *   - `stream` is a hipStream_t (NULL = default stream) that belongs to the CURRENT device;
+ *     all work is enqueued on it, nothing synchronises the host, nothing is allocated;
+ *   - scratch memory is caller-owned: `ws` must hold slr_splat_workspace_bytes(N,C,H,W) bytes,
+ *     16-byte aligned (C = the widest tensor splatted with it), and must not be shared by calls in flight on different streams;
+ *   - return value 0 = success; >0 = hipError_t; <0 = SLR_E_* argument error.
+ *     slr_last_error() returns a thread-local description of the last failure.
+ *   - a non-finite or |.| >= 2^30 target coordinate drops all four corners (reference: UB).
+ */
+#ifndef SLR_SPLAT_H
+#define SLR_SPLAT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLR_ABI_VERSION 1
+
+#define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
+#define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
+
+/* FunctionSoftsplat strType (softsplat.py:667) */
+#define SLR_MODE_SUMMATION 0
+#define SLR_MODE_AVERAGE   1
+#define SLR_MODE_LINEAR    2
+#define SLR_MODE_SOFTMAX   3
+
+/* normaliser handling of slr_splat_normalize / slr_synth_group */
+#define SLR_NORM_ZERO_TO_ONE 0   /* norm==0 -> 1      (softsplat.py:684)                       */
+#define SLR_NORM_CLAMP_EPS   1   /* max(norm, eps)    (animating_softmax_splating.py:923)      */
+
+int         slr_abi_version(void);
+const char *slr_last_error(void);
+
+/* ------------------------------------------------------------------ Euler integration */
+
+/* euler_integration(motion, nsteps) for one sample.
+ * Replaces models/projection/euler_integration_manipulator.py:7-56 (return_all_frames=False).
+ *   motion  [2,H,W]  ch0 = x velocity, ch1 = y velocity (px/frame); multiplied by `sign`
+ *                    (+1 / -1: the models call it with flow and -flow,
+ *                    animating_softmax_splating.py:847-848; an exact sign flip)
+ *   disp    [2,H,W]  out; invalid pixels = max(H,W)+1 in both channels (:55)
+ *   visible [H,W]    out, 1.0/0.0 (:54); may be NULL
+ * Bit-exact with the reference (fp32 adds, round-half-even gather index). */
+int slr_euler_integrate(const float *motion, int H, int W, int nsteps, float sign,
+                        float *disp, float *visible, void *stream);
+
+/* All frames t = 0..nmax in ONE pass: disp_all[t] == euler_integration(sign*motion, t).
+ * Replaces the per-frame re-integration of forward_flow (O(N^2) steps per clip,
+ * animating_softmax_splating.py:847-848); the reference's own return_all_frames=True branch
+ * is broken (euler_integration_manipulator.py:31,50).
+ *   disp_all [nmax+1,2,H,W] out;  vis_all [nmax+1,H,W] out, may be NULL */
+int slr_euler_integrate_all(const float *motion, int H, int W, int nmax, float sign,
+                            float *disp_all, float *vis_all, void *stream);
+
+/* ------------------------------------------------------------------ splat: binning */
+
+/* Bytes of scratch one flow field needs: tile bins (12 B per source pixel worst case), the
+ * work plan, and partial-tile slots for splatting up to C value planes (C = 0: bins only). */
+size_t slr_splat_workspace_bytes(int N, int C, int H, int W);
+
+/* Sort the source pixels of `flow` [N,2,H,W] into per-output-tile bins inside `ws`.
+ * Depends on the flow only -- every tensor splatted with this flow reuses the bins.
+ * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199;
+ * here each workgroup owns an output tile and gathers exactly the sources that land in it.) */
+int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------ splat: forward */
+
+/* _FunctionSoftsplat.forward: summation splat.
+ * Replaces kernel_Softsplat_updateOutput + its launcher, softsplat.py:157-202, 390-424.
+ *   in [N,C,H,W], flow [N,2,H,W] -> out [N,C,H,W] (every element written; no pre-zeroing)
+ * Bins `flow` into `ws` first (slr_splat_bin) unless prebinned != 0. */
+int slr_softsplat_forward(const float *in, const float *flow, float *out,
+                          int N, int C, int H, int W,
+                          void *ws, size_t ws_bytes, int prebinned, void *stream);
+
+/* FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType) fused: weighting, splat and
+ * normalisation in one pass.  Replaces softsplat.py:665-690.
+ *   mode = SLR_MODE_*; metric [N,1,H,W] (ignored for SUMMATION/AVERAGE, may be NULL)
+ *   out [N,C,H,W] = splat(in*m) / splat(m) with splat(m)==0 -> 1   (m = 1 | metric | exp(metric)) */
+int slr_softsplat_mode_forward(const float *in, const float *metric, const float *flow, float *out,
+                               int N, int C, int H, int W, int mode,
+                               void *ws, size_t ws_bytes, int prebinned, void *stream);
+
+/* In-place normalisation of a raw accumulation whose LAST channel is the normaliser:
+ * accum [N,C+1,H,W] -> out [N,C,H,W].  Replaces softsplat.py:681-686 (ZERO_TO_ONE) and
+ * animating_softmax_splating.py:923-924 (CLAMP_EPS, eps = 1e-8). */
+int slr_splat_normalize(const float *accum, float *out, int N, int C, int H, int W,
+                        int norm_mode, float eps, void *stream);
+
+/* The frame-synthesis block of forward_flow for one group of planes sharing a weight plane:
+ *   S   = splat(values*w*a, disp_f) + splat(values*w*(1-a), disp_p)
+ *   nrm = splat(w*a, disp_f)        + splat(w*(1-a), disp_p)
+ *   out = S / max(nrm, eps)                  (exact 0 where nothing lands)
+ * with w = exp(wlogit - *wmax) if wmax != NULL else exp(wlogit) if exp_weights else wlogit.
+ * Replaces animating_softmax_splating.py:849-862, 884-924 (values = start_fs, wlogit = Z,
+ * a = 1 - t/N) and ..._2layers_alpha_seperate.py:950-1045 (second group: values = alpha_fluid,
+ * wlogit = CompositeFluidAlpha_I0).  One sample (the models run bs = 1 at inference).
+ *   values [C,H,W]; wlogit [H,W]; wmax: device pointer to 1 float or NULL
+ *   disp_f, disp_p [2,H,W]; ws_f, ws_p: workspaces ALREADY binned with disp_f / disp_p
+ *   out [C,H,W]; norm_out [H,W] or NULL (the clamped normaliser, for alpha_fluid_mask :1039) */
+int slr_synth_group(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                    const float *disp_f, const float *disp_p, float alpha,
+                    float *out, float *norm_out, int C, int H, int W, float eps,
+                    void *ws_f, void *ws_p, size_t ws_bytes, void *stream);
+
+/* Global max of a tensor (Z.max(), animating_softmax_splating.py:855) -> result[0].
+ * scratch: 1024 floats of device memory. */
+int slr_global_max(const float *x, size_t n, float *result, float *scratch, void *stream);
+
+/* ------------------------------------------------------------------ splat: backward */
+
+/* _FunctionSoftsplat.backward.  Replaces kernel_Softsplat_updateGradInput / updateGradFlow
+ * and their launcher, softsplat.py:204-255, 257-326, 427-478.
+ *   grad_in [N,C,H,W] and/or grad_flow [N,2,H,W]; either may be NULL (needs_input_grad). */
+int slr_softsplat_backward(const float *in, const float *flow, const float *grad_out,
+                           float *grad_in, float *grad_flow,
+                           int N, int C, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------ maximum-splat family */
+
+/* _FunctionMaximumsplat.forward: out[corner] = max(init, max over sources of in*w).
+ * Replaces kernel_Maximumsplat_updateOutput, softsplat.py:12-82, 482-518 (init 0.0, :497). */
+int slr_maxsplat_forward(const float *in, const float *flow, float *out, float init,
+                         int N, int C, int H, int W,
+                         void *ws, size_t ws_bytes, int prebinned, void *stream);
+
+/* _FunctionMaximumWarpNormsplat: max-splat seeded with -1000, then per source pixel the max
+ * over its in-bounds corners and itself.  Replaces softsplat.py:84-155, 576-624.
+ *   scratch [N,C,H,W] receives the intermediate max-warped tensor. */
+int slr_max_warp_norm(const float *in, const float *flow, float *scratch, float *out,
+                      int N, int C, int H, int W,
+                      void *ws, size_t ws_bytes, int prebinned, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLR_SPLAT_H */

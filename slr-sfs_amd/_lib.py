@@ -1,0 +1,120 @@
+"""ctypes binding of libslrsplat.so (C ABI: include/slr_splat.h).  No fallback of any kind."""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libslrsplat.so")
+ABI_VERSION = 1
+
+# every symbol include/slr_splat.h declares
+SYMBOLS = (
+    "slr_abi_version", "slr_last_error",
+    "slr_euler_integrate", "slr_euler_integrate_all",
+    "slr_splat_workspace_bytes", "slr_splat_bin",
+    "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
+    "slr_synth_group", "slr_global_max",
+    "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
+)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of the library (cross-compiles without a GPU)."""
+    import subprocess
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=out)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises RuntimeError (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"slr_sfs_amd: HIP library {LIB_PATH} is missing -- build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C slr-sfs_amd/csrc`). "
+                f"There is no CPU/PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, fp, i, f, sz = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+        L.slr_abi_version.restype = i
+        L.slr_last_error.restype = ctypes.c_char_p
+        L.slr_splat_workspace_bytes.restype = sz
+        L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
+        sig = {
+            "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
+            "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
+            "slr_splat_bin": [fp, i, i, i, i, vp, sz, vp],
+            "slr_softsplat_forward": [fp, fp, fp, i, i, i, i, vp, sz, i, vp],
+            "slr_softsplat_mode_forward": [fp, fp, fp, fp, i, i, i, i, i, vp, sz, i, vp],
+            "slr_splat_normalize": [fp, fp, i, i, i, i, i, f, vp],
+            "slr_synth_group": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, vp, sz, vp],
+            "slr_global_max": [fp, sz, fp, fp, vp],
+            "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
+            "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
+            "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
+        }
+        for name, argtypes in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = i
+        if L.slr_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"slr_sfs_amd: {LIB_PATH} has ABI {L.slr_abi_version()}, expected {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().slr_last_error()
+        raise RuntimeError(f"slr_sfs_amd: {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """HIP stream handle torch is currently using on the tensor's device."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_device(*tensors):
+    """The reference raises NotImplementedError for CPU tensors (models/softsplat.py:418-419)
+    and asserts contiguity (:401-402); same here -- there is no CPU path."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError("slr_sfs_amd operators run on ROCm device tensors only (no CPU path)")
+        if t.dtype != torch.float32:
+            raise TypeError(f"slr_sfs_amd: float32 tensors required, got {t.dtype}")
+        assert t.is_contiguous() is True
+
+
+# ---- scratch: caller-owned workspaces, cached per (device, stream, role, shape) -------------
+_ws_cache = {}
+
+
+def workspace(t, role, N, C, H, W):
+    """A torch-allocated (stream-ordered) workspace for splatting [N,<=C,H,W] on t's device."""
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream, role, N, C, H, W)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = int(lib().slr_splat_workspace_bytes(N, C, H, W))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def clear_workspaces():
+    _ws_cache.clear()

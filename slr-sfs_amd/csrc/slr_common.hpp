@@ -1,0 +1,113 @@
+// slr_common.hpp -- shared host/device helpers for libslrsplat (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/slr_splat.h"
+
+#define SLR_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace slr {
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define SLR_CHECK_ARG(cond, what)                                              \
+    do { if (!(cond)) { slr::set_error("%s: bad argument: %s", __func__, what); return SLR_E_BADARG; } } while (0)
+
+#define SLR_CHECK_HIP(expr)                                                    \
+    do { hipError_t e_ = (expr);                                               \
+         if (e_ != hipSuccess) { slr::set_error("%s: %s", __func__, hipGetErrorString(e_)); return (int)e_; } } while (0)
+
+#define SLR_CHECK_LAUNCH() SLR_CHECK_HIP(hipGetLastError())
+
+// ---- geometry of the output tiling ------------------------------------------------------
+// One workgroup owns a TILE_H x TILE_W block of OUTPUT pixels of one sample ("tile") and a
+// group of channels; its bin lists the source pixels whose bilinear footprint touches the
+// tile.  Long bins are cut into segments of SEG entries so that no workgroup gets more than
+// ~2x the average work; a tile with several segments is finished by the combine kernel.
+constexpr int TILE_W   = 64;      // one wavefront of consecutive x
+constexpr int TILE_H   = 16;
+constexpr int TILE_PIX = TILE_W * TILE_H;
+constexpr int SEG_ONE  = 2 * TILE_PIX;   // segment length, one flow per tile
+constexpr int SEG_TWO  = 4 * TILE_PIX;   // segment length, forward+backward flows per tile
+constexpr int CG_MAX   = 16;             // channels per workgroup (LDS planes), upper bound
+
+// Workspace layout (all offsets 256-byte aligned).  `hdr` is zeroed at the start of binning.
+struct WsLayout {
+    int tiles_x, tiles_y, tiles;          // per sample
+    uint32_t nt;                          // N * tiles
+    uint32_t part_slots;                  // partial-tile slots available to the plan
+    uint32_t items_cap;                   // upper bound of work items (tiles + part_slots)
+    size_t off_count;     // uint32[nt]   entries per tile                 (bin)
+    size_t off_cursor;    // uint32[nt]   fill cursors                     (bin)
+    size_t off_listoff;   // uint32[nt+1] exclusive prefix of count        (bin)
+    size_t off_list;      // uint32[4*N*H*W] source pixel indices          (bin)
+    size_t off_nseg;      // uint32[nt]   segments per tile                (plan)
+    size_t off_partoff;   // uint32[nt]   first partial slot of the tile   (plan)
+    size_t off_items;     // uint2[items_cap] (tile, segment)              (plan)
+    size_t off_totals;    // uint32[4]    total items, total partial slots (plan)
+    size_t off_partial;   // float[part_slots][planes][TILE_PIX]           (main -> combine)
+    size_t part_stride;   // floats per partial slot = planes * TILE_PIX
+    size_t total;
+};
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// C = number of value planes that will be splatted with this workspace (0 = bins only).
+inline WsLayout ws_layout(int N, int C, int H, int W) {
+    WsLayout L;
+    L.tiles_x = (W + TILE_W - 1) / TILE_W;
+    L.tiles_y = (H + TILE_H - 1) / TILE_H;
+    L.tiles = L.tiles_x * L.tiles_y;
+    L.nt = (uint32_t)N * L.tiles;
+    L.part_slots = L.nt / 2 < 64 ? 64 : L.nt / 2;
+    L.items_cap = L.nt + L.part_slots;
+    size_t o = 0;
+    L.off_count = o;   o += al256((size_t)L.nt * 4);
+    L.off_cursor = o;  o += al256((size_t)L.nt * 4);
+    L.off_listoff = o; o += al256(((size_t)L.nt + 1) * 4);
+    L.off_list = o;    o += al256((size_t)4 * N * H * W * 4);
+    L.off_nseg = o;    o += al256((size_t)L.nt * 4);
+    L.off_partoff = o; o += al256((size_t)L.nt * 4);
+    L.off_items = o;   o += al256((size_t)L.items_cap * 8);
+    L.off_totals = o;  o += 256;
+    L.off_partial = o;
+    // every channel group carries one extra plane (the normaliser)
+    int groups = C > 0 ? (C + CG_MAX - 1) / CG_MAX : 0;
+    L.part_stride = (size_t)(C + groups) * TILE_PIX;
+    o += al256((size_t)L.part_slots * L.part_stride * 4);
+    L.total = o;
+    return L;
+}
+
+// ---- bilinear footprint ------------------------------------------------------------------
+// Restates models/softsplat.py:169-184 (target coordinate, NW corner, 4 weights).
+struct Corners {
+    int x0, y0;
+    float w[4];        // NW, NE, SW, SE
+    bool ok;           // coordinate representable (finite, |.| < 2^30)
+};
+
+__device__ __forceinline__ Corners make_corners(float fx, float fy, int x, int y) {
+    Corners c;
+    float X = (float)x + fx;
+    float Y = (float)y + fy;
+    c.ok = (fabsf(X) < 1073741824.0f) && (fabsf(Y) < 1073741824.0f);
+    float flx = floorf(X), fly = floorf(Y);
+    c.x0 = c.ok ? (int)flx : 0;
+    c.y0 = c.ok ? (int)fly : 0;
+    float x1 = (float)(c.x0 + 1), y1 = (float)(c.y0 + 1), x0f = (float)c.x0, y0f = (float)c.y0;
+    c.w[0] = (x1 - X) * (y1 - Y);
+    c.w[1] = (X - x0f) * (y1 - Y);
+    c.w[2] = (x1 - X) * (Y - y0f);
+    c.w[3] = (X - x0f) * (Y - y0f);
+    return c;
+}
+
+__device__ __forceinline__ bool in_image(int cx, int cy, int H, int W) {
+    return (cx >= 0) & (cx < W) & (cy >= 0) & (cy < H);
+}
+
+}  // namespace slr

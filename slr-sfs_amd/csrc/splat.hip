@@ -1,0 +1,658 @@
+// splat.hip -- forward splatting as an OWNER-COMPUTES gather (gfx950, no MFMA, no global atomics).
+//
+// Replaces models/softsplat.py:157-202 (+ the host glue :390-424, :665-690 and the model-side
+// weighting / two-direction accumulation / normalisation of forward_flow).
+//
+// The reference scatters: one thread per ELEMENT, 4 global fp32 atomicAdds each into a
+// pre-zeroed output (softsplat.py:186-199,404) -- C-fold redundant flow/weight math, a memset
+// and an atomic read-modify-write of every output line on top of the algorithmic traffic.
+//
+// Here the scatter is turned around.  The flow is shared by all C channels, so it is cheap
+// to sort it once:
+//   1. bin   (count -> scan -> fill): every source pixel is appended to the bin of each
+//            16x64 OUTPUT tile its 2x2 bilinear footprint touches (<= 4 tiles);
+//   2. plan : bins are cut into segments of <= SEG entries (load balance: Euler-integrated
+//            fluid flows pile up to 7x the average into some tiles);
+//   3. splat: one workgroup = (tile, segment, channel group).  It walks its bin segment --
+//            consecutive entries are consecutive source pixels, so the per-channel plane
+//            reads are coalesced 256-byte wavefront loads -- and accumulates v*w into an LDS
+//            image of the tile with ds_add_f32.  A single-segment tile is normalised in LDS
+//            and written with coalesced float4 stores: every output byte is written exactly
+//            once, never read, never zeroed;
+//   4. combine: the few multi-segment tiles wrote raw partial tiles instead; one workgroup
+//            per (tile, group) sums them in segment order, normalises and stores.
+// HBM traffic = C input planes read + C output planes written (+ the 12 B/pixel index),
+// i.e. the algorithmic bytes, instead of ~2x that for the atomic formulation.
+#include "slr_common.hpp"
+
+#include <stdarg.h>
+
+namespace slr {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// =========================================================================== binning
+
+// Tiles touched by the footprint of one source pixel: <= 2 tile columns x <= 2 tile rows.
+// (scalars, not arrays: dynamically indexed private arrays would be demoted to LDS/scratch)
+struct TileSet {
+    int txa, txb, tya, tyb;     // candidate tile columns / rows
+    bool vxa, vxb, vya, vyb;    // candidate valid (b only when distinct from a)
+};
+
+__device__ __forceinline__ TileSet footprint_tiles(const Corners &c, int H, int W) {
+    TileSet s;
+    const bool xa = c.ok & (c.x0 >= 0) & (c.x0 < W), xb = c.ok & (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
+    const bool ya = c.ok & (c.y0 >= 0) & (c.y0 < H), yb = c.ok & (c.y0 + 1 >= 0) & (c.y0 + 1 < H);
+    s.txa = c.x0 / TILE_W; s.txb = (c.x0 + 1) / TILE_W;      // only used when in range (>= 0)
+    s.tya = c.y0 / TILE_H; s.tyb = (c.y0 + 1) / TILE_H;
+    s.vxa = xa; s.vxb = xb & !(xa & (s.txb == s.txa));
+    s.vya = ya; s.vyb = yb & !(ya & (s.tyb == s.tya));
+    return s;
+}
+
+// Wave-aggregated append: lanes of the wave that target the same tile take consecutive
+// slots in lane order (so a bin stays sorted by source pixel inside every wave's chunk).
+// FILL = false: only count.  Must be called by all 64 lanes (tile < 0 = nothing to add).
+template <bool FILL>
+__device__ __forceinline__ void wave_append(int tile, uint32_t pix, uint32_t *__restrict__ counter,
+                                            const uint32_t *__restrict__ listoff,
+                                            uint32_t *__restrict__ list) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(tile >= 0);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int lt = __shfl(tile, leader);
+        unsigned long long same = __ballot(tile == lt);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counter[lt], (uint32_t)__popcll(same));
+        if (FILL) {
+            base = __shfl(base, leader);
+            if (tile == lt) {
+                uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                list[listoff[lt] + base + rank] = pix;
+            }
+        }
+        todo &= ~same;
+    }
+}
+
+// grid (ceil(HW/256), N).  counter = count[] (FILL=false) or cursor[] (FILL=true).
+template <bool FILL>
+__global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ flow, int H, int W,
+                                                  int tiles_x, int tiles,
+                                                  uint32_t *__restrict__ counter,
+                                                  const uint32_t *__restrict__ listoff,
+                                                  uint32_t *__restrict__ list) {
+    const int HW = H * W;
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    TileSet s = {};
+    if (i < HW) {
+        const float *f = flow + (size_t)n * 2 * HW;
+        int y = i / W, x = i - y * W;
+        Corners c = make_corners(f[i], f[HW + i], x, y);
+        s = footprint_tiles(c, H, W);
+    }
+    const int tb = n * tiles;
+    wave_append<FILL>((s.vya & s.vxa) ? tb + s.tya * tiles_x + s.txa : -1, (uint32_t)i, counter, listoff, list);
+    wave_append<FILL>((s.vya & s.vxb) ? tb + s.tya * tiles_x + s.txb : -1, (uint32_t)i, counter, listoff, list);
+    wave_append<FILL>((s.vyb & s.vxa) ? tb + s.tyb * tiles_x + s.txa : -1, (uint32_t)i, counter, listoff, list);
+    wave_append<FILL>((s.vyb & s.vxb) ? tb + s.tyb * tiles_x + s.txb : -1, (uint32_t)i, counter, listoff, list);
+}
+
+// Block-wide exclusive scan helper (1024 threads), returns the block total.
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *excl, uint32_t *wsum /*[16]*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        uint32_t s = wsum[w];
+        if (w < wid) woff += s;
+        total += s;
+    }
+    __syncthreads();
+    *excl = woff + inc - v;
+    return total;
+}
+
+// listoff = exclusive prefix sum of count (single workgroup of 1024 threads); zeroes cursor.
+__global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *__restrict__ count, uint32_t nt,
+                                                       uint32_t *__restrict__ listoff,
+                                                       uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t wsum[16];
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nt; b += 1024) {
+        uint32_t t = b + threadIdx.x;
+        uint32_t v = t < nt ? count[t] : 0;
+        uint32_t ex;
+        uint32_t tot = block_exscan(v, &ex, wsum);
+        if (t < nt) { listoff[t] = run + ex; cursor[t] = 0; }
+        run += tot;
+    }
+    if (threadIdx.x == 0) listoff[nt] = run;
+}
+
+// Work plan for splatting with one (count1 == nullptr) or two flows per tile:
+// nseg[t] = segments of the concatenated bin, items[] = (tile, segment) work list, partoff[t] =
+// first partial slot of a multi-segment tile.  A tile that does not fit into the partial
+// budget is left in one piece (correct, just slower).  Single workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ count0,
+                                                    const uint32_t *__restrict__ count1, uint32_t nt,
+                                                    uint32_t seg, uint32_t part_slots,
+                                                    uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
+                                                    uint2 *__restrict__ items, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t wsum[16];
+    uint32_t run_items = 0, run_parts = 0;
+    for (uint32_t b = 0; b < nt; b += 1024) {
+        uint32_t t = b + threadIdx.x;
+        uint32_t cnt = 0;
+        if (t < nt) cnt = count0[t] + (count1 ? count1[t] : 0u);
+        uint32_t ns = cnt > seg ? (cnt + seg - 1) / seg : 1u;
+        uint32_t pex;
+        uint32_t ptot = block_exscan(ns > 1 ? ns : 0u, &pex, wsum);
+        if (ns > 1 && run_parts + pex + ns > part_slots) ns = 1;      // budget exhausted
+        // (a dropped tile leaves a hole in the slot numbering; harmless)
+        uint32_t iex;
+        uint32_t itot = block_exscan(t < nt ? ns : 0u, &iex, wsum);
+        if (t < nt) {
+            nseg[t] = ns;
+            partoff[t] = run_parts + pex;
+            for (uint32_t s = 0; s < ns; ++s) items[run_items + iex + s] = make_uint2(t, s);
+        }
+        run_items += itot;
+        run_parts += ptot;
+    }
+    if (threadIdx.x == 0) { totals[0] = run_items; totals[1] = run_parts; }
+}
+
+// =========================================================================== splat
+
+enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
+
+struct SplatArgs {
+    const float *in;        // [N,C,H,W] value planes
+    const float *mul;       // [N,1,H,W] weight plane (metric / Z), or nullptr
+    const float *mulmax;    // device scalar subtracted before exp (MUL_EXP_SHIFT)
+    const float *flow[2];   // [N,2,H,W] per direction (flow[1] unused when ndir == 1)
+    const uint32_t *count[2], *listoff[2], *list[2];
+    float scale[2];         // alpha, 1 - alpha
+    const uint32_t *nseg, *partoff, *totals;
+    const uint2 *items;
+    float *partial;
+    float *out;             // [N,C,H,W]
+    float *norm_out;        // [N,1,H,W] or nullptr
+    size_t part_stride;
+    int N, C, H, W, tiles_x, tiles;
+    int cg, groups, ndir, seg;
+    int mulmode, norm_mode;
+    float eps, init;
+};
+
+__device__ __forceinline__ void lds_max(float *p, float v) {
+    // order-preserving integer view of fp32: signed max for v >= 0, unsigned min for v < 0;
+    // a NaN candidate is ignored, as fmaxf(val, old) does in the reference (softsplat.py:47)
+    if (v != v) return;
+    if (v >= 0.0f) atomicMax((int *)p, __float_as_int(v));
+    else atomicMin((unsigned int *)p, __float_as_uint(v));
+}
+
+__device__ __forceinline__ float finish(float s, float nrm, int norm_mode, float eps) {
+    if (norm_mode == SLR_NORM_ZERO_TO_ONE) return s / (nrm == 0.0f ? 1.0f : nrm);   // softsplat.py:684-686
+    return s / fmaxf(nrm, eps);                                                      // ...splating.py:923-924
+}
+
+
+// The normaliser plane as the models use it (clamp(min=eps) / zero->one applied) -> [H,W] plane.
+__device__ __forceinline__ void store_norm(const float *__restrict__ nrm, float *__restrict__ dst, int H, int W,
+                                           int tx0, int ty0, int norm_mode, float eps) {
+    for (int r = threadIdx.x; r < TILE_PIX; r += blockDim.x) {
+        int ly = r / TILE_W, lx = r - ly * TILE_W;
+        int y = ty0 + ly, x = tx0 + lx;
+        if (y < H && x < W) {
+            float v = nrm[r];
+            v = norm_mode == SLR_NORM_ZERO_TO_ONE ? (v == 0.0f ? 1.0f : v) : fmaxf(v, eps);
+            dst[(size_t)y * W + x] = v;
+        }
+    }
+}
+
+// Store `np` LDS planes of the tile to a [.,H,W] plane stack (dst -> plane 0), optionally
+// dividing by the normaliser plane `nrm` (LDS).  Coalesced: 16 lanes x float4 = one tile row.
+template <bool NORM>
+__device__ __forceinline__ void store_tile(const float *__restrict__ lds, const float *__restrict__ nrm,
+                                           float *__restrict__ dst, int np, int H, int W,
+                                           int tx0, int ty0, int norm_mode, float eps) {
+    const size_t HW = (size_t)H * W;
+    const bool vec = ((W & 3) == 0) && ((((uintptr_t)dst) & 15) == 0);
+    if (vec) {
+        for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += blockDim.x) {
+            int c = q / (TILE_PIX / 4), r = q - c * (TILE_PIX / 4);
+            int ly = r / (TILE_W / 4), lx = (r - ly * (TILE_W / 4)) * 4;
+            int y = ty0 + ly, x = tx0 + lx;
+            if (y < H && x < W) {
+                float4 v = *reinterpret_cast<const float4 *>(&lds[c * TILE_PIX + ly * TILE_W + lx]);
+                if (NORM) {
+                    float4 m = *reinterpret_cast<const float4 *>(&nrm[ly * TILE_W + lx]);
+                    v.x = finish(v.x, m.x, norm_mode, eps);
+                    v.y = finish(v.y, m.y, norm_mode, eps);
+                    v.z = finish(v.z, m.z, norm_mode, eps);
+                    v.w = finish(v.w, m.w, norm_mode, eps);
+                }
+                *reinterpret_cast<float4 *>(&dst[(size_t)c * HW + (size_t)y * W + x]) = v;
+            }
+        }
+    } else {
+        for (int q = threadIdx.x; q < np * TILE_PIX; q += blockDim.x) {
+            int c = q / TILE_PIX, r = q - c * TILE_PIX;
+            int ly = r / TILE_W, lx = r - ly * TILE_W;
+            int y = ty0 + ly, x = tx0 + lx;
+            if (y < H && x < W) {
+                float v = lds[q];
+                if (NORM) v = finish(v, nrm[r], norm_mode, eps);
+                dst[(size_t)c * HW + (size_t)y * W + x] = v;
+            }
+        }
+    }
+}
+
+constexpr int SPLAT_THREADS = 512;
+
+// Accumulate U consecutive channel planes of one bin entry into the LDS tile.  All U plane
+// loads are issued before the first LDS atomic.  o[k] are float indices inside a tile plane:
+// the true corner, or (kb[k] false: corner outside the tile) a harmless in-plane address that
+// receives the neutral element (+0.0 / -inf) -- branch-free, and exact for non-finite inputs
+// because the PRODUCT is replaced, not the weight.
+template <int U, bool MAXOP>
+__device__ __forceinline__ void accumulate(const float *__restrict__ ip, size_t HW, uint32_t pix, int ch,
+                                           float m, const float (&w)[4], const int (&o)[4],
+                                           const bool (&kb)[4], float *__restrict__ lds) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ip[(size_t)(ch + u) * HW + pix];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float *p = lds + (ch + u) * TILE_PIX;
+        const float vm = v[u] * m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (MAXOP) lds_max(p + o[k], kb[k] ? vm * w[k] : -INFINITY);
+            else atomicAdd(p + o[k], kb[k] ? vm * w[k] : 0.0f);
+        }
+    }
+}
+
+// One workgroup = (tile, segment, channel group).  512 threads, LDS = (cg + NORM) tile planes.
+// Workgroup b runs on XCD b % 8 (observed dispatch order); the channel
+// groups of one work item are mapped to the SAME XCD so that the bin, the flow and the weight
+// plane they all re-read are served by that XCD's L2.
+// The walk over the bin is software-pipelined: while entry i is accumulated, the flow of entry
+// i+1 and the index of entry i+2 are already in flight (the three loads are a dependent chain).
+template <bool NORM, bool MAXOP>
+__global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = SPLAT_THREADS;
+    const int G = a.groups;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t item = (slot / G) * 8u + xcd;
+    const int g = slot % G;
+    if (item >= a.totals[0]) return;
+    const uint2 it = a.items[item];
+    const uint32_t t = it.x, s = it.y;
+    const int n = t / a.tiles, tl = t - n * a.tiles;
+    const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
+    const int c0 = g * a.cg;
+    const int nc = min(a.cg, a.C - c0);
+    const int HW = a.H * a.W;
+    const int np = nc + (NORM ? 1 : 0);
+    float *nrm = lds + nc * TILE_PIX;
+    for (int q = threadIdx.x; q < np * TILE_PIX; q += T) lds[q] = MAXOP ? a.init : 0.0f;
+    __syncthreads();
+
+    const float shift = (a.mulmode == MUL_EXP_SHIFT) ? a.mulmax[0] : 0.0f;
+    const bool has_mul = a.mulmode != MUL_ONE;
+    // segment s of the concatenated bin [bin(flow0) ; bin(flow1)]
+    const uint32_t lo = s * (uint32_t)a.seg, hi = lo + (uint32_t)a.seg;
+    uint32_t base = 0;
+    for (int d = 0; d < a.ndir; ++d) {
+        const uint32_t cnt = a.count[d][t];
+        const uint32_t b = lo > base ? lo - base : 0u;                 // range inside this bin
+        const uint32_t e = hi > base ? min(hi - base, cnt) : 0u;
+        base += cnt;
+        if (b >= e) continue;
+        const uint32_t *lst = a.list[d] + a.listoff[d][t];
+        const float *fl = a.flow[d] + (size_t)n * 2 * HW;
+        const float *mp = has_mul ? a.mul + (size_t)n * HW : fl;
+        const float *ip = a.in + ((size_t)n * a.C + c0) * HW;
+        const float sc = a.scale[d];
+
+        uint32_t k = b + threadIdx.x;
+        uint32_t pixA = k < e ? lst[k] : 0u;
+        uint32_t pixB = k + T < e ? lst[k + T] : 0u;
+        float fxA = fl[pixA], fyA = fl[HW + pixA], mA = mp[pixA];
+        for (; k < e; k += T) {
+            const uint32_t pixC = k + 2 * T < e ? lst[k + 2 * T] : 0u;       // index of entry i+2
+            const float fxB = fl[pixB], fyB = fl[HW + pixB], mB = mp[pixB];  // flow of entry i+1
+
+            const uint32_t pix = pixA;
+            const int y = pix / a.W, x = pix - y * a.W;
+            const Corners c = make_corners(fxA, fyA, x, y);
+            float m = sc;
+            if (a.mulmode == MUL_PLANE) m = mA * sc;
+            else if (a.mulmode >= MUL_EXP) m = expf(mA - shift) * sc;
+            // footprint corners that fall into this tile (and into the image)
+            const int lx = c.x0 - tx0, ly = c.y0 - ty0;
+            const bool xa = c.ok & (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W);
+            const bool xb = c.ok & (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
+            const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H);
+            const bool yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
+            const int oc = ly * TILE_W + lx;
+            const int safe = threadIdx.x & 63;       // any in-plane address; lane-distinct banks
+            const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
+            const int o[4] = {kb[0] ? oc : safe, kb[1] ? oc + 1 : safe,
+                              kb[2] ? oc + TILE_W : safe, kb[3] ? oc + TILE_W + 1 : safe};
+            if (NORM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicAdd(nrm + o[q], kb[q] ? m * c.w[q] : 0.0f);
+            }
+            int ch = 0;
+            for (; ch + 8 <= nc; ch += 8) accumulate<8, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds);
+            if (ch + 4 <= nc) { accumulate<4, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds); ch += 4; }
+            if (ch + 2 <= nc) { accumulate<2, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds); ch += 2; }
+            if (ch < nc) accumulate<1, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds);
+
+            pixA = pixB; fxA = fxB; fyA = fyB; mA = mB;
+            pixB = pixC;
+        }
+    }
+    __syncthreads();
+
+    if (a.nseg[t] == 1) {
+        float *dst = a.out + ((size_t)n * a.C + c0) * HW;
+        store_tile<NORM>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+        if (NORM && a.norm_out && g == 0)
+            store_norm(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+    } else {
+        // raw partial tile (values + normaliser) -> scratch; finished by combine_kernel
+        float *dst = a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + (size_t)(c0 + g) * TILE_PIX;
+        for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += T)
+            reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(lds)[q];
+    }
+}
+
+// One workgroup per (tile, channel group); does nothing unless the tile has several segments.
+template <bool NORM, bool MAXOP>
+__global__ __launch_bounds__(256) void combine_kernel(SplatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = a.groups;
+    const uint32_t t = blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const uint32_t ns = a.nseg[t];
+    if (ns <= 1) return;
+    const int n = t / a.tiles, tl = t - n * a.tiles;
+    const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
+    const int c0 = g * a.cg;
+    const int nc = min(a.cg, a.C - c0);
+    const int HW = a.H * a.W;
+    const int np = nc + (NORM ? 1 : 0);
+    float *nrm = lds + nc * TILE_PIX;
+    const float *src = a.partial + (size_t)a.partoff[t] * a.part_stride + (size_t)(c0 + g) * TILE_PIX;
+    for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += 256) {
+        float4 acc = reinterpret_cast<const float4 *>(src)[q];
+        for (uint32_t s = 1; s < ns; ++s) {                       // fixed order: deterministic
+            float4 v = reinterpret_cast<const float4 *>(src + (size_t)s * a.part_stride)[q];
+            if (MAXOP) {
+                acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y);
+                acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
+            } else {
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        reinterpret_cast<float4 *>(lds)[q] = acc;
+    }
+    __syncthreads();
+    float *dst = a.out + ((size_t)n * a.C + c0) * HW;
+    store_tile<NORM>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+    if (NORM && a.norm_out && g == 0)
+        store_norm(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+}
+
+// =========================================================================== small kernels
+
+// accum [N,C+1,H,W] (last channel = normaliser) -> out [N,C,H,W]
+__global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ accum, float *__restrict__ out,
+                                                        int C, int HW, int norm_mode, float eps) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float *ap = accum + (size_t)n * (C + 1) * HW;
+    float *op = out + (size_t)n * C * HW;
+    const float nrm = ap[(size_t)C * HW + i];
+    for (int c = 0; c < C; ++c) op[(size_t)c * HW + i] = finish(ap[(size_t)c * HW + i], nrm, norm_mode, eps);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+// two-stage max: stage 1 grid-stride -> partial[blocks]; stage 2 single block -> result[0]
+__global__ __launch_bounds__(256) void max_stage_kernel(const float *__restrict__ x, size_t n,
+                                                        float *__restrict__ dst) {
+    __shared__ float wm[4];
+    float m = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+}
+
+// =========================================================================== host side
+
+static int choose_cg(int C) {
+    int groups = (C + CG_MAX - 1) / CG_MAX;
+    return (C + groups - 1) / groups;
+}
+
+struct Ws {
+    WsLayout L;
+    char *base;
+    uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals;
+    uint2 *items;
+    float *partial;
+};
+
+static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, const char *who) {
+    w.L = ws_layout(N, C, H, W);
+    if (!ws || ((uintptr_t)ws & 15) || bytes < w.L.total) {
+        set_error("%s: workspace needs %zu bytes (16-byte aligned), got %zu", who, w.L.total, bytes);
+        return SLR_E_WORKSPACE;
+    }
+    w.base = (char *)ws;
+    w.count = (uint32_t *)(w.base + w.L.off_count);
+    w.cursor = (uint32_t *)(w.base + w.L.off_cursor);
+    w.listoff = (uint32_t *)(w.base + w.L.off_listoff);
+    w.list = (uint32_t *)(w.base + w.L.off_list);
+    w.nseg = (uint32_t *)(w.base + w.L.off_nseg);
+    w.partoff = (uint32_t *)(w.base + w.L.off_partoff);
+    w.items = (uint2 *)(w.base + w.L.off_items);
+    w.totals = (uint32_t *)(w.base + w.L.off_totals);
+    w.partial = (float *)(w.base + w.L.off_partial);
+    return 0;
+}
+
+static int check_dims(int N, int C, int H, int W, const char *who) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)N * H * W >= (1LL << 29)) {
+        set_error("%s: bad sizes N=%d C=%d H=%d W=%d", who, N, C, H, W);
+        return SLR_E_BADARG;
+    }
+    return 0;
+}
+
+static int do_bin(const float *flow, int N, int H, int W, Ws &w, hipStream_t st) {
+    SLR_CHECK_HIP(hipMemsetAsync(w.count, 0, (size_t)w.L.nt * 4, st));
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, flow, H, W, w.L.tiles_x, w.L.tiles,
+                       w.count, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w.count, w.L.nt,
+                       w.listoff, w.cursor);
+    hipLaunchKernelGGL(bin_kernel<true>, grid, dim3(256), 0, st, flow, H, W, w.L.tiles_x, w.L.tiles,
+                       w.cursor, (const uint32_t *)w.listoff, w.list);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+// plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
+template <bool NORM, bool MAXOP>
+static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
+    a.cg = choose_cg(a.C);
+    a.groups = (a.C + a.cg - 1) / a.cg;
+    a.tiles_x = w0.L.tiles_x;
+    a.tiles = w0.L.tiles;
+    a.ndir = w1 ? 2 : 1;
+    a.seg = w1 ? SEG_TWO : SEG_ONE;
+    a.count[0] = w0.count; a.listoff[0] = w0.listoff; a.list[0] = w0.list;
+    a.count[1] = w1 ? w1->count : nullptr; a.listoff[1] = w1 ? w1->listoff : nullptr; a.list[1] = w1 ? w1->list : nullptr;
+    a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals;
+    a.partial = w0.partial;
+    a.part_stride = w0.L.part_stride;
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
+                       (const uint32_t *)(w1 ? w1->count : nullptr), w0.L.nt, (uint32_t)a.seg,
+                       w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.totals);
+    const size_t lds = (size_t)(a.cg + (NORM ? 1 : 0)) * TILE_PIX * sizeof(float);
+    const uint32_t blocks = ((w0.L.items_cap + 7) / 8) * 8 * a.groups;
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP>), dim3(blocks), dim3(SPLAT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt * a.groups), dim3(256), lds, st, a);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace slr
+
+using namespace slr;
+
+SLR_EXPORT int slr_abi_version(void) { return SLR_ABI_VERSION; }
+SLR_EXPORT const char *slr_last_error(void) { return slr::g_err; }
+
+SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C < 0 || H <= 0 || W <= 0) return 0;
+    return ws_layout(N, C, H, W).total;
+}
+
+SLR_EXPORT int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes,
+                             void *stream) {
+    SLR_CHECK_ARG(flow, "null flow");
+    if (int e = check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
+    Ws w;
+    if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
+    return do_bin(flow, N, H, W, w, (hipStream_t)stream);
+}
+
+SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *out, int N, int C, int H,
+                                     int W, void *ws, size_t ws_bytes, int prebinned, void *stream) {
+    SLR_CHECK_ARG(in && flow && out, "null pointer");
+    if (int e = check_dims(N, C, H, W, __func__)) return e;
+    Ws w;
+    if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (!prebinned) if (int e = do_bin(flow, N, H, W, w, st)) return e;
+    SplatArgs a = {};
+    a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
+    a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
+    return do_splat<false, false>(a, w, nullptr, st);
+}
+
+SLR_EXPORT int slr_softsplat_mode_forward(const float *in, const float *metric, const float *flow, float *out,
+                                          int N, int C, int H, int W, int mode, void *ws, size_t ws_bytes,
+                                          int prebinned, void *stream) {
+    SLR_CHECK_ARG(mode >= SLR_MODE_SUMMATION && mode <= SLR_MODE_SOFTMAX, "mode");
+    if (mode == SLR_MODE_SUMMATION)
+        return slr_softsplat_forward(in, flow, out, N, C, H, W, ws, ws_bytes, prebinned, stream);
+    SLR_CHECK_ARG(in && flow && out, "null pointer");
+    SLR_CHECK_ARG(mode == SLR_MODE_AVERAGE || metric, "metric required for linear/softmax");
+    if (int e = check_dims(N, C, H, W, __func__)) return e;
+    Ws w;
+    if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (!prebinned) if (int e = do_bin(flow, N, H, W, w, st)) return e;
+    SplatArgs a = {};
+    a.in = in; a.mul = metric; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
+    a.N = N; a.C = C; a.H = H; a.W = W;
+    a.mulmode = mode == SLR_MODE_AVERAGE ? MUL_ONE : mode == SLR_MODE_LINEAR ? MUL_PLANE : MUL_EXP;
+    a.norm_mode = SLR_NORM_ZERO_TO_ONE;
+    return do_splat<true, false>(a, w, nullptr, st);
+}
+
+SLR_EXPORT int slr_synth_group(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                               const float *disp_f, const float *disp_p, float alpha, float *out,
+                               float *norm_out, int C, int H, int W, float eps, void *ws_f, void *ws_p,
+                               size_t ws_bytes, void *stream) {
+    SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && out, "null pointer");
+    if (int e = check_dims(1, C, H, W, __func__)) return e;
+    Ws wf, wp;
+    if (int e = ws_open(wf, 1, C, H, W, ws_f, ws_bytes, __func__)) return e;
+    if (int e = ws_open(wp, 1, C, H, W, ws_p, ws_bytes, __func__)) return e;
+    SplatArgs a = {};
+    a.in = values; a.mul = wlogit; a.mulmax = wmax;
+    a.flow[0] = disp_f; a.flow[1] = disp_p;
+    a.scale[0] = alpha; a.scale[1] = 1.0f - alpha;
+    a.out = out; a.norm_out = norm_out;
+    a.N = 1; a.C = C; a.H = H; a.W = W;
+    a.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
+    a.norm_mode = SLR_NORM_CLAMP_EPS;
+    a.eps = eps;
+    return do_splat<true, false>(a, wf, &wp, (hipStream_t)stream);
+}
+
+SLR_EXPORT int slr_splat_normalize(const float *accum, float *out, int N, int C, int H, int W, int norm_mode,
+                                   float eps, void *stream) {
+    SLR_CHECK_ARG(accum && out, "null pointer");
+    SLR_CHECK_ARG(norm_mode == SLR_NORM_ZERO_TO_ONE || norm_mode == SLR_NORM_CLAMP_EPS, "norm_mode");
+    if (int e = check_dims(N, C, H, W, __func__)) return e;
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(normalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, accum, out, C, H * W,
+                       norm_mode, eps);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_global_max(const float *x, size_t n, float *result, float *scratch, void *stream) {
+    SLR_CHECK_ARG(x && result && scratch && n > 0, "null pointer / empty");
+    int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(max_stage_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+    hipLaunchKernelGGL(max_stage_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)scratch,
+                       (size_t)blocks, result);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *out, float init, int N, int C,
+                                    int H, int W, void *ws, size_t ws_bytes, int prebinned, void *stream) {
+    SLR_CHECK_ARG(in && flow && out, "null pointer");
+    if (int e = check_dims(N, C, H, W, __func__)) return e;
+    Ws w;
+    if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (!prebinned) if (int e = do_bin(flow, N, H, W, w, st)) return e;
+    SplatArgs a = {};
+    a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out; a.init = init;
+    a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
+    return do_splat<false, true>(a, w, nullptr, st);
+}

@@ -1,0 +1,78 @@
+"""Drop-in for the reference's ``models/projection/euler_integration_manipulator.py``.
+
+``euler_integration`` / ``EulerIntegration`` keep the reference's signatures, assertions and
+return values (bit-exact), but one HIP launch integrates all steps (the reference runs a Python
+loop of ~15 torch kernels per step, euler_integration_manipulator.py:36-55).
+``euler_integration_all`` is the O(N) all-frames pass the frame-synthesis pipeline uses.
+"""
+import torch
+import torch.nn as nn
+
+from ._lib import check, lib, ptr, require_device, stream_of
+
+
+def _steps(destination_frame):
+    # the models pass a python int or a 1-element index tensor (animating_softmax_splating.py:847)
+    if torch.is_tensor(destination_frame):
+        return int(destination_frame.reshape(-1)[0].item())
+    return int(destination_frame)
+
+
+def euler_integration(motion, destination_frame, return_all_frames=False):
+    """euler_integration_manipulator.py:7-56.
+
+    :param motion: Eulerian motion field [1,2,H,W] (ch0 = x, ch1 = y velocity).
+    :param destination_frame: number of integration steps.
+    :return: (displacements [1,2,H,W], visible_pixels [1,1,H,W]); invalid pixels carry
+             max(H,W)+1 in both channels.
+    ``return_all_frames=True`` crashes in the reference (:31,50); here it returns the
+    displacement maps of frames 0..destination_frame ([n+1,2,H,W], [n+1,1,H,W]).
+    """
+    assert (motion.dim() == 4)
+    b, c, height, width = motion.shape
+    assert (b == 1), 'Function only implemented for batch = 1'
+    assert (c == 2), f'Input motion field should be Bx2xHxW. Given tensor is: {motion.shape}'
+    n = _steps(destination_frame)
+    if return_all_frames:
+        return euler_integration_all(motion, n)
+    motion = motion.contiguous()
+    require_device(motion)
+    disp = torch.empty_like(motion)
+    vis = motion.new_empty(1, 1, height, width)
+    with torch.cuda.device(motion.device):
+        check(lib().slr_euler_integrate(ptr(motion), height, width, n, 1.0, ptr(disp), ptr(vis),
+                                        stream_of(motion)), "slr_euler_integrate")
+    return disp, vis
+
+
+def euler_integration_all(motion, nmax, sign=1.0, want_visible=True):
+    """Displacement maps to every frame t = 0..nmax in one pass:
+    out[t] == euler_integration(sign*motion, t).  -> ([nmax+1,2,H,W], [nmax+1,1,H,W] or None)"""
+    assert motion.dim() == 4 and motion.shape[0] == 1 and motion.shape[1] == 2
+    motion = motion.contiguous()
+    require_device(motion)
+    _, _, H, W = motion.shape
+    disp = motion.new_empty(nmax + 1, 2, H, W)
+    vis = motion.new_empty(nmax + 1, 1, H, W) if want_visible else None
+    with torch.cuda.device(motion.device):
+        check(lib().slr_euler_integrate_all(ptr(motion), H, W, int(nmax), float(sign), ptr(disp), ptr(vis),
+                                            stream_of(motion)), "slr_euler_integrate_all")
+    return disp, vis
+
+
+class EulerIntegration(nn.Module):
+    """euler_integration_manipulator.py:58-71 (batch wrapper, per-sample step counts)."""
+
+    def __init__(self, opt=None):
+        super().__init__()
+        self.opt = opt
+
+    def forward(self, motion, destination_frame, return_all_frames=False, show_visible_pixels=False):
+        displacements = torch.empty_like(motion)
+        visible_pixels = motion.new_empty(motion.shape[0], 1, motion.shape[2], motion.shape[3])
+        for b in range(motion.shape[0]):
+            displacements[b:b + 1], visible_pixels[b:b + 1] = euler_integration(motion[b:b + 1], destination_frame[b])
+        if show_visible_pixels:
+            return displacements, visible_pixels
+        else:
+            return displacements

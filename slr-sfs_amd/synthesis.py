@@ -1,0 +1,123 @@
+"""Frame synthesis between encoder and decoder -- the data-flow of the reference's
+``forward_flow`` (models/animating_softmax_splating.py:777-981 and
+models/animating_softmax_splating_2layers_alpha_seperate.py:843-1108), restructured for MI355X:
+
+  * Euler integration: ONE all-frames pass per direction per clip (the reference re-integrates
+    from scratch for every frame: t + (N-t) Python-loop steps per frame, N^2 per clip);
+  * per frame: bin the two displacement maps once, then one fused kernel per weight group does
+    exp-weighting, both splat directions, and the normalisation (the reference: 2 cats, ~25
+    elementwise torch kernels over 65-67 planes, 2 atomic-scatter launches).
+
+Index semantics: batch["index"] = [start, middle, end] = [0, t, N-1]:
+forward steps = middle-start = t, backward steps = end-middle+1 = N-t,
+alpha = 1 - (middle-start)/(end-start+1) = 1 - t/N.
+"""
+import torch
+
+from ._lib import check, lib, ptr, require_device, stream_of, workspace
+from .euler_integration_manipulator import euler_integration_all
+
+
+def bin_flow(flow, C, role):
+    """Sort the source pixels of ``flow`` [1,2,H,W] into output-tile bins (slr_splat_bin).
+    Returns the workspace; valid until the next bin_flow with the same role/shape/stream."""
+    require_device(flow)
+    N, _, H, W = flow.shape
+    ws = workspace(flow, role, N, C, H, W)
+    with torch.cuda.device(flow.device):
+        check(lib().slr_splat_bin(ptr(flow), N, C, H, W, ptr(ws), ws.numel(), stream_of(flow)), "slr_splat_bin")
+    return ws
+
+
+def global_max(x):
+    """x.max() as a 1-element device tensor, no host sync (animating_softmax_splating.py:855)."""
+    require_device(x)
+    res = x.new_empty(1)
+    scratch = x.new_empty(1024)
+    with torch.cuda.device(x.device):
+        check(lib().slr_global_max(ptr(x), x.numel(), ptr(res), ptr(scratch), stream_of(x)), "slr_global_max")
+    return res
+
+
+def synth_group(values, wlogit, disp_f, disp_p, alpha, ws_f, ws_p, wmax=None, exp_weights=True,
+                eps=1e-8, return_norm=False):
+    """out = [splat(values*w*alpha, disp_f) + splat(values*w*(1-alpha), disp_p)] / max(same for w, eps)
+    with w = exp(wlogit - wmax) | exp(wlogit) | wlogit.  values [1,C,H,W], wlogit [1,1,H,W]."""
+    require_device(values, wlogit, disp_f, disp_p, wmax)
+    assert values.shape[0] == 1 and wlogit.shape[1] == 1 and disp_f.shape[1] == 2 and disp_p.shape[1] == 2
+    _, C, H, W = values.shape
+    out = torch.empty_like(values)
+    norm = values.new_empty(1, 1, H, W) if return_norm else None
+    with torch.cuda.device(values.device):
+        check(lib().slr_synth_group(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0,
+                                    ptr(disp_f), ptr(disp_p), float(alpha), ptr(out), ptr(norm),
+                                    C, H, W, float(eps), ptr(ws_f), ptr(ws_p), ws_f.numel(),
+                                    stream_of(values)), "slr_synth_group")
+    return (out, norm) if return_norm else out
+
+
+class ClipSynthesizer:
+    """Frame-invariant state of one clip + per-frame decoder-input synthesis.
+
+    baseline:  ClipSynthesizer(fs, Z, motion, N).features(t)                     -> gen_fs
+    SLR v1:    ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=..., alpha_bg=...,
+                               use_alpha0=True, clamp_alpha=True).features(t)   -> gen_fs, alpha_fluid
+    """
+
+    def __init__(self, fs, Z, motion, N, alpha_fluid_logit=None, alpha_bg=None, use_alpha0=True,
+                 clamp_alpha=None, softmax_v1=False, clamp_z=None):
+        require_device(fs, Z, motion)
+        assert fs.shape[0] == 1 and Z.shape[1] == 1 and motion.shape[1] == 2
+        self.N = int(N)
+        self.fs = fs.contiguous()
+        Z = Z.contiguous()
+        self.v1 = alpha_fluid_logit is not None
+        # alpha clamp: only the 2-layer model has it (..._2layers_alpha_seperate.py:952)
+        self.clamp_alpha = self.v1 if clamp_alpha is None else clamp_alpha
+        # Z_f_norm = Z - Z.max() unless use_softmax_splatter_v1 (animating_softmax_splating.py:849-855)
+        if clamp_z is not None:                                        # :856-859 (not the shipped behaviour)
+            Zn = Z if softmax_v1 else Z - Z.max()
+            self.Z, self.zmax = torch.clamp(Zn, min=clamp_z[0], max=clamp_z[1]).contiguous(), None
+        else:
+            self.Z, self.zmax = Z, (None if softmax_v1 else global_max(Z))
+        # all-frames Euler passes: forward t = 0..N-1 steps of +motion, backward 1..N steps of -motion
+        self.disp_f, _ = euler_integration_all(motion, self.N - 1, +1.0, want_visible=False)
+        self.disp_p, _ = euler_integration_all(motion, self.N, -1.0, want_visible=False)
+        self.C = self.fs.shape[1]
+        if self.v1:
+            af = alpha_fluid_logit.contiguous()
+            self.use_alpha0 = bool(use_alpha0)
+            if self.use_alpha0:                                        # ..._2layers_alpha_seperate.py:963-965
+                sg = torch.sigmoid(af)
+                self.A0 = (sg / torch.clamp(sg + alpha_bg, min=1e-8)).contiguous()
+                self.af = af
+            else:                                                      # :974-976: same weights as the features
+                self.fs = torch.cat([self.fs, af], 1).contiguous()
+                self.C += 1
+
+    def alpha(self, t):
+        a = torch.tensor(1.0, dtype=torch.float32) - torch.tensor(float(t), dtype=torch.float32) / \
+            torch.tensor(float(self.N), dtype=torch.float32)          # fp32 arithmetic, as the reference (:860)
+        if self.clamp_alpha:
+            a = torch.clamp(a, min=1.0 / 600.0, max=599.0 / 600.0)
+        return float(a)
+
+    def features(self, t, return_norm=False):
+        """Decoder input for frame t (index = [0, t, N-1])."""
+        t = int(t)
+        assert 0 <= t < self.N
+        disp_f = self.disp_f[t:t + 1]                # t forward steps
+        disp_p = self.disp_p[self.N - t:self.N - t + 1]   # N - t backward steps
+        ws_f = bin_flow(disp_f, self.C, "f")
+        ws_p = bin_flow(disp_p, self.C, "p")
+        a = self.alpha(t)
+        res = synth_group(self.fs, self.Z, disp_f, disp_p, a, ws_f, ws_p, wmax=self.zmax,
+                          return_norm=return_norm)
+        gen, norm = res if return_norm else (res, None)
+        if not self.v1:
+            return (gen, norm) if return_norm else gen
+        if self.use_alpha0:
+            afl = synth_group(self.af, self.A0, disp_f, disp_p, a, ws_f, ws_p, wmax=None, exp_weights=True)
+        else:
+            gen, afl = gen[:, :-1], gen[:, -1:]
+        return (gen, afl, norm) if return_norm else (gen, afl)

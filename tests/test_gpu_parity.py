@@ -1,0 +1,316 @@
+"""GPU parity: HIP kernels (through the Python mirror -> ctypes -> C ABI) vs the CPU oracle and
+the golden fixtures generated from the reference.  Tolerances:
+  * Euler integration, splat backward, maximum-splat family: bit-exact (deterministic order);
+  * summation / normalised splats: 1e-5 abs+rel on O(1) data -- the summation ORDER of a splat
+    is unspecified in the reference itself (racing fp32 atomicAdds, softsplat.py:187-199), so
+    only rounding-noise-level agreement is meaningful; north_star's bound is 1e-4 max-abs.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def S():
+    import slr_sfs_amd
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    slr_sfs_amd._lib.lib()          # fail loudly if the HIP library is missing
+    return slr_sfs_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def load(golden_dir, name):
+    return np.load(f"{golden_dir}/{name}.npz")
+
+
+def smooth_motion(H, W, seed=0, amp=1.5):
+    rng = np.random.default_rng(seed)
+    p1, p2 = rng.uniform(0, 2 * np.pi, 2)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = amp * np.sin(2 * np.pi * (2 * x / W + y / H) + p1)
+    v = amp * np.cos(2 * np.pi * (x / W - 1.5 * y / H) + p2)
+    m = (x >= 0.35 * W).astype(np.float32)
+    return np.stack([u * m, v * m])[None].astype(np.float32)
+
+
+# ------------------------------------------------------------------------------ euler
+
+def test_euler_golden_bit_exact(S, golden_dir):
+    g = load(golden_dir, "euler")
+    for i in range(int(g["count"])):
+        d, v = S.euler_integration(dev(g[f"c{i}_motion"]), int(g[f"c{i}_n"]))
+        tag = str(g[f"c{i}_tag"])
+        assert np.array_equal(host(d), g[f"c{i}_disp"]), tag
+        assert np.array_equal(host(v), g[f"c{i}_vis"]), tag
+
+
+def test_euler_tensor_step_count_and_module(S, golden_dir):
+    g = load(golden_dir, "euler")
+    m, dest = g["module_motion"], g["module_dest"]
+    d, v = S.EulerIntegration()(dev(m), torch.from_numpy(dest.astype(np.int64)).cuda(), show_visible_pixels=True)
+    assert np.array_equal(host(d), g["module_disp"])
+    assert np.array_equal(host(v), g["module_vis"])
+    d1 = S.EulerIntegration()(dev(m), torch.from_numpy(dest.astype(np.int64)))
+    assert np.array_equal(host(d1), g["module_disp"])
+
+
+def test_euler_all_frames_vs_oracle(S, oracle):
+    for (H, W, seed) in [(48, 80, 0), (37, 53, 1)]:
+        m = smooth_motion(H, W, seed, amp=2.5)
+        for sign in (1.0, -1.0):
+            d, v = S.euler_integration_all(dev(m), 60, sign=sign)
+            od, ov = oracle.euler_integration_all(sign * m, 60)
+            assert np.array_equal(host(d), od)
+            assert np.array_equal(host(v), ov)
+
+
+def test_euler_full_size_vs_oracle(S, oracle):
+    m = smooth_motion(768, 1280, 2)
+    d, v = S.euler_integration(dev(m), 59)
+    od, ov = oracle.euler_integration(m, 59)
+    assert np.array_equal(host(d), od) and np.array_equal(host(v), ov)
+    dn, _ = S.euler_integration(dev(-m), 17)
+    dn2, _ = S.euler_integration_all(dev(m), 17, sign=-1.0)
+    assert np.array_equal(host(dn)[0], host(dn2)[17])
+
+
+def test_euler_asserts(S):
+    with pytest.raises(AssertionError):
+        S.euler_integration(torch.zeros(2, 2, 4, 4).cuda(), 1)        # batch must be 1 (:20)
+    with pytest.raises(AssertionError):
+        S.euler_integration(torch.zeros(1, 3, 4, 4).cuda(), 1)        # two channels (:21)
+    with pytest.raises(NotImplementedError):
+        S.euler_integration(torch.zeros(1, 2, 4, 4), 1)               # no CPU path
+
+
+# ------------------------------------------------------------------------------ summation splat
+
+def test_splat_sum_golden_forward_backward(S, golden_dir):
+    g = load(golden_dir, "splat_sum")
+    for i in range(int(g["count"])):
+        tag = str(g[f"c{i}_tag"])
+        x = dev(g[f"c{i}_in"]).requires_grad_(True)
+        fl = dev(g[f"c{i}_flow"]).requires_grad_(True)
+        out = S.softsplat._FunctionSoftsplat.apply(x, fl)
+        np.testing.assert_allclose(host(out), g[f"c{i}_out"], err_msg=tag, **TOL)
+        out.backward(dev(g[f"c{i}_gout"]))
+        assert np.array_equal(host(x.grad), g[f"c{i}_gin"]), tag
+        np.testing.assert_allclose(host(fl.grad), g[f"c{i}_gflow"], rtol=1e-6, atol=1e-6, err_msg=tag)
+
+
+def test_splat_needs_input_grad_subsets(S, golden_dir):
+    g = load(golden_dir, "splat_sum")
+    x, fl, go = g["c3_in"], g["c3_flow"], g["c3_gout"]
+    a = dev(x).requires_grad_(True)
+    S.softsplat._FunctionSoftsplat.apply(a, dev(fl)).backward(dev(go))
+    assert np.array_equal(host(a.grad), g["c3_gin"])
+    b = dev(fl).requires_grad_(True)
+    S.softsplat._FunctionSoftsplat.apply(dev(x), b).backward(dev(go))
+    np.testing.assert_allclose(host(b.grad), g["c3_gflow"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(1, 65, 256, 480), (2, 7, 45, 131), (1, 16, 100, 64), (3, 1, 17, 70)])
+def test_splat_sum_vs_oracle_euler_flow(S, oracle, shape):
+    """Euler-integrated fluid flow (piles sources up -> multi-segment tiles + combine path),
+    odd widths (scalar store path), batch > 1."""
+    N, C, H, W = shape
+    rng = np.random.default_rng(C)
+    flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=3.0), 40 + n)[0] for n in range(N)])
+    x = rng.standard_normal(shape).astype(np.float32)
+    out = S.FunctionSoftsplat(dev(x), dev(flow), None, "summation")
+    np.testing.assert_allclose(host(out), oracle.softsplat_forward(x, flow), **TOL)
+
+
+def test_splat_incoherent_flow_vs_oracle(S, oracle):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 13, 96, 200)).astype(np.float32)
+    flow = rng.uniform(-8, 8, (1, 2, 96, 200)).astype(np.float32)
+    out = S.FunctionSoftsplat(dev(x), dev(flow), None, "summation")
+    np.testing.assert_allclose(host(out), oracle.softsplat_forward(x, flow), **TOL)
+
+
+def test_splat_all_into_one_tile(S, oracle):
+    """Every source lands in one output tile: the bin is far longer than the partial budget."""
+    H, W = 160, 256
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flow = np.stack([(W / 2 - x) * 0.95 + 0.3, (H / 2 - y) * 0.95 - 0.2])[None].astype(np.float32)
+    v = np.random.default_rng(1).standard_normal((1, 3, H, W)).astype(np.float32)
+    out = S.FunctionSoftsplat(dev(v), dev(flow), None, "summation")
+    ref = oracle.softsplat_forward(v, flow)
+    np.testing.assert_allclose(host(out), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_splat_nonfinite_flow_and_input(S, oracle):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 4, 40, 72)).astype(np.float32)
+    flow = rng.uniform(-2, 2, (1, 2, 40, 72)).astype(np.float32)
+    flow[0, 0, 3, 5] = np.nan
+    flow[0, 1, 7, 9] = np.inf
+    flow[0, 0, 8, 1] = 3e9
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    np.testing.assert_allclose(out, oracle.softsplat_forward(x, flow), **TOL)
+    x[0, 1, 20, 63] = np.inf          # lands across a tile edge: must pollute only its own corners
+    flow[0, :, 20, 63] = (0.5, 0.5)
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    ref = oracle.softsplat_forward(x, flow)
+    assert np.array_equal(np.isfinite(out), np.isfinite(ref))
+
+
+def test_splat_asserts(S):
+    z = torch.zeros
+    with pytest.raises(AssertionError):
+        S.FunctionSoftsplat(z(1, 3, 8, 8).cuda(), z(1, 3, 8, 8).cuda(), None, "summation")    # flow depth (:397)
+    with pytest.raises(AssertionError):
+        S.FunctionSoftsplat(z(1, 3, 8, 8).cuda(), z(1, 2, 8, 9).cuda(), None, "summation")    # width (:399)
+    with pytest.raises(AssertionError):
+        S.FunctionSoftsplat(z(1, 3, 8, 8).cuda(), z(1, 2, 8, 8).cuda(), None, "median")       # mode (:667)
+    with pytest.raises(AssertionError):
+        S.FunctionSoftsplat(z(1, 3, 8, 8).cuda(), z(1, 2, 8, 8).cuda(), z(1, 2, 8, 8).cuda(), "softmax")  # metric (:666)
+    with pytest.raises(AssertionError):
+        S.FunctionSoftsplat(z(1, 3, 8, 16).cuda()[:, :, :, ::2], z(1, 2, 8, 8).cuda(), None, "summation")  # contiguous (:401)
+    with pytest.raises(NotImplementedError):
+        S.FunctionSoftsplat(z(1, 3, 8, 8), z(1, 2, 8, 8), None, "summation")                  # CPU (:418-419)
+
+
+# ------------------------------------------------------------------------------ modes / max family
+
+def test_function_softsplat_modes_golden(S, golden_dir):
+    g = load(golden_dir, "splat_modes")
+    for i in range(int(g["count"])):
+        tag = str(g[f"c{i}_tag"])
+        out = S.FunctionSoftsplat(dev(g[f"c{i}_in"]), dev(g[f"c{i}_flow"]), dev(g[f"c{i}_metric"]),
+                                  str(g[f"c{i}_mode"]))
+        np.testing.assert_allclose(host(out), g[f"c{i}_out"], err_msg=tag, rtol=1e-4, atol=1e-5)
+    mod = S.ModuleSoftsplat("summation")
+    out = mod(tenInput=dev(g["module_in"]), tenFlow=dev(g["module_flow"]),
+              tenMetric=torch.ones(1, 1, 12, 20).cuda())
+    np.testing.assert_allclose(host(out), g["module_out"], **TOL)
+
+
+def test_function_softsplat_modes_autograd_path_matches_fused(S):
+    rng = np.random.default_rng(3)
+    x, fl = dev(rng.standard_normal((1, 6, 40, 72))), dev(rng.uniform(-3, 3, (1, 2, 40, 72)))
+    met = dev(rng.standard_normal((1, 1, 40, 72)))
+    for mode in ("average", "linear", "softmax"):
+        m = met.abs() + 0.1 if mode == "linear" else met
+        fused = S.FunctionSoftsplat(x, fl, m, mode)
+        xg = x.clone().requires_grad_(True)
+        comp = S.FunctionSoftsplat(xg, fl, m, mode)
+        np.testing.assert_allclose(host(comp), host(fused), rtol=1e-4, atol=1e-5)
+        comp.sum().backward()
+        assert torch.isfinite(xg.grad).all()
+
+
+def test_max_splat_family_golden(S, golden_dir):
+    g = load(golden_dir, "splat_max")
+    for i in range(int(g["count"])):
+        tag = str(g[f"c{i}_tag"])
+        x, fl = dev(g[f"c{i}_in"]), dev(g[f"c{i}_flow"])
+        assert np.array_equal(host(S.ModuleMaximumsplat()(x, fl)), g[f"c{i}_max"]), tag
+        assert np.array_equal(host(S.ModuleMaximumWarpNormsplat()(x, fl)), g[f"c{i}_warpnorm"]), tag
+
+
+def test_splat_normalize(S):
+    rng = np.random.default_rng(4)
+    acc = rng.standard_normal((2, 5, 9, 33)).astype(np.float32)
+    acc[:, -1] = np.abs(acc[:, -1])
+    acc[0, -1, 2, 3] = 0.0
+    a = S.softsplat.splat_normalize(dev(acc), "zero_to_one")
+    n = acc[:, -1:].copy(); n[n == 0] = 1
+    np.testing.assert_allclose(host(a), acc[:, :-1] / n, rtol=1e-6, atol=0)
+    b = S.softsplat.splat_normalize(dev(acc), "clamp", 1e-8)
+    np.testing.assert_allclose(host(b), acc[:, :-1] / np.maximum(acc[:, -1:], 1e-8), rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------------------------ forward_flow block
+
+@pytest.mark.parametrize("t", [0, 1, 30, 59])
+def test_forward_flow_decoder_input_golden(S, golden_dir, t):
+    g = load(golden_dir, "pipeline_a6")
+    N = int(g["N"])
+    fs, Z, motion = dev(g["fs"]), dev(g["Z"]), dev(g["motion"])
+    gen = host(S.synthesis.ClipSynthesizer(fs, Z, motion, N).features(t))
+    ref = g[f"baseline_t{t}_gen_fs"]
+    np.testing.assert_allclose(gen, ref, rtol=1e-4, atol=1e-5)
+    assert np.array_equal(gen == 0, ref == 0)            # holes exactly 0 (decoder mask is x != 0)
+    a = g["alpha_out"]
+    abg = torch.sigmoid(dev(a[:, 0:1]))
+    for tag, a0 in (("v1", True), ("v1noa0", False)):
+        if f"{tag}_t{t}_gen_fs" not in g:
+            continue
+        cs = S.synthesis.ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=abg,
+                                         use_alpha0=a0)
+        gen, afl = cs.features(t)
+        np.testing.assert_allclose(host(gen), g[f"{tag}_t{t}_gen_fs"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(host(torch.cat([gen, afl], 1)), g[f"{tag}_t{t}_dec_alpha_in"],
+                                   rtol=1e-4, atol=2e-5)
+
+
+def test_synthesis_vs_oracle_mid_size(S, oracle):
+    """256x480 (config C2's grid), 64 features, all frames of a short clip, vs the oracle."""
+    H, W, N = 256, 480, 12
+    rng = np.random.default_rng(11)
+    fs = rng.standard_normal((1, 64, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    m = smooth_motion(H, W, 3, amp=4.0)
+    cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+    for t in (0, 5, 11):
+        np.testing.assert_allclose(host(cs.features(t)), oracle.synth_baseline(fs, Z, m, t, N),
+                                   rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------ full-size properties
+
+def test_full_size_mass_conservation_and_linearity(S):
+    """768x1280, C=65: size-independent properties (the oracle is too slow for every case here).
+    sum_out == sum_in * (in-bounds weight of every source);  splat(a*x + y) == a*splat(x) + splat(y)."""
+    H, W, C = 768, 1280, 65
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(1, C, H, W, device="cuda", generator=g)
+    y = torch.randn(1, C, H, W, device="cuda", generator=g)
+    m = dev(smooth_motion(H, W, 0))
+    flow, _ = S.euler_integration(m, 30)
+    out = S.FunctionSoftsplat(x, flow, None, "summation")
+    # in-bounds weight per source pixel, computed independently with torch ops
+    yy, xx = torch.meshgrid(torch.arange(H, device="cuda", dtype=torch.float32),
+                            torch.arange(W, device="cuda", dtype=torch.float32), indexing="ij")
+    X, Y = xx + flow[0, 0], yy + flow[0, 1]
+    x0, y0 = torch.floor(X), torch.floor(Y)
+    wsum = torch.zeros_like(X, dtype=torch.float64)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            cx, cy = x0 + dx, y0 + dy
+            wx = (x0 + 1 - X) if dx == 0 else (X - x0)
+            wy = (y0 + 1 - Y) if dy == 0 else (Y - y0)
+            inb = (cx >= 0) & (cx < W) & (cy >= 0) & (cy < H)
+            wsum += torch.where(inb, (wx * wy).double(), torch.zeros_like(wsum))
+    expect = (x[0].double() * wsum).sum(dim=(1, 2))
+    got = out[0].double().sum(dim=(1, 2))
+    assert torch.allclose(got, expect, rtol=1e-6, atol=1e-2), (got - expect).abs().max()
+    lin = S.FunctionSoftsplat(2.5 * x + y, flow, None, "summation")
+    ref = 2.5 * out + S.FunctionSoftsplat(y, flow, None, "summation")
+    assert (lin - ref).abs().max().item() < 1e-4
+    # identity flow reproduces the input exactly
+    ident = S.FunctionSoftsplat(x, torch.zeros_like(flow), None, "summation")
+    assert torch.equal(ident, x)
+
+
+def test_full_size_one_plane_vs_oracle(S, oracle):
+    """768x1280 at the heaviest frame (t = 59): a few planes against the oracle."""
+    H, W = 768, 1280
+    m = smooth_motion(H, W, 1)
+    flow = oracle.euler_integration(m, 59)[0]
+    x = np.random.default_rng(2).standard_normal((1, 3, H, W)).astype(np.float32)
+    out = S.FunctionSoftsplat(dev(x), dev(flow), None, "summation")
+    np.testing.assert_allclose(host(out), oracle.softsplat_forward(x, flow), **TOL)
