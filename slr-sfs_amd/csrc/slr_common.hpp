@@ -27,12 +27,18 @@ void set_error(const char *fmt, ...);
 // group of channels; its bin lists the source pixels whose bilinear footprint touches the
 // tile.  Long bins are cut into segments of SEG entries so that no workgroup gets more than
 // ~2x the average work; a tile with several segments is finished by the combine kernel.
+#ifndef SLR_TILE_H
+#define SLR_TILE_H 8
+#endif
+#ifndef SLR_CG_MAX
+#define SLR_CG_MAX 13
+#endif
 constexpr int TILE_W   = 64;      // one wavefront of consecutive x
-constexpr int TILE_H   = 16;
+constexpr int TILE_H   = SLR_TILE_H;
 constexpr int TILE_PIX = TILE_W * TILE_H;
 constexpr int SEG_ONE  = 2 * TILE_PIX;   // segment length, one flow per tile
 constexpr int SEG_TWO  = 4 * TILE_PIX;   // segment length, forward+backward flows per tile
-constexpr int CG_MAX   = 16;             // channels per workgroup (LDS planes), upper bound
+constexpr int CG_MAX   = SLR_CG_MAX;     // channels per workgroup (LDS planes), upper bound
 
 // Workspace layout (all offsets 256-byte aligned).  `hdr` is zeroed at the start of binning.
 struct WsLayout {

@@ -217,13 +217,14 @@ __device__ __forceinline__ float finish(float s, float nrm, int norm_mode, float
 
 
 // The normaliser plane as the models use it (clamp(min=eps) / zero->one applied) -> [H,W] plane.
-__device__ __forceinline__ void store_norm(const float *__restrict__ nrm, float *__restrict__ dst, int H, int W,
+template <typename A>
+__device__ __forceinline__ void store_norm(const A *__restrict__ nrm, float *__restrict__ dst, int H, int W,
                                            int tx0, int ty0, int norm_mode, float eps) {
     for (int r = threadIdx.x; r < TILE_PIX; r += blockDim.x) {
         int ly = r / TILE_W, lx = r - ly * TILE_W;
         int y = ty0 + ly, x = tx0 + lx;
         if (y < H && x < W) {
-            float v = nrm[r];
+            float v = (float)nrm[r];
             v = norm_mode == SLR_NORM_ZERO_TO_ONE ? (v == 0.0f ? 1.0f : v) : fmaxf(v, eps);
             dst[(size_t)y * W + x] = v;
         }
@@ -232,8 +233,8 @@ __device__ __forceinline__ void store_norm(const float *__restrict__ nrm, float 
 
 // Store `np` LDS planes of the tile to a [.,H,W] plane stack (dst -> plane 0), optionally
 // dividing by the normaliser plane `nrm` (LDS).  Coalesced: 16 lanes x float4 = one tile row.
-template <bool NORM>
-__device__ __forceinline__ void store_tile(const float *__restrict__ lds, const float *__restrict__ nrm,
+template <bool NORM, typename A>
+__device__ __forceinline__ void store_tile(const A *__restrict__ lds, const A *__restrict__ nrm,
                                            float *__restrict__ dst, int np, int H, int W,
                                            int tx0, int ty0, int norm_mode, float eps) {
     const size_t HW = (size_t)H * W;
@@ -244,13 +245,14 @@ __device__ __forceinline__ void store_tile(const float *__restrict__ lds, const 
             int ly = r / (TILE_W / 4), lx = (r - ly * (TILE_W / 4)) * 4;
             int y = ty0 + ly, x = tx0 + lx;
             if (y < H && x < W) {
-                float4 v = *reinterpret_cast<const float4 *>(&lds[c * TILE_PIX + ly * TILE_W + lx]);
+                const A *sp = &lds[c * TILE_PIX + ly * TILE_W + lx];
+                float4 v = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
                 if (NORM) {
-                    float4 m = *reinterpret_cast<const float4 *>(&nrm[ly * TILE_W + lx]);
-                    v.x = finish(v.x, m.x, norm_mode, eps);
-                    v.y = finish(v.y, m.y, norm_mode, eps);
-                    v.z = finish(v.z, m.z, norm_mode, eps);
-                    v.w = finish(v.w, m.w, norm_mode, eps);
+                    const A *mp = &nrm[ly * TILE_W + lx];
+                    v.x = finish(v.x, (float)mp[0], norm_mode, eps);
+                    v.y = finish(v.y, (float)mp[1], norm_mode, eps);
+                    v.z = finish(v.z, (float)mp[2], norm_mode, eps);
+                    v.w = finish(v.w, (float)mp[3], norm_mode, eps);
                 }
                 *reinterpret_cast<float4 *>(&dst[(size_t)c * HW + (size_t)y * W + x]) = v;
             }
@@ -261,15 +263,27 @@ __device__ __forceinline__ void store_tile(const float *__restrict__ lds, const 
             int ly = r / TILE_W, lx = r - ly * TILE_W;
             int y = ty0 + ly, x = tx0 + lx;
             if (y < H && x < W) {
-                float v = lds[q];
-                if (NORM) v = finish(v, nrm[r], norm_mode, eps);
+                float v = (float)lds[q];
+                if (NORM) v = finish(v, (float)nrm[r], norm_mode, eps);
                 dst[(size_t)c * HW + (size_t)y * W + x] = v;
             }
         }
     }
 }
 
-constexpr int SPLAT_THREADS = 512;
+#ifndef SLR_SPLAT_THREADS
+#define SLR_SPLAT_THREADS 512
+#endif
+constexpr int SPLAT_THREADS = SLR_SPLAT_THREADS;
+
+// LDS accumulator type.  Sums go through ds_add_f64: on gfx950 the LDS fp32 atomic add
+// (ds_add_f32) retires ~1 lane per 2.6 clocks (170 CU-cycles per wave instruction, measured,
+// tools/ubench/lds_atomic.hip) while ds_add_f64 runs at 7.8 cycles -- 22x faster, and the
+// fp64 accumulation is also closer to the exact sum than any fp32 order.  The maximum splat
+// uses the order-preserving integer view with ds_max_i32 / ds_min_u32 (4.5 cycles).
+template <bool MAXOP> struct Acc { using type = double; };
+template <> struct Acc<true> { using type = float; };
+
 
 // Accumulate U consecutive channel planes of one bin entry into the LDS tile.  All U plane
 // loads are issued before the first LDS atomic.  o[k] are float indices inside a tile plane:
@@ -279,18 +293,29 @@ constexpr int SPLAT_THREADS = 512;
 template <int U, bool MAXOP>
 __device__ __forceinline__ void accumulate(const float *__restrict__ ip, size_t HW, uint32_t pix, int ch,
                                            float m, const float (&w)[4], const int (&o)[4],
-                                           const bool (&kb)[4], float *__restrict__ lds) {
+                                           const bool (&kb)[4], typename Acc<MAXOP>::type *__restrict__ lds) {
     float v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = ip[(size_t)(ch + u) * HW + pix];
+    for (int u = 0; u < U; ++u) {
+#if defined(SLR_ABL) && SLR_ABL == 2      // ablation: no plane loads
+        v[u] = m + (float)u;
+#else
+        v[u] = ip[(size_t)(ch + u) * HW + pix];
+#endif
+    }
+#if defined(SLR_ABL) && SLR_ABL == 1      // ablation: no LDS atomics (loads kept alive)
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" ::"v"(v[u]));
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        float *p = lds + (ch + u) * TILE_PIX;
+        auto *p = lds + (ch + u) * TILE_PIX;
         const float vm = v[u] * m;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (MAXOP) lds_max(p + o[k], kb[k] ? vm * w[k] : -INFINITY);
-            else atomicAdd(p + o[k], kb[k] ? vm * w[k] : 0.0f);
+            if constexpr (MAXOP) lds_max(p + o[k], kb[k] ? vm * w[k] : -INFINITY);
+            else atomicAdd(p + o[k], (double)(kb[k] ? vm * w[k] : 0.0f));
         }
     }
 }
@@ -303,7 +328,9 @@ __device__ __forceinline__ void accumulate(const float *__restrict__ ip, size_t 
 // i+1 and the index of entry i+2 are already in flight (the three loads are a dependent chain).
 template <bool NORM, bool MAXOP>
 __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using A = typename Acc<MAXOP>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    A *lds = reinterpret_cast<A *>(lds_raw);
     constexpr int T = SPLAT_THREADS;
     const int G = a.groups;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -318,8 +345,8 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     const int nc = min(a.cg, a.C - c0);
     const int HW = a.H * a.W;
     const int np = nc + (NORM ? 1 : 0);
-    float *nrm = lds + nc * TILE_PIX;
-    for (int q = threadIdx.x; q < np * TILE_PIX; q += T) lds[q] = MAXOP ? a.init : 0.0f;
+    A *nrm = lds + nc * TILE_PIX;
+    for (int q = threadIdx.x; q < np * TILE_PIX; q += T) lds[q] = MAXOP ? (A)a.init : (A)0;
     __syncthreads();
 
     const float shift = (a.mulmode == MUL_EXP_SHIFT) ? a.mulmax[0] : 0.0f;
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
                               kb[2] ? oc + TILE_W : safe, kb[3] ? oc + TILE_W + 1 : safe};
             if (NORM) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) atomicAdd(nrm + o[q], kb[q] ? m * c.w[q] : 0.0f);
+                for (int q = 0; q < 4; ++q) atomicAdd(nrm + o[q], (A)(kb[q] ? m * c.w[q] : 0.0f));
             }
             int ch = 0;
             for (; ch + 8 <= nc; ch += 8) accumulate<8, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds);
@@ -382,14 +409,16 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 
     if (a.nseg[t] == 1) {
         float *dst = a.out + ((size_t)n * a.C + c0) * HW;
-        store_tile<NORM>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+        store_tile<NORM, A>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
         if (NORM && a.norm_out && g == 0)
-            store_norm(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+            store_norm<A>(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
     } else {
         // raw partial tile (values + normaliser) -> scratch; finished by combine_kernel
         float *dst = a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + (size_t)(c0 + g) * TILE_PIX;
-        for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += T)
-            reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(lds)[q];
+        for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += T) {
+            const A *sp = lds + 4 * q;
+            reinterpret_cast<float4 *>(dst)[q] = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
+        }
     }
 }
 
@@ -425,9 +454,9 @@ __global__ __launch_bounds__(256) void combine_kernel(SplatArgs a) {
     }
     __syncthreads();
     float *dst = a.out + ((size_t)n * a.C + c0) * HW;
-    store_tile<NORM>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+    store_tile<NORM, float>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
     if (NORM && a.norm_out && g == 0)
-        store_norm(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+        store_norm<float>(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
 }
 
 // =========================================================================== small kernels
@@ -534,10 +563,17 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
                        (const uint32_t *)(w1 ? w1->count : nullptr), w0.L.nt, (uint32_t)a.seg,
                        w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.totals);
-    const size_t lds = (size_t)(a.cg + (NORM ? 1 : 0)) * TILE_PIX * sizeof(float);
+    const size_t planes = (size_t)(a.cg + (NORM ? 1 : 0)) * TILE_PIX;
+    const size_t lds = planes * sizeof(typename Acc<MAXOP>::type), lds_c = planes * sizeof(float);
     const uint32_t blocks = ((w0.L.items_cap + 7) / 8) * 8 * a.groups;
+    static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
+    if (!attr_set) {
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
     hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP>), dim3(blocks), dim3(SPLAT_THREADS), lds, st, a);
-    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt * a.groups), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt * a.groups), dim3(256), lds_c, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }

@@ -128,8 +128,13 @@ def test_splat_sum_vs_oracle_euler_flow(S, oracle, shape):
     rng = np.random.default_rng(C)
     flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=3.0), 40 + n)[0] for n in range(N)])
     x = rng.standard_normal(shape).astype(np.float32)
-    out = S.FunctionSoftsplat(dev(x), dev(flow), None, "summation")
-    np.testing.assert_allclose(host(out), oracle.softsplat_forward(x, flow), **TOL)
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    ref = oracle.softsplat_forward(x, flow)
+    # piled-up flows sum hundreds of O(1) terms per pixel: bound the error by the fp32 rounding of
+    # the accumulated magnitude (the splat of |x|), the only order-independent statement
+    bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
+    assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+    assert np.abs(out - ref).max() < 1e-4          # north_star bound
 
 
 def test_splat_incoherent_flow_vs_oracle(S, oracle):

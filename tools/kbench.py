@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--W", type=int, default=1280)
     ap.add_argument("--C", type=int, default=65)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--quick", action="store_true")
     a = ap.parse_args()
     H, W, C = a.H, a.W, a.C
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -77,6 +78,8 @@ def main():
         tsp = timeit(splatonly, a.iters)
         print(json.dumps({"case": name, "shape": [C, H, W], "full_us": tf, "bin_us": tb, "splat_us": tsp,
                           "alg_MB": B / 1e6, "splat_TBps": B / tsp[0] / 1e6, "full_TBps": B / tf[0] / 1e6}))
+    if a.quick:
+        return
     # euler all-frames, both directions
     te = timeit(lambda: S.euler_integration_all(m, 60, want_visible=False), 10, 2)
     print(json.dumps({"case": "euler_all_60", "us": te}))
