@@ -23,22 +23,17 @@ void set_error(const char *fmt, ...);
 #define SLR_CHECK_LAUNCH() SLR_CHECK_HIP(hipGetLastError())
 
 // ---- geometry of the output tiling ------------------------------------------------------
-// One workgroup owns a TILE_H x TILE_W block of OUTPUT pixels of one sample ("tile") and a
-// group of channels; its bin lists the source pixels whose bilinear footprint touches the
-// tile.  Long bins are cut into segments of SEG entries so that no workgroup gets more than
+// One workgroup owns a TILE_H x TILE_W block of OUTPUT pixels of one sample ("tile"); its bin
+// lists the source pixels whose bilinear footprint touches the tile.  Long bins are cut into segments of SEG entries so that no workgroup gets more than
 // ~2x the average work; a tile with several segments is finished by the combine kernel.
 #ifndef SLR_TILE_H
 #define SLR_TILE_H 8
-#endif
-#ifndef SLR_CG_MAX
-#define SLR_CG_MAX 13
 #endif
 constexpr int TILE_W   = 64;      // one wavefront of consecutive x
 constexpr int TILE_H   = SLR_TILE_H;
 constexpr int TILE_PIX = TILE_W * TILE_H;
 constexpr int SEG_ONE  = 2 * TILE_PIX;   // segment length, one flow per tile
 constexpr int SEG_TWO  = 4 * TILE_PIX;   // segment length, forward+backward flows per tile
-constexpr int CG_MAX   = SLR_CG_MAX;     // channels per workgroup (LDS planes), upper bound
 
 // Workspace layout (all offsets 256-byte aligned).  `hdr` is zeroed at the start of binning.
 struct WsLayout {
@@ -80,9 +75,8 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_items = o;   o += al256((size_t)L.items_cap * 8);
     L.off_totals = o;  o += 256;
     L.off_partial = o;
-    // every channel group carries one extra plane (the normaliser)
-    int groups = C > 0 ? (C + CG_MAX - 1) / CG_MAX : 0;
-    L.part_stride = (size_t)(C + groups) * TILE_PIX;
+    // C value planes + the normaliser plane
+    L.part_stride = (size_t)(C + 1) * TILE_PIX;
     o += al256((size_t)L.part_slots * L.part_stride * 4);
     L.total = o;
     return L;

@@ -197,266 +197,258 @@ struct SplatArgs {
     float *norm_out;        // [N,1,H,W] or nullptr
     size_t part_stride;
     int N, C, H, W, tiles_x, tiles;
-    int cg, groups, ndir, seg;
+    int ndir, seg;
     int mulmode, norm_mode;
     float eps, init;
 };
-
-__device__ __forceinline__ void lds_max(float *p, float v) {
-    // order-preserving integer view of fp32: signed max for v >= 0, unsigned min for v < 0;
-    // a NaN candidate is ignored, as fmaxf(val, old) does in the reference (softsplat.py:47)
-    if (v != v) return;
-    if (v >= 0.0f) atomicMax((int *)p, __float_as_int(v));
-    else atomicMin((unsigned int *)p, __float_as_uint(v));
-}
 
 __device__ __forceinline__ float finish(float s, float nrm, int norm_mode, float eps) {
     if (norm_mode == SLR_NORM_ZERO_TO_ONE) return s / (nrm == 0.0f ? 1.0f : nrm);   // softsplat.py:684-686
     return s / fmaxf(nrm, eps);                                                      // ...splating.py:923-924
 }
 
-
-// The normaliser plane as the models use it (clamp(min=eps) / zero->one applied) -> [H,W] plane.
-template <typename A>
-__device__ __forceinline__ void store_norm(const A *__restrict__ nrm, float *__restrict__ dst, int H, int W,
-                                           int tx0, int ty0, int norm_mode, float eps) {
-    for (int r = threadIdx.x; r < TILE_PIX; r += blockDim.x) {
-        int ly = r / TILE_W, lx = r - ly * TILE_W;
-        int y = ty0 + ly, x = tx0 + lx;
-        if (y < H && x < W) {
-            float v = (float)nrm[r];
-            v = norm_mode == SLR_NORM_ZERO_TO_ONE ? (v == 0.0f ? 1.0f : v) : fmaxf(v, eps);
-            dst[(size_t)y * W + x] = v;
-        }
-    }
+__device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps) {
+    return norm_mode == SLR_NORM_ZERO_TO_ONE ? (nrm == 0.0f ? 1.0f : nrm) : fmaxf(nrm, eps);
 }
 
-// Store `np` LDS planes of the tile to a [.,H,W] plane stack (dst -> plane 0), optionally
-// dividing by the normaliser plane `nrm` (LDS).  Coalesced: 16 lanes x float4 = one tile row.
-template <bool NORM, typename A>
-__device__ __forceinline__ void store_tile(const A *__restrict__ lds, const A *__restrict__ nrm,
-                                           float *__restrict__ dst, int np, int H, int W,
-                                           int tx0, int ty0, int norm_mode, float eps) {
-    const size_t HW = (size_t)H * W;
-    const bool vec = ((W & 3) == 0) && ((((uintptr_t)dst) & 15) == 0);
-    if (vec) {
-        for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += blockDim.x) {
-            int c = q / (TILE_PIX / 4), r = q - c * (TILE_PIX / 4);
-            int ly = r / (TILE_W / 4), lx = (r - ly * (TILE_W / 4)) * 4;
-            int y = ty0 + ly, x = tx0 + lx;
-            if (y < H && x < W) {
-                const A *sp = &lds[c * TILE_PIX + ly * TILE_W + lx];
-                float4 v = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
-                if (NORM) {
-                    const A *mp = &nrm[ly * TILE_W + lx];
-                    v.x = finish(v.x, (float)mp[0], norm_mode, eps);
-                    v.y = finish(v.y, (float)mp[1], norm_mode, eps);
-                    v.z = finish(v.z, (float)mp[2], norm_mode, eps);
-                    v.w = finish(v.w, (float)mp[3], norm_mode, eps);
-                }
-                *reinterpret_cast<float4 *>(&dst[(size_t)c * HW + (size_t)y * W + x]) = v;
-            }
-        }
-    } else {
-        for (int q = threadIdx.x; q < np * TILE_PIX; q += blockDim.x) {
-            int c = q / TILE_PIX, r = q - c * TILE_PIX;
-            int ly = r / TILE_W, lx = r - ly * TILE_W;
-            int y = ty0 + ly, x = tx0 + lx;
-            if (y < H && x < W) {
-                float v = (float)lds[q];
-                if (NORM) v = finish(v, (float)nrm[r], norm_mode, eps);
-                dst[(size_t)c * HW + (size_t)y * W + x] = v;
-            }
-        }
-    }
-}
+constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
+constexpr int EPT_MAX = SEG_TWO / SPLAT_THREADS;   // bin entries per work-item, upper bound
+constexpr int CHUNK = 8;                       // channels staged in LDS / accumulated in registers per pass
 
-#ifndef SLR_SPLAT_THREADS
-#define SLR_SPLAT_THREADS 512
-#endif
-constexpr int SPLAT_THREADS = SLR_SPLAT_THREADS;
-
-// LDS accumulator type.  Sums go through ds_add_f64: on gfx950 the LDS fp32 atomic add
-// (ds_add_f32) retires ~1 lane per 2.6 clocks (170 CU-cycles per wave instruction, measured,
-// tools/ubench/lds_atomic.hip) while ds_add_f64 runs at 7.8 cycles -- 22x faster, and the
-// fp64 accumulation is also closer to the exact sum than any fp32 order.  The maximum splat
-// uses the order-preserving integer view with ds_max_i32 / ds_min_u32 (4.5 cycles).
-template <bool MAXOP> struct Acc { using type = double; };
-template <> struct Acc<true> { using type = float; };
-
-
-// Accumulate U consecutive channel planes of one bin entry into the LDS tile.  All U plane
-// loads are issued before the first LDS atomic.  o[k] are float indices inside a tile plane:
-// the true corner, or (kb[k] false: corner outside the tile) a harmless in-plane address that
-// receives the neutral element (+0.0 / -inf) -- branch-free, and exact for non-finite inputs
-// because the PRODUCT is replaced, not the weight.
-template <int U, bool MAXOP>
-__device__ __forceinline__ void accumulate(const float *__restrict__ ip, size_t HW, uint32_t pix, int ch,
-                                           float m, const float (&w)[4], const int (&o)[4],
-                                           const bool (&kb)[4], typename Acc<MAXOP>::type *__restrict__ lds) {
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#if defined(SLR_ABL) && SLR_ABL == 2      // ablation: no plane loads
-        v[u] = m + (float)u;
-#else
-        v[u] = ip[(size_t)(ch + u) * HW + pix];
-#endif
-    }
-#if defined(SLR_ABL) && SLR_ABL == 1      // ablation: no LDS atomics (loads kept alive)
-#pragma unroll
-    for (int u = 0; u < U; ++u) asm volatile("" ::"v"(v[u]));
-    return;
-#endif
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        auto *p = lds + (ch + u) * TILE_PIX;
-        const float vm = v[u] * m;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if constexpr (MAXOP) lds_max(p + o[k], kb[k] ? vm * w[k] : -INFINITY);
-            else atomicAdd(p + o[k], (double)(kb[k] ? vm * w[k] : 0.0f));
-        }
-    }
-}
-
-// One workgroup = (tile, segment, channel group).  512 threads, LDS = (cg + NORM) tile planes.
-// Workgroup b runs on XCD b % 8 (observed dispatch order); the channel
-// groups of one work item are mapped to the SAME XCD so that the bin, the flow and the weight
-// plane they all re-read are served by that XCD's L2.
-// The walk over the bin is software-pipelined: while entry i is accumulated, the flow of entry
-// i+1 and the index of entry i+2 are already in flight (the three loads are a dependent chain).
+// Why no LDS float accumulation: on gfx950 ds_add_f32 retires ~1 lane per 2.6 clocks (170
+// CU-cycles per wave instruction) and even ds_add_f64 (7.8) made the 4-atomics-per-element
+// formulation LDS-bound (tools/ubench/lds_atomic.hip).  Integer LDS atomics are fast (4.5),
+// so they are used ONCE per bin entry to invert the scatter inside the tile:
+//
+//   phase 1  every bin entry of the segment appends (source pixel, weight) records to the
+//            per-OUTPUT-pixel lists of its <= 4 in-tile corners: ds_add_rtn_u32 on a count per
+//            output pixel, a workgroup scan, ds_write_b64 of the records (a CSR in LDS);
+//   phase 2  per chunk of 8 channels: the segment's source values are STAGED in LDS with
+//            coalesced plane loads in bin order (each source value is read from HBM/L2 once per
+//            tile it touches, prefetched one chunk ahead in registers); then one work-item per
+//            output pixel walks its own record list, reads the staged values (ds_read_b32, no
+//            atomics) and accumulates v*w IN REGISTERS, and stores its pixel: every output
+//            byte is written exactly once, coalesced, never read, never zeroed.
+//
+// Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
 template <bool NORM, bool MAXOP>
 __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) {
-    using A = typename Acc<MAXOP>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    A *lds = reinterpret_cast<A *>(lds_raw);
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int T = SPLAT_THREADS;
-    const int G = a.groups;
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t item = (slot / G) * 8u + xcd;
-    const int g = slot % G;
+    uint32_t *cnt = smem;                     // [T]   records per output pixel
+    uint32_t *off = smem + T;                 // [T+1] exclusive prefix (+ wave sums behind it)
+    uint32_t *wsum = smem + 2 * T + 8;        // [T/64]
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + 2 * T + 64);   // [4*seg] (entry index, weight bits)
+    float *val = reinterpret_cast<float *>(rec + 4 * a.seg);     // [CHUNK][seg] staged source values
+
+    const uint32_t item = blockIdx.x;
     if (item >= a.totals[0]) return;
     const uint2 it = a.items[item];
     const uint32_t t = it.x, s = it.y;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
-    const int c0 = g * a.cg;
-    const int nc = min(a.cg, a.C - c0);
     const int HW = a.H * a.W;
-    const int np = nc + (NORM ? 1 : 0);
-    A *nrm = lds + nc * TILE_PIX;
-    for (int q = threadIdx.x; q < np * TILE_PIX; q += T) lds[q] = MAXOP ? (A)a.init : (A)0;
+    const int tid = threadIdx.x;
+
+    cnt[tid] = 0;
     __syncthreads();
 
+    // ---------------- phase 1a: footprints of this work-item's bin entries, slot reservation
     const float shift = (a.mulmode == MUL_EXP_SHIFT) ? a.mulmax[0] : 0.0f;
     const bool has_mul = a.mulmode != MUL_ONE;
-    // segment s of the concatenated bin [bin(flow0) ; bin(flow1)]
-    const uint32_t lo = s * (uint32_t)a.seg, hi = lo + (uint32_t)a.seg;
-    uint32_t base = 0;
-    for (int d = 0; d < a.ndir; ++d) {
-        const uint32_t cnt = a.count[d][t];
-        const uint32_t b = lo > base ? lo - base : 0u;                 // range inside this bin
-        const uint32_t e = hi > base ? min(hi - base, cnt) : 0u;
-        base += cnt;
-        if (b >= e) continue;
-        const uint32_t *lst = a.list[d] + a.listoff[d][t];
-        const float *fl = a.flow[d] + (size_t)n * 2 * HW;
-        const float *mp = has_mul ? a.mul + (size_t)n * HW : fl;
-        const float *ip = a.in + ((size_t)n * a.C + c0) * HW;
-        const float sc = a.scale[d];
-
-        uint32_t k = b + threadIdx.x;
-        uint32_t pixA = k < e ? lst[k] : 0u;
-        uint32_t pixB = k + T < e ? lst[k + T] : 0u;
-        float fxA = fl[pixA], fyA = fl[HW + pixA], mA = mp[pixA];
-        for (; k < e; k += T) {
-            const uint32_t pixC = k + 2 * T < e ? lst[k + 2 * T] : 0u;       // index of entry i+2
-            const float fxB = fl[pixB], fyB = fl[HW + pixB], mB = mp[pixB];  // flow of entry i+1
-
-            const uint32_t pix = pixA;
+    const uint32_t lo = s * (uint32_t)a.seg, hi = lo + (uint32_t)a.seg;   // range of the concatenated bin
+    uint32_t e_pix[EPT_MAX];
+    bool e_val[EPT_MAX];
+    uint32_t e_ts[EPT_MAX][4];      // (output pixel << 16) | slot, 0xffffffff = corner not in tile
+    float e_w[EPT_MAX][4];
+#pragma unroll
+    for (int j = 0; j < EPT_MAX; ++j) {
+        e_pix[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e_ts[j][k] = 0xffffffffu; e_w[j][k] = 0.0f; }
+    }
+    {
+        // entry j of this work-item = element lo + tid + j*T of [bin(flow0) ; bin(flow1)]
+        const uint32_t c0 = a.count[0][t];
+        const uint32_t c1 = a.ndir > 1 ? a.count[1][t] : 0u;
+        const uint32_t *l0 = a.list[0] + a.listoff[0][t];
+        const uint32_t *l1 = a.ndir > 1 ? a.list[1] + a.listoff[1][t] : l0;
+        const float *mp = has_mul ? a.mul + (size_t)n * HW : nullptr;
+        bool (&val)[EPT_MAX] = e_val;
+        int dir[EPT_MAX];
+        // independent index loads first, then the dependent flow / weight loads
+#pragma unroll
+        for (int j = 0; j < EPT_MAX; ++j) {
+            const uint32_t k = lo + tid + j * T;
+            val[j] = (k < hi) & (k < c0 + c1);
+            dir[j] = (k >= c0) ? 1 : 0;
+            e_pix[j] = val[j] ? (dir[j] ? l1[k - c0] : l0[k]) : 0u;
+        }
+        float fx[EPT_MAX], fy[EPT_MAX], mm[EPT_MAX];
+#pragma unroll
+        for (int j = 0; j < EPT_MAX; ++j) {
+            const float *fl = a.flow[dir[j]] + (size_t)n * 2 * HW;
+            fx[j] = val[j] ? fl[e_pix[j]] : 0.0f;
+            fy[j] = val[j] ? fl[HW + e_pix[j]] : 0.0f;
+            mm[j] = (val[j] && has_mul) ? mp[e_pix[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < EPT_MAX; ++j) {
+            if (!val[j]) continue;
+            const uint32_t pix = e_pix[j];
             const int y = pix / a.W, x = pix - y * a.W;
-            const Corners c = make_corners(fxA, fyA, x, y);
-            float m = sc;
-            if (a.mulmode == MUL_PLANE) m = mA * sc;
-            else if (a.mulmode >= MUL_EXP) m = expf(mA - shift) * sc;
-            // footprint corners that fall into this tile (and into the image)
+            const Corners c = make_corners(fx[j], fy[j], x, y);
+            float m = a.scale[dir[j]];
+            if (a.mulmode == MUL_PLANE) m = mm[j] * m;
+            else if (a.mulmode >= MUL_EXP) m = expf(mm[j] - shift) * m;
             const int lx = c.x0 - tx0, ly = c.y0 - ty0;
             const bool xa = c.ok & (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W);
             const bool xb = c.ok & (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
             const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H);
             const bool yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
             const int oc = ly * TILE_W + lx;
-            const int safe = threadIdx.x & 63;       // any in-plane address; lane-distinct banks
             const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
-            const int o[4] = {kb[0] ? oc : safe, kb[1] ? oc + 1 : safe,
-                              kb[2] ? oc + TILE_W : safe, kb[3] ? oc + TILE_W + 1 : safe};
-            if (NORM) {
+            const int tg[4] = {oc, oc + 1, oc + TILE_W, oc + TILE_W + 1};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) atomicAdd(nrm + o[q], (A)(kb[q] ? m * c.w[q] : 0.0f));
+            for (int k = 0; k < 4; ++k) {
+                if (kb[k]) {
+                    const uint32_t slot = atomicAdd(&cnt[tg[k]], 1u);          // ds_add_rtn_u32
+                    e_ts[j][k] = ((uint32_t)tg[k] << 16) | slot;
+                    e_w[j][k] = has_mul || a.ndir > 1 ? m * c.w[k] : c.w[k];
+                }
             }
-            int ch = 0;
-            for (; ch + 8 <= nc; ch += 8) accumulate<8, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds);
-            if (ch + 4 <= nc) { accumulate<4, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds); ch += 4; }
-            if (ch + 2 <= nc) { accumulate<2, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds); ch += 2; }
-            if (ch < nc) accumulate<1, MAXOP>(ip, HW, pix, ch, m, c.w, o, kb, lds);
-
-            pixA = pixB; fxA = fxB; fyA = fyB; mA = mB;
-            pixB = pixC;
         }
     }
     __syncthreads();
 
-    if (a.nseg[t] == 1) {
-        float *dst = a.out + ((size_t)n * a.C + c0) * HW;
-        store_tile<NORM, A>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
-        if (NORM && a.norm_out && g == 0)
-            store_norm<A>(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
-    } else {
-        // raw partial tile (values + normaliser) -> scratch; finished by combine_kernel
-        float *dst = a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + (size_t)(c0 + g) * TILE_PIX;
-        for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += T) {
-            const A *sp = lds + 4 * q;
-            reinterpret_cast<float4 *>(dst)[q] = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
+    // ---------------- phase 1b: exclusive scan of the counts (T values, one per work-item)
+    {
+        const int lane = tid & 63, wid = tid >> 6;
+        const uint32_t v = cnt[tid];
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
         }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) woff += (w < wid) ? wsum[w] : 0u;
+        off[tid] = woff + inc - v;
+        if (tid == T - 1) off[T] = woff + inc;
+    }
+    __syncthreads();
+
+    // ---------------- phase 1c: scatter the records into the per-output-pixel lists
+#pragma unroll
+    for (int j = 0; j < EPT_MAX; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ts = e_ts[j][k];
+            if (ts != 0xffffffffu) rec[off[ts >> 16] + (ts & 0xffffu)] = make_uint2((uint32_t)(tid + j * T), __float_as_uint(e_w[j][k]));
+        }
+    __syncthreads();
+
+    // ---------------- phase 2: stage a chunk of planes in LDS, gather per output pixel
+    const uint32_t r0 = off[tid], r1 = off[tid + 1];
+    const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    const bool inside = (oy < a.H) & (ox < a.W);
+    const bool single = a.nseg[t] == 1;
+    const float *ip = a.in + (size_t)n * a.C * HW;
+    float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
+                       : a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + tid;
+    const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
+    const int seg = a.seg;
+
+    float nrm = 0.0f;
+    if (NORM) {
+        for (uint32_t r = r0; r < r1; ++r) nrm += __uint_as_float(rec[r].y);
+        if (single) {
+            if (a.norm_out && inside) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
+        } else {
+            a.partial[(size_t)(a.partoff[t] + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid] = nrm;
+        }
+    }
+
+    // values of this work-item's bin entries for one chunk of planes (prefetch registers)
+    float pre[EPT_MAX][CHUNK];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < EPT_MAX; ++j)
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u)
+                pre[j][u] = (e_val[j] && c0 + u < a.C) ? ip[(size_t)(c0 + u) * HW + e_pix[j]] : 0.0f;
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < a.C; c0 += CHUNK) {
+#pragma unroll
+        for (int j = 0; j < EPT_MAX; ++j)
+            if (e_val[j]) {
+#pragma unroll
+                for (int u = 0; u < CHUNK; ++u) val[u * seg + tid + j * T] = pre[j][u];
+            }
+        __syncthreads();
+        if (c0 + CHUNK < a.C) prefetch(c0 + CHUNK);          // next chunk's loads fly during the gather
+        float acc[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) acc[u] = MAXOP ? a.init : 0.0f;
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint2 q = rec[r];
+            const float w = __uint_as_float(q.y);
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) {
+                const float v = val[u * seg + q.x];
+                acc[u] = MAXOP ? fmaxf(v * w, acc[u]) : acc[u] + v * w;
+            }
+        }
+        if (inside || !single) {
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u)
+                if (c0 + u < a.C) {
+                    float r = acc[u];
+                    if (NORM && single) r = finish(r, nrm, a.norm_mode, a.eps);
+                    op[(size_t)(c0 + u) * ostride] = r;
+                }
+        }
+        __syncthreads();                                     // val[] is overwritten by the next chunk
     }
 }
 
-// One workgroup per (tile, channel group); does nothing unless the tile has several segments.
+// Multi-segment tiles: sum (max) the raw partial tiles in segment order, normalise, store.
+// grid (nt, ceil(C/CHUNK)); TILE_PIX threads; exits at once for single-segment tiles.
 template <bool NORM, bool MAXOP>
-__global__ __launch_bounds__(256) void combine_kernel(SplatArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int G = a.groups;
-    const uint32_t t = blockIdx.x / G;
-    const int g = blockIdx.x % G;
+__global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatArgs a) {
+    const uint32_t t = blockIdx.x;
     const uint32_t ns = a.nseg[t];
     if (ns <= 1) return;
+    const int c0 = blockIdx.y * CHUNK;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
-    const int c0 = g * a.cg;
-    const int nc = min(a.cg, a.C - c0);
     const int HW = a.H * a.W;
-    const int np = nc + (NORM ? 1 : 0);
-    float *nrm = lds + nc * TILE_PIX;
-    const float *src = a.partial + (size_t)a.partoff[t] * a.part_stride + (size_t)(c0 + g) * TILE_PIX;
-    for (int q = threadIdx.x; q < np * (TILE_PIX / 4); q += 256) {
-        float4 acc = reinterpret_cast<const float4 *>(src)[q];
-        for (uint32_t s = 1; s < ns; ++s) {                       // fixed order: deterministic
-            float4 v = reinterpret_cast<const float4 *>(src + (size_t)s * a.part_stride)[q];
-            if (MAXOP) {
-                acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y);
-                acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
-            } else {
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-        }
-        reinterpret_cast<float4 *>(lds)[q] = acc;
+    const int tid = threadIdx.x;
+    const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    if (oy >= a.H || ox >= a.W) return;
+    const float *src = a.partial + (size_t)a.partoff[t] * a.part_stride + tid;
+    float nrm = 0.0f;
+    if (NORM) {
+        for (uint32_t s = 0; s < ns; ++s) nrm += src[(size_t)s * a.part_stride + (size_t)a.C * TILE_PIX];
+        if (a.norm_out && blockIdx.y == 0)
+            a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
     }
-    __syncthreads();
-    float *dst = a.out + ((size_t)n * a.C + c0) * HW;
-    store_tile<NORM, float>(lds, nrm, dst, nc, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
-    if (NORM && a.norm_out && g == 0)
-        store_norm<float>(nrm, a.norm_out + (size_t)n * HW, a.H, a.W, tx0, ty0, a.norm_mode, a.eps);
+    float *op = a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox;
+    for (int c = c0; c < min(c0 + CHUNK, a.C); ++c) {
+        float acc = src[(size_t)c * TILE_PIX];
+        for (uint32_t s = 1; s < ns; ++s) {                       // fixed order: deterministic
+            const float v = src[(size_t)s * a.part_stride + (size_t)c * TILE_PIX];
+            acc = MAXOP ? fmaxf(acc, v) : acc + v;
+        }
+        if (NORM) acc = finish(acc, nrm, a.norm_mode, a.eps);
+        op[(size_t)c * HW] = acc;
+    }
 }
 
 // =========================================================================== small kernels
@@ -492,11 +484,6 @@ __global__ __launch_bounds__(256) void max_stage_kernel(const float *__restrict_
 }
 
 // =========================================================================== host side
-
-static int choose_cg(int C) {
-    int groups = (C + CG_MAX - 1) / CG_MAX;
-    return (C + groups - 1) / groups;
-}
 
 struct Ws {
     WsLayout L;
@@ -549,8 +536,6 @@ static int do_bin(const float *flow, int N, int H, int W, Ws &w, hipStream_t st)
 // plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
 template <bool NORM, bool MAXOP>
 static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
-    a.cg = choose_cg(a.C);
-    a.groups = (a.C + a.cg - 1) / a.cg;
     a.tiles_x = w0.L.tiles_x;
     a.tiles = w0.L.tiles;
     a.ndir = w1 ? 2 : 1;
@@ -563,17 +548,17 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
                        (const uint32_t *)(w1 ? w1->count : nullptr), w0.L.nt, (uint32_t)a.seg,
                        w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.totals);
-    const size_t planes = (size_t)(a.cg + (NORM ? 1 : 0)) * TILE_PIX;
-    const size_t lds = planes * sizeof(typename Acc<MAXOP>::type), lds_c = planes * sizeof(float);
-    const uint32_t blocks = ((w0.L.items_cap + 7) / 8) * 8 * a.groups;
+    // counts + offsets + wave sums (2*T + 64 words) + 4 records + CHUNK staged values per bin entry
+    const size_t lds = (size_t)(2 * SPLAT_THREADS + 64) * 4 + (size_t)4 * a.seg * 8 + (size_t)CHUNK * a.seg * 4;
     static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
         SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP>), dim3(blocks), dim3(SPLAT_THREADS), lds, st, a);
-    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt * a.groups), dim3(256), lds_c, st, a);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP>), dim3(w0.L.items_cap), dim3(SPLAT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt, (a.C + CHUNK - 1) / CHUNK),
+                       dim3(SPLAT_THREADS), 0, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }

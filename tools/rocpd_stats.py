@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Per-kernel duration summary from a rocprofv3 rocpd (.db) kernel trace -> text (stdout).
+rocprofv3 --kernel-trace writes SQLite in this image; this prints what --stats would."""
+import glob
+import sqlite3
+import sys
+
+
+def main(path):
+    dbs = glob.glob(path + "/**/*.db", recursive=True) if not path.endswith(".db") else [path]
+    for db in dbs:
+        c = sqlite3.connect(db)
+        tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+        kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+        ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+        q = (f"select s.kernel_name, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
+             f"sum(d.end-d.start) from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 6 desc")
+        rows = list(c.execute(q))
+        tot = sum(r[5] for r in rows) or 1
+        print(f"# {db}")
+        print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s} {'pct':>6s}")
+        for r in rows:
+            print(f"{r[0][:70]:70s} {r[1]:6d} {r[2]/1e3:10.1f} {r[3]/1e3:10.1f} {r[4]/1e3:10.1f} {r[5]/1e6:10.3f} {100*r[5]/tot:6.1f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
