@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of BASELINE.json on MI355X.
+
+Metric  : synthesised frames/sec at 768x1280, N=60 (whole job, all GPUs)
+Workload: config C3 of BASELINE.json -- the full baseline pipeline
+          image -> encoder -> [per frame: Euler displacement maps -> fused softmax-splat of
+          64 features (both directions) + normalisation -> partial-conv decoder -> tanh]
+          on a synthetic 768x1280 image + smooth motion field, random-init weights of the
+          reference architecture, fp32.  (--workload c4: the 2-layer SLR v1 pipeline.)
+A step  : ONE 60-frame clip, everything included (encoder, both all-frames Euler passes,
+          60 x (bin + splat + decoder)), frames sharded round-robin over the ranks and
+          assembled with one all-gather (RCCL) -> "scaling": "strong" (total work fixed).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : the splat tile kernel (slr::splat_tile_kernel<true,false>, the kernel that does
+                 the exp-weighted two-direction splat + normalisation of one frame), timed
+                 with HIP events on its launch stream inside the timed steps.
+                 algorithmic bytes per launch = 2 * (2*65+2)*H*W*4 = 1038.1 MB at C3
+                 (B_sum per reference splat call x the 2 calls of one frame).
+  cpu_baseline : the CPU oracle (oracle/, OpenMP over planes) on this box's host cores, same
+                 hot path (Euler + 2 x 65-plane splat + normalise) on a sample of frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, NFRAMES = 768, 1280, 60
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def smooth_motion(h, w, seed=0, amp=1.5):
+    """sinusoidal field, A = 1.5 px/frame, static left 35 %."""
+    rng = np.random.default_rng(seed)
+    p1, p2 = rng.uniform(0, 2 * np.pi, 2)
+    y, x = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    u = amp * np.sin(2 * np.pi * (2 * x / w + y / h) + p1)
+    v = amp * np.cos(2 * np.pi * (x / w - 1.5 * y / h) + p2)
+    m = (x >= 0.35 * w).astype(np.float32)
+    return np.stack([u * m, v * m])[None].astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import slr_sfs_amd as S
+    from slr_sfs_amd import parallel, pipeline, synthesis
+    S._lib.lib()                                   # fail loudly if the HIP library is missing
+
+    torch.manual_seed(0)
+    model = (pipeline.BaselineAnimator() if a.workload == "c3" else pipeline.SLRv1Animator()).to(dev).eval()
+    rng = np.random.default_rng(0)
+    image = torch.from_numpy(rng.uniform(-1, 1, (1, 3, H, W)).astype(np.float32)).to(dev)
+    motion = torch.from_numpy(smooth_motion(H, W)).to(dev)
+    mine = parallel.shard_frames(NFRAMES, rank, world)
+
+    def step():
+        loc = model.synthesize(image, motion, NFRAMES, frames=mine)
+        return parallel.gather_clip(loc, NFRAMES, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    synthesis.kernel_timing = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        clip = step()
+    fence()
+    dt = time.perf_counter() - t0
+    events, synthesis.kernel_timing = synthesis.kernel_timing, None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert clip.shape == (NFRAMES, 3, H, W) and bool(torch.isfinite(clip).all())
+
+    # ---- roofline of the splat tile kernel (this rank's launches inside the timed steps)
+    kus = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in events)
+    k_avg = sum(kus) / len(kus)
+    c_splat = 65 if a.workload == "c3" else 65 + 2        # planes per reference splat call (v1: 67)
+    alg_bytes = 2 * (2 * c_splat + 2) * H * W * 4
+    achieved = alg_bytes / (k_avg * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<true,false>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_us": round(k_avg, 1),
+                "min_us": round(kus[0], 1), "max_us": round(kus[-1], 1), "launches": len(kus)}
+
+    extra = {}
+    cpu = None
+    if rank == 0:
+        # splat stage alone (no networks): Euler passes + 60 x (bin + fused splat + normalise)
+        fs = torch.randn(1, 64, H, W, device=dev)
+        Z = torch.randn(1, 1, H, W, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cs = synthesis.ClipSynthesizer(fs, Z, motion, NFRAMES)
+        for t in range(NFRAMES):
+            g = cs.features(t)
+        torch.cuda.synchronize()
+        extra["splat_stage_fps_1gpu"] = round(NFRAMES / (time.perf_counter() - t1), 1)
+        del g, cs
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(fs.cpu().numpy(), Z.cpu().numpy(), motion.cpu().numpy())
+
+    if rank == 0:
+        line = {
+            "metric": "synthesised frames/sec at 768x1280 N=60",
+            "value": round(NFRAMES * a.steps / dt, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("C3 baseline pipeline encoder->Euler->softmax-splat->pconv2 decoder"
+                                    if a.workload == "c3" else
+                                    "C4 SLR-v1 2-layer pipeline (fluid + background + alpha)") +
+                                   ", 768x1280, N=60, random-init weights of the reference architecture",
+                       "frames_per_step": NFRAMES, "H": H, "W": W,
+                       "parallelism": f"frames sharded over {world} GPU(s), one all-gather per clip"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(fs, Z, motion):
+    """The CPU oracle on the host cores: same hot path, bounded sample (3 frames)."""
+    from oracle import oracle as o          # test infrastructure, used here only as the timed baseline
+    o.build()
+    cores = o.max_threads()
+    frames = (1, 30, 59)
+    t0 = time.perf_counter()
+    for t in frames:
+        o.synth_baseline(fs, Z, motion, t, NFRAMES)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(frames) / dt, 4), "unit": "frames/s (splat stage: Euler + 2x65-plane splat + normalise; "
+            "no encoder/decoder)", "cores": cores, "kind": "port",
+            "sample": f"frames t={list(frames)} of the same 768x1280 N=60 clip, {dt:.1f} s of CPU work"}
+
+
+if __name__ == "__main__":
+    main()

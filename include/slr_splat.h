@@ -46,6 +46,11 @@ extern "C" {
 int         slr_abi_version(void);
 const char *slr_last_error(void);
 
+/* Measurement hook: the NEXT splat call of this thread records hipEvent_t `ev_start` right
+ * before and `ev_stop` right after its tile kernel (the dominant kernel; not the plan/combine
+ * helpers) on the launch stream.  One-shot; NULLs disable.  Used by bench.py for the roofline. */
+void slr_splat_time_next(void *ev_start, void *ev_stop);
+
 /* ------------------------------------------------------------------ Euler integration */
 
 /* euler_integration(motion, nsteps) for one sample.

@@ -11,7 +11,7 @@ ABI_VERSION = 1
 
 # every symbol include/slr_splat.h declares
 SYMBOLS = (
-    "slr_abi_version", "slr_last_error",
+    "slr_abi_version", "slr_last_error", "slr_splat_time_next",
     "slr_euler_integrate", "slr_euler_integrate_all",
     "slr_splat_workspace_bytes", "slr_splat_bin",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
@@ -48,6 +48,8 @@ def lib():
         vp, fp, i, f, sz = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
         L.slr_abi_version.restype = i
         L.slr_last_error.restype = ctypes.c_char_p
+        L.slr_splat_time_next.restype = None
+        L.slr_splat_time_next.argtypes = [vp, vp]
         L.slr_splat_workspace_bytes.restype = sz
         L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
         sig = {

@@ -30,6 +30,7 @@
 namespace slr {
 
 static thread_local char g_err[512] = "";
+static thread_local void *g_ev_start = nullptr, *g_ev_stop = nullptr;   // slr_splat_time_next
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -556,7 +557,10 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
     hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP>), dim3(w0.L.items_cap), dim3(SPLAT_THREADS), lds, st, a);
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+    g_ev_start = g_ev_stop = nullptr;          // one-shot
     hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt, (a.C + CHUNK - 1) / CHUNK),
                        dim3(SPLAT_THREADS), 0, st, a);
     SLR_CHECK_LAUNCH();
@@ -569,6 +573,11 @@ using namespace slr;
 
 SLR_EXPORT int slr_abi_version(void) { return SLR_ABI_VERSION; }
 SLR_EXPORT const char *slr_last_error(void) { return slr::g_err; }
+
+SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {
+    slr::g_ev_start = ev_start;
+    slr::g_ev_stop = ev_stop;
+}
 
 SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {
     if (N <= 0 || C < 0 || H <= 0 || W <= 0) return 0;

@@ -1,0 +1,244 @@
+"""Encoder / decoder networks either side of the splat path, as INFERENCE modules for
+PyTorch-ROCm (MIOpen convolutions).  Out of scope for hand-written kernels (north star:
+"Python host code calling PyTorch-ROCm for the encoder/decoder convolutions"); they exist so
+the full configurations C3/C4 of BASELINE.json can be run and so real checkpoints load.
+
+Own definitions, folded for inference (reference file:line cited per class):
+  * spectral norm (legacy hook, models/layers/blocks.py:5-18): eval-mode weight is
+    weight_orig / (u^T W v), no power iteration -> folded once at load time;
+  * noise-conditioned BN (models/layers/normalization.py:19-90) with the zero noise the test
+    scripts force (bn_noise_misc=True, test_animating/test_baseline_4eval_rawsize.py:127):
+    gain = 1, bias = 0, stored statistics -> a per-channel scale/shift (:219-231);
+  * partial convolution (models/layers/partialconv2d.py:41-81, multi_channel=True): the mask
+    update conv(mask, ones[out,in,k,k]) is the same for every output channel and equals
+    box_filter(sum_c mask); masks are binary so this is exact integer arithmetic in fp32
+    (< 2^24) -> computed on ONE channel instead of a second full-size convolution
+    (halves the decoder FLOPs without changing a bit of its result).
+
+``load_reference_state_dict`` maps the reference's checkpoint key scheme onto these modules.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- building blocks
+
+class AffineBN(nn.Module):
+    """Eval-mode noise-BN with zero noise: y = x*scale - shift, scale = rsqrt(var+eps),
+    shift = mean*scale (fused_bn, models/layers/normalization.py:219-231)."""
+
+    def __init__(self, ch, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("stored_mean", torch.zeros(ch))
+        self.register_buffer("stored_var", torch.ones(ch))
+
+    def forward(self, x):
+        scale = torch.rsqrt(self.stored_var + self.eps).view(1, -1, 1, 1)
+        shift = self.stored_mean.view(1, -1, 1, 1) * scale
+        return x * scale - shift
+
+
+class Conv(nn.Module):
+    """Convolution with its spectral normalisation already folded into ``weight``."""
+
+    def __init__(self, cin, cout, k, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False) if bias else None
+        self.pad = k // 2
+        self.cin, self.k = cin, k
+        nn.init.normal_(self.weight, std=math.sqrt(1.0 / (cin * k * k)))
+
+    def forward(self, x):
+        return F.conv2d(x, self.weight, self.bias, padding=self.pad)
+
+
+class PartialConv(Conv):
+    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81.
+    ``mask`` is [N,1,H,W] (channel-uniform) or [N,Cin,H,W]; returns (out, update_mask [N,1,H,W])."""
+
+    def forward(self, x, mask):
+        msum = mask.sum(1, keepdim=True) if mask.shape[1] != 1 else mask * float(self.cin)
+        # conv(mask, ones[out,in,k,k]) == box_k(sum_c mask), identical for every output channel
+        um = F.avg_pool2d(msum, self.k, stride=1, padding=self.pad, divisor_override=1)     # :61
+        ratio = (self.cin * self.k * self.k) / (um + 1e-8)                                  # :64
+        um = torch.clamp(um, 0, 1)                                                          # :66
+        ratio = ratio * um                                                                  # :67
+        raw = F.conv2d(x * mask, self.weight, self.bias, padding=self.pad)                  # :69
+        if self.bias is not None:
+            b = self.bias.view(1, -1, 1, 1)
+            out = ((raw - b) * ratio + b) * um                                              # :72-74
+        else:
+            out = raw * ratio                                                               # :76
+        return out, um
+
+
+def _resample(kind):
+    if kind == "Down":
+        return lambda x: F.avg_pool2d(x, 3, stride=2, padding=1)
+    if kind == "Up":
+        return lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    if kind:                                                       # encoder "downsample=True"
+        return lambda x: F.avg_pool2d(x, 3, stride=2, padding=1)
+    return lambda x: x
+
+
+def _resample_mask(kind):
+    if kind == "Down":
+        return lambda m: F.max_pool2d(m, 3, stride=2, padding=1)
+    if kind == "Up":
+        return lambda m: F.interpolate(m, scale_factor=2, mode="nearest")
+    return lambda m: m
+
+
+class ResBlock(nn.Module):
+    """ResNet_Block, models/layers/blocks.py:47-87."""
+
+    def __init__(self, cin, cout, resample=None):
+        super().__init__()
+        self.bn1, self.bn2 = AffineBN(cin), AffineBN(cout)
+        self.conv_aa, self.conv_ab = Conv(cin, cout, 3), Conv(cout, cout, 3)
+        self.conv_b = Conv(cin, cout, 1) if (resample or cin != cout) else None
+        self.resample = _resample(resample)
+
+    def forward(self, x):
+        a = self.conv_aa(F.relu(self.bn1(x)))
+        a = self.resample(self.conv_ab(F.relu(self.bn2(a))))
+        b = self.resample(self.conv_b(x)) if self.conv_b is not None else x
+        return a + b
+
+
+class PconvResBlock(nn.Module):
+    """ResNet_Block_Pconv2 with pconv_pbn_woresbias, models/layers/blocks.py:173-248."""
+
+    def __init__(self, cin, cout, resample=None):
+        super().__init__()
+        self.bn1, self.bn2 = AffineBN(cin), AffineBN(cout)
+        self.conv_aa, self.conv_ab = PartialConv(cin, cout, 3), PartialConv(cout, cout, 3)
+        self.conv_b = Conv(cin, cout, 1, bias=False) if (resample or cin != cout) else None   # :192-193
+        self.resample, self.resample_mask = _resample(resample), _resample_mask(resample)
+
+    def forward(self, x, mask):
+        a, m = self.conv_aa(F.relu(self.bn1(x)), mask)                 # :229-231
+        a, m = self.conv_ab(F.relu(self.bn2(a)), m)                    # :233-239
+        a, m = self.resample(a), self.resample_mask(m)                 # :240-241
+        b = self.resample(self.conv_b(x)) if self.conv_b is not None else x   # :243-247
+        return a + b, m
+
+
+# --------------------------------------------------------------------------- networks
+
+_ENC = [3, 32, 32, 32, 64, 64, 64, 64]                      # configs.py:96-106 (ngf = 64)
+_DEC = [64, 128, 256, 256, 128, 128, 128]                   # configs.py:117-127, inner widths
+_UPDOWN = [False, "Down", "Down", False, "Up", "Up", False, False]   # configs.py:128-137
+
+
+class EncoderWithZ(nn.Module):
+    """ResNetEncoder_with_Z, models/networks/architectures.py:155-197: 8 blocks, no down-sampling,
+    last block emits 64 features + 1 Z channel."""
+
+    def __init__(self, cin=3, feat=64):
+        super().__init__()
+        ch = [cin] + _ENC[1:] + [feat + 1]
+        self.blocks = nn.ModuleList(ResBlock(ch[i], ch[i + 1]) for i in range(8))
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return x[:, :-1].contiguous(), x[:, -1:].contiguous()          # :195-197
+
+
+class Encoder(nn.Module):
+    """ResNetEncoder (alpha encoder of SLR v1: 3 -> ... -> 2), architectures.py:121-153."""
+
+    def __init__(self, cin=3, cout=2):
+        super().__init__()
+        ch = [cin] + _ENC[1:] + [cout]
+        self.blocks = nn.ModuleList(ResBlock(ch[i], ch[i + 1]) for i in range(8))
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return x
+
+
+class DecoderPconv2(nn.Module):
+    """ResNetDecoderPconv2, architectures.py:345-375: input mask = (x != 0) (:369)."""
+
+    def __init__(self, cin=64, cout=3):
+        super().__init__()
+        ch = [cin] + _DEC + [cout]
+        self.blocks = nn.ModuleList(PconvResBlock(ch[i], ch[i + 1], _UPDOWN[i]) for i in range(8))
+
+    def forward(self, x):
+        mask = (x != 0).to(x.dtype)
+        for b in self.blocks:
+            x, mask = b(x, mask)
+        return x
+
+
+class BGDecoder(nn.Module):
+    """ResNetBGDecoder (net_bg of SLR v1), architectures.py:233-260, arch 256W8UpDown64BG."""
+
+    def __init__(self, cin=3, cout=3):
+        super().__init__()
+        ch = [cin] + _DEC + [cout]
+        self.blocks = nn.ModuleList(ResBlock(ch[i], ch[i + 1], _UPDOWN[i]) for i in range(8))
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return x
+
+
+# --------------------------------------------------------------------------- checkpoints
+
+def _fold_sn(sd, key):
+    """Effective eval-mode weight of a legacy spectral_norm layer: W / (u^T W_mat v)."""
+    w = sd[key + ".weight_orig"] if key + ".weight_orig" in sd else sd[key + ".weight"]
+    if key + ".weight_u" in sd:
+        u, v = sd[key + ".weight_u"], sd[key + ".weight_v"]
+        sigma = torch.dot(u, torch.mv(w.reshape(w.shape[0], -1), v))
+        w = w / sigma
+    return w
+
+
+def _load_bn(bn, sd, key):
+    """key = '...bn' or '...pbn' of a (Partial)LinearNoiseLayer; zero noise -> gain 1, bias 0."""
+    bn.stored_mean.copy_(sd[key + ".stored_mean"])
+    bn.stored_var.copy_(sd[key + ".stored_var"])
+
+
+def _load_conv(conv, sd, key):
+    conv.weight.data.copy_(_fold_sn(sd, key))
+    if conv.bias is not None:
+        conv.bias.data.copy_(sd[key + ".bias"])
+
+
+@torch.no_grad()
+def load_reference_state_dict(net, sd, prefix):
+    """Fill ``net`` from a reference state dict (SURVEY App. C key scheme).  ``prefix`` e.g.
+    'model.module.encoder.' / 'model.module.projector.' / 'model.module.net_bg.' ..."""
+    sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    for i, blk in enumerate(net.blocks):
+        if isinstance(blk, PconvResBlock):
+            b = f"eblocks.{i}."
+            _load_bn(blk.bn1, sd, b + "bn_noise1.pbn")
+            _load_bn(blk.bn2, sd, b + "bn_noise2.pbn")
+            _load_conv(blk.conv_aa, sd, b + "conv_aa")
+            _load_conv(blk.conv_ab, sd, b + "conv_ab")
+            if blk.conv_b is not None:
+                _load_conv(blk.conv_b, sd, b + "conv_b")
+        else:
+            b = ("eblocks" if isinstance(net, BGDecoder) else "gblocks") + f".{i}."
+            _load_bn(blk.bn1, sd, b + "ch_a.0.bn")
+            _load_bn(blk.bn2, sd, b + "ch_a.3.bn")
+            _load_conv(blk.conv_aa, sd, b + "ch_a.2")
+            _load_conv(blk.conv_ab, sd, b + "ch_a.5")
+            if blk.conv_b is not None:
+                _load_conv(blk.conv_b, sd, b + "ch_b.0")
+    return net

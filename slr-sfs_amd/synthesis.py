@@ -18,6 +18,19 @@ from ._lib import check, lib, ptr, require_device, stream_of, workspace
 from .euler_integration_manipulator import euler_integration_all
 
 
+# bench.py sets this to a list to collect (start, stop) torch events around the tile kernel of
+# every synth_group call with timed=True (through slr_splat_time_next); None = no timing.
+kernel_timing = None
+
+
+def _arm_timer(t):
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for e in ev:
+        e.record(torch.cuda.current_stream(t.device))      # materialises the hipEvent_t handle
+    lib().slr_splat_time_next(ev[0].cuda_event, ev[1].cuda_event)
+    kernel_timing.append(ev)
+
+
 def bin_flow(flow, C, role):
     """Sort the source pixels of ``flow`` [1,2,H,W] into output-tile bins (slr_splat_bin).
     Returns the workspace; valid until the next bin_flow with the same role/shape/stream."""
@@ -40,7 +53,7 @@ def global_max(x):
 
 
 def synth_group(values, wlogit, disp_f, disp_p, alpha, ws_f, ws_p, wmax=None, exp_weights=True,
-                eps=1e-8, return_norm=False):
+                eps=1e-8, return_norm=False, timed=False):
     """out = [splat(values*w*alpha, disp_f) + splat(values*w*(1-alpha), disp_p)] / max(same for w, eps)
     with w = exp(wlogit - wmax) | exp(wlogit) | wlogit.  values [1,C,H,W], wlogit [1,1,H,W]."""
     require_device(values, wlogit, disp_f, disp_p, wmax)
@@ -49,6 +62,8 @@ def synth_group(values, wlogit, disp_f, disp_p, alpha, ws_f, ws_p, wmax=None, ex
     out = torch.empty_like(values)
     norm = values.new_empty(1, 1, H, W) if return_norm else None
     with torch.cuda.device(values.device):
+        if timed and kernel_timing is not None:
+            _arm_timer(values)
         check(lib().slr_synth_group(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0,
                                     ptr(disp_f), ptr(disp_p), float(alpha), ptr(out), ptr(norm),
                                     C, H, W, float(eps), ptr(ws_f), ptr(ws_p), ws_f.numel(),
@@ -112,7 +127,7 @@ class ClipSynthesizer:
         ws_p = bin_flow(disp_p, self.C, "p")
         a = self.alpha(t)
         res = synth_group(self.fs, self.Z, disp_f, disp_p, a, ws_f, ws_p, wmax=self.zmax,
-                          return_norm=return_norm)
+                          return_norm=return_norm, timed=True)
         gen, norm = res if return_norm else (res, None)
         if not self.v1:
             return (gen, norm) if return_norm else gen
