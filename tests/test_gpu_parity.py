@@ -318,3 +318,54 @@ def test_full_size_one_plane_vs_oracle(S, oracle):
     x = np.random.default_rng(2).standard_normal((1, 3, H, W)).astype(np.float32)
     out = S.FunctionSoftsplat(dev(x), dev(flow), None, "summation")
     np.testing.assert_allclose(host(out), oracle.softsplat_forward(x, flow), **TOL)
+
+
+# ------------------------------------------------------------------------------ pipelines
+
+class _Zeros(torch.nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.ch = ch
+
+    def forward(self, x):
+        return x.new_zeros(x.shape[0], self.ch, x.shape[2], x.shape[3])
+
+
+@pytest.mark.parametrize("t", [0, 1, 30, 59])
+def test_v1_compositing_golden(S, golden_dir, t):
+    """PredImg / CompositeFluidAlpha of the reference's v1 forward_flow with zero decoders
+    (fluid = tanh(0), alpha = sigmoid(0)): pins the compositing and the BG / alpha plumbing."""
+    g = load(golden_dir, "pipeline_a6")
+    N = int(g["N"])
+    a = dev(g["alpha_out"])
+    abg = torch.sigmoid(a[:, 0:1])
+    an = S.pipeline.SLRv1Animator(decoder=_Zeros(3), alpha_decoder=_Zeros(1)).cuda()
+    clip = S.synthesis.ClipSynthesizer(dev(g["fs"]), dev(g["Z"]), dev(g["motion"]), N,
+                                       alpha_fluid_logit=a[:, 1:2].contiguous(), alpha_bg=abg)
+    clip.bg, clip.alpha_bg = torch.tanh(dev(g["bg"])), abg
+    out = an.frame(clip, t)
+    np.testing.assert_allclose(host(out["PredImg"]), g[f"v1_t{t}_PredImg"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(out["CompositeFluidAlpha"]), g[f"v1_t{t}_CompositeFluidAlpha"],
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_baseline_forward_flow_api_and_clip(S, oracle):
+    """forward_flow(batch) (reference batch keys) == begin_clip/frame == oracle features + decoder."""
+    H, W, N = 40, 72, 9
+    torch.manual_seed(0)
+    an = S.pipeline.BaselineAnimator().cuda().eval()
+    img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+    m = dev(smooth_motion(H, W, 4, amp=2.0))
+    clip = an.begin_clip(img, m, N)
+    fs, Z = an.encoder(img)
+    frames = an.synthesize(img, m, N)
+    assert frames.shape == (N, 3, H, W) and torch.isfinite(frames).all()
+    for t in (0, 4, 8):
+        ref_feat = oracle.synth_baseline(host(fs), host(Z), host(m), t, N)
+        np.testing.assert_allclose(host(clip.features(t)), ref_feat, rtol=1e-4, atol=1e-5)
+        batch = {"features": [(fs, Z)], "images": [img], "motions": [m], "index": torch.tensor([[0, t, N - 1]])}
+        pred = an.forward_flow(batch)["PredImg"]
+        assert torch.allclose(pred[0], frames[t], atol=1e-5)
+        # decoder applied to the oracle's features gives the same frame (<= 1e-4, north_star)
+        ref_img = torch.tanh(an.projector(dev(ref_feat)))
+        assert (ref_img[0] - frames[t]).abs().max().item() < 1e-4
