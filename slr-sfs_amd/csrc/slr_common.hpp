@@ -33,7 +33,7 @@ constexpr int TILE_W   = 64;      // one wavefront of consecutive x
 constexpr int TILE_H   = SLR_TILE_H;
 constexpr int TILE_PIX = TILE_W * TILE_H;
 constexpr int SEG_ONE  = 2 * TILE_PIX;   // segment length, one flow per tile
-constexpr int SEG_TWO  = 4 * TILE_PIX;   // segment length, forward+backward flows per tile
+constexpr int SEG_TWO  = 3 * TILE_PIX;   // segment length, forward+backward flows per tile
 
 // Workspace layout (all offsets 256-byte aligned).  `hdr` is zeroed at the start of binning.
 struct WsLayout {
@@ -49,6 +49,7 @@ struct WsLayout {
     size_t off_partoff;   // uint32[nt]   first partial slot of the tile   (plan)
     size_t off_items;     // uint2[items_cap] (tile, segment)              (plan)
     size_t off_totals;    // uint32[4]    total items, total partial slots (plan)
+    size_t off_trash;     // float[planes][TILE_PIX]  sink for work-items outside the image
     size_t off_partial;   // float[part_slots][planes][TILE_PIX]           (main -> combine)
     size_t part_stride;   // floats per partial slot = planes * TILE_PIX
     size_t total;
@@ -74,9 +75,10 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_partoff = o; o += al256((size_t)L.nt * 4);
     L.off_items = o;   o += al256((size_t)L.items_cap * 8);
     L.off_totals = o;  o += 256;
-    L.off_partial = o;
     // C value planes + the normaliser plane
     L.part_stride = (size_t)(C + 1) * TILE_PIX;
+    L.off_trash = o;   o += al256(L.part_stride * 4);
+    L.off_partial = o;
     o += al256((size_t)L.part_slots * L.part_stride * 4);
     L.total = o;
     return L;

@@ -30,6 +30,9 @@
 namespace slr {
 
 static thread_local char g_err[512] = "";
+#ifdef SLR_TRACE
+static long long *g_trace;
+#endif
 static thread_local void *g_ev_start = nullptr, *g_ev_stop = nullptr;   // slr_splat_time_next
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -193,7 +196,7 @@ struct SplatArgs {
     float scale[2];         // alpha, 1 - alpha
     const uint32_t *nseg, *partoff, *totals;
     const uint2 *items;
-    float *partial;
+    float *partial, *trash;
     float *out;             // [N,C,H,W]
     float *norm_out;        // [N,1,H,W] or nullptr
     size_t part_stride;
@@ -201,6 +204,7 @@ struct SplatArgs {
     int ndir, seg;
     int mulmode, norm_mode;
     float eps, init;
+    long long *trace;
 };
 
 __device__ __forceinline__ float finish(float s, float nrm, int norm_mode, float eps) {
@@ -212,9 +216,36 @@ __device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps)
     return norm_mode == SLR_NORM_ZERO_TO_ONE ? (nrm == 0.0f ? 1.0f : nrm) : fmaxf(nrm, eps);
 }
 
+#ifdef SLR_TRACE      // development aid: per-workgroup phase timestamps (s_memtime) into a.trace
+#define SLR_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 40 + (slot)] = clock64(); } while (0)
+#else
+#define SLR_STAMP(slot) do { } while (0)
+#endif
+
 constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
-constexpr int EPT_MAX = SEG_TWO / SPLAT_THREADS;   // bin entries per work-item, upper bound
-constexpr int CHUNK = 8;                       // channels staged in LDS / accumulated in registers per pass
+constexpr int RB = 4;                          // records per batch in the gather loop
+constexpr int LMAX = 16;                       // records a work-item walks alone (longer lists: wave-cooperative)
+constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
+// Per-variant shape: EPT bin entries per work-item (segment = EPT*TILE_PIX entries), CHUNK planes
+// staged in LDS / accumulated in registers per pass.  Chosen so that two workgroups fit one CU's
+// 160 KiB of LDS:  one flow  EPT 2, CHUNK 8 -> 3.1 + 36 + 32 = 71 KiB
+//                  two flows EPT 3, CHUNK 4 -> 3.1 + 52 + 24 = 79 KiB
+constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = 8;
+constexpr int EPT_TWO = SEG_TWO / SPLAT_THREADS, CHUNK_TWO = 4;
+// records per segment: <= 4 per entry, + 1 pad per output pixel (list lengths are made odd so the
+// lanes' list walks start on different LDS banks: with the typical 4 records per pixel an
+// unpadded CSR puts lanes i and i+8 on the same bank -> 8-way conflict on every record read)
+__host__ __device__ constexpr int rec_cap(int ept) { return 4 * ept * SPLAT_THREADS + SPLAT_THREADS; }
+
+// 16-byte LDS slot of planes [4h, 4h+4) of staged entry e.  CHUNK 4: one slot per entry, consecutive
+// entries -> consecutive slots (conflict-free ds_read_b128).  CHUNK 8: two slots per entry; the half
+// is XOR-ed with bit 3 of the entry so that a 16-lane group reading the same half of 16 consecutive
+// entries covers all 16 slots of the 256-byte LDS row instead of hitting 8 of them twice.
+template <int CHUNK>
+__device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
+    static_assert(CHUNK == 4 || CHUNK == 8, "staging layout");
+    return CHUNK == 4 ? e : 2u * e + ((uint32_t)h ^ ((e >> 3) & 1u));
+}
 
 // Why no LDS float accumulation: on gfx950 ds_add_f32 retires ~1 lane per 2.6 clocks (170
 // CU-cycles per wave instruction) and even ds_add_f64 (7.8) made the 4-atomics-per-element
@@ -232,15 +263,16 @@ constexpr int CHUNK = 8;                       // channels staged in LDS / accum
 //            byte is written exactly once, coalesced, never read, never zeroed.
 //
 // Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
-template <bool NORM, bool MAXOP>
+template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK>
 __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int T = SPLAT_THREADS;
+    constexpr int SEG = EPT_MAX * T;
     uint32_t *cnt = smem;                     // [T]   records per output pixel
-    uint32_t *off = smem + T;                 // [T+1] exclusive prefix (+ wave sums behind it)
-    uint32_t *wsum = smem + 2 * T + 8;        // [T/64]
-    uint2 *rec = reinterpret_cast<uint2 *>(smem + 2 * T + 64);   // [4*seg] (entry index, weight bits)
-    float *val = reinterpret_cast<float *>(rec + 4 * a.seg);     // [CHUNK][seg] staged source values
+    uint32_t *wsum = smem + T;                // [T/64] wave sums of the scan
+    uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 8);             // [T] exclusive prefix (< 2^16)
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 8 + T / 2);           // [rec_cap] (entry index, weight bits)
+    float4 *val4 = reinterpret_cast<float4 *>(rec + rec_cap(EPT_MAX));     // [SEG][CHUNK/4] staged source values
 
     const uint32_t item = blockIdx.x;
     if (item >= a.totals[0]) return;
@@ -251,6 +283,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     const int HW = a.H * a.W;
     const int tid = threadIdx.x;
 
+    SLR_STAMP(0);
     cnt[tid] = 0;
     __syncthreads();
 
@@ -268,6 +301,17 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { e_ts[j][k] = 0xffffffffu; e_w[j][k] = 0.0f; }
     }
+    const float *ip = a.in + (size_t)n * a.C * HW;
+    const int cmax = a.C - 1;
+    auto prefetch = [&](float (&pre)[EPT_MAX][CHUNK], int c0) {
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const float *plane = ip + (size_t)min(c0 + u, cmax) * HW;
+#pragma unroll
+            for (int j = 0; j < EPT_MAX; ++j) pre[j][u] = plane[e_pix[j]];
+        }
+    };
+    float preA[EPT_MAX][CHUNK], preB[EPT_MAX][CHUNK];
     {
         // entry j of this work-item = element lo + tid + j*T of [bin(flow0) ; bin(flow1)]
         const uint32_t c0 = a.count[0][t];
@@ -285,6 +329,11 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
             dir[j] = (k >= c0) ? 1 : 0;
             e_pix[j] = val[j] ? (dir[j] ? l1[k - c0] : l0[k]) : 0u;
         }
+        SLR_STAMP(28);
+        // the plane loads of the first two chunks only need the source indices: issue them now,
+        // they complete under the footprint math, the LDS atomics and the scan
+        prefetch(preA, 0);
+        prefetch(preB, CHUNK);
         float fx[EPT_MAX], fy[EPT_MAX], mm[EPT_MAX];
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j) {
@@ -320,12 +369,14 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
             }
         }
     }
+    SLR_STAMP(1);
     __syncthreads();
+    SLR_STAMP(2);
 
     // ---------------- phase 1b: exclusive scan of the counts (T values, one per work-item)
     {
         const int lane = tid & 63, wid = tid >> 6;
-        const uint32_t v = cnt[tid];
+        const uint32_t v = cnt[tid] | 1u;              // odd list length (bank spreading, see rec_cap)
         uint32_t inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -337,8 +388,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
         uint32_t woff = 0;
 #pragma unroll
         for (int w = 0; w < T / 64; ++w) woff += (w < wid) ? wsum[w] : 0u;
-        off[tid] = woff + inc - v;
-        if (tid == T - 1) off[T] = woff + inc;
+        off[tid] = (uint16_t)(woff + inc - v);
     }
     __syncthreads();
 
@@ -348,25 +398,59 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t ts = e_ts[j][k];
-            if (ts != 0xffffffffu) rec[off[ts >> 16] + (ts & 0xffffu)] = make_uint2((uint32_t)(tid + j * T), __float_as_uint(e_w[j][k]));
+            if (ts != 0xffffffffu) {
+                rec[off[ts >> 16] + (ts & 0xffffu)] = make_uint2((uint32_t)(tid + j * T), __float_as_uint(e_w[j][k]));
+            }
         }
     __syncthreads();
 
+    SLR_STAMP(3);
     // ---------------- phase 2: stage a chunk of planes in LDS, gather per output pixel
-    const uint32_t r0 = off[tid], r1 = off[tid + 1];
+    // A work-item walks at most LMAX records of its own list; what is left of a longer list (a
+    // "sink" pixel where hundreds of sources converge) is walked by the whole wave, lane-strided,
+    // and wave-reduced -- otherwise one lane serialises thousands of records in every chunk.
+    const uint32_t r0 = off[tid], r1 = r0 + cnt[tid];
+    const int lane = tid & 63;
+    uint32_t wave_recs = r1 - r0;                          // records of this wave's 64 output pixels
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wave_recs += __shfl_xor(wave_recs, d);
+    // own share: twice the wave's average list length (a uniformly compressed region stays
+    // per-lane), at least LMAX
+    // (and only when at least a wave's worth of records is left over: a cooperative pass costs
+    // ~50 cross-lane operations per chunk)
+#ifdef SLR_TRACE
+    {
+        __shared__ uint32_t dbg_max;
+        if (tid == 0) dbg_max = 0;
+        __syncthreads();
+        atomicMax(&dbg_max, r1 - r0);
+        __syncthreads();
+        if (a.trace && tid == 0) { a.trace[(size_t)blockIdx.x * 40 + 33] = dbg_max; a.trace[(size_t)blockIdx.x * 40 + 34] = wave_recs;
+                                   a.trace[(size_t)blockIdx.x * 40 + 35] = a.count[0][t]; a.trace[(size_t)blockIdx.x * 40 + 36] = s; }
+    }
+#endif
+    const uint32_t own = max((uint32_t)LMAX, 2u * ((wave_recs + 63u) >> 6));
+    const uint32_t rl = (r1 - r0 >= own + 64u) ? r0 + own : r1;
+    const unsigned long long heavy = __ballot(r1 > rl);
     const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool inside = (oy < a.H) & (ox < a.W);
     const bool single = a.nseg[t] == 1;
-    const float *ip = a.in + (size_t)n * a.C * HW;
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
-    const int seg = a.seg;
-
     float nrm = 0.0f;
     if (NORM) {
-        for (uint32_t r = r0; r < r1; ++r) nrm += __uint_as_float(rec[r].y);
+        for (uint32_t r = r0; r < rl; ++r) nrm += __uint_as_float(rec[r].y);
+        for (unsigned long long hv = heavy; hv; hv &= hv - 1) {        // long lists: the wave walks them together
+            const int src = __ffsll((long long)hv) - 1;
+            const uint32_t hb = __shfl(rl, src), he = __shfl(r1, src);
+            float part = 0.0f;
+            for (uint32_t r = hb + lane; r < he; r += 64) part += __uint_as_float(rec[r].y);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+            if (lane == src) nrm += part;
+        }
         if (single) {
             if (a.norm_out && inside) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
         } else {
@@ -374,58 +458,109 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
         }
     }
 
-    // values of this work-item's bin entries for one chunk of planes (prefetch registers)
-    float pre[EPT_MAX][CHUNK];
-    auto prefetch = [&](int c0) {
+    // Chunk pipeline, prefetch depth 2: while chunk c is gathered from LDS, the plane loads of
+    // chunks c+1 and c+2 are in flight (registers preA / preB).  All global loads and stores are
+    // UNCONDITIONAL -- invalid entries read pixel 0, planes past C re-read plane C-1, work-items
+    // outside the image and planes past C store into the workspace's trash tile -- so the
+    // compiler knows how many memory operations are younger than the ones it has to wait for
+    // and emits s_waitcnt vmcnt(N) with N > 0 instead of draining everything.
+    float *const trash = a.trash + tid;
+    if (!inside && single) op = trash;
+    const size_t ostr = (!inside && single) ? (size_t)0 : ostride;
+    auto chunk = [&](float (&pre)[EPT_MAX][CHUNK], int c0) {
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j)
 #pragma unroll
-            for (int u = 0; u < CHUNK; ++u)
-                pre[j][u] = (e_val[j] && c0 + u < a.C) ? ip[(size_t)(c0 + u) * HW + e_pix[j]] : 0.0f;
-    };
-    prefetch(0);
-    for (int c0 = 0; c0 < a.C; c0 += CHUNK) {
-#pragma unroll
-        for (int j = 0; j < EPT_MAX; ++j)
-            if (e_val[j]) {
-#pragma unroll
-                for (int u = 0; u < CHUNK; ++u) val[u * seg + tid + j * T] = pre[j][u];
-            }
+            for (int h = 0; h < CHUNK / 4; ++h)
+                val4[vslot<CHUNK>(tid + j * T, h)] = make_float4(pre[j][4 * h], pre[j][4 * h + 1], pre[j][4 * h + 2], pre[j][4 * h + 3]);
+        SLR_STAMP(4 + 3 * (c0 / CHUNK));
         __syncthreads();
-        if (c0 + CHUNK < a.C) prefetch(c0 + CHUNK);          // next chunk's loads fly during the gather
+        SLR_STAMP(5 + 3 * (c0 / CHUNK));
+        prefetch(pre, c0 + 2 * CHUNK);                 // two chunks ahead
         float acc[CHUNK];
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) acc[u] = MAXOP ? a.init : 0.0f;
-        for (uint32_t r = r0; r < r1; ++r) {
-            const uint2 q = rec[r];
-            const float w = __uint_as_float(q.y);
+        // records in batches of RB: all LDS reads of a batch are issued before the first FMA
+        // (the typical output pixel has exactly 4 records: one batch)
+        for (uint32_t r = r0; r < rl; r += RB) {
+            float w[RB];
+            uint32_t e[RB];
 #pragma unroll
-            for (int u = 0; u < CHUNK; ++u) {
-                const float v = val[u * seg + q.x];
-                acc[u] = MAXOP ? fmaxf(v * w, acc[u]) : acc[u] + v * w;
+            for (int k = 0; k < RB; ++k) {
+                const uint2 q = rec[min(r + k, rl - 1)];           // stay inside this pixel's list
+                e[k] = q.x;
+                w[k] = __uint_as_float(q.y);
+            }
+            float v[RB][CHUNK];
+#pragma unroll
+            for (int k = 0; k < RB; ++k)
+#pragma unroll
+                for (int h = 0; h < CHUNK / 4; ++h) {
+                    const float4 q = val4[vslot<CHUNK>(e[k], h)];  // ds_read_b128: 4 planes per LDS instruction
+                    v[k][4 * h] = q.x; v[k][4 * h + 1] = q.y; v[k][4 * h + 2] = q.z; v[k][4 * h + 3] = q.w;
+                }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const bool on = r + k < rl;
+#pragma unroll
+                for (int u = 0; u < CHUNK; ++u) {
+                    if (MAXOP) acc[u] = fmaxf(on ? v[k][u] * w[k] : -INFINITY, acc[u]);
+                    else acc[u] = acc[u] + (on ? v[k][u] * w[k] : 0.0f);
+                }
             }
         }
-        if (inside || !single) {
+        for (unsigned long long hv = heavy; hv; hv &= hv - 1) {        // long lists, cooperatively
+            const int src = __ffsll((long long)hv) - 1;
+            const uint32_t hb = __shfl(rl, src), he = __shfl(r1, src);
+            float part[CHUNK];
 #pragma unroll
-            for (int u = 0; u < CHUNK; ++u)
-                if (c0 + u < a.C) {
-                    float r = acc[u];
-                    if (NORM && single) r = finish(r, nrm, a.norm_mode, a.eps);
-                    op[(size_t)(c0 + u) * ostride] = r;
+            for (int u = 0; u < CHUNK; ++u) part[u] = MAXOP ? -INFINITY : 0.0f;
+            for (uint32_t r = hb + lane; r < he; r += 64) {
+                const uint2 q = rec[r];
+                const float w = __uint_as_float(q.y);
+#pragma unroll
+                for (int h = 0; h < CHUNK / 4; ++h) {
+                    const float4 x = val4[vslot<CHUNK>(q.x, h)];
+                    const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        part[4 * h + i] = MAXOP ? fmaxf(xv[i] * w, part[4 * h + i]) : part[4 * h + i] + xv[i] * w;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const float o = __shfl_xor(part[u], d);
+                    part[u] = MAXOP ? fmaxf(part[u], o) : part[u] + o;
+                }
+                if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], part[u]) : acc[u] + part[u];
+            }
         }
-        __syncthreads();                                     // val[] is overwritten by the next chunk
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            float r = acc[u];
+            if (NORM && single) r = finish(r, nrm, a.norm_mode, a.eps);
+            float *dst = (c0 + u < a.C) ? op + (size_t)(c0 + u) * ostr : trash;
+            *dst = r;
+        }
+        SLR_STAMP(6 + 3 * (c0 / CHUNK));
+        __syncthreads();                               // val[] is overwritten by the next chunk
+    };
+    for (int c0 = 0; c0 < a.C; c0 += 2 * CHUNK) {
+        chunk(preA, c0);
+        if (c0 + CHUNK < a.C) chunk(preB, c0 + CHUNK);
     }
 }
 
 // Multi-segment tiles: sum (max) the raw partial tiles in segment order, normalise, store.
-// grid (nt, ceil(C/CHUNK)); TILE_PIX threads; exits at once for single-segment tiles.
+// grid (nt, ceil(C/COMBINE_CHUNK)); TILE_PIX threads; exits at once for single-segment tiles.
 template <bool NORM, bool MAXOP>
 __global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatArgs a) {
     const uint32_t t = blockIdx.x;
     const uint32_t ns = a.nseg[t];
     if (ns <= 1) return;
-    const int c0 = blockIdx.y * CHUNK;
+    const int c0 = blockIdx.y * COMBINE_CHUNK;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
     const int HW = a.H * a.W;
@@ -441,7 +576,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatArgs a) {
             a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
     }
     float *op = a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox;
-    for (int c = c0; c < min(c0 + CHUNK, a.C); ++c) {
+    for (int c = c0; c < min(c0 + COMBINE_CHUNK, a.C); ++c) {
         float acc = src[(size_t)c * TILE_PIX];
         for (uint32_t s = 1; s < ns; ++s) {                       // fixed order: deterministic
             const float v = src[(size_t)s * a.part_stride + (size_t)c * TILE_PIX];
@@ -491,7 +626,7 @@ struct Ws {
     char *base;
     uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals;
     uint2 *items;
-    float *partial;
+    float *partial, *trash;
 };
 
 static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, const char *who) {
@@ -510,6 +645,7 @@ static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, co
     w.items = (uint2 *)(w.base + w.L.off_items);
     w.totals = (uint32_t *)(w.base + w.L.off_totals);
     w.partial = (float *)(w.base + w.L.off_partial);
+    w.trash = (float *)(w.base + w.L.off_trash);
     return 0;
 }
 
@@ -534,6 +670,21 @@ static int do_bin(const float *flow, int N, int H, int W, Ws &w, hipStream_t st)
     return 0;
 }
 
+template <bool NORM, bool MAXOP, int EPT, int CHUNK>
+static int launch_tile(const SplatArgs &a, uint32_t items_cap, hipStream_t st) {
+    // counts (T words) + wave sums (8) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
+    const size_t lds = (size_t)(SPLAT_THREADS + 8 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
+                       (size_t)CHUNK * EPT * SPLAT_THREADS * 4;
+    static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
+    if (!attr_set) {
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>), dim3(items_cap), dim3(SPLAT_THREADS), lds, st, a);
+    return 0;
+}
+
 // plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
 template <bool NORM, bool MAXOP>
 static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
@@ -545,23 +696,23 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     a.count[1] = w1 ? w1->count : nullptr; a.listoff[1] = w1 ? w1->listoff : nullptr; a.list[1] = w1 ? w1->list : nullptr;
     a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals;
     a.partial = w0.partial;
+    a.trash = w0.trash;
+#ifdef SLR_TRACE
+    a.trace = g_trace;
+#endif
     a.part_stride = w0.L.part_stride;
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
                        (const uint32_t *)(w1 ? w1->count : nullptr), w0.L.nt, (uint32_t)a.seg,
                        w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.totals);
-    // counts + offsets + wave sums (2*T + 64 words) + 4 records + CHUNK staged values per bin entry
-    const size_t lds = (size_t)(2 * SPLAT_THREADS + 64) * 4 + (size_t)4 * a.seg * 8 + (size_t)CHUNK * a.seg * 4;
-    static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP>), dim3(w0.L.items_cap), dim3(SPLAT_THREADS), lds, st, a);
+    if (w1) {
+        if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, w0.L.items_cap, st)) return e;
+    } else {
+        if (int e = launch_tile<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(a, w0.L.items_cap, st)) return e;
+    }
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;          // one-shot
-    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt, (a.C + CHUNK - 1) / CHUNK),
+    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
                        dim3(SPLAT_THREADS), 0, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
@@ -573,6 +724,10 @@ using namespace slr;
 
 SLR_EXPORT int slr_abi_version(void) { return SLR_ABI_VERSION; }
 SLR_EXPORT const char *slr_last_error(void) { return slr::g_err; }
+
+#ifdef SLR_TRACE
+SLR_EXPORT void slr_debug_trace(long long *buf) { g_trace = buf; }
+#endif
 
 SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {
     slr::g_ev_start = ev_start;

@@ -68,6 +68,23 @@ __global__ __launch_bounds__(256) void write4(float4 *out) {
     for (int c = 0; c < C; ++c) out[(size_t)c * (HW / 4) + p] = make_float4(c, c, c, c);
 }
 
+// (g) tile copy: workgroup = TH x TW tile of every plane (the splat tile kernel's access shape)
+template <int TH, int TW, int U>
+__global__ __launch_bounds__(512) void tilecopy(const float *in, float *out) {
+    constexpr int W = 1280, H = 768;
+    const int tiles_x = W / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int ly = threadIdx.x / TW, lx = threadIdx.x % TW;
+    const size_t p = (size_t)(ty0 + ly) * W + tx0 + lx;
+    for (int c = 0; c + U <= C; c += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = in[(size_t)(c + u) * HW + p];
+#pragma unroll
+        for (int u = 0; u < U; ++u) out[(size_t)(c + u) * HW + p] = v[u] * 1.0001f;
+    }
+}
+
 template <typename F>
 void timeit(const char *name, double bytes, F f) {
     hipEvent_t a, b;
@@ -100,6 +117,12 @@ int main() {
     timeit("planes dwordx4 U=1", rw, [&] { planes4<1><<<pb4, 256>>>((float4 *)in, (float4 *)out); });
     timeit("planes dwordx4 U=5", rw, [&] { planes4<5><<<pb4, 256>>>((float4 *)in, (float4 *)out); });
     timeit("planes dwordx4 U=13", rw, [&] { planes4<13><<<pb4, 256>>>((float4 *)in, (float4 *)out); });
+    timeit("tile copy 8x64 U=8", rw, [&] { tilecopy<8, 64, 8><<<HW / 512, 512>>>(in, out); });
+    timeit("tile copy 8x64 U=13", rw, [&] { tilecopy<8, 64, 13><<<HW / 512, 512>>>(in, out); });
+    timeit("tile copy 4x128 U=13", rw, [&] { tilecopy<4, 128, 13><<<HW / 512, 512>>>(in, out); });
+    timeit("tile copy 2x256 U=13", rw, [&] { tilecopy<2, 256, 13><<<HW / 512, 512>>>(in, out); });
+    timeit("tile copy 1x512(640?) skip", rw, [&] { tilecopy<2, 256, 5><<<HW / 512, 512>>>(in, out); });
+    timeit("tile copy 16x32 U=13", rw, [&] { tilecopy<16, 32, 13><<<HW / 512, 512>>>(in, out); });
     timeit("read-only dword U=13", r, [&] { read1<13><<<pb, 256>>>(in, out); });
     timeit("read-only dword U=5", r, [&] { read1<5><<<pb, 256>>>(in, out); });
     timeit("write-only dword", r, [&] { write1<<<pb, 256>>>(out); });
