@@ -152,6 +152,24 @@ int slr_max_warp_norm(const float *in, const float *flow, float *scratch, float 
                       int N, int C, int H, int W,
                       void *ws, size_t ws_bytes, int prebinned, void *stream);
 
+/* ------------------------------------------------------------------ decoder elementwise stages (8 f3) */
+
+/* y = relu(x*scale[c] - shift[c]) * mask: eval-mode noise-BN (zero noise), ReLU and the
+ * input*mask of the following partial convolution in one pass.  Replaces
+ * models/layers/normalization.py:219-231 + blocks.py:229-231 + partialconv2d.py:69.
+ *   mask_channels = 1: mask [N,1,H,W];  = C: mask [N,C,H,W];  = 0: mask = (x != 0)
+ *   (models/networks/architectures.py:369), `mask` ignored. */
+int slr_bn_relu_mask(const float *x, const float *scale, const float *shift, const float *mask,
+                     int mask_channels, float *y, int N, int C, int H, int W, void *stream);
+
+/* Partial-convolution epilogue: out = ((raw - b)*ratio + b)*um (+ residual) with
+ * um = clamp(um_raw,0,1), ratio = winsize/(um_raw + 1e-8)*um.  Replaces
+ * models/layers/partialconv2d.py:64-74 (+ the residual add of blocks.py:248).
+ *   raw [N,C,H,W] convolution output incl. bias; um_raw [N,1,H,W] = box filter of the mask sum;
+ *   residual [N,C,H,W] or NULL; winsize = Cin*k*k. */
+int slr_pconv_epilogue(const float *raw, const float *bias, const float *um_raw, const float *residual,
+                       float *out, float winsize, int N, int C, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ SYMBOLS = (
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
+    "slr_bn_relu_mask", "slr_pconv_epilogue",
 )
 
 _lib = None
@@ -64,6 +65,8 @@ def lib():
             "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
+            "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
+            "slr_pconv_epilogue": [fp, fp, fp, fp, fp, f, i, i, i, i, vp],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)

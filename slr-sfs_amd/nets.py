@@ -23,6 +23,47 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+
+
+def _fused_ok(*ts):
+    """The fused HIP elementwise stages serve fp32 contiguous device tensors without autograd;
+    anything else (the CPU validation against the reference classes) takes the torch ops below,
+    which ARE the definition the kernels are tested against (tests/test_gpu_parity.py)."""
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) and \
+        not (torch.is_grad_enabled() and any(t.requires_grad for t in ts))
+
+
+def bn_relu_mask(x, scale, shift, mask):
+    """relu(x*scale - shift) * mask;  mask None = (x != 0)."""
+    if _fused_ok(x, *([] if mask is None else [mask])):
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().slr_bn_relu_mask(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mask),
+                                                   0 if mask is None else mask.shape[1], _lib.ptr(y), N, C, H, W,
+                                                   _lib.stream_of(x)), "slr_bn_relu_mask")
+        return y
+    m = (x != 0).to(x.dtype) if mask is None else mask
+    return F.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * m
+
+
+def pconv_epilogue(raw, bias, um_raw, winsize, residual=None):
+    """((raw - b)*ratio + b)*um (+ residual), partialconv2d.py:64-74."""
+    if _fused_ok(raw, um_raw, *([] if residual is None else [residual])):
+        N, C, H, W = raw.shape
+        out = torch.empty_like(raw)
+        with torch.cuda.device(raw.device):
+            _lib.check(_lib.lib().slr_pconv_epilogue(_lib.ptr(raw), _lib.ptr(bias), _lib.ptr(um_raw), _lib.ptr(residual),
+                                                     _lib.ptr(out), float(winsize), N, C, H, W,
+                                                     _lib.stream_of(raw)), "slr_pconv_epilogue")
+        return out
+    um = torch.clamp(um_raw, 0, 1)
+    ratio = winsize / (um_raw + 1e-8) * um
+    b = bias.view(1, -1, 1, 1)
+    out = ((raw - b) * ratio + b) * um
+    return out if residual is None else out + residual
+
 
 # --------------------------------------------------------------------------- building blocks
 
@@ -36,10 +77,13 @@ class AffineBN(nn.Module):
         self.register_buffer("stored_mean", torch.zeros(ch))
         self.register_buffer("stored_var", torch.ones(ch))
 
+    def scale_shift(self):
+        scale = torch.rsqrt(self.stored_var + self.eps)
+        return scale, self.stored_mean * scale
+
     def forward(self, x):
-        scale = torch.rsqrt(self.stored_var + self.eps).view(1, -1, 1, 1)
-        shift = self.stored_mean.view(1, -1, 1, 1) * scale
-        return x * scale - shift
+        scale, shift = self.scale_shift()
+        return x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)
 
 
 class Conv(nn.Module):
@@ -58,23 +102,23 @@ class Conv(nn.Module):
 
 
 class PartialConv(Conv):
-    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81.
-    ``mask`` is [N,1,H,W] (channel-uniform) or [N,Cin,H,W]; returns (out, update_mask [N,1,H,W])."""
+    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81,
+    fused with the BN + ReLU in front of it (blocks.py:229-231).
+    ``mask`` is [N,1,H,W] (channel-uniform), [N,Cin,H,W], or None = (x != 0) per channel
+    (architectures.py:369); returns (out, update_mask [N,1,H,W])."""
 
-    def forward(self, x, mask):
-        msum = mask.sum(1, keepdim=True) if mask.shape[1] != 1 else mask * float(self.cin)
-        # conv(mask, ones[out,in,k,k]) == box_k(sum_c mask), identical for every output channel
-        um = F.avg_pool2d(msum, self.k, stride=1, padding=self.pad, divisor_override=1)     # :61
-        ratio = (self.cin * self.k * self.k) / (um + 1e-8)                                  # :64
-        um = torch.clamp(um, 0, 1)                                                          # :66
-        ratio = ratio * um                                                                  # :67
-        raw = F.conv2d(x * mask, self.weight, self.bias, padding=self.pad)                  # :69
-        if self.bias is not None:
-            b = self.bias.view(1, -1, 1, 1)
-            out = ((raw - b) * ratio + b) * um                                              # :72-74
+    def forward(self, x, bn, mask, residual=None):
+        if mask is None:
+            msum = (x != 0).sum(1, keepdim=True).to(x.dtype)
         else:
-            out = raw * ratio                                                               # :76
-        return out, um
+            msum = mask.sum(1, keepdim=True) if mask.shape[1] != 1 else mask * float(self.cin)
+        # conv(mask, ones[out,in,k,k]) == box_k(sum_c mask), identical for every output channel (:61)
+        um_raw = F.avg_pool2d(msum, self.k, stride=1, padding=self.pad, divisor_override=1)
+        scale, shift = bn.scale_shift()
+        xin = bn_relu_mask(x, scale, shift, mask)                                  # BN, ReLU, input*mask (:69)
+        raw = F.conv2d(xin, self.weight, self.bias, padding=self.pad)                            # :69
+        out = pconv_epilogue(raw, self.bias, um_raw, self.cin * self.k * self.k, residual)       # :64-74
+        return out, torch.clamp(um_raw, 0, 1)
 
 
 def _resample(kind):
@@ -121,12 +165,15 @@ class PconvResBlock(nn.Module):
         self.conv_aa, self.conv_ab = PartialConv(cin, cout, 3), PartialConv(cout, cout, 3)
         self.conv_b = Conv(cin, cout, 1, bias=False) if (resample or cin != cout) else None   # :192-193
         self.resample, self.resample_mask = _resample(resample), _resample_mask(resample)
+        self.has_resample = bool(resample)
 
     def forward(self, x, mask):
-        a, m = self.conv_aa(F.relu(self.bn1(x)), mask)                 # :229-231
-        a, m = self.conv_ab(F.relu(self.bn2(a)), m)                    # :233-239
-        a, m = self.resample(a), self.resample_mask(m)                 # :240-241
-        b = self.resample(self.conv_b(x)) if self.conv_b is not None else x   # :243-247
+        a, m = self.conv_aa(x, self.bn1, mask)                                    # :229-231
+        if self.conv_b is None and not self.has_resample:
+            return self.conv_ab(a, self.bn2, m, residual=x)                       # :233-239 + x_a + x_b (:248)
+        a, m = self.conv_ab(a, self.bn2, m)                                       # :233-239
+        a, m = self.resample(a), self.resample_mask(m)                            # :240-241
+        b = self.resample(self.conv_b(x)) if self.conv_b is not None else x       # :243-247
         return a + b, m
 
 
@@ -175,7 +222,7 @@ class DecoderPconv2(nn.Module):
         self.blocks = nn.ModuleList(PconvResBlock(ch[i], ch[i + 1], _UPDOWN[i]) for i in range(8))
 
     def forward(self, x):
-        mask = (x != 0).to(x.dtype)
+        mask = None                                      # (x != 0) per channel, derived inside the first block
         for b in self.blocks:
             x, mask = b(x, mask)
         return x

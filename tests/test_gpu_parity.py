@@ -369,3 +369,44 @@ def test_baseline_forward_flow_api_and_clip(S, oracle):
         # decoder applied to the oracle's features gives the same frame (<= 1e-4, north_star)
         ref_img = torch.tanh(an.projector(dev(ref_feat)))
         assert (ref_img[0] - frames[t]).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------------------ decoder stages (f3)
+
+def test_fused_decoder_stages_match_torch_definition(S):
+    """slr_bn_relu_mask / slr_pconv_epilogue vs the torch composition in nets.py (same order of
+    operations: bit-exact), float4 and scalar paths, all mask kinds."""
+    nets = S.nets
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (N, C, H, W) in [(1, 8, 16, 24), (2, 5, 7, 9)]:
+        x = torch.randn(N, C, H, W, device="cuda", generator=g)
+        x[:, :, 2:5, 3:7] = 0
+        scale = torch.rand(C, device="cuda", generator=g) + 0.5
+        shift = torch.randn(C, device="cuda", generator=g)
+        m1 = (torch.rand(N, 1, H, W, device="cuda", generator=g) > 0.3).float()
+        mc = (torch.rand(N, C, H, W, device="cuda", generator=g) > 0.3).float()
+        for mask in (None, m1, mc):
+            ref = torch.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * ((x != 0).float() if mask is None else mask)
+            assert torch.equal(nets.bn_relu_mask(x, scale, shift, mask), ref)
+        raw = torch.randn(N, C, H, W, device="cuda", generator=g)
+        bias = torch.randn(C, device="cuda", generator=g)
+        umr = torch.randint(0, 28, (N, 1, H, W), device="cuda", generator=g).float()
+        res = torch.randn(N, C, H, W, device="cuda", generator=g)
+        um = torch.clamp(umr, 0, 1)
+        ratio = 27.0 / (umr + 1e-8) * um
+        b = bias.view(1, -1, 1, 1)
+        ref = ((raw - b) * ratio + b) * um
+        assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0), ref)
+        assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0, res), ref + res)
+
+
+def test_decoder_gpu_matches_cpu_definition(S):
+    """Whole partial-conv decoder: device (fused stages + MIOpen) vs CPU (pure torch) within conv noise."""
+    torch.manual_seed(5)
+    dec = S.nets.DecoderPconv2(64, 3).eval()
+    x = torch.randn(1, 64, 32, 48)
+    x[:, :, 6:20, 10:30] = 0
+    with torch.no_grad():
+        ref = dec(x)
+        out = dec.cuda()(x.cuda()).cpu()
+    assert (out - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
