@@ -113,9 +113,13 @@ def main():
     c_splat = 65 if a.workload == "c3" else 65 + 2        # planes per reference splat call (v1: 67)
     alg_bytes = 2 * (2 * c_splat + 2) * H * W * 4
     achieved = alg_bytes / (k_avg * 1e-6) / 1e9
-    roofline = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<true,false>", "achieved": round(achieved, 1),
+    traffic = None          # HBM bytes per launch from the PMC passes (profiles/, measured separately)
+    tf = os.path.join(ROOT, "profiles", "r1_splat_traffic.json")
+    if a.workload == "c3" and os.path.exists(tf):
+        traffic = json.load(open(tf))["traffic_bytes_per_launch"]
+    roofline = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<true,false,3,4>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_us": round(k_avg, 1),
+                "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_us": round(k_avg, 1),
                 "min_us": round(kus[0], 1), "max_us": round(kus[-1], 1), "launches": len(kus)}
 
     extra = {}

@@ -223,6 +223,7 @@ __device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps)
 #endif
 
 constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
+constexpr int XCD_GROUP = 4;                    // neighbouring tiles kept on one XCD (L2 halo reuse)
 constexpr int RB = 4;                          // records per batch in the gather loop
 constexpr int LMAX = 16;                       // records a work-item walks alone (longer lists: wave-cooperative)
 constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
@@ -274,8 +275,15 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 8 + T / 2);           // [rec_cap] (entry index, weight bits)
     float4 *val4 = reinterpret_cast<float4 *>(rec + rec_cap(EPT_MAX));     // [SEG][CHUNK/4] staged source values
 
-    const uint32_t item = blockIdx.x;
-    if (item >= a.totals[0]) return;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
+    // Groups of XCD_GROUP consecutive work items (= horizontally neighbouring tiles) are placed on
+    // the same XCD, groups round-robin over the XCDs: a tile's column halo (bin entries owned by
+    // the tile to its left: one 128-byte line per row for 4 useful bytes) is then served by that
+    // XCD's L2 instead of HBM, while heavy image regions still spread over all XCDs.
+    const uint32_t total = a.totals[0];
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t item = ((slot / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + slot % XCD_GROUP;
+    if (item >= total) return;
     const uint2 it = a.items[item];
     const uint32_t t = it.x, s = it.y;
     const int n = t / a.tiles, tl = t - n * a.tiles;
@@ -681,7 +689,7 @@ static int launch_tile(const SplatArgs &a, uint32_t items_cap, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>), dim3(items_cap), dim3(SPLAT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>), dim3(((items_cap + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP), dim3(SPLAT_THREADS), lds, st, a);
     return 0;
 }
 
