@@ -410,3 +410,45 @@ def test_decoder_gpu_matches_cpu_definition(S):
         ref = dec(x)
         out = dec.cuda()(x.cuda()).cpu()
     assert (out - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------ edge shapes
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 2, 1, 7), (2, 3, 5, 1), (1, 1, 8, 64), (1, 17, 9, 65), (4, 2, 3, 5)])
+def test_tiny_and_ragged_shapes(S, oracle, shape):
+    N, C, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    flow = rng.uniform(-2.5, 2.5, (N, 2, H, W)).astype(np.float32)
+    met = rng.standard_normal((N, 1, H, W)).astype(np.float32)
+    np.testing.assert_allclose(host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation")),
+                               oracle.softsplat_forward(x, flow), **TOL)
+    np.testing.assert_allclose(host(S.FunctionSoftsplat(dev(x), dev(flow), dev(met), "softmax")),
+                               oracle.function_softsplat(x, flow, met, "softmax"), rtol=1e-4, atol=1e-5)
+    gi, gf = oracle.softsplat_backward(x, flow, x)
+    a, b = dev(x).requires_grad_(True), dev(flow).requires_grad_(True)
+    S.softsplat._FunctionSoftsplat.apply(a, b).backward(dev(x))
+    assert np.array_equal(host(a.grad), gi)
+    np.testing.assert_allclose(host(b.grad), gf, rtol=1e-6, atol=1e-6)
+    if N == 1:
+        m = rng.uniform(-1.5, 1.5, (1, 2, H, W)).astype(np.float32)
+        d, v = S.euler_integration(dev(m), 4)
+        od, ov = oracle.euler_integration(m, 4)
+        assert np.array_equal(host(d), od) and np.array_equal(host(v), ov)
+
+
+def test_streams_and_workspace_reuse(S, oracle):
+    """Calls on a side stream, interleaved shapes (workspace cache keyed by stream/shape)."""
+    rng = np.random.default_rng(8)
+    xs = [rng.standard_normal((1, 4, 24, 40)).astype(np.float32), rng.standard_normal((1, 6, 17, 33)).astype(np.float32)]
+    fl = [rng.uniform(-3, 3, (1, 2, 24, 40)).astype(np.float32), rng.uniform(-3, 3, (1, 2, 17, 33)).astype(np.float32)]
+    side = torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(side):
+        dx, df = [dev(a) for a in xs], [dev(a) for a in fl]
+        for rep in range(3):
+            for i in (0, 1):
+                outs.append((i, S.FunctionSoftsplat(dx[i], df[i], None, "summation")))
+    side.synchronize()
+    for i, o in outs:
+        np.testing.assert_allclose(host(o), oracle.softsplat_forward(xs[i], fl[i]), **TOL)
