@@ -447,6 +447,22 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
+    // register-resident head of this pixel's record list (see the gather loop)
+    constexpr uint32_t NULL_E = SEG;                   // staged-entry index of the all-zero slot
+    constexpr int KREG = 2 * EPT_MAX;                  // 4 records for one flow, 6 for two
+    float cw[KREG];
+    uint32_t ce[KREG];
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+        const bool on = r0 + k < rl;
+        const uint2 q = rec[on ? r0 + k : 0u];
+        ce[k] = on ? q.x : NULL_E;
+        cw[k] = on ? __uint_as_float(q.y) : 0.0f;
+    }
+#pragma unroll
+    for (int h = 0; h < CHUNK / 4; ++h)
+        if (tid == 0) val4[vslot<CHUNK>(NULL_E, h)] = make_float4(0.f, 0.f, 0.f, 0.f);
+
     float nrm = 0.0f;
     if (NORM) {
         for (uint32_t r = r0; r < rl; ++r) nrm += __uint_as_float(rec[r].y);
@@ -488,34 +504,52 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
         float acc[CHUNK];
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) acc[u] = MAXOP ? a.init : 0.0f;
-        // records in batches of RB: all LDS reads of a batch are issued before the first FMA
-        // (the typical output pixel has exactly 4 records: one batch)
-        for (uint32_t r = r0; r < rl; r += RB) {
+        // The first KREG records of the pixel live in registers (loaded once, reused by every chunk);
+        // longer lists continue from LDS in batches of RB.  All LDS reads of a batch are issued
+        // before its first FMA.  Missing records point at the zeroed NULL entry with weight 0:
+        // fma(0, 0, acc) == acc, so the loop body needs no selects.
+        {
+            float v[KREG][CHUNK];
+#pragma unroll
+            for (int k = 0; k < KREG; ++k)
+#pragma unroll
+                for (int h = 0; h < CHUNK / 4; ++h) {
+                    const float4 q = val4[vslot<CHUNK>(ce[k], h)];     // ds_read_b128: 4 planes per LDS instruction
+                    v[k][4 * h] = q.x; v[k][4 * h + 1] = q.y; v[k][4 * h + 2] = q.z; v[k][4 * h + 3] = q.w;
+                }
+#pragma unroll
+            for (int k = 0; k < KREG; ++k)
+#pragma unroll
+                for (int u = 0; u < CHUNK; ++u) {
+                    if (MAXOP) acc[u] = fmaxf(ce[k] != NULL_E ? v[k][u] * cw[k] : -INFINITY, acc[u]);
+                    else acc[u] = __builtin_fmaf(v[k][u], cw[k], acc[u]);
+                }
+        }
+        for (uint32_t r = r0 + KREG; r < rl; r += RB) {
             float w[RB];
             uint32_t e[RB];
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
-                const uint2 q = rec[min(r + k, rl - 1)];           // stay inside this pixel's list
-                e[k] = q.x;
-                w[k] = __uint_as_float(q.y);
+                const bool on = r + k < rl;
+                const uint2 q = rec[on ? r + k : r];
+                e[k] = on ? q.x : NULL_E;
+                w[k] = on ? __uint_as_float(q.y) : 0.0f;
             }
             float v[RB][CHUNK];
 #pragma unroll
             for (int k = 0; k < RB; ++k)
 #pragma unroll
                 for (int h = 0; h < CHUNK / 4; ++h) {
-                    const float4 q = val4[vslot<CHUNK>(e[k], h)];  // ds_read_b128: 4 planes per LDS instruction
+                    const float4 q = val4[vslot<CHUNK>(e[k], h)];
                     v[k][4 * h] = q.x; v[k][4 * h + 1] = q.y; v[k][4 * h + 2] = q.z; v[k][4 * h + 3] = q.w;
                 }
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const bool on = r + k < rl;
+            for (int k = 0; k < RB; ++k)
 #pragma unroll
                 for (int u = 0; u < CHUNK; ++u) {
-                    if (MAXOP) acc[u] = fmaxf(on ? v[k][u] * w[k] : -INFINITY, acc[u]);
-                    else acc[u] = acc[u] + (on ? v[k][u] * w[k] : 0.0f);
+                    if (MAXOP) acc[u] = fmaxf(e[k] != NULL_E ? v[k][u] * w[k] : -INFINITY, acc[u]);
+                    else acc[u] = __builtin_fmaf(v[k][u], w[k], acc[u]);
                 }
-            }
         }
         for (unsigned long long hv = heavy; hv; hv &= hv - 1) {        // long lists, cooperatively
             const int src = __ffsll((long long)hv) - 1;
@@ -532,7 +566,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
                     const float xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        part[4 * h + i] = MAXOP ? fmaxf(xv[i] * w, part[4 * h + i]) : part[4 * h + i] + xv[i] * w;
+                        part[4 * h + i] = MAXOP ? fmaxf(xv[i] * w, part[4 * h + i]) : __builtin_fmaf(xv[i], w, part[4 * h + i]);
                 }
             }
 #pragma unroll
@@ -682,7 +716,7 @@ template <bool NORM, bool MAXOP, int EPT, int CHUNK>
 static int launch_tile(const SplatArgs &a, uint32_t items_cap, hipStream_t st) {
     // counts (T words) + wave sums (8) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
     const size_t lds = (size_t)(SPLAT_THREADS + 8 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
-                       (size_t)CHUNK * EPT * SPLAT_THREADS * 4;
+                       (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4;          // + the all-zero NULL entry
     static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
         SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>,
