@@ -105,10 +105,35 @@ __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ flow
         s = footprint_tiles(c, H, W);
     }
     const int tb = n * tiles;
-    wave_append<FILL>((s.vya & s.vxa) ? tb + s.tya * tiles_x + s.txa : -1, (uint32_t)i, counter, listoff, list);
-    wave_append<FILL>((s.vya & s.vxb) ? tb + s.tya * tiles_x + s.txb : -1, (uint32_t)i, counter, listoff, list);
-    wave_append<FILL>((s.vyb & s.vxa) ? tb + s.tyb * tiles_x + s.txa : -1, (uint32_t)i, counter, listoff, list);
-    wave_append<FILL>((s.vyb & s.vxb) ? tb + s.tyb * tiles_x + s.txb : -1, (uint32_t)i, counter, listoff, list);
+    int tile[4] = {(s.vya & s.vxa) ? tb + s.tya * tiles_x + s.txa : -1, (s.vya & s.vxb) ? tb + s.tya * tiles_x + s.txb : -1,
+                   (s.vyb & s.vxa) ? tb + s.tyb * tiles_x + s.txa : -1, (s.vyb & s.vxb) ? tb + s.tyb * tiles_x + s.txb : -1};
+    // Fast path: the lanes of a wave (64 consecutive pixels of a row) almost always agree on the
+    // tile of a footprint slot.  The reservation atomics of the four slots' first tiles are issued
+    // back to back (one memory round trip instead of four); lanes that disagree fall through to
+    // the generic wave_append loop.
+    const int lane = threadIdx.x & 63;
+    int leader[4], lt[4];
+    unsigned long long same[4];
+    uint32_t base[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long todo = __ballot(tile[k] >= 0);
+        leader[k] = todo ? __ffsll((long long)todo) - 1 : 0;
+        lt[k] = __shfl(tile[k], leader[k]);
+        same[k] = todo ? __ballot(tile[k] == lt[k]) : 0ull;
+        base[k] = 0;
+        if (same[k] && lane == leader[k]) base[k] = atomicAdd(&counter[lt[k]], (uint32_t)__popcll(same[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (FILL && same[k]) {
+            const uint32_t b = __shfl(base[k], leader[k]);
+            if (tile[k] == lt[k] && tile[k] >= 0)
+                list[listoff[lt[k]] + b + (uint32_t)__popcll(same[k] & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        }
+        if (tile[k] == lt[k]) tile[k] = -1;                      // served
+        wave_append<FILL>(tile[k], (uint32_t)i, counter, listoff, list);   // leftovers (rare)
+    }
 }
 
 // Block-wide exclusive scan helper (1024 threads), returns the block total.
