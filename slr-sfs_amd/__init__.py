@@ -11,7 +11,7 @@ GPU (so the build can be checked), but every operator raises if the library is m
 tensors are not on a ROCm device.
 """
 from . import _lib  # noqa: F401
-from . import softsplat, euler_integration_manipulator, synthesis, nets, pipeline, parallel  # noqa: F401
+from . import softsplat, euler_integration_manipulator, synthesis, nets, pipeline, parallel, io  # noqa: F401
 from .softsplat import FunctionSoftsplat, ModuleSoftsplat, ModuleMaximumsplat, ModuleMaximumWarpNormsplat  # noqa: F401
 from .euler_integration_manipulator import euler_integration, EulerIntegration, euler_integration_all  # noqa: F401
 from .dropin import install_into_reference  # noqa: F401
