@@ -157,6 +157,7 @@ def main():
         line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                               # rank 0's extra measurements are done: leave together
         dist.destroy_process_group()
 
 

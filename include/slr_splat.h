@@ -162,13 +162,17 @@ int slr_max_warp_norm(const float *in, const float *flow, float *scratch, float 
 int slr_bn_relu_mask(const float *x, const float *scale, const float *shift, const float *mask,
                      int mask_channels, float *y, int N, int C, int H, int W, void *stream);
 
-/* Partial-convolution epilogue: out = ((raw - b)*ratio + b)*um (+ residual) with
- * um = clamp(um_raw,0,1), ratio = winsize/(um_raw + 1e-8)*um.  Replaces
- * models/layers/partialconv2d.py:64-74 (+ the residual add of blocks.py:248).
- *   raw [N,C,H,W] convolution output incl. bias; um_raw [N,1,H,W] = box filter of the mask sum;
- *   residual [N,C,H,W] or NULL; winsize = Cin*k*k. */
-int slr_pconv_epilogue(const float *raw, const float *bias, const float *um_raw, const float *residual,
-                       float *out, float winsize, int N, int C, int H, int W, void *stream);
+/* Partial-convolution epilogue on the bias-free convolution output raw0:
+ *   o = (raw0*ratio + b)*um,  um = clamp(um_raw,0,1),  ratio = winsize/(um_raw + 1e-8)*um
+ * then optionally  o += residual            (blocks.py:248)
+ * or               o  = relu(o*next_scale - next_shift)*um   (BN + ReLU + input*mask of the next
+ *                       partial convolution of the block, blocks.py:233-236 / partialconv2d.py:69).
+ * Replaces models/layers/partialconv2d.py:64-74.
+ *   raw0 [N,C,H,W]; um_raw [N,1,H,W] = box filter of the mask sum; residual [N,C,H,W] or NULL;
+ *   next_scale/next_shift [C] or NULL (exclusive with residual); winsize = Cin*k*k. */
+int slr_pconv_epilogue(const float *raw0, const float *bias, const float *um_raw, const float *residual,
+                       const float *next_scale, const float *next_shift, float *out, float winsize,
+                       int N, int C, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -39,14 +39,22 @@ __global__ __launch_bounds__(256) void bn_relu_mask_kernel(const V *__restrict__
     }
 }
 
-// out = ((raw - b[c]) * ratio + b[c]) * um  (+ res),   ratio = winsize/(umr + 1e-8) * um,  um = clamp(umr, 0, 1)
-// raw [N,C,H,W] conv output incl. bias, umr [N,1,H,W] box-filtered mask sum (partialconv2d.py:61-74)
-template <bool RES, typename V>
+// Partial-convolution epilogue (partialconv2d.py:61-74) on the BIAS-FREE convolution output raw0:
+//   o = (raw0 * ratio + b[c]) * um,   ratio = winsize/(umr + 1e-8) * um,   um = clamp(umr, 0, 1)
+// (the reference forms raw0 + b inside the convolution and subtracts b again; skipping that
+// round trip differs by <= 1 ulp of |raw0 + b| and saves a full-size bias-add pass)
+//   RES:  o += res                                   (residual add, blocks.py:248)
+//   NEXT: o  = relu(o*scale2[c] - shift2[c]) * um    (BN + ReLU + input*mask of the NEXT partial
+//                                                     convolution, whose mask is this update mask)
+template <bool RES, bool NEXT, typename V>
 __global__ __launch_bounds__(256) void pconv_epilogue_kernel(const V *__restrict__ raw, const float *__restrict__ bias,
                                                              const V *__restrict__ umr, const V *__restrict__ res,
-                                                             V *__restrict__ out, float winsize, int C, int HWv) {
+                                                             const float *__restrict__ scale2,
+                                                             const float *__restrict__ shift2, V *__restrict__ out,
+                                                             float winsize, int C, int HWv) {
     const int c = blockIdx.y, n = blockIdx.z;
     const float b = bias[c];
+    const float sc = NEXT ? scale2[c] : 1.0f, sh = NEXT ? shift2[c] : 0.0f;
     const size_t base = ((size_t)n * C + c) * HWv;
     constexpr int L = sizeof(V) / 4;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HWv; i += gridDim.x * 256) {
@@ -62,8 +70,9 @@ __global__ __launch_bounds__(256) void pconv_epilogue_kernel(const V *__restrict
             const float um = fminf(fmaxf(uf[k], 0.0f), 1.0f);                // :66
             // scalar / tensor is reciprocal(tensor) * scalar in torch (Tensor.__rtruediv__): same here
             const float ratio = (1.0f / (uf[k] + 1e-8f)) * winsize * um;     // :64,67
-            float o = ((vf[k] - b) * ratio + b) * um;                        // :72-74
+            float o = (vf[k] * ratio + b) * um;                              // :72-74
             if (RES) o += rf[k];                                             // blocks.py:248
+            if (NEXT) o = fmaxf(o * sc - sh, 0.0f) * um;                     // blocks.py:233-236, partialconv2d.py:69
             vf[k] = o;
         }
         out[base + i] = v;
@@ -101,19 +110,30 @@ SLR_EXPORT int slr_bn_relu_mask(const float *x, const float *scale, const float 
     return 0;
 }
 
-SLR_EXPORT int slr_pconv_epilogue(const float *raw, const float *bias, const float *um_raw, const float *residual,
-                                  float *out, float winsize, int N, int C, int H, int W, void *stream) {
-    SLR_CHECK_ARG(raw && bias && um_raw && out, "null pointer");
+SLR_EXPORT int slr_pconv_epilogue(const float *raw0, const float *bias, const float *um_raw, const float *residual,
+                                  const float *next_scale, const float *next_shift, float *out, float winsize,
+                                  int N, int C, int H, int W, void *stream) {
+    SLR_CHECK_ARG(raw0 && bias && um_raw && out, "null pointer");
+    SLR_CHECK_ARG(!next_scale == !next_shift, "next_scale / next_shift go together");
+    SLR_CHECK_ARG(!(residual && next_scale), "residual and next-BN fusion are exclusive");
     SLR_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && C <= 65535 && N <= 65535, "sizes");
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W;
-    const bool v4 = (HW % 4 == 0) && !(((uintptr_t)raw | (uintptr_t)out | (uintptr_t)um_raw | (uintptr_t)residual) & 15);
-#define LAUNCH(R, V, n)                                                                                    \
+    const bool v4 = (HW % 4 == 0) && !(((uintptr_t)raw0 | (uintptr_t)out | (uintptr_t)um_raw | (uintptr_t)residual) & 15);
+#define LAUNCH(R, X, V, n)                                                                                 \
     launch_planes<V>([&](dim3 g, hipStream_t s) {                                                            \
-        hipLaunchKernelGGL((pconv_epilogue_kernel<R, V>), g, dim3(256), 0, s, (const V *)raw, bias,        \
-                           (const V *)um_raw, (const V *)residual, (V *)out, winsize, C, n); }, N, C, n, st)
-    if (v4) { if (residual) LAUNCH(true, float4, HW / 4); else LAUNCH(false, float4, HW / 4); }
-    else    { if (residual) LAUNCH(true, float, HW);      else LAUNCH(false, float, HW); }
+        hipLaunchKernelGGL((pconv_epilogue_kernel<R, X, V>), g, dim3(256), 0, s, (const V *)raw0, bias,    \
+                           (const V *)um_raw, (const V *)residual, next_scale, next_shift, (V *)out,      \
+                           winsize, C, n); }, N, C, n, st)
+    if (v4) {
+        if (residual) LAUNCH(true, false, float4, HW / 4);
+        else if (next_scale) LAUNCH(false, true, float4, HW / 4);
+        else LAUNCH(false, false, float4, HW / 4);
+    } else {
+        if (residual) LAUNCH(true, false, float, HW);
+        else if (next_scale) LAUNCH(false, true, float, HW);
+        else LAUNCH(false, false, float, HW);
+    }
 #undef LAUNCH
     SLR_CHECK_LAUNCH();
     return 0;

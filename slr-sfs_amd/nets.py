@@ -48,21 +48,26 @@ def bn_relu_mask(x, scale, shift, mask):
     return F.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * m
 
 
-def pconv_epilogue(raw, bias, um_raw, winsize, residual=None):
-    """((raw - b)*ratio + b)*um (+ residual), partialconv2d.py:64-74."""
-    if _fused_ok(raw, um_raw, *([] if residual is None else [residual])):
-        N, C, H, W = raw.shape
-        out = torch.empty_like(raw)
-        with torch.cuda.device(raw.device):
-            _lib.check(_lib.lib().slr_pconv_epilogue(_lib.ptr(raw), _lib.ptr(bias), _lib.ptr(um_raw), _lib.ptr(residual),
-                                                     _lib.ptr(out), float(winsize), N, C, H, W,
-                                                     _lib.stream_of(raw)), "slr_pconv_epilogue")
+def pconv_epilogue(raw0, bias, um_raw, winsize, residual=None, next_bn=None):
+    """(raw0*ratio + b)*um on the bias-free convolution output, then `+ residual` or the next
+    convolution's relu(bn(.))*um  (partialconv2d.py:64-74, blocks.py:233-236,248)."""
+    if _fused_ok(raw0, um_raw, *([] if residual is None else [residual])):
+        N, C, H, W = raw0.shape
+        out = torch.empty_like(raw0)
+        sc, sh = next_bn if next_bn is not None else (None, None)
+        with torch.cuda.device(raw0.device):
+            _lib.check(_lib.lib().slr_pconv_epilogue(_lib.ptr(raw0), _lib.ptr(bias), _lib.ptr(um_raw), _lib.ptr(residual),
+                                                     _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(out), float(winsize),
+                                                     N, C, H, W, _lib.stream_of(raw0)), "slr_pconv_epilogue")
         return out
     um = torch.clamp(um_raw, 0, 1)
     ratio = winsize / (um_raw + 1e-8) * um
-    b = bias.view(1, -1, 1, 1)
-    out = ((raw - b) * ratio + b) * um
-    return out if residual is None else out + residual
+    out = (raw0 * ratio + bias.view(1, -1, 1, 1)) * um
+    if residual is not None:
+        out = out + residual
+    if next_bn is not None:
+        out = F.relu(out * next_bn[0].view(1, -1, 1, 1) - next_bn[1].view(1, -1, 1, 1)) * um
+    return out
 
 
 # --------------------------------------------------------------------------- building blocks
@@ -102,22 +107,17 @@ class Conv(nn.Module):
 
 
 class PartialConv(Conv):
-    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81,
-    fused with the BN + ReLU in front of it (blocks.py:229-231).
-    ``mask`` is [N,1,H,W] (channel-uniform), [N,Cin,H,W], or None = (x != 0) per channel
-    (architectures.py:369); returns (out, update_mask [N,1,H,W])."""
+    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81.
+    ``xin`` is the already activated and masked input relu(bn(x))*mask (blocks.py:229-231,
+    partialconv2d.py:69); ``msum`` [N,1,H,W] the channel sum of its mask.
+    Returns (out, update_mask [N,1,H,W]); with ``next_bn`` the output is already the activated,
+    masked input of the block's second convolution."""
 
-    def forward(self, x, bn, mask, residual=None):
-        if mask is None:
-            msum = (x != 0).sum(1, keepdim=True).to(x.dtype)
-        else:
-            msum = mask.sum(1, keepdim=True) if mask.shape[1] != 1 else mask * float(self.cin)
+    def forward(self, xin, msum, residual=None, next_bn=None):
         # conv(mask, ones[out,in,k,k]) == box_k(sum_c mask), identical for every output channel (:61)
         um_raw = F.avg_pool2d(msum, self.k, stride=1, padding=self.pad, divisor_override=1)
-        scale, shift = bn.scale_shift()
-        xin = bn_relu_mask(x, scale, shift, mask)                                  # BN, ReLU, input*mask (:69)
-        raw = F.conv2d(xin, self.weight, self.bias, padding=self.pad)                            # :69
-        out = pconv_epilogue(raw, self.bias, um_raw, self.cin * self.k * self.k, residual)       # :64-74
+        raw0 = F.conv2d(xin, self.weight, None, padding=self.pad)                                # bias joins in the epilogue
+        out = pconv_epilogue(raw0, self.bias, um_raw, self.cin * self.k * self.k, residual, next_bn)   # :64-74
         return out, torch.clamp(um_raw, 0, 1)
 
 
@@ -151,9 +151,9 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         a = self.conv_aa(F.relu(self.bn1(x)))
-        a = self.resample(self.conv_ab(F.relu(self.bn2(a))))
-        b = self.resample(self.conv_b(x)) if self.conv_b is not None else x
-        return a + b
+        a = self.conv_ab(F.relu(self.bn2(a)))
+        b = self.conv_b(x) if self.conv_b is not None else x
+        return self.resample(a + b)          # == resample(a) + resample(b): both resamplers are linear
 
 
 class PconvResBlock(nn.Module):
@@ -168,13 +168,18 @@ class PconvResBlock(nn.Module):
         self.has_resample = bool(resample)
 
     def forward(self, x, mask):
-        a, m = self.conv_aa(x, self.bn1, mask)                                    # :229-231
-        if self.conv_b is None and not self.has_resample:
-            return self.conv_ab(a, self.bn2, m, residual=x)                       # :233-239 + x_a + x_b (:248)
-        a, m = self.conv_ab(a, self.bn2, m)                                       # :233-239
-        a, m = self.resample(a), self.resample_mask(m)                            # :240-241
-        b = self.resample(self.conv_b(x)) if self.conv_b is not None else x       # :243-247
-        return a + b, m
+        # mask: None = (x != 0) per channel (architectures.py:369), else [N,1,H,W] channel-uniform
+        s1, h1 = self.bn1.scale_shift()
+        xin = bn_relu_mask(x, s1, h1, mask)                                        # :229-231
+        msum = (x != 0).sum(1, keepdim=True).to(x.dtype) if mask is None else mask * float(x.shape[1])
+        a, m = self.conv_aa(xin, msum, next_bn=self.bn2.scale_shift())             # -> relu(bn2(.))*m (:233-236)
+        msum = m * float(a.shape[1])
+        # x_a + x_b (:248).  The reference resamples the two branches separately and adds; avg-pool
+        # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
+        # rounding, lets the residual join the epilogue, and halves the resampling work.
+        skip = self.conv_b(x) if self.conv_b is not None else x                    # :243-247
+        a, m = self.conv_ab(a, msum, residual=skip)                                # :237-239
+        return self.resample(a), self.resample_mask(m)                             # :240-241
 
 
 # --------------------------------------------------------------------------- networks

@@ -394,10 +394,11 @@ def test_fused_decoder_stages_match_torch_definition(S):
         res = torch.randn(N, C, H, W, device="cuda", generator=g)
         um = torch.clamp(umr, 0, 1)
         ratio = 27.0 / (umr + 1e-8) * um
-        b = bias.view(1, -1, 1, 1)
-        ref = ((raw - b) * ratio + b) * um
+        ref = (raw * ratio + bias.view(1, -1, 1, 1)) * um
         assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0), ref)
         assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0, res), ref + res)
+        nxt = torch.relu(ref * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * um
+        assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0, next_bn=(scale, shift)), nxt)
 
 
 def test_decoder_gpu_matches_cpu_definition(S):
