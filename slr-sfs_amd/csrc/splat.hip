@@ -175,15 +175,26 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *__restric
     if (threadIdx.x == 0) listoff[nt] = run;
 }
 
+// Everything a tile workgroup needs to know about its work item, in ONE 32-byte record (one scalar
+// load instead of a chain of dependent lookups through items -> count/listoff/nseg/partoff).
+struct ItemDesc {
+    uint32_t tile, seg;          // tile index (n*tiles + tile), segment of its concatenated bin
+    uint32_t cnt0, cnt1;         // entries in the bin of flow 0 / flow 1
+    uint32_t off0, off1;         // where those bins start in list[0] / list[1]
+    uint32_t nseg, partoff;      // segments of the tile; first partial slot (multi-segment tiles)
+};
+
 // Work plan for splatting with one (count1 == nullptr) or two flows per tile:
 // nseg[t] = segments of the concatenated bin, items[] = (tile, segment) work list, partoff[t] =
 // first partial slot of a multi-segment tile.  A tile that does not fit into the partial
 // budget is left in one piece (correct, just slower).  Single workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ count0,
-                                                    const uint32_t *__restrict__ count1, uint32_t nt,
+                                                    const uint32_t *__restrict__ count1,
+                                                    const uint32_t *__restrict__ listoff0,
+                                                    const uint32_t *__restrict__ listoff1, uint32_t nt,
                                                     uint32_t seg, uint32_t part_slots,
                                                     uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
-                                                    uint2 *__restrict__ items, uint32_t *__restrict__ totals) {
+                                                    ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
     __shared__ uint32_t wsum[16];
     uint32_t run_items = 0, run_parts = 0;
     for (uint32_t b = 0; b < nt; b += 1024) {
@@ -200,7 +211,11 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         if (t < nt) {
             nseg[t] = ns;
             partoff[t] = run_parts + pex;
-            for (uint32_t s = 0; s < ns; ++s) items[run_items + iex + s] = make_uint2(t, s);
+            ItemDesc d;
+            d.tile = t; d.cnt0 = count0[t]; d.cnt1 = count1 ? count1[t] : 0u;
+            d.off0 = listoff0[t]; d.off1 = listoff1 ? listoff1[t] : 0u;
+            d.nseg = ns; d.partoff = run_parts + pex;
+            for (uint32_t s = 0; s < ns; ++s) { d.seg = s; items[run_items + iex + s] = d; }
         }
         run_items += itot;
         run_parts += ptot;
@@ -220,7 +235,7 @@ struct SplatArgs {
     const uint32_t *count[2], *listoff[2], *list[2];
     float scale[2];         // alpha, 1 - alpha
     const uint32_t *nseg, *partoff, *totals;
-    const uint2 *items;
+    const ItemDesc *items;
     float *partial, *trash;
     float *out;             // [N,C,H,W]
     float *norm_out;        // [N,1,H,W] or nullptr
@@ -309,8 +324,8 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     const uint32_t slot = blockIdx.x >> 3;
     const uint32_t item = ((slot / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + slot % XCD_GROUP;
     if (item >= total) return;
-    const uint2 it = a.items[item];
-    const uint32_t t = it.x, s = it.y;
+    const ItemDesc it = a.items[item];
+    const uint32_t t = it.tile, s = it.seg;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
     const int HW = a.H * a.W;
@@ -347,10 +362,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     float preA[EPT_MAX][CHUNK], preB[EPT_MAX][CHUNK];
     {
         // entry j of this work-item = element lo + tid + j*T of [bin(flow0) ; bin(flow1)]
-        const uint32_t c0 = a.count[0][t];
-        const uint32_t c1 = a.ndir > 1 ? a.count[1][t] : 0u;
-        const uint32_t *l0 = a.list[0] + a.listoff[0][t];
-        const uint32_t *l1 = a.ndir > 1 ? a.list[1] + a.listoff[1][t] : l0;
+        const uint32_t c0 = it.cnt0, c1 = it.cnt1;
+        const uint32_t *l0 = a.list[0] + it.off0;
+        const uint32_t *l1 = a.ndir > 1 ? a.list[1] + it.off1 : l0;
         const float *mp = has_mul ? a.mul + (size_t)n * HW : nullptr;
         bool (&val)[EPT_MAX] = e_val;
         int dir[EPT_MAX];
@@ -468,9 +482,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool inside = (oy < a.H) & (ox < a.W);
-    const bool single = a.nseg[t] == 1;
+    const bool single = it.nseg == 1;
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
-                       : a.partial + (size_t)(a.partoff[t] + s) * a.part_stride + tid;
+                       : a.partial + (size_t)(it.partoff + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
     // register-resident head of this pixel's record list (see the gather loop)
     constexpr uint32_t NULL_E = SEG;                   // staged-entry index of the all-zero slot
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
         if (single) {
             if (a.norm_out && inside) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
         } else {
-            a.partial[(size_t)(a.partoff[t] + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid] = nrm;
+            a.partial[(size_t)(it.partoff + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid] = nrm;
         }
     }
 
@@ -692,7 +706,7 @@ struct Ws {
     WsLayout L;
     char *base;
     uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals;
-    uint2 *items;
+    ItemDesc *items;
     float *partial, *trash;
 };
 
@@ -709,7 +723,7 @@ static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, co
     w.list = (uint32_t *)(w.base + w.L.off_list);
     w.nseg = (uint32_t *)(w.base + w.L.off_nseg);
     w.partoff = (uint32_t *)(w.base + w.L.off_partoff);
-    w.items = (uint2 *)(w.base + w.L.off_items);
+    w.items = (ItemDesc *)(w.base + w.L.off_items);
     w.totals = (uint32_t *)(w.base + w.L.off_totals);
     w.partial = (float *)(w.base + w.L.off_partial);
     w.trash = (float *)(w.base + w.L.off_trash);
@@ -769,7 +783,8 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
 #endif
     a.part_stride = w0.L.part_stride;
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
-                       (const uint32_t *)(w1 ? w1->count : nullptr), w0.L.nt, (uint32_t)a.seg,
+                       (const uint32_t *)(w1 ? w1->count : nullptr), (const uint32_t *)w0.listoff,
+                       (const uint32_t *)(w1 ? w1->listoff : nullptr), w0.L.nt, (uint32_t)a.seg,
                        w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.totals);
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
     if (w1) {
