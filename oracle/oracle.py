@@ -164,7 +164,7 @@ def _exp32(x):
     return np.exp(x.astype(np.float32)).astype(np.float32)
 
 
-def synth_baseline(fs, Z, motion, t, N, clamp_z=None):
+def synth_baseline(fs, Z, motion, t, N, clamp_z=None, variant=None):
     """Decoder input of AnimatingSoftmaxSplating.forward_flow for index=[0,t,N-1]
     -- animating_softmax_splating.py:847-862,884-924.  fs [1,64,H,W], Z [1,1,H,W],
     motion [1,2,H,W] -> gen_fs [1,64,H,W].  clamp_z=None is the shipped behaviour
@@ -173,7 +173,12 @@ def synth_baseline(fs, Z, motion, t, N, clamp_z=None):
     f32 = np.float32
     disp_f, _ = euler_integration(motion, t)                            # :847  m - s
     disp_p, _ = euler_integration(-motion, N - t)                       # :848  e - m + 1
-    Zn = Z - Z.max()                                                    # :855
+    if variant == "v2":                                                 # :849-851
+        Zn = Z - maximum_warp_norm_splat(Z, disp_f)
+    elif variant == "v1":                                               # :852-853
+        Zn = Z
+    else:
+        Zn = Z - Z.max()                                                # :855
     if clamp_z is not None:
         Zn = np.clip(Zn, f32(clamp_z[0]), f32(clamp_z[1]))              # :859
     alpha = f32(1.0) - f32(t) / f32(N)                                  # :860  1 - (m-s)/(e-s+1)

@@ -80,7 +80,7 @@ class ClipSynthesizer:
     """
 
     def __init__(self, fs, Z, motion, N, alpha_fluid_logit=None, alpha_bg=None, use_alpha0=True,
-                 clamp_alpha=None, softmax_v1=False, clamp_z=None):
+                 clamp_alpha=None, softmax_v1=False, softmax_v2=False, clamp_z=None):
         require_device(fs, Z, motion)
         assert fs.shape[0] == 1 and Z.shape[1] == 1 and motion.shape[1] == 2
         self.N = int(N)
@@ -89,8 +89,12 @@ class ClipSynthesizer:
         self.v1 = alpha_fluid_logit is not None
         # alpha clamp: only the 2-layer model has it (..._2layers_alpha_seperate.py:952)
         self.clamp_alpha = self.v1 if clamp_alpha is None else clamp_alpha
-        # Z_f_norm = Z - Z.max() unless use_softmax_splatter_v1 (animating_softmax_splating.py:849-855)
-        if clamp_z is not None:                                        # :856-859 (not the shipped behaviour)
+        # Z_f_norm = Z - Z.max() unless use_softmax_splatter_v1 / _v2 (animating_softmax_splating.py:849-855)
+        self.softmax_v2 = bool(softmax_v2)       # per-frame shift by the maximum-warp-norm splat of Z (:849-851)
+        self.clamp_z = clamp_z
+        if self.softmax_v2:
+            self.Z, self.zmax = Z, None
+        elif clamp_z is not None:                                        # :856-859 (not the shipped behaviour)
             Zn = Z if softmax_v1 else Z - Z.max()
             self.Z, self.zmax = torch.clamp(Zn, min=clamp_z[0], max=clamp_z[1]).contiguous(), None
         else:
@@ -126,7 +130,13 @@ class ClipSynthesizer:
         ws_f = bin_flow(disp_f, self.C, "f")
         ws_p = bin_flow(disp_p, self.C, "p")
         a = self.alpha(t)
-        res = synth_group(self.fs, self.Z, disp_f, disp_p, a, ws_f, ws_p, wmax=self.zmax,
+        Zt = self.Z
+        if self.softmax_v2:                      # Z_f_max = maximum_warp_norm_splater(Z_f, forward_flow)  (:849-851)
+            from .softsplat import _FunctionMaximumWarpNormsplat
+            Zt = self.Z - _FunctionMaximumWarpNormsplat(self.Z, disp_f.contiguous())
+            if self.clamp_z is not None:
+                Zt = torch.clamp(Zt, min=self.clamp_z[0], max=self.clamp_z[1])
+        res = synth_group(self.fs, Zt, disp_f, disp_p, a, ws_f, ws_p, wmax=self.zmax,
                           return_norm=return_norm, timed=True)
         gen, norm = res if return_norm else (res, None)
         if not self.v1:

@@ -453,3 +453,20 @@ def test_streams_and_workspace_reuse(S, oracle):
     side.synchronize()
     for i, o in outs:
         np.testing.assert_allclose(host(o), oracle.softsplat_forward(xs[i], fl[i]), **TOL)
+
+
+@pytest.mark.parametrize("variant", ["v1", "v2"])
+def test_softmax_splatter_variants_vs_oracle(S, oracle, variant):
+    """--use_softmax_splatter_v1 (no shift) and _v2 (shift by the maximum-warp-norm splat of Z,
+    animating_softmax_splating.py:849-853) against the oracle, with and without the Z clamp (:856-859)."""
+    H, W, N = 48, 80, 10
+    rng = np.random.default_rng(21)
+    fs = rng.standard_normal((1, 64, H, W)).astype(np.float32)
+    Z = (rng.standard_normal((1, 1, H, W)) * 2).astype(np.float32)
+    m = smooth_motion(H, W, 6, amp=2.5)
+    for clamp in (None, (-20.0, 20.0)):
+        cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, softmax_v1=(variant == "v1"),
+                                         softmax_v2=(variant == "v2"), clamp_z=clamp)
+        for t in (0, 4, 9):
+            ref = oracle.synth_baseline(fs, Z, m, t, N, clamp_z=clamp, variant=variant)
+            np.testing.assert_allclose(host(cs.features(t)), ref, rtol=2e-4, atol=2e-5)

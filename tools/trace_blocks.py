@@ -25,7 +25,7 @@ for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", d
     t0 = t[:, 0].min()
     print(name, "active blocks", len(t), "kernel span (ticks)", (t[:, 4:31].max() - t0))
     d = lambda a, b: np.median(t[:, b] - t[:, a])
-    print("  idx loads:", d(0, 28), " rest of 1a:", d(28, 1), " barrier:", d(1, 2), " scan+records:", d(2, 3), " -> first stage done:", d(3, 4))
+    print("  phase1a:", d(0, 1), " barrier:", d(1, 2), " scan+records:", d(2, 3), " -> first stage done:", d(3, 4))
     for c in range(9):
         b = 4 + 3 * c
         print(f"  chunk {c}: barrier wait {np.median(t[:, b+1]-t[:, b]):8.0f}  gather+store {np.median(t[:, b+2]-t[:, b+1]):8.0f}" +
