@@ -87,7 +87,11 @@ __device__ __forceinline__ void wave_append(int tile, uint32_t pix, uint32_t *__
     }
 }
 
-// grid (ceil(HW/256), N).  counter = count[] (FILL=false) or cursor[] (FILL=true).
+// grid (ceil(HW / (256*BIN_PPT)), N).  counter = count[] (FILL=false) or cursor[] (FILL=true).
+// The kernel is latency-bound (flow load -> footprint -> reservation atomic -> list store), so
+// every work-item handles BIN_PPT pixels (256 apart: each wave still sees 64 consecutive
+// pixels of a row per step) with all flow loads, then all fast-path reservations, in flight at once.
+constexpr int BIN_PPT = 4;
 template <bool FILL>
 __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ flow, int H, int W,
                                                   int tiles_x, int tiles,
@@ -96,44 +100,57 @@ __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ flow
                                                   uint32_t *__restrict__ list) {
     const int HW = H * W;
     const int n = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    TileSet s = {};
-    if (i < HW) {
-        const float *f = flow + (size_t)n * 2 * HW;
-        int y = i / W, x = i - y * W;
-        Corners c = make_corners(f[i], f[HW + i], x, y);
-        s = footprint_tiles(c, H, W);
-    }
-    const int tb = n * tiles;
-    int tile[4] = {(s.vya & s.vxa) ? tb + s.tya * tiles_x + s.txa : -1, (s.vya & s.vxb) ? tb + s.tya * tiles_x + s.txb : -1,
-                   (s.vyb & s.vxa) ? tb + s.tyb * tiles_x + s.txa : -1, (s.vyb & s.vxb) ? tb + s.tyb * tiles_x + s.txb : -1};
-    // Fast path: the lanes of a wave (64 consecutive pixels of a row) almost always agree on the
-    // tile of a footprint slot.  The reservation atomics of the four slots' first tiles are issued
-    // back to back (one memory round trip instead of four); lanes that disagree fall through to
-    // the generic wave_append loop.
     const int lane = threadIdx.x & 63;
-    int leader[4], lt[4];
-    unsigned long long same[4];
-    uint32_t base[4];
+    const float *f = flow + (size_t)n * 2 * HW;
+    const int tb = n * tiles;
+    int pix[BIN_PPT];
+    float fx[BIN_PPT], fy[BIN_PPT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned long long todo = __ballot(tile[k] >= 0);
-        leader[k] = todo ? __ffsll((long long)todo) - 1 : 0;
-        lt[k] = __shfl(tile[k], leader[k]);
-        same[k] = todo ? __ballot(tile[k] == lt[k]) : 0ull;
-        base[k] = 0;
-        if (same[k] && lane == leader[k]) base[k] = atomicAdd(&counter[lt[k]], (uint32_t)__popcll(same[k]));
+    for (int p = 0; p < BIN_PPT; ++p) {
+        pix[p] = (blockIdx.x * BIN_PPT + p) * 256 + threadIdx.x;
+        const int q = pix[p] < HW ? pix[p] : 0;
+        fx[p] = f[q];
+        fy[p] = f[HW + q];
     }
+    int tile[BIN_PPT][4], leader[BIN_PPT][4], lt[BIN_PPT][4];
+    unsigned long long same[BIN_PPT][4];
+    uint32_t base[BIN_PPT][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (FILL && same[k]) {
-            const uint32_t b = __shfl(base[k], leader[k]);
-            if (tile[k] == lt[k] && tile[k] >= 0)
-                list[listoff[lt[k]] + b + (uint32_t)__popcll(same[k] & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    for (int p = 0; p < BIN_PPT; ++p) {
+        TileSet s = {};
+        if (pix[p] < HW) {
+            const int y = pix[p] / W, x = pix[p] - y * W;
+            s = footprint_tiles(make_corners(fx[p], fy[p], x, y), H, W);
         }
-        if (tile[k] == lt[k]) tile[k] = -1;                      // served
-        wave_append<FILL>(tile[k], (uint32_t)i, counter, listoff, list);   // leftovers (rare)
+        tile[p][0] = (s.vya & s.vxa) ? tb + s.tya * tiles_x + s.txa : -1;
+        tile[p][1] = (s.vya & s.vxb) ? tb + s.tya * tiles_x + s.txb : -1;
+        tile[p][2] = (s.vyb & s.vxa) ? tb + s.tyb * tiles_x + s.txa : -1;
+        tile[p][3] = (s.vyb & s.vxb) ? tb + s.tyb * tiles_x + s.txb : -1;
+        // Fast path: the lanes of a wave (64 consecutive pixels of a row) almost always agree on
+        // the tile of a footprint slot; one reservation per slot, issued without waiting.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long todo = __ballot(tile[p][k] >= 0);
+            leader[p][k] = todo ? __ffsll((long long)todo) - 1 : 0;
+            lt[p][k] = __shfl(tile[p][k], leader[p][k]);
+            same[p][k] = todo ? __ballot(tile[p][k] == lt[p][k]) : 0ull;
+            base[p][k] = 0;
+            if (same[p][k] && lane == leader[p][k])
+                base[p][k] = atomicAdd(&counter[lt[p][k]], (uint32_t)__popcll(same[p][k]));
+        }
     }
+#pragma unroll
+    for (int p = 0; p < BIN_PPT; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (FILL && same[p][k]) {
+                const uint32_t b = __shfl(base[p][k], leader[p][k]);
+                if (tile[p][k] == lt[p][k] && tile[p][k] >= 0)
+                    list[listoff[lt[p][k]] + b + (uint32_t)__popcll(same[p][k] & ((1ull << lane) - 1ull))] = (uint32_t)pix[p];
+            }
+            if (tile[p][k] == lt[p][k]) tile[p][k] = -1;                       // served
+            wave_append<FILL>(tile[p][k], (uint32_t)pix[p], counter, listoff, list);   // lanes that disagree (rare)
+        }
 }
 
 // Block-wide exclusive scan helper (1024 threads), returns the block total.
@@ -740,7 +757,7 @@ static int check_dims(int N, int C, int H, int W, const char *who) {
 
 static int do_bin(const float *flow, int N, int H, int W, Ws &w, hipStream_t st) {
     SLR_CHECK_HIP(hipMemsetAsync(w.count, 0, (size_t)w.L.nt * 4, st));
-    dim3 grid((H * W + 255) / 256, N);
+    dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), N);
     hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, flow, H, W, w.L.tiles_x, w.L.tiles,
                        w.count, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w.count, w.L.nt,
