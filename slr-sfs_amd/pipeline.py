@@ -18,6 +18,47 @@ from . import nets
 from .synthesis import ClipSynthesizer
 
 
+def _features_ahead(clip, frames):
+    """Yield clip.features(t) for t in frames, computing frame i+1's features on a side HIP stream
+    while the caller's (current) stream is busy with frame i's decoder: the splat stage is
+    HBM-bound, the decoder convolutions are compute-bound, so they overlap well.  Tensors that
+    cross streams are registered with the caching allocator (record_stream)."""
+    frames = list(frames)
+    if not frames:
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    side.wait_stream(main)                       # per-clip state (fs, Z, displacement maps) is ready
+
+    def launch(t):
+        with torch.cuda.stream(side):
+            out = clip.features(t)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return out, ev
+
+    nxt = launch(frames[0])
+    for i in range(len(frames)):
+        out, ev = nxt
+        if i + 1 < len(frames):
+            nxt = launch(frames[i + 1])
+        main.wait_event(ev)
+        for x in (out if isinstance(out, tuple) else (out,)):
+            x.record_stream(main)
+        yield out
+    side.wait_stream(main)
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = device.index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def prepare_motion(flow, H, W, speed=1.0, align=None, N=None):
     """Motion preparation of the test scripts (test_baseline_4eval_rawsize.py:173-184,222-226):
     scale a [1,2,h,w] field to the working grid, nearest-resize it, optional speed alignment."""
@@ -65,8 +106,8 @@ class BaselineAnimator(torch.nn.Module):
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, t in enumerate(frames):
-            out[i] = self.frame(clip, t)[0]
+        for i, gen_fs in enumerate(_features_ahead(clip, frames)):
+            out[i] = torch.tanh(self.projector(gen_fs))[0]
         return out
 
 
@@ -94,7 +135,9 @@ class SLRv1Animator(torch.nn.Module):
 
     @torch.no_grad()
     def frame(self, clip, t):
-        gen_fs, alpha_fluid = clip.features(t)                      # :950-1045
+        return self._decode(clip, *clip.features(t))                # :950-1045
+
+    def _decode(self, clip, gen_fs, alpha_fluid):
         fluid = torch.tanh(self.projector(gen_fs))                  # :1048-1049
         fluid_alpha = torch.sigmoid(self.net_alpha_decoder(torch.cat([gen_fs, alpha_fluid], 1)))   # :1052-1054
         alpha_norm = torch.clamp(fluid_alpha + clip.alpha_bg, min=1e-8)                            # :1056-1057
@@ -107,6 +150,6 @@ class SLRv1Animator(torch.nn.Module):
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, t in enumerate(frames):
-            out[i] = self.frame(clip, t)["PredImg"][0]
+        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames)):
+            out[i] = self._decode(clip, gen_fs, alpha_fluid)["PredImg"][0]
         return out

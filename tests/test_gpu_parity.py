@@ -470,3 +470,30 @@ def test_softmax_splatter_variants_vs_oracle(S, oracle, variant):
         for t in (0, 4, 9):
             ref = oracle.synth_baseline(fs, Z, m, t, N, clamp_z=clamp, variant=variant)
             np.testing.assert_allclose(host(cs.features(t)), ref, rtol=2e-4, atol=2e-5)
+
+
+def test_synthesize_stream_overlap_equals_sequential(S):
+    """synthesize() computes frame i+1's features on a side stream under frame i's decoder.  The
+    features must match the plain per-frame path to summation-order noise (bins are filled in a
+    non-deterministic order, like the reference's atomics), the frames to that noise amplified by
+    the random-weight decoder."""
+    H, W, N = 40, 72, 7
+    torch.manual_seed(1)
+    for an in (S.pipeline.BaselineAnimator().cuda().eval(), S.pipeline.SLRv1Animator().cuda().eval()):
+        img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+        m = dev(smooth_motion(H, W, 5, amp=2.0))
+        order = [0, 2, 3, 6]
+        for rep in range(2):
+            clip = an.begin_clip(img, m, N)
+            ahead = [tuple(x.clone() for x in (o if isinstance(o, tuple) else (o,)))
+                     for o in S.pipeline._features_ahead(clip, order)]
+            torch.cuda.synchronize()
+            for got, t in zip(ahead, order):
+                ref = clip.features(t)
+                for g, r in zip(got, ref if isinstance(ref, tuple) else (ref,)):
+                    assert torch.allclose(g, r, rtol=1e-5, atol=1e-5), (rep, t)
+            frames = an.synthesize(img, m, N, frames=order)
+            for i, t in enumerate(order):
+                f = an.frame(clip, t)
+                f = f["PredImg"] if isinstance(f, dict) else f
+                assert (frames[i] - f[0]).abs().max().item() < 5e-3, (rep, t)
