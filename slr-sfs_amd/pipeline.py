@@ -18,13 +18,18 @@ from . import nets
 from .synthesis import ClipSynthesizer
 
 
-def _features_ahead(clip, frames):
-    """Yield clip.features(t) for t in frames, computing frame i+1's features on a side HIP stream
-    while the caller's (current) stream is busy with frame i's decoder: the splat stage is
-    HBM-bound, the decoder convolutions are compute-bound, so they overlap well.  Tensors that
-    cross streams are registered with the caching allocator (record_stream)."""
+def _features_ahead(clip, frames, overlap=True):
+    """Yield clip.features(t) for t in frames.  overlap=True computes frame i+1's features on a
+    side HIP stream while the caller's (current) stream is busy with frame i's decoder (the splat
+    stage is HBM-bound, the decoder convolutions compute-bound).  Measured on MI355X at C3: +1 %
+    frames/s, but the splat kernel itself runs 1.6x longer next to the convolutions (244 -> 403 us),
+    so it is OFF by default; tensors that cross streams are registered with the caching allocator."""
     frames = list(frames)
     if not frames:
+        return
+    if not overlap:
+        for t in frames:
+            yield clip.features(t)
         return
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
@@ -101,12 +106,12 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None):
+    def synthesize(self, image, motion, N, frames=None, overlap=False):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device."""
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, gen_fs in enumerate(_features_ahead(clip, frames)):
+        for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = torch.tanh(self.projector(gen_fs))[0]
         return out
 
@@ -146,10 +151,10 @@ class SLRv1Animator(torch.nn.Module):
                 "CompositeFluidAlpha": fluid_alpha / alpha_norm}                                   # :1087-1093
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None):
+    def synthesize(self, image, motion, N, frames=None, overlap=False):
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames)):
+        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = self._decode(clip, gen_fs, alpha_fluid)["PredImg"][0]
         return out

@@ -492,7 +492,7 @@ def test_synthesize_stream_overlap_equals_sequential(S):
                 ref = clip.features(t)
                 for g, r in zip(got, ref if isinstance(ref, tuple) else (ref,)):
                     assert torch.allclose(g, r, rtol=1e-5, atol=1e-5), (rep, t)
-            frames = an.synthesize(img, m, N, frames=order)
+            frames = an.synthesize(img, m, N, frames=order, overlap=bool(rep))
             for i, t in enumerate(order):
                 f = an.frame(clip, t)
                 f = f["PredImg"] if isinstance(f, dict) else f
