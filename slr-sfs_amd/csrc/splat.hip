@@ -10,19 +10,21 @@
 // Here the scatter is turned around.  The flow is shared by all C channels, so it is cheap
 // to sort it once:
 //   1. bin   (count -> scan -> fill): every source pixel is appended to the bin of each
-//            16x64 OUTPUT tile its 2x2 bilinear footprint touches (<= 4 tiles);
+//            8x64 OUTPUT tile its 2x2 bilinear footprint touches (<= 4 tiles);
 //   2. plan : bins are cut into segments of <= SEG entries (load balance: Euler-integrated
-//            fluid flows pile up to 7x the average into some tiles);
-//   3. splat: one workgroup = (tile, segment, channel group).  It walks its bin segment --
-//            consecutive entries are consecutive source pixels, so the per-channel plane
-//            reads are coalesced 256-byte wavefront loads -- and accumulates v*w into an LDS
-//            image of the tile with ds_add_f32.  A single-segment tile is normalised in LDS
-//            and written with coalesced float4 stores: every output byte is written exactly
-//            once, never read, never zeroed;
-//   4. combine: the few multi-segment tiles wrote raw partial tiles instead; one workgroup
-//            per (tile, group) sums them in segment order, normalises and stores.
-// HBM traffic = C input planes read + C output planes written (+ the 12 B/pixel index),
-// i.e. the algorithmic bytes, instead of ~2x that for the atomic formulation.
+//            fluid flows pile up to 7x the average into some tiles) -> work items;
+//   3. splat: one workgroup = one work item (tile, segment), one work-item per output pixel.
+//            Phase 1 inverts the scatter inside the tile: integer LDS atomics (once per bin
+//            entry, not per channel) build a per-output-pixel list of (entry, weight) records.
+//            Phase 2 stages the segment's source values in LDS chunk by chunk (coalesced plane
+//            loads in bin order, prefetched two chunks ahead) and every work-item accumulates its
+//            own pixel in registers.  A single-segment tile is normalised in registers and
+//            written with coalesced stores: every output byte is written exactly once, never
+//            read, never zeroed.  (details at splat_tile_kernel)
+//   4. combine: the few multi-segment tiles wrote raw partial tiles instead; they are summed
+//            in segment order, normalised and stored.
+// HBM traffic ~ C input planes read (x1.14 bin halo) + C output planes written + 4 B per bin entry,
+// i.e. about the algorithmic bytes, instead of ~2x that for the atomic formulation.
 #include "slr_common.hpp"
 
 #include <stdarg.h>
