@@ -27,11 +27,18 @@ from . import _lib
 
 
 def _fused_ok(*ts):
-    """The fused HIP elementwise stages serve fp32 contiguous device tensors without autograd;
-    anything else (the CPU validation against the reference classes) takes the torch ops below,
-    which ARE the definition the kernels are tested against (tests/test_gpu_parity.py)."""
-    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) and \
-        not (torch.is_grad_enabled() and any(t.requires_grad for t in ts))
+    """Device tensors ALWAYS take the fused HIP elementwise stages (fp32, contiguous, no autograd
+    -- anything else on a device raises: there is no silent torch path on the GPU).  CPU tensors
+    (only the validation of these definitions against the reference classes, which runs where the
+    reference checkout is) take the torch composition below, which IS the definition the kernels
+    are tested against bit for bit (tests/test_gpu_parity.py)."""
+    if not any(t.is_cuda for t in ts):
+        return False
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts):
+        raise ValueError("slr_sfs_amd.nets: fused decoder stages need fp32 contiguous tensors on one device")
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        raise RuntimeError("slr_sfs_amd.nets are inference modules: run them under torch.no_grad()")
+    return True
 
 
 def bn_relu_mask(x, scale, shift, mask):
