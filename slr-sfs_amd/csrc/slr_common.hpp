@@ -47,6 +47,7 @@ struct WsLayout {
     size_t off_list;      // uint32[4*N*H*W] source pixel indices          (bin)
     size_t off_nseg;      // uint32[nt]   segments per tile                (plan)
     size_t off_partoff;   // uint32[nt]   first partial slot of the tile   (plan)
+    size_t off_multi;     // uint32[nt]   compact list of multi-segment tiles (plan)
     size_t off_items;     // ItemDesc[items_cap] (32 B per work item)           (plan)
     size_t off_totals;    // uint32[4]    total items, total partial slots (plan)
     size_t off_trash;     // float[planes][TILE_PIX]  sink for work-items outside the image
@@ -73,6 +74,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_list = o;    o += al256((size_t)4 * N * H * W * 4);
     L.off_nseg = o;    o += al256((size_t)L.nt * 4);
     L.off_partoff = o; o += al256((size_t)L.nt * 4);
+    L.off_multi = o;   o += al256((size_t)L.nt * 4);
     L.off_items = o;   o += al256((size_t)L.items_cap * 32);
     L.off_totals = o;  o += 256;
     // C value planes + the normaliser plane

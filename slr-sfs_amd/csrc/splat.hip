@@ -213,9 +213,10 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ listoff1, uint32_t nt,
                                                     uint32_t seg, uint32_t part_slots,
                                                     uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
-                                                    ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
+                                                    ItemDesc *__restrict__ items, uint32_t *__restrict__ multi,
+                                                    uint32_t *__restrict__ totals) {
     __shared__ uint32_t wsum[16];
-    uint32_t run_items = 0, run_parts = 0;
+    uint32_t run_items = 0, run_parts = 0, run_multi = 0;
     for (uint32_t b = 0; b < nt; b += 1024) {
         uint32_t t = b + threadIdx.x;
         uint32_t cnt = 0;
@@ -225,6 +226,10 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         uint32_t ptot = block_exscan(ns > 1 ? ns : 0u, &pex, wsum);
         if (ns > 1 && run_parts + pex + ns > part_slots) ns = 1;      // budget exhausted
         // (a dropped tile leaves a hole in the slot numbering; harmless)
+        uint32_t mex;                                                  // compact list of multi-segment tiles
+        uint32_t mtot = block_exscan(ns > 1 ? 1u : 0u, &mex, wsum);
+        if (ns > 1) multi[run_multi + mex] = t;
+        run_multi += mtot;
         uint32_t iex;
         uint32_t itot = block_exscan(t < nt ? ns : 0u, &iex, wsum);
         if (t < nt) {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         run_items += itot;
         run_parts += ptot;
     }
-    if (threadIdx.x == 0) { totals[0] = run_items; totals[1] = run_parts; }
+    if (threadIdx.x == 0) { totals[0] = run_items; totals[1] = run_parts; totals[3] = run_multi; }
 }
 
 // =========================================================================== splat
@@ -253,7 +258,7 @@ struct SplatArgs {
     const float *flow[2];   // [N,2,H,W] per direction (flow[1] unused when ndir == 1)
     const uint32_t *count[2], *listoff[2], *list[2];
     float scale[2];         // alpha, 1 - alpha
-    const uint32_t *nseg, *partoff, *totals;
+    const uint32_t *nseg, *partoff, *totals, *multi;
     const ItemDesc *items;
     float *partial, *trash;
     float *out;             // [N,C,H,W]
@@ -654,12 +659,13 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 }
 
 // Multi-segment tiles: sum (max) the raw partial tiles in segment order, normalise, store.
-// grid (nt, ceil(C/COMBINE_CHUNK)); TILE_PIX threads; exits at once for single-segment tiles.
+// grid (max multi-segment tiles, ceil(C/COMBINE_CHUNK)); TILE_PIX threads; workgroups past the
+// number of multi-segment tiles of this plan (totals[3]) exit at once.
 template <bool NORM, bool MAXOP>
 __global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatArgs a) {
-    const uint32_t t = blockIdx.x;
+    if (blockIdx.x >= a.totals[3]) return;
+    const uint32_t t = a.multi[blockIdx.x];
     const uint32_t ns = a.nseg[t];
-    if (ns <= 1) return;
     const int c0 = blockIdx.y * COMBINE_CHUNK;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(256) void max_stage_kernel(const float *__restrict_
 struct Ws {
     WsLayout L;
     char *base;
-    uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals;
+    uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals, *multi;
     ItemDesc *items;
     float *partial, *trash;
 };
@@ -742,6 +748,7 @@ static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, co
     w.list = (uint32_t *)(w.base + w.L.off_list);
     w.nseg = (uint32_t *)(w.base + w.L.off_nseg);
     w.partoff = (uint32_t *)(w.base + w.L.off_partoff);
+    w.multi = (uint32_t *)(w.base + w.L.off_multi);
     w.items = (ItemDesc *)(w.base + w.L.off_items);
     w.totals = (uint32_t *)(w.base + w.L.off_totals);
     w.partial = (float *)(w.base + w.L.off_partial);
@@ -794,7 +801,7 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     a.seg = w1 ? SEG_TWO : SEG_ONE;
     a.count[0] = w0.count; a.listoff[0] = w0.listoff; a.list[0] = w0.list;
     a.count[1] = w1 ? w1->count : nullptr; a.listoff[1] = w1 ? w1->listoff : nullptr; a.list[1] = w1 ? w1->list : nullptr;
-    a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals;
+    a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals; a.multi = w0.multi;
     a.partial = w0.partial;
     a.trash = w0.trash;
 #ifdef SLR_TRACE
@@ -804,7 +811,7 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
                        (const uint32_t *)(w1 ? w1->count : nullptr), (const uint32_t *)w0.listoff,
                        (const uint32_t *)(w1 ? w1->listoff : nullptr), w0.L.nt, (uint32_t)a.seg,
-                       w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.totals);
+                       w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.multi, w0.totals);
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
     if (w1) {
         if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, w0.L.items_cap, st)) return e;
@@ -813,7 +820,8 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     }
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;          // one-shot
-    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.nt, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
+    // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
+    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.part_slots / 2, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
                        dim3(SPLAT_THREADS), 0, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
