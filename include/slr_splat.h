@@ -84,6 +84,11 @@ size_t slr_splat_workspace_bytes(int N, int C, int H, int W);
  * here each workgroup owns an output tile and gathers exactly the sources that land in it.) */
 int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
 
+/* slr_splat_bin for two flow fields of the same shape at once (the forward and the backward
+ * displacement map of a frame): same launches, about the time of one. */
+int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W,
+                       void *ws_a, void *ws_b, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------ splat: forward */
 
 /* _FunctionSoftsplat.forward: summation splat.

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 SYMBOLS = (
     "slr_abi_version", "slr_last_error", "slr_splat_time_next",
     "slr_euler_integrate", "slr_euler_integrate_all",
-    "slr_splat_workspace_bytes", "slr_splat_bin",
+    "slr_splat_workspace_bytes", "slr_splat_bin", "slr_splat_bin_pair",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
@@ -57,6 +57,7 @@ def lib():
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
             "slr_splat_bin": [fp, i, i, i, i, vp, sz, vp],
+            "slr_splat_bin_pair": [fp, fp, i, i, i, i, vp, vp, sz, vp],
             "slr_softsplat_forward": [fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_softsplat_mode_forward": [fp, fp, fp, fp, i, i, i, i, i, vp, sz, i, vp],
             "slr_splat_normalize": [fp, fp, i, i, i, i, i, f, vp],

@@ -94,12 +94,19 @@ __device__ __forceinline__ void wave_append(int tile, uint32_t pix, uint32_t *__
 // every work-item handles BIN_PPT pixels (256 apart: each wave still sees 64 consecutive
 // pixels of a row per step) with all flow loads, then all fast-path reservations, in flight at once.
 constexpr int BIN_PPT = 4;
+// Up to two flow fields are binned by the same launches (blockIdx.z picks the flow): the forward
+// and the backward displacement map of a frame (the kernels are latency-bound, so two flows cost
+// about as much as one).
+struct BinSet {
+    const float *flow[2];
+    uint32_t *count[2], *cursor[2], *listoff[2], *list[2];
+};
 template <bool FILL>
-__global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ flow, int H, int W,
-                                                  int tiles_x, int tiles,
-                                                  uint32_t *__restrict__ counter,
-                                                  const uint32_t *__restrict__ listoff,
-                                                  uint32_t *__restrict__ list) {
+__global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int tiles_x, int tiles) {
+    const float *__restrict__ flow = b.flow[blockIdx.z];
+    uint32_t *__restrict__ counter = FILL ? b.cursor[blockIdx.z] : b.count[blockIdx.z];
+    const uint32_t *__restrict__ listoff = b.listoff[blockIdx.z];
+    uint32_t *__restrict__ list = b.list[blockIdx.z];
     const int HW = H * W;
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -177,14 +184,15 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *excl, uin
     return total;
 }
 
-// listoff = exclusive prefix sum of count (single workgroup of 1024 threads); zeroes cursor.
-__global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *__restrict__ count, uint32_t nt,
-                                                       uint32_t *__restrict__ listoff,
-                                                       uint32_t *__restrict__ cursor) {
+// listoff = exclusive prefix sum of count (one workgroup of 1024 threads per flow); zeroes cursor.
+__global__ __launch_bounds__(1024) void offsets_kernel(BinSet b, uint32_t nt) {
+    const uint32_t *__restrict__ count = b.count[blockIdx.x];
+    uint32_t *__restrict__ listoff = b.listoff[blockIdx.x];
+    uint32_t *__restrict__ cursor = b.cursor[blockIdx.x];
     __shared__ uint32_t wsum[16];
     uint32_t run = 0;
-    for (uint32_t b = 0; b < nt; b += 1024) {
-        uint32_t t = b + threadIdx.x;
+    for (uint32_t b0 = 0; b0 < nt; b0 += 1024) {
+        uint32_t t = b0 + threadIdx.x;
         uint32_t v = t < nt ? count[t] : 0;
         uint32_t ex;
         uint32_t tot = block_exscan(v, &ex, wsum);
@@ -764,15 +772,21 @@ static int check_dims(int N, int C, int H, int W, const char *who) {
     return 0;
 }
 
-static int do_bin(const float *flow, int N, int H, int W, Ws &w, hipStream_t st) {
-    SLR_CHECK_HIP(hipMemsetAsync(w.count, 0, (size_t)w.L.nt * 4, st));
-    dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), N);
-    hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, flow, H, W, w.L.tiles_x, w.L.tiles,
-                       w.count, (const uint32_t *)nullptr, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w.count, w.L.nt,
-                       w.listoff, w.cursor);
-    hipLaunchKernelGGL(bin_kernel<true>, grid, dim3(256), 0, st, flow, H, W, w.L.tiles_x, w.L.tiles,
-                       w.cursor, (const uint32_t *)w.listoff, w.list);
+// Bin one flow (w1 == nullptr) or two flows of the same shape into their workspaces.
+static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N, int H, int W, hipStream_t st) {
+    const int nf = w1 ? 2 : 1;
+    BinSet b = {};
+    Ws *ws[2] = {&w0, w1};
+    const float *fl[2] = {flow0, flow1};
+    for (int k = 0; k < nf; ++k) {
+        b.flow[k] = fl[k];
+        b.count[k] = ws[k]->count; b.cursor[k] = ws[k]->cursor; b.listoff[k] = ws[k]->listoff; b.list[k] = ws[k]->list;
+        SLR_CHECK_HIP(hipMemsetAsync(ws[k]->count, 0, (size_t)w0.L.nt * 4, st));
+    }
+    dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), N, nf);
+    hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, b, H, W, w0.L.tiles_x, w0.L.tiles);
+    hipLaunchKernelGGL(offsets_kernel, dim3(nf), dim3(1024), 0, st, b, w0.L.nt);
+    hipLaunchKernelGGL(bin_kernel<true>, grid, dim3(256), 0, st, b, H, W, w0.L.tiles_x, w0.L.tiles);
     SLR_CHECK_LAUNCH();
     return 0;
 }
@@ -854,7 +868,18 @@ SLR_EXPORT int slr_splat_bin(const float *flow, int N, int C, int H, int W, void
     if (int e = check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
-    return do_bin(flow, N, H, W, w, (hipStream_t)stream);
+    return do_bin(flow, w, nullptr, nullptr, N, H, W, (hipStream_t)stream);
+}
+
+SLR_EXPORT int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W, void *ws_a,
+                                  void *ws_b, size_t ws_bytes, void *stream) {
+    SLR_CHECK_ARG(flow_a && flow_b, "null flow");
+    SLR_CHECK_ARG(ws_a != ws_b, "the two flows need separate workspaces");
+    if (int e = check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
+    Ws wa, wb;
+    if (int e = ws_open(wa, N, C, H, W, ws_a, ws_bytes, __func__)) return e;
+    if (int e = ws_open(wb, N, C, H, W, ws_b, ws_bytes, __func__)) return e;
+    return do_bin(flow_a, wa, flow_b, &wb, N, H, W, (hipStream_t)stream);
 }
 
 SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *out, int N, int C, int H,
@@ -864,7 +889,7 @@ SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (!prebinned) if (int e = do_bin(flow, N, H, W, w, st)) return e;
+    if (!prebinned) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
@@ -883,7 +908,7 @@ SLR_EXPORT int slr_softsplat_mode_forward(const float *in, const float *metric, 
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (!prebinned) if (int e = do_bin(flow, N, H, W, w, st)) return e;
+    if (!prebinned) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.mul = metric; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
     a.N = N; a.C = C; a.H = H; a.W = W;
@@ -944,7 +969,7 @@ SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *o
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (!prebinned) if (int e = do_bin(flow, N, H, W, w, st)) return e;
+    if (!prebinned) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out; a.init = init;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;

@@ -42,6 +42,18 @@ def bin_flow(flow, C, role):
     return ws
 
 
+def bin_flow_pair(flow_a, flow_b, C):
+    """bin_flow for the forward and the backward displacement map of a frame in one go."""
+    require_device(flow_a, flow_b)
+    assert flow_a.shape == flow_b.shape
+    N, _, H, W = flow_a.shape
+    ws_a, ws_b = workspace(flow_a, "f", N, C, H, W), workspace(flow_a, "p", N, C, H, W)
+    with torch.cuda.device(flow_a.device):
+        check(lib().slr_splat_bin_pair(ptr(flow_a), ptr(flow_b), N, C, H, W, ptr(ws_a), ptr(ws_b), ws_a.numel(),
+                                       stream_of(flow_a)), "slr_splat_bin_pair")
+    return ws_a, ws_b
+
+
 def global_max(x):
     """x.max() as a 1-element device tensor, no host sync (animating_softmax_splating.py:855)."""
     require_device(x)
@@ -127,8 +139,7 @@ class ClipSynthesizer:
         assert 0 <= t < self.N
         disp_f = self.disp_f[t:t + 1]                # t forward steps
         disp_p = self.disp_p[self.N - t:self.N - t + 1]   # N - t backward steps
-        ws_f = bin_flow(disp_f, self.C, "f")
-        ws_p = bin_flow(disp_p, self.C, "p")
+        ws_f, ws_p = bin_flow_pair(disp_f, disp_p, self.C)
         a = self.alpha(t)
         Zt = self.Z
         if self.softmax_v2:                      # Z_f_max = maximum_warp_norm_splater(Z_f, forward_flow)  (:849-851)
