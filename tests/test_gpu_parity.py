@@ -497,3 +497,32 @@ def test_synthesize_stream_overlap_equals_sequential(S):
                 f = an.frame(clip, t)
                 f = f["PredImg"] if isinstance(f, dict) else f
                 assert (frames[i] - f[0]).abs().max().item() < 5e-3, (rep, t)
+
+
+def test_c_abi_prebinned_reuse_and_errors(S, oracle):
+    """Straight through ctypes: bin once, splat two tensors with the same bins (prebinned = 1);
+    workspace too small / misaligned is refused with SLR_E_WORKSPACE."""
+    from slr_sfs_amd._lib import lib, ptr, stream_of
+    L = lib()
+    rng = np.random.default_rng(31)
+    N, C, H, W = 1, 5, 33, 70
+    fl = rng.uniform(-3, 3, (N, 2, H, W)).astype(np.float32)
+    xs = [rng.standard_normal((N, C, H, W)).astype(np.float32) for _ in range(2)]
+    dfl = dev(fl)
+    nbytes = int(L.slr_splat_workspace_bytes(N, C, H, W))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    st = stream_of(dfl)
+    assert L.slr_splat_bin(ptr(dfl), N, C, H, W, ptr(ws), nbytes, st) == 0
+    for x in xs:
+        dx, out = dev(x), torch.empty(N, C, H, W, device="cuda")
+        assert L.slr_softsplat_forward(ptr(dx), ptr(dfl), ptr(out), N, C, H, W, ptr(ws), nbytes, 1, st) == 0
+        np.testing.assert_allclose(host(out), oracle.softsplat_forward(x, fl), **TOL)
+    dx, out = dev(xs[0]), torch.empty(N, C, H, W, device="cuda")
+    assert L.slr_softsplat_forward(ptr(dx), ptr(dfl), ptr(out), N, C, H, W, ptr(ws), nbytes // 2, 0, st) == -2
+    assert b"workspace" in L.slr_last_error()
+    off = ws[8:]                                              # 8-byte offset: not 16-byte aligned
+    assert L.slr_softsplat_forward(ptr(dx), ptr(dfl), ptr(out), N, C, H, W, ptr(off), nbytes - 8, 0, st) == -2
+    res, scratch = torch.empty(1, device="cuda"), torch.empty(1024, device="cuda")
+    big = dev(rng.standard_normal(300001).astype(np.float32))
+    assert L.slr_global_max(ptr(big), big.numel(), ptr(res), ptr(scratch), st) == 0
+    assert float(res) == float(big.max())
