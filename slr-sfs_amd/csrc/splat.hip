@@ -796,11 +796,15 @@ static int launch_tile(const SplatArgs &a, uint32_t items_cap, hipStream_t st) {
     // counts (T words) + wave sums (8) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
     const size_t lds = (size_t)(SPLAT_THREADS + 8 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
                        (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4;          // + the all-zero NULL entry
-    static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
+    // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    SLR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>), dim3(((items_cap + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP), dim3(SPLAT_THREADS), lds, st, a);
     return 0;
