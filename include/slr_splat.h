@@ -163,7 +163,8 @@ int slr_max_warp_norm(const float *in, const float *flow, float *scratch, float 
  * input*mask of the following partial convolution in one pass.  Replaces
  * models/layers/normalization.py:219-231 + blocks.py:229-231 + partialconv2d.py:69.
  *   mask_channels = 1: mask [N,1,H,W];  = C: mask [N,C,H,W];  = 0: mask = (x != 0)
- *   (models/networks/architectures.py:369), `mask` ignored. */
+ *   (models/networks/architectures.py:369);  = -1: no mask (plain BN + ReLU of the encoder /
+ *   background blocks, blocks.py:66-74).  `mask` is ignored for 0 and -1. */
 int slr_bn_relu_mask(const float *x, const float *scale, const float *shift, const float *mask,
                      int mask_channels, float *y, int N, int C, int H, int W, void *stream);
 

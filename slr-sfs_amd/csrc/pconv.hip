@@ -12,7 +12,8 @@
 namespace slr {
 
 // y = relu(x*scale[c] - shift[c]) * mask      mask: [N,1,H,W], [N,C,H,W], or derived as (x != 0)
-// MASK: 0 = one-channel, 1 = per-channel tensor, 2 = (x != 0)
+// MASK: 0 = one-channel, 1 = per-channel tensor, 2 = (x != 0), 3 = no mask (plain BN + ReLU of the
+// non-partial blocks: models/layers/blocks.py:66-74)
 template <int MASK, typename V>
 __global__ __launch_bounds__(256) void bn_relu_mask_kernel(const V *__restrict__ x, const float *__restrict__ scale,
                                                            const float *__restrict__ shift,
@@ -26,14 +27,16 @@ __global__ __launch_bounds__(256) void bn_relu_mask_kernel(const V *__restrict__
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HWv; i += gridDim.x * 256) {
         V v = x[base + i];
         V m;
-        if (MASK != 2) m = mask[mbase + i];
+        if (MASK < 2) m = mask[mbase + i];
         float *vf = reinterpret_cast<float *>(&v);
         const float *mf = reinterpret_cast<const float *>(&m);
 #pragma unroll
         for (int k = 0; k < L; ++k) {
             const float xv = vf[k];
+            const float r = fmaxf(xv * sc - sh, 0.0f);       // fused_bn :231, ReLU
+            if (MASK == 3) { vf[k] = r; continue; }
             const float mk = MASK == 2 ? (xv != 0.0f ? 1.0f : 0.0f) : mf[k];
-            vf[k] = fmaxf(xv * sc - sh, 0.0f) * mk;          // fused_bn :231, ReLU, input*mask :69
+            vf[k] = r * mk;                                  // input*mask :69
         }
         y[base + i] = v;
     }
@@ -93,18 +96,19 @@ using namespace slr;
 SLR_EXPORT int slr_bn_relu_mask(const float *x, const float *scale, const float *shift, const float *mask,
                                 int mask_channels, float *y, int N, int C, int H, int W, void *stream) {
     SLR_CHECK_ARG(x && scale && shift && y, "null pointer");
-    SLR_CHECK_ARG(mask_channels == 0 || (mask && (mask_channels == 1 || mask_channels == C)), "mask");
+    SLR_CHECK_ARG(mask_channels == 0 || mask_channels == -1 || (mask && (mask_channels == 1 || mask_channels == C)), "mask");
     SLR_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && C <= 65535 && N <= 65535, "sizes");
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W;
     const bool v4 = (HW % 4 == 0) && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)mask) & 15);
-    const int mode = mask_channels == 0 ? 2 : (mask_channels == 1 ? 0 : 1);
+    const int mode = mask_channels == -1 ? 3 : mask_channels == 0 ? 2 : (mask_channels == 1 ? 0 : 1);
+    if (mode >= 2) mask = nullptr;
 #define LAUNCH(M, V, n)                                                                                   \
     launch_planes<V>([&](dim3 g, hipStream_t s) {                                                           \
         hipLaunchKernelGGL((bn_relu_mask_kernel<M, V>), g, dim3(256), 0, s, (const V *)x, scale, shift,   \
                            (const V *)mask, (V *)y, C, n); }, N, C, n, st)
-    if (v4) { if (mode == 0) LAUNCH(0, float4, HW / 4); else if (mode == 1) LAUNCH(1, float4, HW / 4); else LAUNCH(2, float4, HW / 4); }
-    else    { if (mode == 0) LAUNCH(0, float, HW);      else if (mode == 1) LAUNCH(1, float, HW);      else LAUNCH(2, float, HW); }
+    if (v4) { if (mode == 0) LAUNCH(0, float4, HW / 4); else if (mode == 1) LAUNCH(1, float4, HW / 4); else if (mode == 2) LAUNCH(2, float4, HW / 4); else LAUNCH(3, float4, HW / 4); }
+    else    { if (mode == 0) LAUNCH(0, float, HW);      else if (mode == 1) LAUNCH(1, float, HW);      else if (mode == 2) LAUNCH(2, float, HW);      else LAUNCH(3, float, HW); }
 #undef LAUNCH
     SLR_CHECK_LAUNCH();
     return 0;

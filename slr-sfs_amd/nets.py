@@ -42,17 +42,20 @@ def _fused_ok(*ts):
 
 
 def bn_relu_mask(x, scale, shift, mask):
-    """relu(x*scale - shift) * mask;  mask None = (x != 0)."""
-    if _fused_ok(x, *([] if mask is None else [mask])):
+    """relu(x*scale - shift) * mask;  mask None = (x != 0), mask False = no mask."""
+    if _fused_ok(x, *([mask] if torch.is_tensor(mask) else [])):
         N, C, H, W = x.shape
         y = torch.empty_like(x)
+        mc = -1 if mask is False else 0 if mask is None else mask.shape[1]
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().slr_bn_relu_mask(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mask),
-                                                   0 if mask is None else mask.shape[1], _lib.ptr(y), N, C, H, W,
-                                                   _lib.stream_of(x)), "slr_bn_relu_mask")
+            _lib.check(_lib.lib().slr_bn_relu_mask(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift),
+                                                   _lib.ptr(mask) if torch.is_tensor(mask) else None, mc, _lib.ptr(y),
+                                                   N, C, H, W, _lib.stream_of(x)), "slr_bn_relu_mask")
         return y
-    m = (x != 0).to(x.dtype) if mask is None else mask
-    return F.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * m
+    y = F.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1))
+    if mask is False:
+        return y
+    return y * ((x != 0).to(x.dtype) if mask is None else mask)
 
 
 def pconv_epilogue(raw0, bias, um_raw, winsize, residual=None, next_bn=None):
@@ -157,8 +160,8 @@ class ResBlock(nn.Module):
         self.resample = _resample(resample)
 
     def forward(self, x):
-        a = self.conv_aa(F.relu(self.bn1(x)))
-        a = self.conv_ab(F.relu(self.bn2(a)))
+        a = self.conv_aa(bn_relu_mask(x, *self.bn1.scale_shift(), False))
+        a = self.conv_ab(bn_relu_mask(a, *self.bn2.scale_shift(), False))
         b = self.conv_b(x) if self.conv_b is not None else x
         return self.resample(a + b)          # == resample(a) + resample(b): both resamplers are linear
 

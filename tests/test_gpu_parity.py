@@ -388,6 +388,8 @@ def test_fused_decoder_stages_match_torch_definition(S):
         for mask in (None, m1, mc):
             ref = torch.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * ((x != 0).float() if mask is None else mask)
             assert torch.equal(nets.bn_relu_mask(x, scale, shift, mask), ref)
+        assert torch.equal(nets.bn_relu_mask(x, scale, shift, False),
+                           torch.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)))
         raw = torch.randn(N, C, H, W, device="cuda", generator=g)
         bias = torch.randn(C, device="cuda", generator=g)
         umr = torch.randint(0, 28, (N, 1, H, W), device="cuda", generator=g).float()
