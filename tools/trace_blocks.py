@@ -1,4 +1,6 @@
-"""Phase timeline of the tile kernel's workgroups (needs a -DSLR_TRACE build; development aid)."""
+"""Phase timeline of the tile kernel's workgroups (development aid).  Needs the tracing build:
+    make -C slr-sfs_amd/csrc -B OUT=../lib/var_trace.so DEFS=-DSLR_TRACE
+(one-flow kernel only: the stamp table has room for its 9 chunks)."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
