@@ -295,7 +295,10 @@ __device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps)
 #endif
 
 constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
-constexpr int XCD_GROUP = 4;                    // neighbouring tiles kept on one XCD (L2 halo reuse)
+#ifndef SLR_XCD_GROUP
+#define SLR_XCD_GROUP 4
+#endif
+constexpr int XCD_GROUP = SLR_XCD_GROUP;                    // neighbouring tiles kept on one XCD (L2 halo reuse)
 constexpr int RB = 4;                          // records per batch in the gather loop
 constexpr int LMAX = 16;                       // records a work-item walks alone (longer lists: wave-cooperative)
 constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
