@@ -1,0 +1,16 @@
+"""Timing of the backward kernels (development aid)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import slr_sfs_amd as S
+from kbench import timeit, smooth_motion
+from slr_sfs_amd._lib import check, lib, ptr, stream_of
+H, W, C = 768, 1280, 65
+x = torch.randn(1, C, H, W, device="cuda"); go = torch.randn(1, C, H, W, device="cuda")
+m = smooth_motion(H, W); dall, _ = S.euler_integration_all(m, 60)
+gi = torch.empty_like(x); gf = torch.empty(1, 2, H, W, device="cuda")
+L = lib(); st = stream_of(x)
+for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", dall[30:31].contiguous())):
+    t1 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), None, 1, C, H, W, st), "b"), 10)
+    t2 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), None, ptr(gf), 1, C, H, W, st), "b"), 10)
+    B = 2 * C * H * W * 4
+    print(name, "grad_input us", t1, f"{B/t1[1]/1e6:.2f} TB/s", " grad_flow us", t2, f"{B/t2[1]/1e6:.2f} TB/s")
