@@ -21,15 +21,21 @@ __global__ __launch_bounds__(256) void grad_input_kernel(const float *__restrict
     const Corners c = make_corners(f[i], f[HW + i], x, y);
     const bool k0 = c.ok & in_image(c.x0, c.y0, H, W), k1 = c.ok & in_image(c.x0 + 1, c.y0, H, W);
     const bool k2 = c.ok & in_image(c.x0, c.y0 + 1, H, W), k3 = c.ok & in_image(c.x0 + 1, c.y0 + 1, H, W);
+    // Branch-free channel loop: out-of-image corners read a valid address (this pixel) and their
+    // PRODUCT is replaced by +0.0, so the sum has the reference's terms in the reference's order
+    // (adding +0.0 changes nothing but the sign of a -0.0) and the loads of several channels overlap.
     const int o = c.y0 * W + c.x0;
+    const int o0 = k0 ? o : i, o1 = k1 ? o + 1 : i, o2 = k2 ? o + W : i, o3 = k3 ? o + W + 1 : i;
     const float *gp = gout + (size_t)n * C * HW;
     float *op = gin + (size_t)n * C * HW;
+#pragma unroll 4
     for (int ch = 0; ch < C; ++ch, gp += HW, op += HW) {
+        const float a0 = gp[o0], a1 = gp[o1], a2 = gp[o2], a3 = gp[o3];
         float g = 0.0f;
-        if (k0) g += gp[o] * c.w[0];
-        if (k1) g += gp[o + 1] * c.w[1];
-        if (k2) g += gp[o + W] * c.w[2];
-        if (k3) g += gp[o + W + 1] * c.w[3];
+        g += k0 ? a0 * c.w[0] : 0.0f;
+        g += k1 ? a1 * c.w[1] : 0.0f;
+        g += k2 ? a2 * c.w[2] : 0.0f;
+        g += k3 ? a3 * c.w[3] : 0.0f;
         op[i] = g;
     }
 }
@@ -59,15 +65,18 @@ __global__ __launch_bounds__(256) void grad_flow_kernel(const float *__restrict_
     const bool k0 = ok & in_image(x0, y0, H, W), k1 = ok & in_image(x0 + 1, y0, H, W);
     const bool k2 = ok & in_image(x0, y0 + 1, H, W), k3 = ok & in_image(x0 + 1, y0 + 1, H, W);
     const int o = y0 * W + x0;
+    const int o0 = k0 ? o : i, o1 = k1 ? o + 1 : i, o2 = k2 ? o + W : i, o3 = k3 ? o + W + 1 : i;   // see grad_input_kernel
     const float *ip = in + (size_t)n * C * HW;
     const float *gp = gout + (size_t)n * C * HW;
     float gx = 0.0f, gy = 0.0f;
+#pragma unroll 4
     for (int ch = 0; ch < C; ++ch, ip += HW, gp += HW) {
         const float v = ip[i];
-        if (k0) { const float t = v * gp[o];         gx += t * dx[0]; gy += t * dy[0]; }
-        if (k1) { const float t = v * gp[o + 1];     gx += t * dx[1]; gy += t * dy[1]; }
-        if (k2) { const float t = v * gp[o + W];     gx += t * dx[2]; gy += t * dy[2]; }
-        if (k3) { const float t = v * gp[o + W + 1]; gx += t * dx[3]; gy += t * dy[3]; }
+        const float t0 = v * gp[o0], t1 = v * gp[o1], t2 = v * gp[o2], t3 = v * gp[o3];
+        gx += k0 ? t0 * dx[0] : 0.0f; gy += k0 ? t0 * dy[0] : 0.0f;
+        gx += k1 ? t1 * dx[1] : 0.0f; gy += k1 ? t1 * dy[1] : 0.0f;
+        gx += k2 ? t2 * dx[2] : 0.0f; gy += k2 ? t2 * dy[2] : 0.0f;
+        gx += k3 ? t3 * dx[3] : 0.0f; gy += k3 ? t3 * dy[3] : 0.0f;
     }
     gflow[(size_t)n * 2 * HW + i] = gx;
     gflow[(size_t)n * 2 * HW + HW + i] = gy;
