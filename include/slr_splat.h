@@ -169,16 +169,18 @@ int slr_bn_relu_mask(const float *x, const float *scale, const float *shift, con
                      int mask_channels, float *y, int N, int C, int H, int W, void *stream);
 
 /* Partial-convolution epilogue on the bias-free convolution output raw0:
+ *   um_raw = mask_box*mask_scale  (= conv(mask, ones[out,in,k,k]), partialconv2d.py:61: the k x k box
+ *            filter of a channel-uniform mask times Cin, or of the channel sum of the mask times 1)
  *   o = (raw0*ratio + b)*um,  um = clamp(um_raw,0,1),  ratio = winsize/(um_raw + 1e-8)*um
  * then optionally  o += residual            (blocks.py:248)
  * or               o  = relu(o*next_scale - next_shift)*um   (BN + ReLU + input*mask of the next
  *                       partial convolution of the block, blocks.py:233-236 / partialconv2d.py:69).
  * Replaces models/layers/partialconv2d.py:64-74.
- *   raw0 [N,C,H,W]; um_raw [N,1,H,W] = box filter of the mask sum; residual [N,C,H,W] or NULL;
- *   next_scale/next_shift [C] or NULL (exclusive with residual); winsize = Cin*k*k. */
-int slr_pconv_epilogue(const float *raw0, const float *bias, const float *um_raw, const float *residual,
-                       const float *next_scale, const float *next_shift, float *out, float winsize,
-                       int N, int C, int H, int W, void *stream);
+ *   raw0 [N,C,H,W]; mask_box [N,1,H,W]; residual [N,C,H,W] or NULL; next_scale/next_shift [C] or
+ *   NULL (exclusive with residual); um_out [N,1,H,W] or NULL receives um; winsize = Cin*k*k. */
+int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_box, float mask_scale,
+                       const float *residual, const float *next_scale, const float *next_shift,
+                       float *out, float *um_out, float winsize, int N, int C, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,7 @@ def lib():
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
-            "slr_pconv_epilogue": [fp, fp, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
+            "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void pconv_epilogue_kernel(const V *__restrict
                                                              const V *__restrict__ umr, const V *__restrict__ res,
                                                              const float *__restrict__ scale2,
                                                              const float *__restrict__ shift2, V *__restrict__ out,
-                                                             float winsize, int C, int HWv) {
+                                                             V *__restrict__ um_out, float mscale, float winsize,
+                                                             int C, int HWv) {
     const int c = blockIdx.y, n = blockIdx.z;
     const float b = bias[c];
     const float sc = NEXT ? scale2[c] : 1.0f, sh = NEXT ? shift2[c] : 0.0f;
@@ -62,7 +63,12 @@ __global__ __launch_bounds__(256) void pconv_epilogue_kernel(const V *__restrict
     constexpr int L = sizeof(V) / 4;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HWv; i += gridDim.x * 256) {
         V v = raw[base + i];
-        const V u = umr[(size_t)n * HWv + i];
+        V u = umr[(size_t)n * HWv + i];            // box filter of the mask; x mscale = conv(mask, ones) (:61)
+        {
+            float *uw = reinterpret_cast<float *>(&u);
+#pragma unroll
+            for (int k = 0; k < L; ++k) uw[k] *= mscale;
+        }
         V r;
         if (RES) r = res[base + i];
         float *vf = reinterpret_cast<float *>(&v);
@@ -79,6 +85,13 @@ __global__ __launch_bounds__(256) void pconv_epilogue_kernel(const V *__restrict
             vf[k] = o;
         }
         out[base + i] = v;
+        if (um_out && c == 0) {                   // the update mask for the next layer, written once
+            V m = u;
+            float *mw = reinterpret_cast<float *>(&m);
+#pragma unroll
+            for (int k = 0; k < L; ++k) mw[k] = fminf(fmaxf(mw[k], 0.0f), 1.0f);
+            um_out[(size_t)n * HWv + i] = m;
+        }
     }
 }
 
@@ -114,21 +127,23 @@ SLR_EXPORT int slr_bn_relu_mask(const float *x, const float *scale, const float 
     return 0;
 }
 
-SLR_EXPORT int slr_pconv_epilogue(const float *raw0, const float *bias, const float *um_raw, const float *residual,
-                                  const float *next_scale, const float *next_shift, float *out, float winsize,
-                                  int N, int C, int H, int W, void *stream) {
+SLR_EXPORT int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_box, float mask_scale,
+                                  const float *residual, const float *next_scale, const float *next_shift,
+                                  float *out, float *um_out, float winsize, int N, int C, int H, int W,
+                                  void *stream) {
+    const float *um_raw = mask_box;
     SLR_CHECK_ARG(raw0 && bias && um_raw && out, "null pointer");
     SLR_CHECK_ARG(!next_scale == !next_shift, "next_scale / next_shift go together");
     SLR_CHECK_ARG(!(residual && next_scale), "residual and next-BN fusion are exclusive");
     SLR_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && C <= 65535 && N <= 65535, "sizes");
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W;
-    const bool v4 = (HW % 4 == 0) && !(((uintptr_t)raw0 | (uintptr_t)out | (uintptr_t)um_raw | (uintptr_t)residual) & 15);
+    const bool v4 = (HW % 4 == 0) && !(((uintptr_t)raw0 | (uintptr_t)out | (uintptr_t)um_raw | (uintptr_t)residual | (uintptr_t)um_out) & 15);
 #define LAUNCH(R, X, V, n)                                                                                 \
     launch_planes<V>([&](dim3 g, hipStream_t s) {                                                            \
         hipLaunchKernelGGL((pconv_epilogue_kernel<R, X, V>), g, dim3(256), 0, s, (const V *)raw0, bias,    \
                            (const V *)um_raw, (const V *)residual, next_scale, next_shift, (V *)out,      \
-                           winsize, C, n); }, N, C, n, st)
+                           (V *)um_out, mask_scale, winsize, C, n); }, N, C, n, st)
     if (v4) {
         if (residual) LAUNCH(true, false, float4, HW / 4);
         else if (next_scale) LAUNCH(false, true, float4, HW / 4);

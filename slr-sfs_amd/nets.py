@@ -58,18 +58,22 @@ def bn_relu_mask(x, scale, shift, mask):
     return y * ((x != 0).to(x.dtype) if mask is None else mask)
 
 
-def pconv_epilogue(raw0, bias, um_raw, winsize, residual=None, next_bn=None):
+def pconv_epilogue(raw0, bias, mask_box, mask_scale, winsize, residual=None, next_bn=None):
     """(raw0*ratio + b)*um on the bias-free convolution output, then `+ residual` or the next
-    convolution's relu(bn(.))*um  (partialconv2d.py:64-74, blocks.py:233-236,248)."""
-    if _fused_ok(raw0, um_raw, *([] if residual is None else [residual])):
+    convolution's relu(bn(.))*um  (partialconv2d.py:61-74, blocks.py:233-236,248).
+    um_raw = mask_box*mask_scale.  Returns (out, um)."""
+    if _fused_ok(raw0, mask_box, *([] if residual is None else [residual])):
         N, C, H, W = raw0.shape
         out = torch.empty_like(raw0)
+        um = torch.empty_like(mask_box)
         sc, sh = next_bn if next_bn is not None else (None, None)
         with torch.cuda.device(raw0.device):
-            _lib.check(_lib.lib().slr_pconv_epilogue(_lib.ptr(raw0), _lib.ptr(bias), _lib.ptr(um_raw), _lib.ptr(residual),
-                                                     _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(out), float(winsize),
-                                                     N, C, H, W, _lib.stream_of(raw0)), "slr_pconv_epilogue")
-        return out
+            _lib.check(_lib.lib().slr_pconv_epilogue(_lib.ptr(raw0), _lib.ptr(bias), _lib.ptr(mask_box), float(mask_scale),
+                                                     _lib.ptr(residual), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(out),
+                                                     _lib.ptr(um), float(winsize), N, C, H, W,
+                                                     _lib.stream_of(raw0)), "slr_pconv_epilogue")
+        return out, um
+    um_raw = mask_box * mask_scale
     um = torch.clamp(um_raw, 0, 1)
     ratio = winsize / (um_raw + 1e-8) * um
     out = (raw0 * ratio + bias.view(1, -1, 1, 1)) * um
@@ -77,7 +81,7 @@ def pconv_epilogue(raw0, bias, um_raw, winsize, residual=None, next_bn=None):
         out = out + residual
     if next_bn is not None:
         out = F.relu(out * next_bn[0].view(1, -1, 1, 1) - next_bn[1].view(1, -1, 1, 1)) * um
-    return out
+    return out, um
 
 
 # --------------------------------------------------------------------------- building blocks
@@ -93,8 +97,13 @@ class AffineBN(nn.Module):
         self.register_buffer("stored_var", torch.ones(ch))
 
     def scale_shift(self):
-        scale = torch.rsqrt(self.stored_var + self.eps)
-        return scale, self.stored_mean * scale
+        """(scale, shift), computed once per device (statistics are frozen at inference; loading a
+        state dict resets the cache)."""
+        c = self.__dict__.get("_ss")
+        if c is None or c[0].device != self.stored_var.device:
+            scale = torch.rsqrt(self.stored_var + self.eps)
+            c = self.__dict__["_ss"] = (scale, self.stored_mean * scale)
+        return c
 
     def forward(self, x):
         scale, shift = self.scale_shift()
@@ -119,16 +128,16 @@ class Conv(nn.Module):
 class PartialConv(Conv):
     """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81.
     ``xin`` is the already activated and masked input relu(bn(x))*mask (blocks.py:229-231,
-    partialconv2d.py:69); ``msum`` [N,1,H,W] the channel sum of its mask.
+    partialconv2d.py:69); ``mplane`` [N,1,H,W] with conv(mask, ones) == box_k(mplane)*mscale:
+    the channel-uniform mask and Cin, or the channel sum of a per-channel mask and 1.
     Returns (out, update_mask [N,1,H,W]); with ``next_bn`` the output is already the activated,
     masked input of the block's second convolution."""
 
-    def forward(self, xin, msum, residual=None, next_bn=None):
-        # conv(mask, ones[out,in,k,k]) == box_k(sum_c mask), identical for every output channel (:61)
-        um_raw = F.avg_pool2d(msum, self.k, stride=1, padding=self.pad, divisor_override=1)
-        raw0 = F.conv2d(xin, self.weight, None, padding=self.pad)                                # bias joins in the epilogue
-        out = pconv_epilogue(raw0, self.bias, um_raw, self.cin * self.k * self.k, residual, next_bn)   # :64-74
-        return out, torch.clamp(um_raw, 0, 1)
+    def forward(self, xin, mplane, mscale, residual=None, next_bn=None):
+        # conv(mask, ones[out,in,k,k]) is the same k x k box sum for every output channel (:61)
+        box = F.avg_pool2d(mplane, self.k, stride=1, padding=self.pad, divisor_override=1)
+        raw0 = F.conv2d(xin, self.weight, None, padding=self.pad)                  # bias joins in the epilogue
+        return pconv_epilogue(raw0, self.bias, box, mscale, self.cin * self.k * self.k, residual, next_bn)
 
 
 def _resample(kind):
@@ -181,14 +190,16 @@ class PconvResBlock(nn.Module):
         # mask: None = (x != 0) per channel (architectures.py:369), else [N,1,H,W] channel-uniform
         s1, h1 = self.bn1.scale_shift()
         xin = bn_relu_mask(x, s1, h1, mask)                                        # :229-231
-        msum = (x != 0).sum(1, keepdim=True).to(x.dtype) if mask is None else mask * float(x.shape[1])
-        a, m = self.conv_aa(xin, msum, next_bn=self.bn2.scale_shift())             # -> relu(bn2(.))*m (:233-236)
-        msum = m * float(a.shape[1])
+        if mask is None:
+            mplane, mscale = (x != 0).sum(1, keepdim=True).to(x.dtype), 1.0
+        else:
+            mplane, mscale = mask, float(x.shape[1])
+        a, m = self.conv_aa(xin, mplane, mscale, next_bn=self.bn2.scale_shift())   # -> relu(bn2(.))*m (:233-236)
         # x_a + x_b (:248).  The reference resamples the two branches separately and adds; avg-pool
         # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
         # rounding, lets the residual join the epilogue, and halves the resampling work.
         skip = self.conv_b(x) if self.conv_b is not None else x                    # :243-247
-        a, m = self.conv_ab(a, msum, residual=skip)                                # :237-239
+        a, m = self.conv_ab(a, m, float(a.shape[1]), residual=skip)                # :237-239
         return self.resample(a), self.resample_mask(m)                             # :240-241
 
 
@@ -273,6 +284,7 @@ def _load_bn(bn, sd, key):
     """key = '...bn' or '...pbn' of a (Partial)LinearNoiseLayer; zero noise -> gain 1, bias 0."""
     bn.stored_mean.copy_(sd[key + ".stored_mean"])
     bn.stored_var.copy_(sd[key + ".stored_var"])
+    bn.__dict__.pop("_ss", None)
 
 
 def _load_conv(conv, sd, key):

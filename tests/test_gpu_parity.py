@@ -392,15 +392,17 @@ def test_fused_decoder_stages_match_torch_definition(S):
                            torch.relu(x * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)))
         raw = torch.randn(N, C, H, W, device="cuda", generator=g)
         bias = torch.randn(C, device="cuda", generator=g)
-        umr = torch.randint(0, 28, (N, 1, H, W), device="cuda", generator=g).float()
         res = torch.randn(N, C, H, W, device="cuda", generator=g)
+        box = torch.randint(0, 10, (N, 1, H, W), device="cuda", generator=g).float()
+        umr = box * 3.0
         um = torch.clamp(umr, 0, 1)
         ratio = 27.0 / (umr + 1e-8) * um
         ref = (raw * ratio + bias.view(1, -1, 1, 1)) * um
-        assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0), ref)
-        assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0, res), ref + res)
+        out, um_k = nets.pconv_epilogue(raw, bias, box, 3.0, 27.0)
+        assert torch.equal(out, ref) and torch.equal(um_k, um)
+        assert torch.equal(nets.pconv_epilogue(raw, bias, box, 3.0, 27.0, res)[0], ref + res)
         nxt = torch.relu(ref * scale.view(1, -1, 1, 1) - shift.view(1, -1, 1, 1)) * um
-        assert torch.equal(nets.pconv_epilogue(raw, bias, umr, 27.0, next_bn=(scale, shift)), nxt)
+        assert torch.equal(nets.pconv_epilogue(raw, bias, box, 3.0, 27.0, next_bn=(scale, shift))[0], nxt)
 
 
 def test_decoder_gpu_matches_cpu_definition(S):
