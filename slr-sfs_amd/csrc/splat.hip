@@ -346,8 +346,8 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     constexpr int SEG = EPT_MAX * T;
     uint32_t *cnt = smem;                     // [T]   records per output pixel
     uint32_t *wsum = smem + T;                // [T/64] wave sums of the scan
-    uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 8);             // [T] exclusive prefix (< 2^16)
-    uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 8 + T / 2);           // [rec_cap] (entry index, weight bits)
+    uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 16);            // [T] exclusive prefix (< 2^16)
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 16 + T / 2);          // [rec_cap] (entry index, weight bits)
     float4 *val4 = reinterpret_cast<float4 *>(rec + rec_cap(EPT_MAX));     // [SEG][CHUNK/4] staged source values
 
     // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
@@ -796,8 +796,8 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
 
 template <bool NORM, bool MAXOP, int EPT, int CHUNK>
 static int launch_tile(const SplatArgs &a, uint32_t items_cap, hipStream_t st) {
-    // counts (T words) + wave sums (8) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
-    const size_t lds = (size_t)(SPLAT_THREADS + 8 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
+    // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
+    const size_t lds = (size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
                        (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4;          // + the all-zero NULL entry
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
     // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
