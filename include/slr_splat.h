@@ -107,7 +107,7 @@ int slr_softsplat_mode_forward(const float *in, const float *metric, const float
                                int N, int C, int H, int W, int mode,
                                void *ws, size_t ws_bytes, int prebinned, void *stream);
 
-/* In-place normalisation of a raw accumulation whose LAST channel is the normaliser:
+/* Normalisation of a raw accumulation whose LAST channel is the normaliser:
  * accum [N,C+1,H,W] -> out [N,C,H,W].  Replaces softsplat.py:681-686 (ZERO_TO_ONE) and
  * animating_softmax_splating.py:923-924 (CLAMP_EPS, eps = 1e-8). */
 int slr_splat_normalize(const float *accum, float *out, int N, int C, int H, int W,
