@@ -48,6 +48,7 @@ struct WsLayout {
     size_t off_nseg;      // uint32[nt]   segments per tile                (plan)
     size_t off_partoff;   // uint32[nt]   first partial slot of the tile   (plan)
     size_t off_multi;     // uint32[nt]   compact list of multi-segment tiles (plan)
+    size_t off_whole;     // uint32[nt]   work items that cover a whole over-budget tile (plan)
     size_t off_items;     // ItemDesc[items_cap] (32 B per work item)           (plan)
     size_t off_totals;    // uint32[4]    total items, total partial slots (plan)
     size_t off_trash;     // float[planes][TILE_PIX]  sink for work-items outside the image
@@ -65,7 +66,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.tiles_y = (H + TILE_H - 1) / TILE_H;
     L.tiles = L.tiles_x * L.tiles_y;
     L.nt = (uint32_t)N * L.tiles;
-    L.part_slots = L.nt / 2 < 64 ? 64 : L.nt / 2;
+    L.part_slots = L.nt < 64 ? 64 : L.nt;       // one partial-tile slot per tile on average
     L.items_cap = L.nt + L.part_slots;
     size_t o = 0;
     L.off_count = o;   o += al256((size_t)L.nt * 4);
@@ -75,6 +76,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_nseg = o;    o += al256((size_t)L.nt * 4);
     L.off_partoff = o; o += al256((size_t)L.nt * 4);
     L.off_multi = o;   o += al256((size_t)L.nt * 4);
+    L.off_whole = o;   o += al256((size_t)L.nt * 4);
     L.off_items = o;   o += al256((size_t)L.items_cap * 32);
     L.off_totals = o;  o += 256;
     // C value planes + the normaliser plane

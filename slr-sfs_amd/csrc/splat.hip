@@ -208,7 +208,8 @@ struct ItemDesc {
     uint32_t tile, seg;          // tile index (n*tiles + tile), segment of its concatenated bin
     uint32_t cnt0, cnt1;         // entries in the bin of flow 0 / flow 1
     uint32_t off0, off1;         // where those bins start in list[0] / list[1]
-    uint32_t nseg, partoff;      // segments of the tile; first partial slot (multi-segment tiles)
+    uint32_t nseg, partoff;      // segments of the tile (0: this item covers the whole tile, segment by
+                                 // segment); first partial slot (multi-segment tiles)
 };
 
 // Work plan for splatting with one (count1 == nullptr) or two flows per tile:
@@ -222,9 +223,9 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
                                                     uint32_t seg, uint32_t part_slots,
                                                     uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
                                                     ItemDesc *__restrict__ items, uint32_t *__restrict__ multi,
-                                                    uint32_t *__restrict__ totals) {
+                                                    uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals) {
     __shared__ uint32_t wsum[16];
-    uint32_t run_items = 0, run_parts = 0, run_multi = 0;
+    uint32_t run_items = 0, run_parts = 0, run_multi = 0, run_whole = 0;
     for (uint32_t b = 0; b < nt; b += 1024) {
         uint32_t t = b + threadIdx.x;
         uint32_t cnt = 0;
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         uint32_t ns = cnt > seg ? (cnt + seg - 1) / seg : 1u;
         uint32_t pex;
         uint32_t ptot = block_exscan(ns > 1 ? ns : 0u, &pex, wsum);
-        if (ns > 1 && run_parts + pex + ns > part_slots) ns = 1;      // budget exhausted
+        const bool whole = ns > 1 && run_parts + pex + ns > part_slots;   // partial-slot budget exhausted:
+        if (whole) ns = 1;               // one workgroup walks ALL segments of the tile itself (ItemDesc.nseg = 0)
         // (a dropped tile leaves a hole in the slot numbering; harmless)
         uint32_t mex;                                                  // compact list of multi-segment tiles
         uint32_t mtot = block_exscan(ns > 1 ? 1u : 0u, &mex, wsum);
@@ -240,19 +242,23 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         run_multi += mtot;
         uint32_t iex;
         uint32_t itot = block_exscan(t < nt ? ns : 0u, &iex, wsum);
+        uint32_t wex;                                                  // compact list of whole-tile items
+        uint32_t wtot = block_exscan(whole ? 1u : 0u, &wex, wsum);
+        if (whole) whole_items[run_whole + wex] = run_items + iex;
+        run_whole += wtot;
         if (t < nt) {
             nseg[t] = ns;
             partoff[t] = run_parts + pex;
             ItemDesc d;
             d.tile = t; d.cnt0 = count0[t]; d.cnt1 = count1 ? count1[t] : 0u;
             d.off0 = listoff0[t]; d.off1 = listoff1 ? listoff1[t] : 0u;
-            d.nseg = ns; d.partoff = run_parts + pex;
+            d.nseg = whole ? 0u : ns; d.partoff = run_parts + pex;
             for (uint32_t s = 0; s < ns; ++s) { d.seg = s; items[run_items + iex + s] = d; }
         }
         run_items += itot;
         run_parts += ptot;
     }
-    if (threadIdx.x == 0) { totals[0] = run_items; totals[1] = run_parts; totals[3] = run_multi; }
+    if (threadIdx.x == 0) { totals[0] = run_items; totals[1] = run_parts; totals[3] = run_multi; totals[4] = run_whole; }
 }
 
 // =========================================================================== splat
@@ -266,7 +272,7 @@ struct SplatArgs {
     const float *flow[2];   // [N,2,H,W] per direction (flow[1] unused when ndir == 1)
     const uint32_t *count[2], *listoff[2], *list[2];
     float scale[2];         // alpha, 1 - alpha
-    const uint32_t *nseg, *partoff, *totals, *multi;
+    const uint32_t *nseg, *partoff, *totals, *multi, *whole_items;
     const ItemDesc *items;
     float *partial, *trash;
     float *out;             // [N,C,H,W]
@@ -339,7 +345,7 @@ __device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
 //            byte is written exactly once, coalesced, never read, never zeroed.
 //
 // Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
-template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK>
+template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE>
 __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int T = SPLAT_THREADS;
@@ -355,17 +361,37 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     // the same XCD, groups round-robin over the XCDs: a tile's column halo (bin entries owned by
     // the tile to its left: one 128-byte line per row for 4 useful bytes) is then served by that
     // XCD's L2 instead of HBM, while heavy image regions still spread over all XCDs.
-    const uint32_t total = a.totals[0];
-    const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t item = ((slot / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + slot % XCD_GROUP;
-    if (item >= total) return;
+    uint32_t item;
+    if (!WHOLE) {
+        const uint32_t total = a.totals[0];
+        const uint32_t slot = blockIdx.x >> 3;
+        item = ((slot / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + slot % XCD_GROUP;
+        if (item >= total) return;
+    } else {                                           // the (rare) whole-tile items, grid-strided
+        if (blockIdx.x >= a.totals[4]) return;
+        item = a.whole_items[blockIdx.x];
+    }
+  for (uint32_t wi = blockIdx.x;;) {                   // one pass unless WHOLE
     const ItemDesc it = a.items[item];
-    const uint32_t t = it.tile, s = it.seg;
+    const uint32_t t = it.tile;
+    // Normally one workgroup = one segment.  A tile whose segments did not fit into the partial-slot
+    // budget (pathological flows: everything converging into a few tiles) is walked segment by
+    // segment by ONE workgroup: every work-item keeps accumulating its own output pixel through
+    // global memory (its own earlier store), and normalises after the last segment.
+    // That is a separate instantiation (WHOLE) launched after the main one; the main kernel skips
+    // those items, so its code carries no loop.
+    constexpr bool whole = WHOLE;
+    if ((it.nseg == 0) != WHOLE) return;
+    const uint32_t nloop = WHOLE ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;
+    float nrm_total = 0.0f;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
     const int HW = a.H * a.W;
     const int tid = threadIdx.x;
 
+  for (uint32_t si = 0; si < nloop; ++si) {
+    const uint32_t s = whole ? si : it.seg;
+    const bool first = si == 0, last = si + 1 == nloop;
     SLR_STAMP(0);
     cnt[tid] = 0;
     __syncthreads();
@@ -517,7 +543,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool inside = (oy < a.H) & (ox < a.W);
-    const bool single = it.nseg == 1;
+    const bool single = it.nseg <= 1;               // results go straight to the output tensor
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)(it.partoff + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
@@ -549,8 +575,10 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
             for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
             if (lane == src) nrm += part;
         }
+        nrm_total += nrm;
+        nrm = nrm_total;                                  // all segments seen so far (whole-tile items)
         if (single) {
-            if (a.norm_out && inside) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
+            if (a.norm_out && inside && last) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
         } else {
             a.partial[(size_t)(it.partoff + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid] = nrm;
         }
@@ -656,8 +684,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
             float r = acc[u];
-            if (NORM && single) r = finish(r, nrm, a.norm_mode, a.eps);
             float *dst = (c0 + u < a.C) ? op + (size_t)(c0 + u) * ostr : trash;
+            if (whole && !first) r = MAXOP ? fmaxf(r, *dst) : r + *dst;      // earlier segments of this tile
+            if (NORM && single && last) r = finish(r, nrm, a.norm_mode, a.eps);
             *dst = r;
         }
         SLR_STAMP(6 + 3 * (c0 / CHUNK));
@@ -667,6 +696,12 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
         chunk(preA, c0);
         if (c0 + CHUNK < a.C) chunk(preB, c0 + CHUNK);
     }
+  }
+    if (!WHOLE) break;
+    wi += gridDim.x;
+    if (wi >= a.totals[4]) break;
+    item = a.whole_items[wi];
+  }
 }
 
 // Multi-segment tiles: sum (max) the raw partial tiles in segment order, normalise, store.
@@ -741,7 +776,7 @@ __global__ __launch_bounds__(256) void max_stage_kernel(const float *__restrict_
 struct Ws {
     WsLayout L;
     char *base;
-    uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals, *multi;
+    uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals, *multi, *whole_items;
     ItemDesc *items;
     float *partial, *trash;
 };
@@ -760,6 +795,7 @@ static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, co
     w.nseg = (uint32_t *)(w.base + w.L.off_nseg);
     w.partoff = (uint32_t *)(w.base + w.L.off_partoff);
     w.multi = (uint32_t *)(w.base + w.L.off_multi);
+    w.whole_items = (uint32_t *)(w.base + w.L.off_whole);
     w.items = (ItemDesc *)(w.base + w.L.off_items);
     w.totals = (uint32_t *)(w.base + w.L.off_totals);
     w.partial = (float *)(w.base + w.L.off_partial);
@@ -794,23 +830,34 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
     return 0;
 }
 
-template <bool NORM, bool MAXOP, int EPT, int CHUNK>
-static int launch_tile(const SplatArgs &a, uint32_t items_cap, hipStream_t st) {
-    // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
-    const size_t lds = (size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
-                       (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4;          // + the all-zero NULL entry
+template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE>
+static int launch_tile_variant(const SplatArgs &a, uint32_t grid, size_t lds, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
     // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
     static bool attr_set[64] = {};
     int dev = 0;
     SLR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>,
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK>), dim3(((items_cap + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP), dim3(SPLAT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>), dim3(grid), dim3(SPLAT_THREADS), lds, st, a);
     return 0;
+}
+
+template <bool NORM, bool MAXOP, int EPT, int CHUNK>
+static int launch_tile(const SplatArgs &a, uint32_t items_cap, uint32_t nt, hipStream_t st) {
+    // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
+    const size_t lds = (size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
+                       (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4;          // + the all-zero NULL entry
+    const uint32_t grid = ((items_cap + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
+    if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(a, grid, lds, st)) return e;
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));         // the dominant kernel only
+    g_ev_start = g_ev_stop = nullptr;                                                // one-shot
+    // tiles that did not fit the partial-slot budget (none for ordinary flows: the workgroups exit at once)
+    return launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(a, nt < 256u ? nt : 256u, lds, st);
 }
 
 // plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
@@ -822,7 +869,7 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     a.seg = w1 ? SEG_TWO : SEG_ONE;
     a.count[0] = w0.count; a.listoff[0] = w0.listoff; a.list[0] = w0.list;
     a.count[1] = w1 ? w1->count : nullptr; a.listoff[1] = w1 ? w1->listoff : nullptr; a.list[1] = w1 ? w1->list : nullptr;
-    a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals; a.multi = w0.multi;
+    a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals; a.multi = w0.multi; a.whole_items = w0.whole_items;
     a.partial = w0.partial;
     a.trash = w0.trash;
 #ifdef SLR_TRACE
@@ -832,15 +879,12 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
                        (const uint32_t *)(w1 ? w1->count : nullptr), (const uint32_t *)w0.listoff,
                        (const uint32_t *)(w1 ? w1->listoff : nullptr), w0.L.nt, (uint32_t)a.seg,
-                       w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.multi, w0.totals);
-    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
+                       w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.multi, w0.whole_items, w0.totals);
     if (w1) {
-        if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, w0.L.items_cap, st)) return e;
+        if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, w0.L.items_cap, w0.L.nt, st)) return e;
     } else {
-        if (int e = launch_tile<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(a, w0.L.items_cap, st)) return e;
+        if (int e = launch_tile<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(a, w0.L.items_cap, w0.L.nt, st)) return e;
     }
-    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
-    g_ev_start = g_ev_stop = nullptr;          // one-shot
     // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
     hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.part_slots / 2, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
                        dim3(SPLAT_THREADS), 0, st, a);

@@ -530,3 +530,39 @@ def test_c_abi_prebinned_reuse_and_errors(S, oracle):
     big = dev(rng.standard_normal(300001).astype(np.float32))
     assert L.slr_global_max(ptr(big), big.numel(), ptr(res), ptr(scratch), st) == 0
     assert float(res) == float(big.max())
+
+
+def test_splat_over_budget_tiles_whole_tile_path(S, oracle):
+    """More segments than partial-tile slots (everything converges into one tile of a larger
+    image): the over-budget tile is walked segment by segment by one workgroup (WHOLE kernel)."""
+    H, W = 320, 640
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flow = np.stack([(W / 2 - x) * 0.97 + 0.3, (H / 2 - y) * 0.97 - 0.2])[None].astype(np.float32)
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal((1, 9, H, W)).astype(np.float32)
+    met = (rng.standard_normal((1, 1, H, W)) * 0.5).astype(np.float32)
+    ref = oracle.softsplat_forward(v, flow)
+    out = host(S.FunctionSoftsplat(dev(v), dev(flow), None, "summation"))
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    refn = oracle.function_softsplat(v, flow, met, "softmax")
+    outn = host(S.FunctionSoftsplat(dev(v), dev(flow), dev(met), "softmax"))
+    np.testing.assert_allclose(outn, refn, rtol=1e-3, atol=1e-4)
+    mx = host(S.ModuleMaximumsplat()(dev(v), dev(flow)))
+    assert np.array_equal(mx, oracle.maxsplat_forward(v, flow))
+
+
+@pytest.mark.parametrize("kind", ["row", "column", "shrink"])
+def test_splat_collapsing_flows_vs_oracle(S, oracle, kind):
+    """Everything collapses onto one row / one column / a 4x smaller image: long bins, many
+    segments per tile, partial tiles + combine (and the whole-tile path when slots run out)."""
+    H, W = 200, 328
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    z = np.zeros_like(x)
+    flow = {"row": np.stack([z, (H / 2 - y) * 0.999 - 0.2]),
+            "column": np.stack([(W / 2 - x) * 0.999 + 0.3, z]),
+            "shrink": np.stack([(W / 2 - x) * 0.75, (H / 2 - y) * 0.75])}[kind][None].astype(np.float32)
+    v = np.random.default_rng(7).standard_normal((1, 10, H, W)).astype(np.float32)
+    ref = oracle.softsplat_forward(v, flow)
+    out = host(S.FunctionSoftsplat(dev(v), dev(flow), None, "summation"))
+    bound = 4e-6 * oracle.softsplat_forward(np.abs(v), flow) + 1e-6
+    assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
