@@ -566,3 +566,38 @@ def test_splat_collapsing_flows_vs_oracle(S, oracle, kind):
     out = host(S.FunctionSoftsplat(dev(v), dev(flow), None, "summation"))
     bound = 4e-6 * oracle.softsplat_forward(np.abs(v), flow) + 1e-6
     assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+
+
+def test_randomised_shapes_flows_modes_vs_oracle(S, oracle):
+    """Seeded sweep over shapes, channel counts, batch sizes, flow families (incl. collapsing and
+    far-out-of-range flows) and all four modes, every case against the oracle."""
+    rng = np.random.default_rng(20260928)
+    modes = ["summation", "average", "linear", "softmax"]
+    for case in range(40):
+        N, C = int(rng.integers(1, 4)), int(rng.integers(1, 21))
+        H, W = int(rng.integers(1, 90)), int(rng.integers(1, 210))
+        y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        kind = case % 6
+        if kind == 0:
+            fl = rng.uniform(-3, 3, (N, 2, H, W))
+        elif kind == 1:
+            fl = rng.uniform(-60, 60, (N, 2, H, W))
+        elif kind == 2:
+            fl = np.stack([(W / 2 - x) * rng.uniform(0.5, 1.0), (H / 2 - y) * rng.uniform(0.5, 1.0)])[None].repeat(N, 0)
+        elif kind == 3:
+            fl = np.stack([np.sin(x / 7 + y / 11) * 6, np.cos(x / 9 - y / 5) * 6])[None].repeat(N, 0)
+        elif kind == 4:
+            fl = rng.integers(-5, 6, (N, 2, H, W)).astype(np.float32)
+        else:
+            fl = rng.uniform(-2, 2, (N, 2, H, W))
+            fl[rng.random(fl.shape) < 0.02] = np.nan
+        fl = fl.astype(np.float32)
+        v = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        met = (rng.standard_normal((N, 1, H, W)) * 0.7).astype(np.float32)
+        mode = modes[case % 4]
+        m = np.abs(met) + 0.1 if mode == "linear" else met
+        ref = oracle.function_softsplat(v, fl, m, mode)
+        out = host(S.FunctionSoftsplat(dev(v), dev(fl), dev(m), mode))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.allclose(out, ref, rtol=2e-4, atol=2e-5 * scale), (case, N, C, H, W, kind, mode,
+                                                                       float(np.abs(out - ref).max()))
