@@ -601,3 +601,28 @@ def test_randomised_shapes_flows_modes_vs_oracle(S, oracle):
         scale = max(1.0, float(np.abs(ref).max()))
         assert np.allclose(out, ref, rtol=2e-4, atol=2e-5 * scale), (case, N, C, H, W, kind, mode,
                                                                        float(np.abs(out - ref).max()))
+
+
+def test_fused_synthesis_with_sink_motion_vs_oracle(S, oracle):
+    """Motion field pointing at a sink: after a few Euler steps thousands of sources share a few
+    output pixels in both splat directions (multi-segment tiles, long record lists, whole-tile
+    path) -- fused two-direction kernel against the oracle, baseline and SLR-v1 packing."""
+    H, W, N = 120, 200, 16
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    dx, dy = W * 0.6 - x, H * 0.4 - y
+    r = np.sqrt(dx * dx + dy * dy) + 1e-3
+    m = np.stack([dx / r * np.minimum(r, 4.0), dy / r * np.minimum(r, 4.0)])[None].astype(np.float32)
+    rng = np.random.default_rng(17)
+    fs = rng.standard_normal((1, 64, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    a = rng.standard_normal((1, 2, H, W)).astype(np.float32)
+    abg = (1 / (1 + np.exp(-a[:, 0:1]))).astype(np.float32)
+    cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+    cv = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=dev(abg))
+    for t in (1, 8, 15):
+        ref = oracle.synth_baseline(fs, Z, m, t, N)
+        np.testing.assert_allclose(host(cs.features(t)), ref, rtol=2e-4, atol=2e-5)
+        g, afl, _ = oracle.synth_v1(fs, Z, a[:, 1:2], abg, m, t, N)
+        gg, aa = cv.features(t)
+        np.testing.assert_allclose(host(gg), g, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(host(aa), afl, rtol=2e-4, atol=5e-5)
