@@ -25,3 +25,19 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+def large_case(golden_dir, tag):
+    """Inputs of the full-size digest fixtures (tests/golden/large_digests.npz), regenerated from
+    the same seeds tools/make_golden.py used; only digests of the REFERENCE's outputs are stored."""
+    import numpy as np
+    g = np.load(f"{golden_dir}/large_digests.npz")
+    _, C, H, W = [int(v) for v in g[f"{tag}_shape"]]
+    r2 = np.random.default_rng(1000 + H)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.5 * np.sin(2 * np.pi * (2 * x / W + y / H) + 0.7)
+    v = 1.5 * np.cos(2 * np.pi * (x / W - 1.5 * y / H) + 2.1)
+    msk = (x >= 0.35 * W).astype(np.float32)
+    motion = np.stack([u * msk, v * msk])[None].astype(np.float32)
+    inp = r2.standard_normal((1, C, H, W)).astype(np.float32)
+    return g, motion, inp, int(g[f"{tag}_steps"])

@@ -626,3 +626,22 @@ def test_fused_synthesis_with_sink_motion_vs_oracle(S, oracle):
         gg, aa = cv.features(t)
         np.testing.assert_allclose(host(gg), g, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(host(aa), afl, rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("tag", ["c2", "c3"])
+def test_full_size_reference_digests(S, golden_dir, tag):
+    """HIP path vs digests of the REFERENCE's own outputs at the C2 / C3 grids (no oracle involved):
+    Euler displacement maps bit-exact, summation splat at 4096 sampled positions, plane sums,
+    L2 norms, and the exact number of holes."""
+    from conftest import large_case
+    g, motion, inp, steps = large_case(golden_dir, tag)
+    disp, vis = S.euler_integration(dev(motion), steps)
+    hd = host(disp)
+    assert np.array_equal(hd.ravel()[g[f"{tag}_disp_pos"]], g[f"{tag}_disp_val"])
+    assert np.array_equal(hd.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_disp_sum"])
+    assert float(vis.sum()) == float(g[f"{tag}_vis_sum"])
+    out = host(S.FunctionSoftsplat(dev(inp), disp, None, "summation"))
+    np.testing.assert_allclose(out.ravel()[g[f"{tag}_out_pos"]], g[f"{tag}_out_val"], **TOL)
+    np.testing.assert_allclose(out.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_out_sum"], rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(np.sqrt((out.astype(np.float64) ** 2).sum(axis=(2, 3))), g[f"{tag}_out_l2"], rtol=1e-5)
+    assert int((out == 0).sum()) == int(g[f"{tag}_holes"])

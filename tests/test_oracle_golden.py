@@ -92,3 +92,18 @@ def test_forward_flow_decoder_input(oracle, golden_dir, t):
                                    rtol=1e-5, atol=5e-6)
         # holes are exact zeros: the partial-conv decoder masks on x != 0 (architectures.py:369)
         assert np.array_equal(gen == 0, g[f"{tag}_t{t}_gen_fs"] == 0)
+
+
+@pytest.mark.parametrize("tag", ["c2", "c3"])
+def test_full_size_digests(oracle, golden_dir, tag):
+    """Oracle vs digests of the reference's outputs at the C2 (256x480) and C3 (768x1280) grids."""
+    from conftest import large_case
+    g, motion, inp, steps = large_case(golden_dir, tag)
+    disp, vis = oracle.euler_integration(motion, steps)
+    assert np.array_equal(disp.ravel()[g[f"{tag}_disp_pos"]], g[f"{tag}_disp_val"])
+    assert np.array_equal(disp.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_disp_sum"])
+    assert float(vis.sum()) == float(g[f"{tag}_vis_sum"])
+    out = oracle.softsplat_forward(inp, disp)
+    assert np.array_equal(out.ravel()[g[f"{tag}_out_pos"]], g[f"{tag}_out_val"])      # same summation order: exact
+    np.testing.assert_allclose(out.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_out_sum"], rtol=1e-12)
+    assert int((out == 0).sum()) == int(g[f"{tag}_holes"])

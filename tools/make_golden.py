@@ -227,6 +227,34 @@ def main():
     m1["count"] = np.int32(idx)
     np.savez_compressed(os.path.join(OUT, "splat_max.npz"), **m1)
 
+    # ---- L1: full-size digests (config C3 grid 768x1280; C2 grid 256x480) ------------------
+    # inputs are regenerated from seeds by the tests; only digests of the reference's outputs are stored
+    l1 = {}
+    for tag, (H, W, C, steps) in {"c3": (768, 1280, 3, 30), "c2": (256, 480, 4, 59)}.items():
+        r2 = np.random.default_rng(1000 + H)
+        y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        u = 1.5 * np.sin(2 * np.pi * (2 * x / W + y / H) + 0.7)
+        v = 1.5 * np.cos(2 * np.pi * (x / W - 1.5 * y / H) + 2.1)
+        msk = (x >= 0.35 * W).astype(np.float32)
+        motion = np.stack([u * msk, v * msk])[None].astype(np.float32)
+        disp, vis = eim.euler_integration(torch.from_numpy(motion), steps)
+        disp = disp.numpy().astype(np.float32)
+        inp = r2.standard_normal((1, C, H, W)).astype(np.float32)
+        out = ss._FunctionSoftsplat.apply(cudalike(inp), cudalike(disp)).numpy().astype(np.float32)
+        pos = r2.integers(0, out.size, 4096)
+        l1[f"{tag}_shape"] = np.array([1, C, H, W], np.int32)
+        l1[f"{tag}_steps"] = np.int32(steps)
+        l1[f"{tag}_disp_sum"] = disp.astype(np.float64).sum(axis=(2, 3))
+        l1[f"{tag}_vis_sum"] = np.float64(vis.numpy().sum())
+        l1[f"{tag}_disp_pos"] = r2.integers(0, disp.size, 4096)
+        l1[f"{tag}_disp_val"] = disp.ravel()[l1[f"{tag}_disp_pos"]]
+        l1[f"{tag}_out_sum"] = out.astype(np.float64).sum(axis=(2, 3))
+        l1[f"{tag}_out_l2"] = np.sqrt((out.astype(np.float64) ** 2).sum(axis=(2, 3)))
+        l1[f"{tag}_out_pos"] = pos
+        l1[f"{tag}_out_val"] = out.ravel()[pos]
+        l1[f"{tag}_holes"] = np.int64((out == 0).sum())
+    np.savez_compressed(os.path.join(OUT, "large_digests.npz"), **l1)
+
     if True:
         from make_golden_pipeline import capture_pipeline
         capture_pipeline(ss, eim, OUT, rng, cudalike)
