@@ -182,6 +182,22 @@ int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_b
                        const float *residual, const float *next_scale, const float *next_shift,
                        float *out, float *um_out, float winsize, int N, int C, int H, int W, void *stream);
 
+/* ------------------------------------------------------------------ decoder convolution on the matrix cores (8 f3) */
+
+/* 3x3 / stride 1 / zero-pad 1 convolution, fp32 in / fp32 out, WITHOUT bias: the `conv(input*mask)` of
+ * models/layers/partialconv2d.py:69 (bias = NULL: it joins in slr_pconv_epilogue) and the plain 3x3
+ * convolutions of models/layers/blocks.py:66-74 (bias added to the scaled accumulators).  Implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands
+ * (x = hi + lo in f16, three MFMAs per product, fp32 accumulation; csrc/conv.hip): fp32-class
+ * accuracy at several times the rate of the fp32 matrix pipe.
+ *   weights are prepared once per layer with slr_conv3x3_split_weights into a buffer of
+ *   slr_conv3x3_weight_bytes(Cout, Cin) bytes; `wscale` is a power of two that brings max|w|
+ *   near 2^12 (f16 range) and must be passed unchanged to the forward call.
+ *   Requirements: Cout % 64 == 0, Cin % 16 == 0 (other layers stay with MIOpen). */
+size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
+int slr_conv3x3_split_weights(const float *w, void *wsplit, int Cout, int Cin, float wscale, void *stream);
+int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias /* [Cout] or NULL */, float *out,
+                        int N, int Cin, int Cout, int H, int W, float wscale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

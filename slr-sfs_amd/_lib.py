@@ -18,6 +18,7 @@ SYMBOLS = (
     "slr_synth_group", "slr_global_max",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue",
+    "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward",
 )
 
 _lib = None
@@ -53,6 +54,8 @@ def lib():
         L.slr_splat_time_next.argtypes = [vp, vp]
         L.slr_splat_workspace_bytes.restype = sz
         L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
+        L.slr_conv3x3_weight_bytes.restype = sz
+        L.slr_conv3x3_weight_bytes.argtypes = [i, i]
         sig = {
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
@@ -68,6 +71,8 @@ def lib():
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
+            "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
+            "slr_conv3x3_forward": [fp, vp, fp, fp, i, i, i, i, i, f, vp],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)

@@ -122,7 +122,41 @@ class Conv(nn.Module):
         nn.init.normal_(self.weight, std=math.sqrt(1.0 / (cin * k * k)))
 
     def forward(self, x):
-        return F.conv2d(x, self.weight, self.bias, padding=self.pad)
+        return self.conv(x, self.bias)
+
+    def _split_weights(self):
+        """Split-f16 weights of the matrix-core kernel (csrc/conv.hip), prepared once per device /
+        weight version: (buffer, wscale)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        c = self.__dict__.get("_wsplit")
+        if c is None or c[0] != key:
+            L = _lib.lib()
+            amax = float(w.abs().max())
+            wscale = 2.0 ** math.floor(math.log2(4096.0 / amax)) if amax > 0 else 1.0
+            buf = torch.empty(L.slr_conv3x3_weight_bytes(w.shape[0], w.shape[1]), dtype=torch.uint8, device=w.device)
+            with torch.cuda.device(w.device):
+                _lib.check(L.slr_conv3x3_split_weights(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale,
+                                                       _lib.stream_of(w)), "slr_conv3x3_split_weights")
+            c = self.__dict__["_wsplit"] = (key, buf, wscale)
+        return c[1], c[2]
+
+    def conv(self, x, bias):
+        """The convolution proper.  3x3 layers with Cin % 16 == 0 and Cout % 64 == 0 (all but the
+        3-channel ends of the networks) run on the matrix cores through the split-f16 implicit
+        GEMM of csrc/conv.hip; the rest (1x1 skips, 3-channel layers, CPU validation) is MIOpen /
+        torch."""
+        cout, cin = self.weight.shape[:2]
+        if self.k == 3 and cin % 16 == 0 and cout % 64 == 0 and _fused_ok(x):
+            N, _, H, W = x.shape
+            buf, wscale = self._split_weights()
+            out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
+                                                          N, cin, cout, H, W, wscale, _lib.stream_of(x)),
+                           "slr_conv3x3_forward")
+            return out
+        return F.conv2d(x, self.weight, bias, padding=self.pad)
 
 
 class PartialConv(Conv):
@@ -136,7 +170,7 @@ class PartialConv(Conv):
     def forward(self, xin, mplane, mscale, residual=None, next_bn=None):
         # conv(mask, ones[out,in,k,k]) is the same k x k box sum for every output channel (:61)
         box = F.avg_pool2d(mplane, self.k, stride=1, padding=self.pad, divisor_override=1)
-        raw0 = F.conv2d(xin, self.weight, None, padding=self.pad)                  # bias joins in the epilogue
+        raw0 = self.conv(xin, None)                                                # bias joins in the epilogue
         return pconv_epilogue(raw0, self.bias, box, mscale, self.cin * self.k * self.k, residual, next_bn)
 
 
@@ -288,6 +322,7 @@ def _load_bn(bn, sd, key):
 
 
 def _load_conv(conv, sd, key):
+    conv.__dict__.pop("_wsplit", None)
     conv.weight.data.copy_(_fold_sn(sd, key))
     if conv.bias is not None:
         conv.bias.data.copy_(sd[key + ".bias"])

@@ -645,3 +645,54 @@ def test_full_size_reference_digests(S, golden_dir, tag):
     np.testing.assert_allclose(out.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_out_sum"], rtol=1e-5, atol=1e-2)
     np.testing.assert_allclose(np.sqrt((out.astype(np.float64) ** 2).sum(axis=(2, 3))), g[f"{tag}_out_l2"], rtol=1e-5)
     assert int((out == 0).sum()) == int(g[f"{tag}_holes"])
+
+
+def test_decoder_matrix_core_conv_vs_fp64(S):
+    """The split-f16 matrix-core convolution (csrc/conv.hip) inside the partial-conv decoder: whole-decoder
+    output vs the same decoder with every convolution evaluated in fp64 by torch (test-only patch), next to
+    the error of the MIOpen fp32 path on the same input.  Tolerance 5e-5 on outputs of magnitude ~5."""
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    torch.manual_seed(3)
+    dec = nets.DecoderPconv2(64, 3).cuda().eval()
+    with torch.no_grad():
+        for m in dec.modules():
+            if hasattr(m, "stored_mean"):
+                m.stored_mean.normal_(0, 0.3)
+                m.stored_var.uniform_(0.5, 1.5)
+        x = torch.randn(1, 64, 72, 136, device="cuda")
+        x[:, :, 20:50, 30:80] = 0
+        y = dec(x)
+        orig = nets.Conv.conv
+        try:
+            nets.Conv.conv = lambda self, t, b: F.conv2d(t.double(), self.weight.double(), None if b is None else b.double(),
+                                                         padding=self.pad).float()
+            y64 = dec(x)
+            nets.Conv.conv = lambda self, t, b: F.conv2d(t, self.weight, b, padding=self.pad)
+            y32 = dec(x)
+        finally:
+            nets.Conv.conv = orig
+    e_hip, e_mio = (y - y64).abs().max().item(), (y32 - y64).abs().max().item()
+    assert y64.abs().max().item() > 1.0
+    assert e_hip < 5e-5, (e_hip, e_mio)
+    assert e_hip < 8 * e_mio + 1e-6, (e_hip, e_mio)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,bias", [(16, 64, 9, 33, False), (32, 128, 19, 45, True), (64, 64, 64, 96, False),
+                                               (48, 192, 8, 32, True), (16, 64, 1, 1, True)])
+def test_conv3x3_matrix_core_kernel(S, cin, cout, h, w, bias):
+    """slr_conv3x3_forward through the C ABI vs an fp64 convolution: ragged sizes (blocks cut by the image
+    border, zero padding), 64- and 128-channel workgroup variants, optional bias, batch of 2."""
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin + h)
+    conv = nets.Conv(cin, cout, 3, bias=bias).cuda()
+    if bias:
+        conv.bias.data.normal_()
+    x = torch.randn(2, cin, h, w, device="cuda") * 3
+    with torch.no_grad():
+        y = conv(x)
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
+    assert conv.__dict__.get("_wsplit") is not None          # the matrix-core path ran
+    scale = ref.abs().max().item()
+    assert (y - ref).abs().max().item() < 4e-6 * max(scale, 1.0)
