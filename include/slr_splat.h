@@ -184,19 +184,41 @@ int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_b
 
 /* ------------------------------------------------------------------ decoder convolution on the matrix cores (8 f3) */
 
-/* 3x3 / stride 1 / zero-pad 1 convolution, fp32 in / fp32 out, WITHOUT bias: the `conv(input*mask)` of
- * models/layers/partialconv2d.py:69 (bias = NULL: it joins in slr_pconv_epilogue) and the plain 3x3
- * convolutions of models/layers/blocks.py:66-74 (bias added to the scaled accumulators).  Implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands
- * (x = hi + lo in f16, three MFMAs per product, fp32 accumulation; csrc/conv.hip): fp32-class
- * accuracy at several times the rate of the fp32 matrix pipe.
- *   weights are prepared once per layer with slr_conv3x3_split_weights into a buffer of
+/* 3x3 / stride 1 / zero-pad 1 convolution, fp32 in / fp32 out: implicit GEMM on
+ * v_mfma_f32_32x32x16_f16 with split operands (x = hi + lo in f16, three MFMAs per product, fp32
+ * accumulation; csrc/conv.hip): fp32-class accuracy (2-5e-6 abs on outputs of magnitude 4, like
+ * MIOpen's fp32 Winograd) at several times the rate of the fp32 matrix pipe.  Any Cin / Cout
+ * (channels are zero-padded to multiples of 16 / 32 inside the weight buffer).
+ *   Weights are prepared once per layer with slr_conv3x3_split_weights into a buffer of
  *   slr_conv3x3_weight_bytes(Cout, Cin) bytes; `wscale` is a power of two that brings max|w|
- *   near 2^12 (f16 range) and must be passed unchanged to the forward call.
- *   Requirements: Cout % 64 == 0, Cin % 16 == 0 (other layers stay with MIOpen). */
+ *   near 2^12 (f16 range) and must be passed unchanged to the forward calls. */
 size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
-int slr_conv3x3_split_weights(const float *w, void *wsplit, int Cout, int Cin, float wscale, void *stream);
-int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias /* [Cout] or NULL */, float *out,
-                        int N, int Cin, int Cout, int H, int W, float wscale, void *stream);
+int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit, int Cout, int Cin,
+                              float wscale, void *stream);
+
+/* out = conv3x3(pre(in)) + bias, pre(x) = relu(x*pre_scale[c] - pre_shift[c]) when pre_scale is given
+ * (eval-mode noise-BN + ReLU in front of the convolution, models/layers/blocks.py:66-74 +
+ * normalization.py:219-231), identity otherwise.  bias [Cout] or NULL. */
+int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, float *out,
+                        int N, int Cin, int Cout, int H, int W, float wscale,
+                        const float *pre_scale, const float *pre_shift, void *stream);
+
+/* One partial convolution of ResNet_Block_Pconv2 in a single kernel
+ * (models/layers/partialconv2d.py:41-81 with blocks.py:229-239,248):
+ *   xin = relu(x*pre_scale - pre_shift) * mask     (prologue; skipped when pre_scale is NULL: x is
+ *         then the already activated and masked input, i.e. the output of a previous call with
+ *         next_scale / next_shift)
+ *         pre_mask_mode  1: mask = pre_mask [N,1,H,W];  0: mask = (x != 0) per element
+ *         (models/networks/architectures.py:369);  -1: no mask
+ *   raw0 = conv3x3(xin)                             (bias-free)
+ *   out  = epilogue(raw0) exactly as slr_pconv_epilogue: (raw0*ratio + b)*um, then `+ residual`
+ *          or relu(.*next_scale - next_shift)*um;  um -> um_out.   winsize = Cin*9.
+ * Same operations in the same order as slr_bn_relu_mask -> convolution -> slr_pconv_epilogue. */
+int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift,
+                         const float *pre_mask, int pre_mask_mode, const void *wsplit, float wscale,
+                         const float *bias, const float *mask_box, float mask_scale,
+                         const float *residual, const float *next_scale, const float *next_shift,
+                         float *out, float *um_out, int N, int Cin, int Cout, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ SYMBOLS = (
     "slr_synth_group", "slr_global_max",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue",
-    "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward",
+    "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
 )
 
 _lib = None
@@ -72,7 +72,8 @@ def lib():
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
-            "slr_conv3x3_forward": [fp, vp, fp, fp, i, i, i, i, i, f, vp],
+            "slr_conv3x3_forward": [fp, vp, fp, fp, i, i, i, i, i, f, fp, fp, vp],
+            "slr_pconv3x3_forward": [fp, fp, fp, fp, i, vp, f, fp, fp, f, fp, fp, fp, fp, fp, i, i, i, i, i, vp],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)

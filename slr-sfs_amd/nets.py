@@ -121,8 +121,8 @@ class Conv(nn.Module):
         self.cin, self.k = cin, k
         nn.init.normal_(self.weight, std=math.sqrt(1.0 / (cin * k * k)))
 
-    def forward(self, x):
-        return self.conv(x, self.bias)
+    def forward(self, x, pre_bn=None):
+        return self.conv(x, self.bias, pre_bn)
 
     def _split_weights(self):
         """Split-f16 weights of the matrix-core kernel (csrc/conv.hip), prepared once per device /
@@ -141,37 +141,69 @@ class Conv(nn.Module):
             c = self.__dict__["_wsplit"] = (key, buf, wscale)
         return c[1], c[2]
 
-    def conv(self, x, bias):
-        """The convolution proper.  3x3 layers with Cin % 16 == 0 and Cout % 64 == 0 (all but the
-        3-channel ends of the networks) run on the matrix cores through the split-f16 implicit
-        GEMM of csrc/conv.hip; the rest (1x1 skips, 3-channel layers, CPU validation) is MIOpen /
-        torch."""
-        cout, cin = self.weight.shape[:2]
-        if self.k == 3 and cin % 16 == 0 and cout % 64 == 0 and _fused_ok(x):
+    def conv(self, x, bias, pre_bn=None):
+        """conv(relu(bn(x))) + bias (``pre_bn`` = (scale, shift) of the BN in front, or None).
+        3x3 layers on a device run on the matrix cores (split-f16 implicit GEMM of csrc/conv.hip,
+        BN + ReLU fused into its prologue); 1x1 skips go to MIOpen; CPU tensors (validation against
+        the reference classes) take the torch composition."""
+        if self.k == 3 and _fused_ok(x):
+            cout, cin = self.weight.shape[:2]
             N, _, H, W = x.shape
             buf, wscale = self._split_weights()
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+            sc, sh = pre_bn if pre_bn is not None else (None, None)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
-                                                          N, cin, cout, H, W, wscale, _lib.stream_of(x)),
-                           "slr_conv3x3_forward")
+                                                          N, cin, cout, H, W, wscale, _lib.ptr(sc), _lib.ptr(sh),
+                                                          _lib.stream_of(x)), "slr_conv3x3_forward")
             return out
+        if pre_bn is not None:
+            x = bn_relu_mask(x, pre_bn[0], pre_bn[1], False)
         return F.conv2d(x, self.weight, bias, padding=self.pad)
 
 
 class PartialConv(Conv):
-    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81.
-    ``xin`` is the already activated and masked input relu(bn(x))*mask (blocks.py:229-231,
-    partialconv2d.py:69); ``mplane`` [N,1,H,W] with conv(mask, ones) == box_k(mplane)*mscale:
-    the channel-uniform mask and Cin, or the channel sum of a per-channel mask and 1.
-    Returns (out, update_mask [N,1,H,W]); with ``next_bn`` the output is already the activated,
-    masked input of the block's second convolution."""
+    """PartialConv2d(multi_channel=True, return_mask=True), models/layers/partialconv2d.py:41-81,
+    together with the BN + ReLU + input*mask in front of it (blocks.py:229-236).
 
-    def forward(self, xin, mplane, mscale, residual=None, next_bn=None):
-        # conv(mask, ones[out,in,k,k]) is the same k x k box sum for every output channel (:61)
+    ``mask``: [N,1,H,W] channel-uniform mask, or None = (x != 0) per element
+    (models/networks/architectures.py:369; needs ``pre_bn``).  ``pre_bn`` = (scale, shift): the input
+    of the convolution is relu(x*scale - shift)*mask; None: ``x`` is already that tensor (the output
+    of the previous partial convolution called with ``next_bn``).
+    conv(mask, ones[out,in,k,k]) (:61) is the same k x k box sum for every output channel:
+    box_k(mplane)*mscale with (mplane, mscale) = (mask, Cin) or (channel sum of the per-element
+    mask, 1) -- exact integer arithmetic in fp32.
+    Returns (out, update_mask [N,1,H,W]); with ``next_bn`` the output is already the activated,
+    masked input of the block's second convolution.  On a device all of this is ONE kernel
+    (slr_pconv3x3_forward); on the CPU the torch composition that defines it."""
+
+    def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None):
+        cin = x.shape[1]
+        if mask is None:
+            assert pre_bn is not None
+            mplane, mscale = (x != 0).sum(1, keepdim=True).to(x.dtype), 1.0
+        else:
+            mplane, mscale = mask, float(cin)
         box = F.avg_pool2d(mplane, self.k, stride=1, padding=self.pad, divisor_override=1)
-        raw0 = self.conv(xin, None)                                                # bias joins in the epilogue
-        return pconv_epilogue(raw0, self.bias, box, mscale, self.cin * self.k * self.k, residual, next_bn)
+        if self.k == 3 and _fused_ok(x, box, *([] if residual is None else [residual])):
+            N, _, H, W = x.shape
+            cout = self.weight.shape[0]
+            buf, wscale = self._split_weights()
+            out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+            um = torch.empty_like(box)
+            psc, psh = pre_bn if pre_bn is not None else (None, None)
+            nsc, nsh = next_bn if next_bn is not None else (None, None)
+            mode = -1 if pre_bn is None else (0 if mask is None else 1)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().slr_pconv3x3_forward(
+                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask) if mode == 1 else None, mode,
+                    _lib.ptr(buf), wscale, _lib.ptr(self.bias), _lib.ptr(box), float(mscale), _lib.ptr(residual),
+                    _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um), N, cin, cout, H, W,
+                    _lib.stream_of(x)), "slr_pconv3x3_forward")
+            return out, um
+        xin = bn_relu_mask(x, pre_bn[0], pre_bn[1], mask) if pre_bn is not None else x
+        raw0 = F.conv2d(xin, self.weight, None, padding=self.pad)                  # bias joins in the epilogue
+        return pconv_epilogue(raw0, self.bias, box, mscale, cin * self.k * self.k, residual, next_bn)
 
 
 def _resample(kind):
@@ -203,8 +235,8 @@ class ResBlock(nn.Module):
         self.resample = _resample(resample)
 
     def forward(self, x):
-        a = self.conv_aa(bn_relu_mask(x, *self.bn1.scale_shift(), False))
-        a = self.conv_ab(bn_relu_mask(a, *self.bn2.scale_shift(), False))
+        a = self.conv_aa(x, self.bn1.scale_shift())            # BN + ReLU ride in the convolution's prologue
+        a = self.conv_ab(a, self.bn2.scale_shift())
         b = self.conv_b(x) if self.conv_b is not None else x
         return self.resample(a + b)          # == resample(a) + resample(b): both resamplers are linear
 
@@ -222,18 +254,12 @@ class PconvResBlock(nn.Module):
 
     def forward(self, x, mask):
         # mask: None = (x != 0) per channel (architectures.py:369), else [N,1,H,W] channel-uniform
-        s1, h1 = self.bn1.scale_shift()
-        xin = bn_relu_mask(x, s1, h1, mask)                                        # :229-231
-        if mask is None:
-            mplane, mscale = (x != 0).sum(1, keepdim=True).to(x.dtype), 1.0
-        else:
-            mplane, mscale = mask, float(x.shape[1])
-        a, m = self.conv_aa(xin, mplane, mscale, next_bn=self.bn2.scale_shift())   # -> relu(bn2(.))*m (:233-236)
+        a, m = self.conv_aa(x, mask, next_bn=self.bn2.scale_shift(), pre_bn=self.bn1.scale_shift())   # :229-236
         # x_a + x_b (:248).  The reference resamples the two branches separately and adds; avg-pool
         # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
         # rounding, lets the residual join the epilogue, and halves the resampling work.
         skip = self.conv_b(x) if self.conv_b is not None else x                    # :243-247
-        a, m = self.conv_ab(a, m, float(a.shape[1]), residual=skip)                # :237-239
+        a, m = self.conv_ab(a, m, residual=skip)                                   # :237-239
         return self.resample(a), self.resample_mask(m)                             # :240-241
 
 

@@ -648,41 +648,37 @@ def test_full_size_reference_digests(S, golden_dir, tag):
 
 
 def test_decoder_matrix_core_conv_vs_fp64(S):
-    """The split-f16 matrix-core convolution (csrc/conv.hip) inside the partial-conv decoder: whole-decoder
-    output vs the same decoder with every convolution evaluated in fp64 by torch (test-only patch), next to
-    the error of the MIOpen fp32 path on the same input.  Tolerance 5e-5 on outputs of magnitude ~5."""
-    import torch.nn.functional as F
+    """Partial-conv decoder on the device (every 3x3 convolution = ONE fused split-f16 matrix-core kernel,
+    csrc/conv.hip) vs the torch composition of the same modules evaluated in fp64 on the CPU (the
+    definition that tests/test_nets_vs_reference.py validates against the reference's classes), next to
+    the error of that composition in fp32.  Tolerance 5e-5 on outputs of magnitude ~5."""
+    import copy
     from slr_sfs_amd import nets
     torch.manual_seed(3)
-    dec = nets.DecoderPconv2(64, 3).cuda().eval()
+    dec = nets.DecoderPconv2(64, 3).eval()
     with torch.no_grad():
         for m in dec.modules():
             if hasattr(m, "stored_mean"):
                 m.stored_mean.normal_(0, 0.3)
                 m.stored_var.uniform_(0.5, 1.5)
-        x = torch.randn(1, 64, 72, 136, device="cuda")
+        x = torch.randn(1, 64, 72, 136)
         x[:, :, 20:50, 30:80] = 0
-        y = dec(x)
-        orig = nets.Conv.conv
-        try:
-            nets.Conv.conv = lambda self, t, b: F.conv2d(t.double(), self.weight.double(), None if b is None else b.double(),
-                                                         padding=self.pad).float()
-            y64 = dec(x)
-            nets.Conv.conv = lambda self, t, b: F.conv2d(t, self.weight, b, padding=self.pad)
-            y32 = dec(x)
-        finally:
-            nets.Conv.conv = orig
-    e_hip, e_mio = (y - y64).abs().max().item(), (y32 - y64).abs().max().item()
+        y32 = dec(x)
+        y64 = copy.deepcopy(dec).double()(x.double())
+        y = dec.cuda()(x.cuda()).cpu()
+    e_hip, e_f32 = (y.double() - y64).abs().max().item(), (y32.double() - y64).abs().max().item()
     assert y64.abs().max().item() > 1.0
-    assert e_hip < 5e-5, (e_hip, e_mio)
-    assert e_hip < 8 * e_mio + 1e-6, (e_hip, e_mio)
+    assert e_hip < 5e-5, (e_hip, e_f32)
+    assert e_hip < 10 * e_f32 + 1e-6, (e_hip, e_f32)
 
 
 @pytest.mark.parametrize("cin,cout,h,w,bias", [(16, 64, 9, 33, False), (32, 128, 19, 45, True), (64, 64, 64, 96, False),
-                                               (48, 192, 8, 32, True), (16, 64, 1, 1, True)])
+                                               (48, 192, 8, 32, True), (16, 64, 1, 1, True), (3, 32, 17, 40, True),
+                                               (128, 3, 24, 70, True), (3, 3, 16, 32, True), (20, 70, 11, 35, False)])
 def test_conv3x3_matrix_core_kernel(S, cin, cout, h, w, bias):
     """slr_conv3x3_forward through the C ABI vs an fp64 convolution: ragged sizes (blocks cut by the image
-    border, zero padding), 64- and 128-channel workgroup variants, optional bias, batch of 2."""
+    border, zero padding), channel counts that are not multiples of 16 / 32 (zero-padded weights), the
+    128- / 64- / 32-channel workgroup variants, optional bias, BN + ReLU prologue, batch of 2."""
     import torch.nn.functional as F
     from slr_sfs_amd import nets
     torch.manual_seed(cin + h)
@@ -690,9 +686,45 @@ def test_conv3x3_matrix_core_kernel(S, cin, cout, h, w, bias):
     if bias:
         conv.bias.data.normal_()
     x = torch.randn(2, cin, h, w, device="cuda") * 3
+    sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda")
     with torch.no_grad():
         y = conv(x)
         ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
+        yb = conv(x, (sc, sh))
+        xb = F.relu(x * sc.view(1, -1, 1, 1) - sh.view(1, -1, 1, 1))          # fp32, as the prologue computes it
+        refb = F.conv2d(xb.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
     assert conv.__dict__.get("_wsplit") is not None          # the matrix-core path ran
-    scale = ref.abs().max().item()
-    assert (y - ref).abs().max().item() < 4e-6 * max(scale, 1.0)
+    for got, want in ((y, ref), (yb, refb)):
+        assert (got - want).abs().max().item() < 4e-6 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,mode", [(64, 64, 24, 70, "derived"), (64, 128, 16, 64, "plane"),
+                                               (128, 3, 9, 40, "plane"), (32, 32, 20, 33, "chain")])
+def test_pconv3x3_fused_equals_staged(S, cin, cout, h, w, mode):
+    """The one-kernel partial convolution (prologue + matrix-core convolution + epilogue) against the
+    staged path through the separately tested kernels: slr_bn_relu_mask -> slr_conv3x3_forward (bias-free)
+    -> slr_pconv_epilogue.  Same operations in the same order on the same accumulators: bit-exact,
+    including the update mask, with residual and with next-BN fusion."""
+    from slr_sfs_amd import nets
+    import torch.nn.functional as F
+    torch.manual_seed(cout + w)
+    pc = nets.PartialConv(cin, cout, 3).cuda()
+    pc.bias.data.normal_()
+    x = torch.randn(2, cin, h, w, device="cuda")
+    x[:, :, 3:8, 5:20] = 0
+    sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3
+    nsc, nsh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.3
+    res = torch.randn(2, cout, h, w, device="cuda")
+    mask = None if mode == "derived" else (torch.rand(2, 1, h, w, device="cuda") > 0.3).float()
+    pre = None if mode == "chain" else (sc, sh)
+    with torch.no_grad():
+        for kw in ({"residual": res}, {"next_bn": (nsc, nsh)}, {}):
+            out, um = pc(x, mask, pre_bn=pre, **kw)
+            # staged
+            xin = nets.bn_relu_mask(x, sc, sh, mask) if pre is not None else x
+            mplane, mscale = ((x != 0).sum(1, keepdim=True).float(), 1.0) if mask is None else (mask, float(cin))
+            box = F.avg_pool2d(mplane, 3, stride=1, padding=1, divisor_override=1)
+            raw0 = nets.Conv.conv(pc, xin, None)
+            out2, um2 = nets.pconv_epilogue(raw0, pc.bias, box, mscale, cin * 9, kw.get("residual"), kw.get("next_bn"))
+            assert torch.equal(um, um2)
+            assert torch.equal(out, out2), (out - out2).abs().max().item()

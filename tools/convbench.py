@@ -33,7 +33,7 @@ def conv_hip(x, buf, wscale, cout):
     return out
 
 
-def timeit(fn, n=10):
+def timeit(fn, n=30):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
