@@ -33,6 +33,8 @@
 //     accumulator register a pair of 128-byte row segments of the NCHW output.
 #include "slr_common.hpp"
 
+#include <type_traits>
+
 namespace slr {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -43,7 +45,9 @@ constexpr int CV_HW = CV_W + 2, CV_HH = CV_H + 2;  // input halo block
 constexpr int CV_NPX = CV_HW * CV_HH;              // 340 halo pixels
 constexpr int CV_ITEMS = 2 * CV_NPX;               // (pixel, 8-channel group) staging items per chunk
 constexpr int CV_THREADS = 256;
-constexpr int CV_ROUNDS = (CV_ITEMS + CV_THREADS - 1) / CV_THREADS;   // 3
+#ifndef CV_EXP
+#define CV_EXP 0          // development experiments (tools/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging
+#endif
 constexpr float CV_XSCALE = 64.0f;                 // activations are scaled by 2^6 before the split
 constexpr int CV_MAXCIN = 1024;                    // prologue scale/shift table in LDS
 
@@ -74,12 +78,13 @@ __host__ __device__ inline int conv_cin_pad(int Cin) { return (Cin + 15) / 16 * 
 
 // CPW: 32-channel output tiles per wave; WCO: waves along the output channels (workgroup covers
 // 32*CPW*WCO channels); the other 4/WCO wave rows split the 8 block rows.
-template <int CPW, int WCO>
+template <int CPW, int WCO, bool PRE>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
     __shared__ h8 xs[2][2][2][CV_NPX];             // [buffer][hi|lo][8-channel group][halo pixel]
-    __shared__ __attribute__((aligned(16))) float pss[2][CV_MAXCIN];   // prologue scale / shift per (padded) input channel
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float4 pss4[2][CV_MAXCIN / 4];      // prologue scale / shift (x CV_XSCALE) per (padded) input channel
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps tile bases in SGPRs
     const int wc = wave % WCO, wp = wave / WCO;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int x0 = tx * CV_W, y0 = ty * CV_H;
@@ -91,70 +96,93 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     const float *inb = a.in + (size_t)n * a.Cin * HW;
     const int pre = a.pre;
 
-    if (pre != PRE_NONE) {
-        for (int i = tid; i < nchunk * 16; i += CV_THREADS) {
-            pss[0][i] = i < a.Cin ? a.pre_scale[i] : 0.0f;
-            pss[1][i] = i < a.Cin ? a.pre_shift[i] : 0.0f;
+    if (PRE) {
+        float *pssw = reinterpret_cast<float *>(&pss4[0][0]);
+        for (int i = tid; i < nchunk * 16; i += CV_THREADS) {       // padded channels: scale = shift = 0 -> 0
+            pssw[i] = i < a.Cin ? a.pre_scale[i] * CV_XSCALE : 0.0f;
+            pssw[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] * CV_XSCALE : 0.0f;
         }
     }
 
-    // staging items of this work-item: (halo pixel, 8-channel group), constant over the chunks
-    int s_off[CV_ROUNDS], s_dst[CV_ROUNDS], s_g8[CV_ROUNDS];
-    bool s_ok[CV_ROUNDS];
-    float s_m[CV_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < CV_ROUNDS; ++r) {
-        const int i = tid + r * CV_THREADS;
-        const int g = i >= CV_NPX ? 1 : 0, p = i - g * CV_NPX;
-        const int pr = p / CV_HW, pc = p - pr * CV_HW;
+    // Staging of a chunk = 680 (halo pixel, 8-channel group) items in three rounds:
+    //   round 0: pixel tid, channels 0-7;   round 1: pixel tid, channels 8-15;
+    //   round 2: work-items < 168: pixel 256 + tid % 84, channels 8 * (tid / 84) .. +7.
+    // Rounds 0/1 address a wave-uniform plane base + one 32-bit lane offset (no address VALU).
+    const int gB = tid >= 84 ? 1 : 0;
+    const int pB = 256 + tid - 84 * gB;
+    const bool liveB = tid < 168;
+    bool okA, okB;
+    int offA, offB;
+    {
+        const int pr = tid / CV_HW, pc = tid - pr * CV_HW;
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-        const bool live = i < CV_ITEMS;
-        s_ok[r] = live & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
-        s_off[r] = s_ok[r] ? gy * a.W + gx : 0;
-        s_g8[r] = g * 8;
-        s_dst[r] = live ? g * CV_NPX + p : -1;
-        s_m[r] = (pre == PRE_BN_MASK && s_ok[r]) ? a.pre_mask[(size_t)n * HW + s_off[r]] : 1.0f;
+        okA = (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        offA = okA ? gy * a.W + gx : 0;
     }
-    float st[CV_ROUNDS][8];
-    auto load_chunk = [&](int c) {
+    {
+        const int pr = pB / CV_HW, pc = pB - pr * CV_HW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        okB = liveB & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        offB = okB ? gy * a.W + gx : 0;
+    }
+    // per-item multiplier: the [N,1,H,W] mask value (1 without a mask), 0 for the zero padding outside
+    // the image; without a prologue it also carries the 2^6 pre-scale of the split
+    const float unit = PRE ? 1.0f : CV_XSCALE;
+    const float mA = okA ? (pre == PRE_BN_MASK ? a.pre_mask[(size_t)n * HW + offA] : unit) : 0.0f;
+    const float mB = okB ? (pre == PRE_BN_MASK ? a.pre_mask[(size_t)n * HW + offB] : unit) : 0.0f;
+    const bool nonzero_mask = pre == PRE_BN_NONZERO;
+    // R = staging round; c = chunk.  Channels past Cin re-read the last plane: finite values that meet
+    // zero weights (and zero scale / shift with a prologue).
+    auto load_round = [&](auto R, int c, float (&st)[8]) {
 #pragma unroll
-        for (int r = 0; r < CV_ROUNDS; ++r)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)                // channels past Cin re-read the last plane (zeroed below)
-                st[r][j] = inb[(size_t)min(c * 16 + s_g8[r] + j, cmax) * HW + s_off[r]];
-    };
-    const bool has_pre = pre != PRE_NONE, nonzero_mask = pre == PRE_BN_NONZERO;
-    auto store_chunk = [&](int buf, int c) {
-#pragma unroll
-        for (int r = 0; r < CV_ROUNDS; ++r) {
-            if (s_dst[r] < 0) continue;
-            const int cb = c * 16 + s_g8[r];
-            // branch-free prologue (selects only): normalization.py:231, ReLU, partialconv2d.py:69
-            float sc[8], sh[8];
-            *reinterpret_cast<float4 *>(&sc[0]) = *reinterpret_cast<const float4 *>(&pss[0][cb]);
-            *reinterpret_cast<float4 *>(&sc[4]) = *reinterpret_cast<const float4 *>(&pss[0][cb + 4]);
-            *reinterpret_cast<float4 *>(&sh[0]) = *reinterpret_cast<const float4 *>(&pss[1][cb]);
-            *reinterpret_cast<float4 *>(&sh[4]) = *reinterpret_cast<const float4 *>(&pss[1][cb + 4]);
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = st[r][j];
-                const float mk = nonzero_mask ? (x != 0.0f ? 1.0f : 0.0f) : s_m[r];     // s_m = 1 without a mask
-                const float y = fmaxf(x * sc[j] - sh[j], 0.0f) * mk;
-                v[j] = (s_ok[r] & (cb + j <= cmax)) ? (has_pre ? y : x) : 0.0f;       // zero padding (border, channels)
+        for (int j = 0; j < 8; ++j) {
+            if (R.value < 2) {
+                const float *pl = inb + (size_t)min(c * 16 + R.value * 8 + j, cmax) * HW;       // wave-uniform
+                st[j] = pl[(unsigned)offA];
+            } else {
+                st[j] = inb[(unsigned)(min(c * 16 + gB * 8 + j, cmax) * HW + offB)];
             }
-            h8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = v[j] * CV_XSCALE;
-                const _Float16 h = (_Float16)x;
-                hi[j] = h;
-                lo[j] = (_Float16)(x - (float)h);
-            }
-            (&xs[buf][0][0][0])[s_dst[r]] = hi;
-            (&xs[buf][1][0][0])[s_dst[r]] = lo;
         }
     };
+    // prologue (normalization.py:231, ReLU, partialconv2d.py:69; 2^6 folded into scale / shift, which
+    // commutes with the roundings) + split + LDS store: straight-line code, no selects on validity.
+    // In three pieces (begin / one value / finish) so the main loop can slot the values between MFMAs.
+    struct Stage { int cb; float mk0; h8 hi, lo; };
+    const float *pss = reinterpret_cast<const float *>(&pss4[0][0]);
+    auto stage_begin = [&](auto R, int c, Stage &g) {
+        g.cb = c * 16 + (R.value < 2 ? R.value * 8 : gB * 8);
+        g.mk0 = R.value < 2 ? mA : mB;
+    };
+    auto stage_value = [&](int j, Stage &g, const float (&st)[8]) {
+        const float x = st[j];
+        float v;
+        if (PRE) {           // scale / shift are read per value (2 broadcast LDS reads) rather than held in 16 registers
+            const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : g.mk0;
+            v = fmaxf(x * pss[g.cb + j] - pss[CV_MAXCIN + g.cb + j], 0.0f) * mk;
+        } else {
+            v = x * g.mk0;
+        }
+        const _Float16 h = (_Float16)v;
+        g.hi[j] = h;
+        g.lo[j] = (_Float16)(v - (float)h);
+    };
+    auto stage_finish = [&](auto R, int buf, const Stage &g) {
+        const int dst = R.value == 0 ? tid : (R.value == 1 ? CV_NPX + tid : gB * CV_NPX + pB);
+        if (R.value < 2 || liveB) {
+            (&xs[buf][0][0][0])[dst] = g.hi;
+            (&xs[buf][1][0][0])[dst] = g.lo;
+        }
+    };
+    auto store_round = [&](auto R, int buf, int c, const float (&st)[8]) {
+        Stage g;
+        stage_begin(R, c, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage_value(j, g, st);
+        stage_finish(R, buf, g);
+    };
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
 
     f16v acc[CPW][PT];
 #pragma unroll
@@ -164,124 +192,170 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.0f;
 
-    load_chunk(0);
-    __syncthreads();                                   // pss
-    store_chunk(0, 0);
+    __syncthreads();                                   // pss4
+    {
+        float s0[8], s1[8], s2[8];                     // first chunk: all three rounds in flight at once
+        load_round(R0{}, 0, s0);
+        load_round(R1{}, 0, s1);
+        load_round(R2{}, 0, s2);
+        store_round(R0{}, 0, 0, s0);
+        store_round(R1{}, 0, 0, s1);
+        store_round(R2{}, 0, 0, s2);
+    }
     __syncthreads();
+    float st[8];
 
     const int bcol = lane & 31, bgrp = lane >> 5;
     // A fragments (weights) come straight from global memory / L2, one tap ahead of their use.
     // Fragment (cot, chunk, tap, half) = 64 consecutive 16-byte vectors, lane l takes vector l.
     const size_t wtile = (size_t)nchunk * 9 * 2 * 64;            // vectors per 32-channel tile
-    const h8 *wbase = a.w + (size_t)cot0 * wtile + lane;
+    const h8 *wbase = a.w + (size_t)cot0 * wtile;                // wave-uniform
     h8 a_cur[CPW][2], a_nxt[CPW][2];
     auto load_a = [&](h8 (&dst)[CPW][2], int g /* chunk * 9 + tap */) {
 #pragma unroll
         for (int ct = 0; ct < CPW; ++ct) {
-            const h8 *q = wbase + ct * wtile + (size_t)g * 128;
-            dst[ct][0] = q[0];
-            dst[ct][1] = q[64];
+            const h8 *q = wbase + ct * wtile + (size_t)g * 128;     // uniform base, lane offset
+            dst[ct][0] = q[(unsigned)lane];
+            dst[ct][1] = q[(unsigned)lane + 64u];
         }
     };
     load_a(a_cur, 0);
     const int glast = nchunk * 9 - 1;
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) load_chunk(c + 1);
+        const int cn = min(c + 1, nchunk - 1);         // the chunk staged under this one's MFMAs (the last
+                                                       // iteration re-stages its own chunk: harmless, and it keeps
+                                                       // every load unconditional -> counted vmcnt waits)
         const h8 *xh = &xs[buf][0][bgrp][0], *xl = &xs[buf][1][bgrp][0];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - kh * 3;
             // keeps the B fragments of different taps from being kept live together (the 36 distinct
             // ones of a chunk would take 144 registers and spill); LDS has the bandwidth to re-read them
+#if !(CV_EXP & 1)
             asm volatile("" ::: "memory");
-            load_a(a_nxt, min(c * 9 + tap + 1, glast));           // unconditional: counted vmcnt waits
+#endif
+            // staging of the next chunk, one round per three taps: 8 registers in flight instead of 24.
+            // Loads are issued at the top of taps 0 / 2 / 5 and consumed (prologue, split, LDS store) in
+            // taps 2 / 5 / 8, where that VALU work is interleaved with the tap's MFMAs (below).
+#if !(CV_EXP & 4)
+            if (tap == 0) load_round(R0{}, cn, st);
+#endif
+#if !(CV_EXP & 2)
+            load_a(a_nxt, min(c * 9 + tap + 1, glast));
+#endif
+            __builtin_amdgcn_sched_barrier(0);         // loads are issued HERE, a whole tap ahead of their use
             h8 bh[PT], bl[PT];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
+#if CV_EXP & 1
+                const int p = (wp * PT + pt) * CV_HW + bcol;        // experiment: same fragments for every tap (CSE)
+#else
                 const int p = (wp * PT + pt + kh) * CV_HW + kw + bcol;
+#endif
                 bh[pt] = xh[p];
                 bl[pt] = xl[p];
             }
-            // the three partial products, each over all CPW x PT accumulator tiles: consecutive
-            // MFMAs never touch the same accumulator (small terms first)
+            const bool stage_tap = !(CV_EXP & 4) && (tap == 2 || tap == 5 || tap == 8);
+            Stage sg;
+            if (stage_tap) {
+                if (tap == 2) stage_begin(R0{}, cn, sg);
+                if (tap == 5) stage_begin(R1{}, cn, sg);
+                if (tap == 8) stage_begin(R2{}, cn, sg);
+            }
+            // The three partial products (small terms first), each over all CPW x PT accumulator tiles:
+            // consecutive MFMAs never touch the same accumulator.  In a staging tap the 8 values of the
+            // round are converted BETWEEN groups of MFMAs (order pinned by scheduling barriers), so that
+            // VALU work issues in the shadow of the matrix pipe instead of in front of it.
+            constexpr int NM = 3 * CPW * PT;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
+            for (int i = 0; i < NM; ++i) {
+                const int part = i / (CPW * PT), pt = (i / CPW) % PT, ct = i % CPW;
+                const h8 av = part == 0 ? a_cur[ct][1] : a_cur[ct][0];
+                const h8 bv = part == 1 ? bl[pt] : bh[pt];
+                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[ct][pt], 0, 0, 0);
+                if (stage_tap) {
+                    const int j0 = i * 8 / NM, j1 = (i + 1) * 8 / NM;
+                    if (j1 > j0) {
 #pragma unroll
-                for (int ct = 0; ct < CPW; ++ct)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[ct][1], bh[pt], acc[ct][pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                for (int ct = 0; ct < CPW; ++ct)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[ct][0], bl[pt], acc[ct][pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                for (int ct = 0; ct < CPW; ++ct)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[ct][0], bh[pt], acc[ct][pt], 0, 0, 0);
+                        for (int j = j0; j < j1; ++j) stage_value(j, sg, st);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (stage_tap) {
+                if (tap == 2) { stage_finish(R0{}, buf ^ 1, sg); load_round(R1{}, cn, st); }
+                if (tap == 5) { stage_finish(R1{}, buf ^ 1, sg); load_round(R2{}, cn, st); }
+                if (tap == 8) stage_finish(R2{}, buf ^ 1, sg);
+            }
+#if !(CV_EXP & 2)
 #pragma unroll
             for (int ct = 0; ct < CPW; ++ct) { a_cur[ct][0] = a_nxt[ct][0]; a_cur[ct][1] = a_nxt[ct][1]; }
+#endif
         }
-        if (c + 1 < nchunk) store_chunk(buf ^ 1, c + 1);
         __syncthreads();
     }
 
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel).
     // Work-items outside the image / channels past Cout are clamped for the loads and skipped for
     // the stores; all loads of a tile are issued before its first store.
-    // Straight-line code: absent operands are read through a valid stand-in address and selected
-    // away, so the optional stages cost selects instead of branches.
+    // The optional stages are uniform branches around whole 16-register blocks (never per element),
+    // and every block issues all its loads before its arithmetic.
     const bool partial = a.partial != 0, has_bias = a.bias != nullptr, has_res = a.residual != nullptr,
                has_next = a.next_scale != nullptr;
-    const float *dummy = reinterpret_cast<const float *>(a.w);        // >= 144 * Cout floats
-    const float *bp = has_bias ? a.bias : dummy;
-    const float *nsp = has_next ? a.next_scale : dummy, *nhp = has_next ? a.next_shift : dummy;
-    const float *mbp = partial ? a.mask_box : a.in;
     float *outp = a.out;
-    const float *resid = has_res ? a.residual : outp;
     const int ox = x0 + bcol;
     const bool xin_img = ox < a.W;
     const int cout1 = a.Cout - 1;
     const float mscale = a.mask_scale, winsize = a.winsize, unscale = a.unscale;
 #pragma unroll
     for (int ct = 0; ct < CPW; ++ct) {
-        float eb[16], esc[16], esh[16];
+        int co[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = min((cot0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * bgrp, cout1);
-            const float b = bp[co], s2 = nsp[co], h2 = nhp[co];
-            eb[r] = has_bias ? b : 0.0f;
-            esc[r] = s2;
-            esh[r] = h2;
+        for (int r = 0; r < 16; ++r) co[r] = (cot0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * bgrp;
+        float eb[16], esc[16], esh[16];
+        if (has_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) eb[r] = a.bias[min(co[r], cout1)];
+        }
+        if (has_next) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { esc[r] = a.next_scale[min(co[r], cout1)]; esh[r] = a.next_shift[min(co[r], cout1)]; }
         }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int oy = y0 + wp * PT + pt;
             const bool ok = xin_img & (oy < a.H);
             const size_t pix = ok ? (size_t)oy * a.W + ox : 0;
-            const float u = mbp[(size_t)n * HW + pix] * mscale;            // partialconv2d.py:61-67
-            const float um = fminf(fmaxf(u, 0.0f), 1.0f);
-            const float ratio = (1.0f / (u + 1e-8f)) * winsize * um;       // torch: scalar / tensor = reciprocal * scalar
-            if (partial && ok && a.um_out && ct == 0 && blockIdx.y == 0 && wc == 0 && bgrp == 0)
-                a.um_out[(size_t)n * HW + pix] = um;
-            float rv[16];
+            float o[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = min((cot0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * bgrp, cout1);
-                rv[r] = resid[((size_t)n * a.Cout + co) * HW + pix];
+            for (int r = 0; r < 16; ++r) o[r] = acc[ct][pt][r] * unscale;
+            if (partial) {
+                const float u = a.mask_box[(size_t)n * HW + pix] * mscale;     // partialconv2d.py:61-67
+                const float um = fminf(fmaxf(u, 0.0f), 1.0f);
+                const float ratio = (1.0f / (u + 1e-8f)) * winsize * um;       // torch: scalar / tensor = reciprocal * scalar
+                if (ok && a.um_out && ct == 0 && blockIdx.y == 0 && wc == 0 && bgrp == 0)
+                    a.um_out[(size_t)n * HW + pix] = um;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = (o[r] * ratio + eb[r]) * um;                   // :72-74
+                if (has_res) {                                                                      // blocks.py:248
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] += rv[r];
+                }
+                if (has_next) {                                                                     // blocks.py:233-236
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = fmaxf(o[r] * esc[r] - esh[r], 0.0f) * um;
+                }
+            } else if (has_bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] += eb[r];
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = (cot0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * bgrp;
-                const float raw = acc[ct][pt][r] * unscale;
-                float o = (raw * ratio + eb[r]) * um;                               // :72-74
-                o = has_res ? o + rv[r] : o;                                        // blocks.py:248
-                const float nx = fmaxf(o * esc[r] - esh[r], 0.0f) * um;             // blocks.py:233-236
-                o = has_next ? nx : o;
-                o = partial ? o : raw + eb[r];                                      // plain convolution (+ bias)
-                if (ok && co <= cout1) outp[((size_t)n * a.Cout + co) * HW + pix] = o;
-            }
+            for (int r = 0; r < 16; ++r)
+                if (ok && co[r] <= cout1) outp[((size_t)n * a.Cout + co[r]) * HW + pix] = o[r];
         }
     }
 }
@@ -332,9 +406,15 @@ static int conv_launch(ConvArgs &a, float wscale, hipStream_t st) {
     const int tiles = a.tiles_x * ((a.H + CV_H - 1) / CV_H);
     const int ct = conv_cout_tile(a.Cout);
     const dim3 grid(tiles, conv_cout_pad(a.Cout) / ct, a.N);
-    if (ct == 128) hipLaunchKernelGGL((conv3x3_split_kernel<2, 2>), grid, dim3(CV_THREADS), 0, st, a);
-    else if (ct == 64) hipLaunchKernelGGL((conv3x3_split_kernel<2, 1>), grid, dim3(CV_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_split_kernel<1, 1>), grid, dim3(CV_THREADS), 0, st, a);
+#define CV_LAUNCH(CPW, WCO)                                                                                     \
+    do {                                                                                                       \
+        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true>), grid, dim3(CV_THREADS), 0, st, a);  \
+        else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false>), grid, dim3(CV_THREADS), 0, st, a);    \
+    } while (0)
+    if (ct == 128) CV_LAUNCH(2, 2);
+    else if (ct == 64) CV_LAUNCH(2, 1);
+    else CV_LAUNCH(1, 1);
+#undef CV_LAUNCH
     SLR_CHECK_LAUNCH();
     return 0;
 }
