@@ -208,17 +208,18 @@ int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, 
  *   xin = relu(x*pre_scale - pre_shift) * mask     (prologue; skipped when pre_scale is NULL: x is
  *         then the already activated and masked input, i.e. the output of a previous call with
  *         next_scale / next_shift)
- *         pre_mask_mode  1: mask = pre_mask [N,1,H,W];  0: mask = (x != 0) per element
- *         (models/networks/architectures.py:369);  -1: no mask
+ *         mask [N,1,H,W]: channel-uniform mask;  mask = NULL: the per-element mask (x != 0) of
+ *         models/networks/architectures.py:369 (needs pre_scale and Cin % 16 == 0)
  *   raw0 = conv3x3(xin)                             (bias-free)
+ *   um_raw = conv(mask, ones[Cout,Cin,3,3]) (:61) = box3x3(mask)*Cin, resp. box3x3(sum_c (x != 0));
+ *            computed inside the kernel from the mask plane of the block's halo (exact integers)
  *   out  = epilogue(raw0) exactly as slr_pconv_epilogue: (raw0*ratio + b)*um, then `+ residual`
- *          or relu(.*next_scale - next_shift)*um;  um -> um_out.   winsize = Cin*9.
+ *          or relu(.*next_scale - next_shift)*um;  um = clamp(um_raw, 0, 1) -> um_out.
  * Same operations in the same order as slr_bn_relu_mask -> convolution -> slr_pconv_epilogue. */
-int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift,
-                         const float *pre_mask, int pre_mask_mode, const void *wsplit, float wscale,
-                         const float *bias, const float *mask_box, float mask_scale,
-                         const float *residual, const float *next_scale, const float *next_shift,
-                         float *out, float *um_out, int N, int Cin, int Cout, int H, int W, void *stream);
+int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                         const void *wsplit, float wscale, const float *bias, const float *residual,
+                         const float *next_scale, const float *next_shift, float *out, float *um_out,
+                         int N, int Cin, int Cout, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -61,12 +61,12 @@ struct ConvArgs {
     float unscale;         // 1 / (CV_XSCALE * wscale)
     // prologue: relu(x*pre_scale[c] - pre_shift[c]) * mask
     int pre;
-    const float *pre_scale, *pre_shift, *pre_mask;     // [Cin], [Cin], [N,1,H,W]
+    const float *pre_scale, *pre_shift;                // [Cin]
+    const float *mask;     // [N,1,H,W] channel-uniform mask (prologue mask and/or mask plane of the update), or nullptr
     // epilogue
     const float *bias;     // [Cout] or nullptr
     int partial;           // partial-convolution epilogue (bias required)
-    const float *mask_box; // [N,1,H,W] k x k box sum of the mask plane
-    float mask_scale, winsize;
+    float mask_scale, winsize;   // conv(mask, ones) = box3x3(mask plane) * mask_scale; Cin * 9
     const float *residual, *next_scale, *next_shift;
     float *um_out;         // [N,1,H,W] or nullptr
 };
@@ -82,6 +82,8 @@ template <int CPW, int WCO, bool PRE>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
     __shared__ h8 xs[2][2][2][CV_NPX];             // [buffer][hi|lo][8-channel group][halo pixel]
+    __shared__ float mpl[CV_NPX];                  // mask plane over the halo block (0 outside the image)
+    __shared__ float mplB[2][CV_NPX - 256];        // derived mask: per-group counts of the round-2 pixels
     __shared__ float4 pss4[2][CV_MAXCIN / 4];      // prologue scale / shift (x CV_XSCALE) per (padded) input channel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps tile bases in SGPRs
@@ -128,8 +130,15 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // per-item multiplier: the [N,1,H,W] mask value (1 without a mask), 0 for the zero padding outside
     // the image; without a prologue it also carries the 2^6 pre-scale of the split
     const float unit = PRE ? 1.0f : CV_XSCALE;
-    const float mA = okA ? (pre == PRE_BN_MASK ? a.pre_mask[(size_t)n * HW + offA] : unit) : 0.0f;
-    const float mB = okB ? (pre == PRE_BN_MASK ? a.pre_mask[(size_t)n * HW + offB] : unit) : 0.0f;
+    const float mvA = (a.mask && okA) ? a.mask[(size_t)n * HW + offA] : 0.0f;
+    const float mvB = (a.mask && okB) ? a.mask[(size_t)n * HW + offB] : 0.0f;
+    if (a.mask) {                                      // mask plane of the halo block, for the 3x3 box sum of the epilogue
+        mpl[tid] = mvA;
+        if (tid < CV_NPX - 256) mpl[256 + tid] = mvB;
+    }
+    const float mA = okA ? (pre == PRE_BN_MASK ? mvA : unit) : 0.0f;
+    const float mB = okB ? (pre == PRE_BN_MASK ? mvB : unit) : 0.0f;
+    float cnt[3] = {0.0f, 0.0f, 0.0f};                 // derived mask: non-zero inputs per staging item, over all chunks
     const bool nonzero_mask = pre == PRE_BN_NONZERO;
     // R = staging round; c = chunk.  Channels past Cin re-read the last plane: finite values that meet
     // zero weights (and zero scale / shift with a prologue).
@@ -147,11 +156,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // prologue (normalization.py:231, ReLU, partialconv2d.py:69; 2^6 folded into scale / shift, which
     // commutes with the roundings) + split + LDS store: straight-line code, no selects on validity.
     // In three pieces (begin / one value / finish) so the main loop can slot the values between MFMAs.
-    struct Stage { int cb; float mk0; h8 hi, lo; };
+    struct Stage { int cb; float mk0, fresh, cnt; h8 hi, lo; };
     const float *pss = reinterpret_cast<const float *>(&pss4[0][0]);
     auto stage_begin = [&](auto R, int c, Stage &g) {
         g.cb = c * 16 + (R.value < 2 ? R.value * 8 : gB * 8);
         g.mk0 = R.value < 2 ? mA : mB;
+        g.cnt = 0.0f;
     };
     auto stage_value = [&](int j, Stage &g, const float (&st)[8]) {
         const float x = st[j];
@@ -159,6 +169,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         if (PRE) {           // scale / shift are read per value (2 broadcast LDS reads) rather than held in 16 registers
             const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : g.mk0;
             v = fmaxf(x * pss[g.cb + j] - pss[CV_MAXCIN + g.cb + j], 0.0f) * mk;
+            g.cnt += mk;                                 // (x != 0) inside the image: the derived mask's channel sum
         } else {
             v = x * g.mk0;
         }
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         g.lo[j] = (_Float16)(v - (float)h);
     };
     auto stage_finish = [&](auto R, int buf, const Stage &g) {
+        cnt[R.value] += g.cnt * g.fresh;
         const int dst = R.value == 0 ? tid : (R.value == 1 ? CV_NPX + tid : gB * CV_NPX + pB);
         if (R.value < 2 || liveB) {
             (&xs[buf][0][0][0])[dst] = g.hi;
@@ -176,6 +188,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     auto store_round = [&](auto R, int buf, int c, const float (&st)[8]) {
         Stage g;
         stage_begin(R, c, g);
+        g.fresh = 1.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage_value(j, g, st);
         stage_finish(R, buf, g);
@@ -258,6 +271,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             }
             const bool stage_tap = !(CV_EXP & 4) && (tap == 2 || tap == 5 || tap == 8);
             Stage sg;
+            sg.fresh = c + 1 < nchunk ? 1.0f : 0.0f;   // the last iteration re-stages its own chunk: not counted twice
             if (stage_tap) {
                 if (tap == 2) stage_begin(R0{}, cn, sg);
                 if (tap == 5) stage_begin(R1{}, cn, sg);
@@ -296,6 +310,14 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         __syncthreads();
     }
 
+    if (pre == PRE_BN_NONZERO) {                       // mask plane = channel sum of (x != 0)  (architectures.py:369,
+        mpl[tid] = cnt[0] + cnt[1];                    // partialconv2d.py:61 with a per-element mask)
+        if (liveB) mplB[gB][pB - 256] = cnt[2];
+        __syncthreads();
+        if (tid < CV_NPX - 256) mpl[256 + tid] = mplB[0][tid] + mplB[1][tid];
+    }
+    __syncthreads();                                   // mpl complete (written before the main loop otherwise)
+
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel).
     // Work-items outside the image / channels past Cout are clamped for the loads and skipped for
     // the stores; all loads of a tile are issued before its first store.
@@ -331,7 +353,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = acc[ct][pt][r] * unscale;
             if (partial) {
-                const float u = a.mask_box[(size_t)n * HW + pix] * mscale;     // partialconv2d.py:61-67
+                float box = 0.0f;                                  // conv(mask, ones): 3x3 box sum, zero padded (:61)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) box += mpl[(wp * PT + pt + dy) * CV_HW + bcol + dx];
+                const float u = box * mscale;                      // exact small integers in fp32
                 const float um = fminf(fmaxf(u, 0.0f), 1.0f);
                 const float ratio = (1.0f / (u + 1e-8f)) * winsize * um;       // torch: scalar / tensor = reciprocal * scalar
                 if (ok && a.um_out && ct == 0 && blockIdx.y == 0 && wc == 0 && bgrp == 0)
@@ -440,26 +467,26 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     return conv_launch(a, wscale, (hipStream_t)stream);
 }
 
-SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift,
-                                    const float *pre_mask, int pre_mask_mode, const void *wsplit, float wscale,
-                                    const float *bias, const float *mask_box, float mask_scale,
-                                    const float *residual, const float *next_scale, const float *next_shift,
-                                    float *out, float *um_out, int N, int Cin, int Cout, int H, int W, void *stream) {
-    SLR_CHECK_ARG(x && wsplit && bias && mask_box && out, "null pointer");
+SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                                    const void *wsplit, float wscale, const float *bias, const float *residual,
+                                    const float *next_scale, const float *next_shift, float *out, float *um_out,
+                                    int N, int Cin, int Cout, int H, int W, void *stream) {
+    SLR_CHECK_ARG(x && wsplit && bias && out, "null pointer");
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
     SLR_CHECK_ARG(!pre_scale || Cin <= CV_MAXCIN, "prologue supports Cin <= 1024");
-    SLR_CHECK_ARG(pre_mask_mode == -1 || pre_mask_mode == 0 || (pre_mask_mode == 1 && pre_mask), "pre_mask_mode");
-    SLR_CHECK_ARG(pre_scale || pre_mask_mode == -1, "a prologue mask needs pre_scale / pre_shift");
+    SLR_CHECK_ARG(mask || (pre_scale && Cin % 16 == 0),
+                  "mask = NULL (derived from x != 0) needs the raw input (pre_scale / pre_shift) and Cin % 16 == 0");
     SLR_CHECK_ARG(!next_scale == !next_shift, "next_scale / next_shift go together");
     SLR_CHECK_ARG(!(residual && next_scale), "residual and next-BN fusion are exclusive");
     if (int e = conv_check_dims(N, Cin, Cout, H, W)) return e;
     ConvArgs a = {};
     a.in = x; a.w = (const h8 *)wsplit; a.bias = bias; a.out = out;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    a.pre = !pre_scale ? PRE_NONE : pre_mask_mode == 1 ? PRE_BN_MASK : pre_mask_mode == 0 ? PRE_BN_NONZERO : PRE_BN;
-    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_mask = pre_mask;
+    a.pre = !pre_scale ? PRE_NONE : (mask ? PRE_BN_MASK : PRE_BN_NONZERO);
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.mask = mask;
     a.partial = 1;
-    a.mask_box = mask_box; a.mask_scale = mask_scale; a.winsize = (float)Cin * 9.0f;
+    a.mask_scale = mask ? (float)Cin : 1.0f;           // channel-uniform mask: Cin identical planes (partialconv2d.py:61)
+    a.winsize = (float)Cin * 9.0f;
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
     return conv_launch(a, wscale, (hipStream_t)stream);
 }

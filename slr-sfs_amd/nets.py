@@ -175,34 +175,34 @@ class PartialConv(Conv):
     mask, 1) -- exact integer arithmetic in fp32.
     Returns (out, update_mask [N,1,H,W]); with ``next_bn`` the output is already the activated,
     masked input of the block's second convolution.  On a device all of this is ONE kernel
-    (slr_pconv3x3_forward); on the CPU the torch composition that defines it."""
+    (slr_pconv3x3_forward, which also forms the box sum and the per-element mask from the staged
+    input); on the CPU the torch composition that defines it."""
 
     def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None):
         cin = x.shape[1]
-        if mask is None:
-            assert pre_bn is not None
-            mplane, mscale = (x != 0).sum(1, keepdim=True).to(x.dtype), 1.0
-        else:
-            mplane, mscale = mask, float(cin)
-        box = F.avg_pool2d(mplane, self.k, stride=1, padding=self.pad, divisor_override=1)
-        if self.k == 3 and _fused_ok(x, box, *([] if residual is None else [residual])):
+        assert mask is not None or pre_bn is not None
+        if self.k == 3 and _fused_ok(x, *([] if mask is None else [mask]), *([] if residual is None else [residual])) \
+                and (mask is not None or cin % 16 == 0):
             N, _, H, W = x.shape
             cout = self.weight.shape[0]
             buf, wscale = self._split_weights()
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
-            um = torch.empty_like(box)
+            um = torch.empty(N, 1, H, W, device=x.device, dtype=x.dtype)
             psc, psh = pre_bn if pre_bn is not None else (None, None)
             nsc, nsh = next_bn if next_bn is not None else (None, None)
-            mode = -1 if pre_bn is None else (0 if mask is None else 1)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_pconv3x3_forward(
-                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask) if mode == 1 else None, mode,
-                    _lib.ptr(buf), wscale, _lib.ptr(self.bias), _lib.ptr(box), float(mscale), _lib.ptr(residual),
-                    _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um), N, cin, cout, H, W,
-                    _lib.stream_of(x)), "slr_pconv3x3_forward")
+                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale,
+                    _lib.ptr(self.bias), _lib.ptr(residual), _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um),
+                    N, cin, cout, H, W, _lib.stream_of(x)), "slr_pconv3x3_forward")
             return out, um
+        if mask is None:
+            mplane, mscale = (x != 0).sum(1, keepdim=True).to(x.dtype), 1.0
+        else:
+            mplane, mscale = mask, float(cin)
+        box = F.avg_pool2d(mplane, self.k, stride=1, padding=self.pad, divisor_override=1)
         xin = bn_relu_mask(x, pre_bn[0], pre_bn[1], mask) if pre_bn is not None else x
-        raw0 = F.conv2d(xin, self.weight, None, padding=self.pad)                  # bias joins in the epilogue
+        raw0 = self.conv(xin, None)                                                # bias joins in the epilogue
         return pconv_epilogue(raw0, self.bias, box, mscale, cin * self.k * self.k, residual, next_bn)
 
 
