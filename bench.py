@@ -136,6 +136,7 @@ def main():
         torch.cuda.synchronize()
         extra["splat_stage_fps_1gpu"] = round(NFRAMES / (time.perf_counter() - t1), 1)
         del g, cs
+        extra["roofline_conv"] = conv_roofline(dev)
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(fs.cpu().numpy(), Z.cpu().numpy(), motion.cpu().numpy())
 
@@ -159,6 +160,41 @@ def main():
     if world > 1:
         dist.barrier()                               # rank 0's extra measurements are done: leave together
         dist.destroy_process_group()
+
+
+def conv_roofline(dev):
+    """Second kernel of the frame (and since the splat is fused, the dominant one by time): the
+    matrix-core partial convolution, timed with HIP events on its launch stream (torch's current
+    stream) on the decoder's heaviest layer shape.  `achieved` counts the ALGORITHMIC flops of the
+    convolution (2*9*Cin*Cout*H*W); the kernel issues 3 f16 MFMAs per product (split operands),
+    `issued` = 3 x achieved is what the matrix pipe executes; peak = dense f16 MFMA rate."""
+    from slr_sfs_amd import nets
+    cin = cout = 128
+    pc = nets.PartialConv(cin, cout, 3).to(dev)
+    x = torch.randn(1, cin, H, W, device=dev)
+    mask = (torch.rand(1, 1, H, W, device=dev) > 0.1).float()
+    sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.3
+    nb = (torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.3)
+    with torch.no_grad():
+        for _ in range(5):
+            pc(x, mask, next_bn=nb, pre_bn=(sc, sh))
+        evs = []
+        for _ in range(30):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pc(x, mask, next_bn=nb, pre_bn=(sc, sh))
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+    us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+    avg = sum(us) / len(us)
+    flops = 2.0 * 9 * cin * cout * H * W
+    ach = flops / (avg * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "slr::conv3x3_split_kernel<2,2,true> (128->128, 768x1280, BN+mask prologue, "
+                                       "partial-conv epilogue)",
+            "achieved": round(ach, 1), "issued": round(3 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(ach / 2500.0, 4), "frac_issued": round(3 * ach / 2500.0, 4),
+            "fp32_mfma_peak": 157.3, "avg_us": round(avg, 1), "min_us": round(us[0], 1), "launches": len(us)}
 
 
 def cpu_baseline(fs, Z, motion):

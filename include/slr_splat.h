@@ -221,6 +221,22 @@ int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pr
                          const float *next_scale, const float *next_shift, float *out, float *um_out,
                          int N, int Cin, int Cout, int H, int W, void *stream);
 
+/* ------------------------------------------------------------------ decoder resampling stages (8 f3) */
+
+/* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad): "Down" of models/layers/blocks.py:196-199.
+ *   in [N,C,H,W] -> out [N,C,(H-1)/2+1,(W-1)/2+1] */
+int slr_avgpool3x3s2(const float *in, float *out, int N, int C, int H, int W, void *stream);
+
+/* nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False): "Up" of blocks.py:200-203.
+ *   in [N,C,H,W] -> out [N,C,2H,2W] */
+int slr_upsample_bilinear2x(const float *in, float *out, int N, int C, int H, int W, void *stream);
+
+/* 1x1 convolution onto 1..4 output channels (the skip branch of the decoder's last block,
+ * blocks.py:192-193,243-247 with configs.py:117-137): out = bias + w . in;  w [Cout,Cin], bias [Cout] or NULL.
+ *   Requires H*W % 4 == 0 and 16-byte aligned tensors. */
+int slr_conv1x1_small(const float *in, const float *w, const float *bias, float *out,
+                      int N, int Cin, int Cout, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SYMBOLS = (
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
+    "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
 )
 
 _lib = None
@@ -74,6 +75,9 @@ def lib():
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv3x3_forward": [fp, vp, fp, fp, i, i, i, i, i, f, fp, fp, vp],
             "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, vp],
+            "slr_avgpool3x3s2": [fp, fp, i, i, i, i, vp],
+            "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, vp],
+            "slr_conv1x1_small": [fp, fp, fp, fp, i, i, i, i, i, vp],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)

@@ -43,7 +43,6 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int CV_W = 32, CV_H = 8;                 // output block
 constexpr int CV_HW = CV_W + 2, CV_HH = CV_H + 2;  // input halo block
 constexpr int CV_NPX = CV_HW * CV_HH;              // 340 halo pixels
-constexpr int CV_ITEMS = 2 * CV_NPX;               // (pixel, 8-channel group) staging items per chunk
 constexpr int CV_THREADS = 256;
 #ifndef CV_EXP
 #define CV_EXP 0          // development experiments (tools/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging

@@ -159,6 +159,14 @@ class Conv(nn.Module):
             return out
         if pre_bn is not None:
             x = bn_relu_mask(x, pre_bn[0], pre_bn[1], False)
+        if self.k == 1 and self.weight.shape[0] <= 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and _fused_ok(x):
+            N, cin, H, W = x.shape                      # skip branch onto the 3 output channels: HBM-bound HIP kernel
+            cout = self.weight.shape[0]
+            out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().slr_conv1x1_small(_lib.ptr(x), _lib.ptr(self.weight), _lib.ptr(bias), _lib.ptr(out),
+                                                        N, cin, cout, H, W, _lib.stream_of(x)), "slr_conv1x1_small")
+            return out
         return F.conv2d(x, self.weight, bias, padding=self.pad)
 
 
@@ -206,13 +214,35 @@ class PartialConv(Conv):
         return pconv_epilogue(raw0, self.bias, box, mscale, cin * self.k * self.k, residual, next_bn)
 
 
+def avgpool_down(x):
+    """nn.AvgPool2d(3, stride=2, padding=1), blocks.py:196-199."""
+    if _fused_ok(x):
+        N, C, H, W = x.shape
+        out = torch.empty(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().slr_avgpool3x3s2(_lib.ptr(x), _lib.ptr(out), N, C, H, W, _lib.stream_of(x)),
+                       "slr_avgpool3x3s2")
+        return out
+    return F.avg_pool2d(x, 3, stride=2, padding=1)
+
+
+def upsample_up(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear'), blocks.py:200-203."""
+    if _fused_ok(x):
+        N, C, H, W = x.shape
+        out = torch.empty(N, C, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().slr_upsample_bilinear2x(_lib.ptr(x), _lib.ptr(out), N, C, H, W, _lib.stream_of(x)),
+                       "slr_upsample_bilinear2x")
+        return out
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+
+
 def _resample(kind):
-    if kind == "Down":
-        return lambda x: F.avg_pool2d(x, 3, stride=2, padding=1)
     if kind == "Up":
-        return lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
-    if kind:                                                       # encoder "downsample=True"
-        return lambda x: F.avg_pool2d(x, 3, stride=2, padding=1)
+        return upsample_up
+    if kind:                                                       # "Down" / encoder "downsample=True"
+        return avgpool_down
     return lambda x: x
 
 

@@ -728,3 +728,35 @@ def test_pconv3x3_fused_equals_staged(S, cin, cout, h, w, mode):
             out2, um2 = nets.pconv_epilogue(raw0, pc.bias, box, mscale, cin * 9, kw.get("residual"), kw.get("next_bn"))
             assert torch.equal(um, um2)
             assert torch.equal(out, out2), (out - out2).abs().max().item()
+
+
+@pytest.mark.parametrize("c,h,w", [(3, 7, 9), (5, 16, 32), (2, 33, 70), (4, 1, 1)])
+def test_resample_kernels(S, c, h, w):
+    """slr_avgpool3x3s2 / slr_upsample_bilinear2x vs torch's nn.AvgPool2d(3,2,1) / bilinear x2 on odd and even sizes."""
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    torch.manual_seed(h)
+    x = torch.randn(2, c, h, w, device="cuda")
+    d = nets.avgpool_down(x)
+    ref = F.avg_pool2d(x.cpu().double(), 3, stride=2, padding=1)
+    assert d.shape == ref.shape
+    np.testing.assert_allclose(host(d), ref.numpy(), rtol=0, atol=2e-6)
+    u = nets.upsample_up(x)
+    refu = F.interpolate(x.cpu().double(), scale_factor=2, mode="bilinear", align_corners=False)
+    assert u.shape == refu.shape
+    np.testing.assert_allclose(host(u), refu.numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("cin,cout,bias", [(128, 3, False), (7, 1, True), (64, 4, True)])
+def test_conv1x1_small(S, cin, cout, bias):
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin)
+    conv = nets.Conv(cin, cout, 1, bias=bias).cuda()
+    if bias:
+        conv.bias.data.normal_()
+    x = torch.randn(2, cin, 12, 34, device="cuda")
+    with torch.no_grad():
+        y = conv(x)
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None)
+    assert (y - ref).abs().max().item() < 5e-6
