@@ -29,13 +29,36 @@ import torch.nn.functional as F
 from . import _lib
 
 
+_CPU_REFERENCE = False
+
+
+class cpu_reference:
+    """Context manager for the TESTS that validate these module definitions against the reference's own
+    classes (which only exist where the reference checkout is, on the CPU): inside it, CPU tensors run
+    the torch composition that defines every fused stage.  Outside it CPU tensors raise, like the
+    reference's operators do (models/softsplat.py:418-419): the product has no CPU path."""
+
+    def __enter__(self):
+        global _CPU_REFERENCE
+        self._prev, _CPU_REFERENCE = _CPU_REFERENCE, True
+        return self
+
+    def __exit__(self, *exc):
+        global _CPU_REFERENCE
+        _CPU_REFERENCE = self._prev
+        return False
+
+
 def _fused_ok(*ts):
-    """Device tensors ALWAYS take the fused HIP elementwise stages (fp32, contiguous, no autograd
-    -- anything else on a device raises: there is no silent torch path on the GPU).  CPU tensors
-    (only the validation of these definitions against the reference classes, which runs where the
-    reference checkout is) take the torch composition below, which IS the definition the kernels
-    are tested against bit for bit (tests/test_gpu_parity.py)."""
+    """Device tensors ALWAYS take the HIP kernels (fp32, contiguous, no autograd -- anything else on a
+    device raises: there is no silent torch path on the GPU).  CPU tensors raise NotImplementedError
+    unless the caller is inside ``cpu_reference()`` (validation of these definitions against the
+    reference classes): then they take the torch composition, which IS the definition the kernels are
+    tested against (tests/test_gpu_parity.py)."""
     if not any(t.is_cuda for t in ts):
+        if not _CPU_REFERENCE:
+            raise NotImplementedError("slr_sfs_amd.nets run on ROCm device tensors only (no CPU path); the torch "
+                                      "definition used for validation is available inside nets.cpu_reference()")
         return False
     if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts):
         raise ValueError("slr_sfs_amd.nets: fused decoder stages need fp32 contiguous tensors on one device")

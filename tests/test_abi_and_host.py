@@ -50,6 +50,13 @@ def test_operators_refuse_cpu_tensors_and_have_no_fallback():
         S.euler_integration(z(1, 2, 8, 8), 3)
     with pytest.raises(NotImplementedError):
         S.ModuleMaximumsplat()(z(1, 3, 8, 8), z(1, 2, 8, 8))
+    # the networks either side of the path as well: CPU tensors raise unless a TEST opts into the torch
+    # definition (nets.cpu_reference(), used to validate the modules against the reference's classes)
+    from slr_sfs_amd import nets
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        nets.DecoderPconv2(64, 3).eval()(z(1, 64, 8, 8))
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        nets.Conv(16, 64, 3)(z(1, 16, 8, 8))
     # the product never imports the oracle
     import sys
     assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules if "slr" in m)

@@ -663,8 +663,9 @@ def test_decoder_matrix_core_conv_vs_fp64(S):
                 m.stored_var.uniform_(0.5, 1.5)
         x = torch.randn(1, 64, 72, 136)
         x[:, :, 20:50, 30:80] = 0
-        y32 = dec(x)
-        y64 = copy.deepcopy(dec).double()(x.double())
+        with nets.cpu_reference():
+            y32 = dec(x)
+            y64 = copy.deepcopy(dec).double()(x.double())
         y = dec.cuda()(x.cuda()).cpu()
     e_hip, e_f32 = (y.double() - y64).abs().max().item(), (y32.double() - y64).abs().max().item()
     assert y64.abs().max().item() > 1.0

@@ -61,7 +61,8 @@ def _check(refnet, mine, x, prefix="", tol=2e-4):
     from slr_sfs_amd import nets
     sd = {prefix + k: v for k, v in refnet.state_dict().items()}
     nets.load_reference_state_dict(mine, sd, prefix)
-    a, b = refnet(x), mine.eval()(x)
+    with nets.cpu_reference():                      # the torch definition of the fused stages, on the CPU
+        a, b = refnet(x), mine.eval()(x)
     if not isinstance(a, tuple):
         a, b = (a,), (b,)
     for ra, rb in zip(a, b):
