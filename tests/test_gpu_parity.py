@@ -406,13 +406,14 @@ def test_fused_decoder_stages_match_torch_definition(S):
 
 
 def test_decoder_gpu_matches_cpu_definition(S):
-    """Whole partial-conv decoder: device (fused stages + MIOpen) vs CPU (pure torch) within conv noise."""
+    """Whole partial-conv decoder: device (fused matrix-core kernels) vs its torch definition on the CPU."""
     torch.manual_seed(5)
     dec = S.nets.DecoderPconv2(64, 3).eval()
     x = torch.randn(1, 64, 32, 48)
     x[:, :, 6:20, 10:30] = 0
     with torch.no_grad():
-        ref = dec(x)
+        with S.nets.cpu_reference():
+            ref = dec(x)
         out = dec.cuda()(x.cuda()).cpu()
     assert (out - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
 
