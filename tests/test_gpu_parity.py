@@ -762,3 +762,16 @@ def test_conv1x1_small(S, cin, cout, bias):
         y = conv(x)
         ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None)
     assert (y - ref).abs().max().item() < 5e-6
+
+
+def test_conv3x3_saturates_instead_of_nan(S):
+    """Activations beyond the f16 range of the split (|x| * 2^6 > 65504) saturate; no inf / NaN escapes."""
+    from slr_sfs_amd import nets
+    torch.manual_seed(1)
+    conv = nets.Conv(16, 64, 3, bias=False).cuda()
+    x = torch.randn(1, 16, 8, 32, device="cuda")
+    x[0, 3, 4, 7] = 5.0e4
+    x[0, 5, 2, 9] = -3.0e38
+    with torch.no_grad():
+        y = conv(x)
+    assert bool(torch.isfinite(y).all())
