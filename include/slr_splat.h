@@ -196,10 +196,11 @@ size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
 int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit, int Cout, int Cin,
                               float wscale, void *stream);
 
-/* out = conv3x3(pre(in)) + bias, pre(x) = relu(x*pre_scale[c] - pre_shift[c]) when pre_scale is given
- * (eval-mode noise-BN + ReLU in front of the convolution, models/layers/blocks.py:66-74 +
- * normalization.py:219-231), identity otherwise.  bias [Cout] or NULL. */
-int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, float *out,
+/* out = conv3x3(pre(in)) + bias + residual, pre(x) = relu(x*pre_scale[c] - pre_shift[c]) when pre_scale
+ * is given (eval-mode noise-BN + ReLU in front of the convolution, models/layers/blocks.py:66-74 +
+ * normalization.py:219-231), identity otherwise.  bias [Cout] or NULL; residual [N,Cout,H,W] or NULL
+ * (the x_a + x_b of ResNet_Block, blocks.py:87). */
+int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual, float *out,
                         int N, int Cin, int Cout, int H, int W, float wscale,
                         const float *pre_scale, const float *pre_shift, void *stream);
 

@@ -73,7 +73,7 @@ def lib():
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
-            "slr_conv3x3_forward": [fp, vp, fp, fp, i, i, i, i, i, f, fp, fp, vp],
+            "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, fp, fp, vp],
             "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, vp],
             "slr_avgpool3x3s2": [fp, fp, i, i, i, i, vp],
             "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, vp],

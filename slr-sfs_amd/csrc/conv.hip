@@ -379,9 +379,18 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[r] = fmaxf(o[r] * esc[r] - esh[r], 0.0f) * um;
                 }
-            } else if (has_bias) {
+            } else {                                       // plain convolution: (+ bias) (+ residual, blocks.py:87)
+                if (has_bias) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] += eb[r];
+                    for (int r = 0; r < 16; ++r) o[r] += eb[r];
+                }
+                if (has_res) {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] += rv[r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -455,9 +464,9 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
     return 0;
 }
 
-SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, float *out, int N, int Cin,
-                                   int Cout, int H, int W, float wscale, const float *pre_scale,
-                                   const float *pre_shift, void *stream) {
+SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual,
+                                   float *out, int N, int Cin, int Cout, int H, int W, float wscale,
+                                   const float *pre_scale, const float *pre_shift, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
     SLR_CHECK_ARG(!pre_scale || Cin <= CV_MAXCIN, "prologue supports Cin <= 1024");
@@ -467,6 +476,7 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.pre = pre_scale ? PRE_BN : PRE_NONE;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift;
+    a.residual = residual;
     return conv_launch(a, wscale, (hipStream_t)stream);
 }
 

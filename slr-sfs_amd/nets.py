@@ -147,8 +147,8 @@ class Conv(nn.Module):
         self.cin, self.k = cin, k
         nn.init.normal_(self.weight, std=math.sqrt(1.0 / (cin * k * k)))
 
-    def forward(self, x, pre_bn=None):
-        return self.conv(x, self.bias, pre_bn)
+    def forward(self, x, pre_bn=None, residual=None):
+        return self.conv(x, self.bias, pre_bn, residual)
 
     def _split_weights(self):
         """Split-f16 weights of the matrix-core kernel (csrc/conv.hip), prepared once per device /
@@ -167,22 +167,24 @@ class Conv(nn.Module):
             c = self.__dict__["_wsplit"] = (key, buf, wscale)
         return c[1], c[2]
 
-    def conv(self, x, bias, pre_bn=None):
-        """conv(relu(bn(x))) + bias (``pre_bn`` = (scale, shift) of the BN in front, or None).
+    def conv(self, x, bias, pre_bn=None, residual=None):
+        """conv(relu(bn(x))) + bias + residual (``pre_bn`` = (scale, shift) of the BN in front, or None).
         3x3 layers on a device run on the matrix cores (split-f16 implicit GEMM of csrc/conv.hip,
         BN + ReLU fused into its prologue); 1x1 skips go to MIOpen; CPU tensors (validation against
         the reference classes) take the torch composition."""
-        if self.k == 3 and _fused_ok(x):
+        if self.k == 3 and _fused_ok(x, *([] if residual is None else [residual])):
             cout, cin = self.weight.shape[:2]
             N, _, H, W = x.shape
             buf, wscale = self._split_weights()
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             sc, sh = pre_bn if pre_bn is not None else (None, None)
             with torch.cuda.device(x.device):
-                _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
+                _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out),
                                                           N, cin, cout, H, W, wscale, _lib.ptr(sc), _lib.ptr(sh),
                                                           _lib.stream_of(x)), "slr_conv3x3_forward")
             return out
+        if residual is not None:
+            return self.conv(x, bias, pre_bn) + residual
         if pre_bn is not None:
             x = bn_relu_mask(x, pre_bn[0], pre_bn[1], False)
         if self.k == 1 and self.weight.shape[0] <= 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and _fused_ok(x):
@@ -292,9 +294,9 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         a = self.conv_aa(x, self.bn1.scale_shift())            # BN + ReLU ride in the convolution's prologue
-        a = self.conv_ab(a, self.bn2.scale_shift())
         b = self.conv_b(x) if self.conv_b is not None else x
-        return self.resample(a + b)          # == resample(a) + resample(b): both resamplers are linear
+        a = self.conv_ab(a, self.bn2.scale_shift(), residual=b)    # x_a + x_b (:87) joins the convolution's epilogue
+        return self.resample(a)              # == resample(x_a) + resample(x_b): both resamplers are linear
 
 
 class PconvResBlock(nn.Module):

@@ -695,8 +695,10 @@ def test_conv3x3_matrix_core_kernel(S, cin, cout, h, w, bias):
         yb = conv(x, (sc, sh))
         xb = F.relu(x * sc.view(1, -1, 1, 1) - sh.view(1, -1, 1, 1))          # fp32, as the prologue computes it
         refb = F.conv2d(xb.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
+        res = torch.randn_like(y)
+        yr, refr = conv(x, None, res), ref + res.double()      # residual joins the epilogue (ResNet_Block x_a + x_b)
     assert conv.__dict__.get("_wsplit") is not None          # the matrix-core path ran
-    for got, want in ((y, ref), (yb, refb)):
+    for got, want in ((y, ref), (yb, refb), (yr, refr)):
         assert (got - want).abs().max().item() < 4e-6 * max(want.abs().max().item(), 1.0)
 
 
