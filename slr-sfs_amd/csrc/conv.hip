@@ -252,8 +252,9 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             asm volatile("" ::: "memory");
 #endif
             // staging of the next chunk, one round per three taps: 8 registers in flight instead of 24.
-            // Loads are issued at the top of taps 0 / 2 / 5 and consumed (prologue, split, LDS store) in
-            // taps 2 / 5 / 8, where that VALU work is interleaved with the tap's MFMAs (below).
+            // A round's loads are issued at the top of tap 0 / the end of taps 2 and 5 and consumed
+            // (prologue, split, LDS store) in taps 2 / 5 / 8, where that VALU work is interleaved with
+            // the tap's MFMAs (below).
 #if !(CV_EXP & 4)
             if (tap == 0) load_round(R0{}, cn, st);
 #endif
