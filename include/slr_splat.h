@@ -210,7 +210,7 @@ int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, 
  *         then the already activated and masked input, i.e. the output of a previous call with
  *         next_scale / next_shift)
  *         mask [N,1,H,W]: channel-uniform mask;  mask = NULL: the per-element mask (x != 0) of
- *         models/networks/architectures.py:369 (needs pre_scale and Cin % 16 == 0)
+ *         models/networks/architectures.py:369 (needs pre_scale: x must be the raw input)
  *   raw0 = conv3x3(xin)                             (bias-free)
  *   um_raw = conv(mask, ones[Cout,Cin,3,3]) (:61) = box3x3(mask)*Cin, resp. box3x3(sum_c (x != 0));
  *            computed inside the kernel from the mask plane of the block's halo (exact integers)

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         if (PRE) {           // scale / shift are read per value (2 broadcast LDS reads) rather than held in 16 registers
             const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : g.mk0;
             v = fmaxf(x * pss[g.cb + j] - pss[CV_MAXCIN + g.cb + j], 0.0f) * mk;
-            g.cnt += mk;                                 // (x != 0) inside the image: the derived mask's channel sum
+            g.cnt += (g.cb + j <= cmax) ? mk : 0.0f;     // (x != 0) inside the image, real channels only: the derived
+                                                         // mask's channel sum
         } else {
             v = x * g.mk0;
         }
@@ -488,8 +489,7 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     SLR_CHECK_ARG(x && wsplit && bias && out, "null pointer");
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
     SLR_CHECK_ARG(!pre_scale || Cin <= CV_MAXCIN, "prologue supports Cin <= 1024");
-    SLR_CHECK_ARG(mask || (pre_scale && Cin % 16 == 0),
-                  "mask = NULL (derived from x != 0) needs the raw input (pre_scale / pre_shift) and Cin % 16 == 0");
+    SLR_CHECK_ARG(mask || pre_scale, "mask = NULL (derived from x != 0) needs the raw input, i.e. pre_scale / pre_shift");
     SLR_CHECK_ARG(!next_scale == !next_shift, "next_scale / next_shift go together");
     SLR_CHECK_ARG(!(residual && next_scale), "residual and next-BN fusion are exclusive");
     if (int e = conv_check_dims(N, Cin, Cout, H, W)) return e;

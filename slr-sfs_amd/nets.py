@@ -217,8 +217,7 @@ class PartialConv(Conv):
     def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None):
         cin = x.shape[1]
         assert mask is not None or pre_bn is not None
-        if self.k == 3 and _fused_ok(x, *([] if mask is None else [mask]), *([] if residual is None else [residual])) \
-                and (mask is not None or cin % 16 == 0):
+        if self.k == 3 and _fused_ok(x, *([] if mask is None else [mask]), *([] if residual is None else [residual])):
             N, _, H, W = x.shape
             cout = self.weight.shape[0]
             buf, wscale = self._split_weights()

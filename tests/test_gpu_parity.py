@@ -702,7 +702,7 @@ def test_conv3x3_matrix_core_kernel(S, cin, cout, h, w, bias):
         assert (got - want).abs().max().item() < 4e-6 * max(want.abs().max().item(), 1.0)
 
 
-@pytest.mark.parametrize("cin,cout,h,w,mode", [(64, 64, 24, 70, "derived"), (64, 128, 16, 64, "plane"),
+@pytest.mark.parametrize("cin,cout,h,w,mode", [(64, 64, 24, 70, "derived"), (65, 128, 12, 40, "derived"), (64, 128, 16, 64, "plane"),
                                                (128, 3, 9, 40, "plane"), (32, 32, 20, 33, "chain")])
 def test_pconv3x3_fused_equals_staged(S, cin, cout, h, w, mode):
     """The one-kernel partial convolution (prologue + matrix-core convolution + epilogue) against the
