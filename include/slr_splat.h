@@ -222,6 +222,15 @@ int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pr
                          const float *next_scale, const float *next_shift, float *out, float *um_out,
                          int N, int Cin, int Cout, int H, int W, void *stream);
 
+/* 1x1 convolution (skip branch of the residual blocks, models/layers/blocks.py:192-193,243-247) on the same
+ * split-f16 arithmetic: out = conv1x1(in) + bias.  HBM-bound, no LDS.  Weights prepared once per layer with
+ * slr_conv1x1_split_weights into slr_conv1x1_weight_bytes(Cout, Cin) bytes; wscale as for the 3x3 kernel. */
+size_t slr_conv1x1_weight_bytes(int Cout, int Cin);
+int slr_conv1x1_split_weights(const float *w /* [Cout,Cin,1,1] */, void *wsplit, int Cout, int Cin,
+                              float wscale, void *stream);
+int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias /* [Cout] or NULL */, float *out,
+                        int N, int Cin, int Cout, int H, int W, float wscale, void *stream);
+
 /* ------------------------------------------------------------------ decoder resampling stages (8 f3) */
 
 /* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad): "Down" of models/layers/blocks.py:196-199.

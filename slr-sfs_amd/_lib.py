@@ -19,6 +19,7 @@ SYMBOLS = (
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
+    "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
 )
 
@@ -57,6 +58,8 @@ def lib():
         L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
         L.slr_conv3x3_weight_bytes.restype = sz
         L.slr_conv3x3_weight_bytes.argtypes = [i, i]
+        L.slr_conv1x1_weight_bytes.restype = sz
+        L.slr_conv1x1_weight_bytes.argtypes = [i, i]
         sig = {
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
@@ -73,6 +76,8 @@ def lib():
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
+            "slr_conv1x1_split_weights": [fp, vp, i, i, f, vp],
+            "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, vp],
             "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, fp, fp, vp],
             "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, vp],
             "slr_avgpool3x3s2": [fp, fp, i, i, i, i, vp],

@@ -401,18 +401,121 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     }
 }
 
-// w [Cout,Cin,3,3] fp32 -> split f16 weights in fragment order over the PADDED channel counts
-// (zero weights for the padding), scaled by wscale (a power of two)
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolution (the skip branch of the residual blocks, models/layers/blocks.py:192-193,243-247)
+// on the same split-f16 MFMA arithmetic.  HBM-bound (one read of the input, one write of the
+// output) and free of LDS and barriers: the B fragment of v_mfma_f32_32x32x16_f16 (lane l: pixel
+// l&31, channels 8*(l>>5)..+7) is exactly what 8 coalesced plane loads per lane deliver, so a wave
+// converts its 32 pixels x 16 channels in registers and multiplies them with all NCT 32-channel
+// weight tiles (A fragments from global memory / L2).  Input loads run two chunks ahead.
+constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (streaming several was measured slower:
+                                                   // the stores of a tile share vmcnt with the next tile's loads)
+template <int NCT>
+__global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restrict__ in, const h8 *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ out,
+                                                            int Cin, int Cout, int HW, int nchunk, float unscale) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    const int cot0 = blockIdx.y * NCT;
+    const int pcol = lane & 31, grp = lane >> 5;
+    // (tile, chunk) is ONE software-pipelined sequence g = tile * nchunk + chunk
+    const int p0 = ((blockIdx.x * 4 + wave) * C1_TILES) * 32 + pcol;
+    const int cmax = Cin - 1;
+    const int gend = C1_TILES * nchunk;
+    const float *inb = in + (size_t)n * Cin * HW;
+    auto load_x = [&](float (&x)[8], int g) {          // channels past Cin re-read the last plane (zero weights)
+        g = min(g, gend - 1);
+        const int t = g / nchunk, c = g - t * nchunk;
+        const int p = p0 + t * 32;
+        const unsigned poff = p < HW ? p : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = inb[(size_t)min(c * 16 + grp * 8 + j, cmax) * HW + poff];
+    };
+    const h8 *wb = w + (size_t)cot0 * nchunk * 128 + lane;      // fragment (tile, chunk, half): 64 vectors
+    auto load_a = [&](h8 (&d)[NCT][2], int g) {
+        const int c = g % nchunk;
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+            const h8 *q = wb + ((size_t)t * nchunk + c) * 128;
+            d[t][0] = q[0];
+            d[t][1] = q[64];
+        }
+    };
+    // epilogue constants
+    const int cout1 = Cout - 1;
+    const bool has_bias = bias != nullptr;
+    const float *bp = has_bias ? bias : in;
+    f16v acc[NCT];
+    float x0[8], x1[8], x2[8];
+    h8 a_cur[NCT][2], a_nxt[NCT][2];
+    load_x(x0, 0);
+    load_a(a_cur, 0);
+    load_x(x1, 1);
+    for (int tile = 0, g = 0; tile < C1_TILES; ++tile) {
+        const int p = p0 + tile * 32;
+        const bool ok = p < HW;
+        const float okf = ok ? CV_XSCALE : 0.0f;
+#pragma unroll
+        for (int t = 0; t < NCT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int c = 0; c < nchunk; ++c, ++g) {
+            // everything issued here is for LATER chunks and unconditional, so the waits below are counted:
+            // the weights of chunk g+1 and the input of chunk g+2 stay in flight under this chunk's MFMAs
+            load_a(a_nxt, g + 1);
+            load_x(x2, g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            h8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = __builtin_amdgcn_fmed3f(x0[j] * okf, -65472.0f, 65472.0f);
+                const _Float16 h = (_Float16)v;
+                bh[j] = h;
+                bl[j] = (_Float16)(v - (float)h);
+            }
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][1], bh, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][0], bl, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][0], bh, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x0[j] = x1[j]; x1[j] = x2[j]; }
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) { a_cur[t][0] = a_nxt[t][0]; a_cur[t][1] = a_nxt[t][1]; }
+        }
+        // straight-line epilogue: clamped bias loads first, then masked stores
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+            float b[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = bp[min((cot0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * grp, cout1)];
+                b[r] = has_bias ? v : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (cot0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * grp;
+                if (ok && co <= cout1) out[((size_t)n * Cout + co) * HW + p] = acc[t][r] * unscale + b[r];
+            }
+        }
+    }
+}
+
+// w [Cout,Cin,k,k] fp32 (taps = k*k = 9 or 1) -> split f16 weights in fragment order over the PADDED
+// channel counts (zero weights for the padding), scaled by wscale (a power of two)
 __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ ws,
-                                                                 int Cout, int Cin, int CoutP, int CinP, float wscale) {
-    const int total = CoutP * CinP * 9;
+                                                                 int Cout, int Cin, int CoutP, int CinP, int taps,
+                                                                 float wscale) {
+    const int total = CoutP * CinP * taps;
     const int nchunk = CinP >> 4;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int tap = i % 9, ci = (i / 9) % CinP, co = i / (9 * CinP);
-        const float x = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] * wscale : 0.0f;
+        const int tap = i % taps, ci = (i / taps) % CinP, co = i / (taps * CinP);
+        const float x = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] * wscale : 0.0f;
         const _Float16 h = (_Float16)x;
         const _Float16 l = (_Float16)(x - (float)h);
-        const size_t frag = (((size_t)(co >> 5) * nchunk + (ci >> 4)) * 9 + tap) * 2;
+        const size_t frag = (((size_t)(co >> 5) * nchunk + (ci >> 4)) * taps + tap) * 2;
         const int within = ((ci & 15) >> 3) * 256 + (co & 31) * 8 + (ci & 7);     // [ci group][co][8 ci]
         ws[frag * 512 + within] = h;
         ws[(frag + 1) * 512 + within] = l;
@@ -435,7 +538,45 @@ SLR_EXPORT int slr_conv3x3_split_weights(const float *w, void *wsplit, int Cout,
     const int CoutP = conv_cout_pad(Cout), CinP = conv_cin_pad(Cin);
     const int total = CoutP * CinP * 9;
     hipLaunchKernelGGL(conv_split_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
-                       (_Float16 *)wsplit, Cout, Cin, CoutP, CinP, wscale);
+                       (_Float16 *)wsplit, Cout, Cin, CoutP, CinP, 9, wscale);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+// 1x1: output channels in groups of NCT*32 <= 128 per workgroup row (64 accumulator registers: 3 waves per SIMD;
+// wider layers re-read the input once per 128 channels, mostly from L2)
+static int conv1x1_nct(int Cout) { const int t = (Cout + 31) / 32; return t > 2 ? 4 : (t > 1 ? 2 : 1); }
+static int conv1x1_cout_pad(int Cout) { const int g = conv1x1_nct(Cout) * 32; return (Cout + g - 1) / g * g; }
+
+SLR_EXPORT size_t slr_conv1x1_weight_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)conv1x1_cout_pad(Cout) * conv_cin_pad(Cin) * 2 * sizeof(_Float16);
+}
+
+SLR_EXPORT int slr_conv1x1_split_weights(const float *w, void *wsplit, int Cout, int Cin, float wscale, void *stream) {
+    SLR_CHECK_ARG(w && wsplit, "null pointer");
+    SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)conv1x1_cout_pad(Cout) * conv_cin_pad(Cin) < (1LL << 30), "sizes");
+    SLR_CHECK_ARG(wscale > 0.0f, "wscale");
+    const int CoutP = conv1x1_cout_pad(Cout), CinP = conv_cin_pad(Cin);
+    const int total = CoutP * CinP;
+    hipLaunchKernelGGL(conv_split_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       (_Float16 *)wsplit, Cout, Cin, CoutP, CinP, 1, wscale);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias, float *out, int N, int Cin,
+                                   int Cout, int H, int W, float wscale, void *stream) {
+    SLR_CHECK_ARG(in && wsplit && out, "null pointer");
+    SLR_CHECK_ARG(N > 0 && N < 65536 && Cin > 0 && Cout > 0 && Cout < (1 << 20) && H > 0 && W > 0 &&
+                  (long long)Cin * H * W < (1LL << 40) && (long long)H * W < (1LL << 31) - 128, "sizes");
+    const int HW = H * W, nchunk = conv_cin_pad(Cin) / 16, nct = conv1x1_nct(Cout);
+    const float unscale = 1.0f / (CV_XSCALE * wscale);
+    const dim3 grid((HW + 128 * C1_TILES - 1) / (128 * C1_TILES), conv1x1_cout_pad(Cout) / (nct * 32), N);
+    hipStream_t st = (hipStream_t)stream;
+#define C1_LAUNCH(T) hipLaunchKernelGGL(conv1x1_split_kernel<T>, grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale)
+    if (nct == 4) C1_LAUNCH(4); else if (nct == 2) C1_LAUNCH(2); else C1_LAUNCH(1);
+#undef C1_LAUNCH
     SLR_CHECK_LAUNCH();
     return 0;
 }

@@ -160,18 +160,21 @@ class Conv(nn.Module):
             L = _lib.lib()
             amax = float(w.abs().max())
             wscale = 2.0 ** math.floor(math.log2(4096.0 / amax)) if amax > 0 else 1.0
-            buf = torch.empty(L.slr_conv3x3_weight_bytes(w.shape[0], w.shape[1]), dtype=torch.uint8, device=w.device)
+            nbytes, split = ((L.slr_conv3x3_weight_bytes, L.slr_conv3x3_split_weights) if self.k == 3 else
+                             (L.slr_conv1x1_weight_bytes, L.slr_conv1x1_split_weights))
+            buf = torch.empty(nbytes(w.shape[0], w.shape[1]), dtype=torch.uint8, device=w.device)
             with torch.cuda.device(w.device):
-                _lib.check(L.slr_conv3x3_split_weights(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale,
-                                                       _lib.stream_of(w)), "slr_conv3x3_split_weights")
+                _lib.check(split(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale, _lib.stream_of(w)),
+                           "slr_conv_split_weights")
             c = self.__dict__["_wsplit"] = (key, buf, wscale)
         return c[1], c[2]
 
     def conv(self, x, bias, pre_bn=None, residual=None):
         """conv(relu(bn(x))) + bias + residual (``pre_bn`` = (scale, shift) of the BN in front, or None).
-        3x3 layers on a device run on the matrix cores (split-f16 implicit GEMM of csrc/conv.hip,
-        BN + ReLU fused into its prologue); 1x1 skips go to MIOpen; CPU tensors (validation against
-        the reference classes) take the torch composition."""
+        On a device 3x3 layers run on the matrix cores (split-f16 implicit GEMM of csrc/conv.hip, BN +
+        ReLU fused into its prologue, bias / residual into its epilogue) and so do the 1x1 skips; CPU
+        tensors (validation against the reference classes, inside nets.cpu_reference()) take the torch
+        composition."""
         if self.k == 3 and _fused_ok(x, *([] if residual is None else [residual])):
             cout, cin = self.weight.shape[:2]
             N, _, H, W = x.shape
@@ -194,6 +197,16 @@ class Conv(nn.Module):
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv1x1_small(_lib.ptr(x), _lib.ptr(self.weight), _lib.ptr(bias), _lib.ptr(out),
                                                         N, cin, cout, H, W, _lib.stream_of(x)), "slr_conv1x1_small")
+            return out
+        if self.k == 1 and _fused_ok(x):                 # the other 1x1 skip branches: split-f16 MFMA, HBM-bound
+            N, cin, H, W = x.shape
+            cout = self.weight.shape[0]
+            buf, wscale = self._split_weights()
+            out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().slr_conv1x1_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
+                                                          N, cin, cout, H, W, wscale, _lib.stream_of(x)),
+                           "slr_conv1x1_forward")
             return out
         return F.conv2d(x, self.weight, bias, padding=self.pad)
 

@@ -777,3 +777,22 @@ def test_conv3x3_saturates_instead_of_nan(S):
     with torch.no_grad():
         y = conv(x)
     assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("cin,cout,h,w,bias", [(64, 128, 16, 40, False), (128, 256, 9, 33, True), (3, 32, 7, 19, True),
+                                               (256, 128, 8, 16, False), (64, 65, 5, 27, True), (20, 300, 6, 10, True)])
+def test_conv1x1_matrix_core_kernel(S, cin, cout, h, w, bias):
+    """slr_conv1x1_forward (skip branches) vs an fp64 convolution: all workgroup variants (32..256 channels per
+    row and more than 256), ragged pixel counts and channel counts, batch of 2."""
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin + cout)
+    conv = nets.Conv(cin, cout, 1, bias=bias).cuda()
+    if bias:
+        conv.bias.data.normal_()
+    x = torch.randn(2, cin, h, w, device="cuda") * 2
+    with torch.no_grad():
+        y = conv(x)
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None)
+    assert conv.__dict__.get("_wsplit") is not None
+    assert (y - ref).abs().max().item() < 4e-6 * max(ref.abs().max().item(), 1.0)
