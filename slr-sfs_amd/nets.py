@@ -2,8 +2,8 @@
 so the full configurations C3/C4 of BASELINE.json can be run and real checkpoints load.
 On a device every 3x3 (partial) convolution, with the BN / ReLU / mask / ratio / bias / residual
 stages around it, is ONE hand-written matrix-core kernel (csrc/conv.hip, split-f16 implicit GEMM),
-the resampling stages are HIP kernels (csrc/resample.hip) and only the 1x1 skip convolutions with
->= 64 output channels go to MIOpen.  On the CPU (validation against the reference's own classes,
+the 1x1 skip convolutions run on the same arithmetic and the resampling stages are HIP kernels
+(csrc/resample.hip): nothing goes to MIOpen.  On the CPU (validation against the reference's own classes,
 tests/test_nets_vs_reference.py) the same modules run the torch composition that defines them.
 
 Own definitions, folded for inference (reference file:line cited per class):
