@@ -796,3 +796,30 @@ def test_conv1x1_matrix_core_kernel(S, cin, cout, h, w, bias):
         ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None)
     assert conv.__dict__.get("_wsplit") is not None
     assert (y - ref).abs().max().item() < 4e-6 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("which", ["encoder_z", "bg_decoder", "alpha_encoder"])
+def test_plain_resnet_nets_vs_fp64_definition(S, which):
+    """Encoder / background decoder / alpha encoder on the device (matrix-core 3x3 with BN+ReLU prologue, bias and
+    residual epilogue; split-f16 1x1 skips; HIP resampling) vs the torch definition of the same modules in fp64."""
+    import copy
+    from slr_sfs_amd import nets
+    torch.manual_seed(11)
+    net = {"encoder_z": lambda: nets.EncoderWithZ(), "bg_decoder": lambda: nets.BGDecoder(),
+           "alpha_encoder": lambda: nets.Encoder(3, 2)}[which]().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "stored_mean"):
+                m.stored_mean.normal_(0, 0.3)
+                m.stored_var.uniform_(0.5, 1.5)
+            if isinstance(m, nets.Conv) and m.bias is not None:
+                m.bias.normal_(0, 0.1)
+        x = torch.rand(1, 3, 40, 72) * 2 - 1
+        with nets.cpu_reference():
+            ref = copy.deepcopy(net).double()(x.double())
+        out = net.cuda()(x.cuda())
+    ref = ref if isinstance(ref, tuple) else (ref,)
+    out = out if isinstance(out, tuple) else (out,)
+    for o, r in zip(out, ref):
+        scale = max(r.abs().max().item(), 1.0)
+        assert (o.cpu().double() - r).abs().max().item() < 2e-5 * scale
