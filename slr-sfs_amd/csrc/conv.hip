@@ -408,6 +408,11 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 // l&31, channels 8*(l>>5)..+7) is exactly what 8 coalesced plane loads per lane deliver, so a wave
 // converts its 32 pixels x 16 channels in registers and multiplies them with all NCT 32-channel
 // weight tiles (A fragments from global memory / L2).  Input loads run two chunks ahead.
+#ifndef C1_EXP
+#define C1_EXP 0          // development experiments (tools/conv1x1bench.py), 64->128 at 768x1280, 249 us as shipped:
+                         // 1 no stores 128 us, 2 no input loads 162 us, 4 no prefetch registers 251 us -- the read and
+                         // the write phase of a wave barely overlap; 128-byte segments per plane cap both
+#endif
 constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (streaming several was measured slower:
                                                    // the stores of a tile share vmcnt with the next tile's loads)
 template <int NCT>
@@ -430,7 +435,11 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
         const int p = p0 + t * 32;
         const unsigned poff = p < HW ? p : 0;
 #pragma unroll
+#if C1_EXP & 2
+        for (int j = 0; j < 8; ++j) x[j] = (float)(c + j);
+#else
         for (int j = 0; j < 8; ++j) x[j] = inb[(size_t)min(c * 16 + grp * 8 + j, cmax) * HW + poff];
+#endif
     };
     const h8 *wb = w + (size_t)cot0 * nchunk * 128 + lane;      // fragment (tile, chunk, half): 64 vectors
     auto load_a = [&](h8 (&d)[NCT][2], int g) {
@@ -463,8 +472,12 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
         for (int c = 0; c < nchunk; ++c, ++g) {
             // everything issued here is for LATER chunks and unconditional, so the waits below are counted:
             // the weights of chunk g+1 and the input of chunk g+2 stay in flight under this chunk's MFMAs
+#if C1_EXP & 4
+            load_x(x1, g + 1);                          // experiment: depth-1 input prefetch, weights loaded in place
+#else
             load_a(a_nxt, g + 1);
             load_x(x2, g + 2);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             h8 bh, bl;
 #pragma unroll
@@ -480,10 +493,16 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][0], bl, acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][0], bh, acc[t], 0, 0, 0);
+#if C1_EXP & 4
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x0[j] = x1[j];
+            load_a(a_cur, g + 1);
+#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) { x0[j] = x1[j]; x1[j] = x2[j]; }
 #pragma unroll
             for (int t = 0; t < NCT; ++t) { a_cur[t][0] = a_nxt[t][0]; a_cur[t][1] = a_nxt[t][1]; }
+#endif
         }
         // straight-line epilogue: clamped bias loads first, then masked stores
 #pragma unroll
@@ -497,7 +516,12 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (cot0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * grp;
-                if (ok && co <= cout1) out[((size_t)n * Cout + co) * HW + p] = acc[t][r] * unscale + b[r];
+#if C1_EXP & 1
+                if (ok && co <= cout1 && acc[t][r] == 12345.678f)
+#else
+                if (ok && co <= cout1)
+#endif
+                    out[((size_t)n * Cout + co) * HW + p] = acc[t][r] * unscale + b[r];
             }
         }
     }
