@@ -194,7 +194,10 @@ def conv_roofline(dev):
                                        "partial-conv epilogue)",
             "achieved": round(ach, 1), "issued": round(3 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(ach / 2500.0, 4), "frac_issued": round(3 * ach / 2500.0, 4),
-            "fp32_mfma_peak": 157.3, "avg_us": round(avg, 1), "min_us": round(us[0], 1), "launches": len(us)}
+            "fp32_mfma_peak": 157.3, "avg_us": round(avg, 1), "min_us": round(us[0], 1), "launches": len(us),
+            "precision": "fp32 in/out, fp32 accumulation; operands split into two f16 halves (22 significant bits), "
+                         "3 MFMAs per product; measured whole-decoder max-abs error vs fp64 1.0e-5 "
+                         "(torch fp32: 0.5e-5) -- tests/test_gpu_parity.py, tools/decerr.py"}
 
 
 def cpu_baseline(fs, Z, motion):
