@@ -823,3 +823,52 @@ def test_plain_resnet_nets_vs_fp64_definition(S, which):
     for o, r in zip(out, ref):
         scale = max(r.abs().max().item(), 1.0)
         assert (o.cpu().double() - r).abs().max().item() < 2e-5 * scale
+
+
+def test_conv_kernels_randomised_sweep(S):
+    """30 random (Cin, Cout, H, W, N, options) cases: plain 3x3 (bias / BN prologue / residual), 1x1, and the
+    one-kernel partial convolution vs its staged definition (bit-exact)."""
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    rng = np.random.default_rng(2024)
+    for case in range(30):
+        cin, cout = int(rng.integers(1, 70)), int(rng.integers(1, 140))
+        h, w, n = int(rng.integers(1, 20)), int(rng.integers(1, 70)), int(rng.integers(1, 3))
+        torch.manual_seed(case)
+        x = torch.randn(n, cin, h, w, device="cuda") * float(rng.uniform(0.1, 4))
+        x[:, :, : h // 2, : w // 3] = 0
+        with torch.no_grad():
+            # plain 3x3
+            use_bias, use_pre, use_res = (bool(v) for v in rng.integers(0, 2, 3))
+            conv = nets.Conv(cin, cout, 3, bias=use_bias).cuda()
+            if use_bias:
+                conv.bias.data.normal_()
+            sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.5
+            res = torch.randn(n, cout, h, w, device="cuda") if use_res else None
+            y = conv(x, (sc, sh) if use_pre else None, res)
+            xin = F.relu(x * sc.view(1, -1, 1, 1) - sh.view(1, -1, 1, 1)) if use_pre else x
+            ref = F.conv2d(xin.double(), conv.weight.double(), conv.bias.double() if use_bias else None, padding=1)
+            if use_res:
+                ref = ref + res.double()
+            assert (y - ref).abs().max().item() < 5e-6 * max(ref.abs().max().item(), 1.0), ("3x3", case, cin, cout, h, w)
+            # 1x1
+            c1 = nets.Conv(cin, cout, 1, bias=use_bias).cuda()
+            y1 = c1(x)
+            r1 = F.conv2d(x.double(), c1.weight.double(), c1.bias.double() if use_bias else None)
+            assert (y1 - r1).abs().max().item() < 5e-6 * max(r1.abs().max().item(), 1.0), ("1x1", case, cin, cout, h, w)
+            # partial convolution: fused vs staged, bit-exact
+            pc = nets.PartialConv(cin, cout, 3).cuda()
+            pc.bias.data.normal_()
+            mode = ("derived", "plane", "chain")[int(rng.integers(0, 3))]
+            mask = None if mode == "derived" else (torch.rand(n, 1, h, w, device="cuda") > 0.3).float()
+            pre = None if mode == "chain" else (sc, sh)
+            nsc, nsh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.3
+            kw = ({"residual": torch.randn(n, cout, h, w, device="cuda")}, {"next_bn": (nsc, nsh)}, {})[int(rng.integers(0, 3))]
+            out, um = pc(x, mask, pre_bn=pre, **kw)
+            xs_ = nets.bn_relu_mask(x, sc, sh, mask) if pre is not None else x
+            mplane, mscale = ((x != 0).sum(1, keepdim=True).float(), 1.0) if mask is None else (mask, float(cin))
+            box = F.avg_pool2d(mplane, 3, stride=1, padding=1, divisor_override=1)
+            out2, um2 = nets.pconv_epilogue(nets.Conv.conv(pc, xs_, None), pc.bias, box, mscale, cin * 9,
+                                            kw.get("residual"), kw.get("next_bn"))
+            assert torch.equal(um, um2), ("um", case, mode, cin, cout, h, w)
+            assert torch.equal(out, out2), ("pconv", case, mode, cin, cout, h, w, (out - out2).abs().max().item())
