@@ -212,6 +212,9 @@ struct ItemDesc {
                                  // segment); first partial slot (multi-segment tiles)
 };
 
+#ifndef SLR_HEAVY_SLACK
+#define SLR_HEAVY_SLACK 24     // a list this much longer than the wave's share is walked by the whole wave (64: +10 % time)
+#endif
 #ifndef SLR_PLAN_SY
 #define SLR_PLAN_SY 1
 #endif
@@ -328,7 +331,10 @@ constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel
 #endif
 constexpr int XCD_GROUP = SLR_XCD_GROUP;                    // neighbouring tiles kept on one XCD (L2 halo reuse)
 constexpr int RB = 4;                          // records per batch in the gather loop
-constexpr int LMAX = 16;                       // records a work-item walks alone (longer lists: wave-cooperative)
+#ifndef SLR_LMAX
+#define SLR_LMAX 16
+#endif
+constexpr int LMAX = SLR_LMAX;                       // records a work-item walks alone (longer lists: wave-cooperative)
 constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 // Per-variant shape: EPT bin entries per work-item (segment = EPT*TILE_PIX entries), CHUNK planes
 // staged in LDS / accumulated in registers per pass.  Chosen so that two workgroups fit one CU's
@@ -545,9 +551,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) wave_recs += __shfl_xor(wave_recs, d);
     // own share: twice the wave's average list length (a uniformly compressed region stays
-    // per-lane), at least LMAX
-    // (and only when at least a wave's worth of records is left over: a cooperative pass costs
-    // ~50 cross-lane operations per chunk)
+    // per-lane), at least LMAX; what is left of a longer list goes to the whole wave once it exceeds
+    // SLR_HEAVY_SLACK records (a cooperative pass costs ~50 cross-lane operations per chunk, a lane
+    // walking alone ~10 per record while the other 63 wait: measured optimum 16-32 on the Euler clips)
 #ifdef SLR_TRACE
     {
         __shared__ uint32_t dbg_max;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     }
 #endif
     const uint32_t own = max((uint32_t)LMAX, 2u * ((wave_recs + 63u) >> 6));
-    const uint32_t rl = (r1 - r0 >= own + 64u) ? r0 + own : r1;
+    const uint32_t rl = (r1 - r0 >= own + (uint32_t)SLR_HEAVY_SLACK) ? r0 + own : r1;
     const unsigned long long heavy = __ballot(r1 > rl);
     const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
     const int oy = ty0 + ly, ox = tx0 + lx;
