@@ -340,7 +340,8 @@ constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 // staged in LDS / accumulated in registers per pass.  Chosen so that two workgroups fit one CU's
 // 160 KiB of LDS:  one flow  EPT 2, CHUNK 8 -> 3.1 + 36 + 32 = 71 KiB
 //                  two flows EPT 3, CHUNK 4 -> 3.1 + 52 + 24 = 79 KiB
-constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = 8;
+constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = 8;     // (CHUNK 4 measures the same: the chunk count /
+                                                                    // barrier count is not what bounds the kernel)
 constexpr int EPT_TWO = SEG_TWO / SPLAT_THREADS, CHUNK_TWO = 4;
 // records per segment: <= 4 per entry, + 1 pad per output pixel (list lengths are made odd so the
 // lanes' list walks start on different LDS banks: with the typical 4 records per pixel an
