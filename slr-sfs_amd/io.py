@@ -1,6 +1,6 @@
 """Input / output formats either side of the path: what the reference's test
 scripts read and write (test_animating/test_baseline_4eval_rawsize.py:51-68,156-184,246-274).
-torch + numpy + PIL only (cv2 / torchvision / lz4framed are not in the image)."""
+torch + numpy + PIL only (cv2 / torchvision / lz4framed are not in the image; the LZ4 frame decoder is here)."""
 import json
 import os
 import pickle
@@ -32,22 +32,97 @@ def write_flo(path, flow_hw2):
         flow_hw2.tofile(f)
 
 
+def lz4_frame_decompress(raw):
+    """LZ4 *frame* format -> bytes (what ``lz4framed.decompress`` does in the reference's
+    ``load_compressed_tensor``, utils/utils.py:111-115; the package is not in the MI355X image).
+    Written from the public frame / block format description: magic 0x184D2204, FLG / BD descriptor
+    (+ optional content size and dictionary id, header checksum byte), data blocks of
+    [u32 size | bit 31 = stored uncompressed][payload][optional block checksum], end mark 0,
+    optional content checksum.  Checksums are skipped, not verified.  A block is a series of
+    sequences: token (literal length << 4 | match length - 4), 255-extended lengths, literals,
+    u16 little-endian match offset into the output produced so far (copies may overlap)."""
+    mv = memoryview(raw)
+    if len(mv) < 7 or int.from_bytes(mv[0:4], "little") != 0x184D2204:
+        raise ValueError("not an LZ4 frame")
+    flg = mv[4]
+    if (flg >> 6) != 1:
+        raise ValueError("unsupported LZ4 frame version")
+    block_checksum, has_size, content_checksum, has_dict = (flg >> 4) & 1, (flg >> 3) & 1, (flg >> 2) & 1, flg & 1
+    pos = 6 + 8 * has_size + 4 * has_dict + 1                # FLG, BD, [size], [dict id], header checksum
+    expected = int.from_bytes(mv[6:14], "little") if has_size else None
+    out = bytearray()
+    while True:
+        if pos + 4 > len(mv):
+            raise ValueError("truncated LZ4 frame")
+        bsz = int.from_bytes(mv[pos:pos + 4], "little")
+        pos += 4
+        if bsz == 0:                                          # end mark
+            break
+        stored = bsz >> 31
+        bsz &= 0x7FFFFFFF
+        if pos + bsz > len(mv):
+            raise ValueError("truncated LZ4 block")
+        if stored:
+            out += mv[pos:pos + bsz]
+        else:
+            _lz4_block(mv[pos:pos + bsz], out)
+        pos += bsz + 4 * block_checksum
+    if expected is not None and expected != len(out):
+        raise ValueError(f"LZ4 frame: content size {expected} != decoded {len(out)}")
+    return bytes(out)
+
+
+def _lz4_block(src, out):
+    i, n = 0, len(src)
+    while i < n:
+        token = src[i]
+        i += 1
+        lit = token >> 4
+        if lit == 15:
+            while True:
+                b = src[i]
+                i += 1
+                lit += b
+                if b != 255:
+                    break
+        out += src[i:i + lit]
+        i += lit
+        if i >= n:                                            # the last sequence has literals only
+            break
+        off = src[i] | (src[i + 1] << 8)
+        i += 2
+        if off == 0 or off > len(out):
+            raise ValueError("corrupt LZ4 block (bad match offset)")
+        mlen = (token & 15) + 4
+        if (token & 15) == 15:
+            while True:
+                b = src[i]
+                i += 1
+                mlen += b
+                if b != 255:
+                    break
+        start = len(out) - off
+        if off >= mlen:
+            out += out[start:start + mlen]
+        else:                                                 # overlapping copy: the pattern repeats
+            pat = bytes(out[start:])
+            out += (pat * (mlen // off + 1))[:mlen]
+
+
 def load_motion(path):
     """Motion field as the test scripts load it -> float32 tensor [1,2,h,w] (:168-172).
-    .flo, or .pth: the reference's lz4framed-compressed pickle (utils/utils.py:111-115) when
-    lz4framed is importable, else a plain torch.save / pickle of the same array."""
+    .flo, or .pth: the reference's LZ4-frame-compressed pickle of a numpy array
+    (``load_compressed_tensor``, utils/utils.py:111-115), decoded here without the lz4framed package;
+    a plain torch.save / pickle of the same array is accepted as well.
+    (Like the reference, this unpickles the file: only load motion files you trust.)"""
     if path.endswith(".flo"):
         return torch.from_numpy(read_flo(path)).permute(2, 0, 1).contiguous().unsqueeze(0)
     with open(path, "rb") as f:
         raw = f.read()
-    try:
-        import lz4framed                                   # not in the MI355X image
-        arr = pickle.loads(lz4framed.decompress(raw))
-    except ImportError:
-        try:
-            arr = torch.load(path, map_location="cpu", weights_only=False)
-        except Exception as e:                             # pragma: no cover
-            raise RuntimeError(f"{path}: lz4framed-compressed motion needs the lz4framed package") from e
+    if raw[:4] == b"\x04\x22\x4d\x18":
+        arr = pickle.loads(lz4_frame_decompress(raw))
+    else:
+        arr = torch.load(path, map_location="cpu", weights_only=False)
     t = torch.as_tensor(np.asarray(arr), dtype=torch.float32)
     return t if t.dim() == 4 else t.unsqueeze(0)
 

@@ -69,3 +69,95 @@ def test_prepare_motion_matches_script_arithmetic():
     ref = torch.nn.functional.interpolate(ref, (W, W)) * frame / N
     out = pipeline.prepare_motion(flow, W, W, speed, frame, N)
     assert torch.allclose(out, ref)
+
+
+# ------------------------------------------------------------------ LZ4-framed .pth (utils/utils.py:111-115)
+
+def _lz4_block_encode(data):
+    """Tiny greedy LZ4 block encoder (test helper): hash of 4-byte windows, min match 4, last 5 bytes literal."""
+    out, i, anchor, n, table = bytearray(), 0, 0, len(data), {}
+
+    def emit(lit, mlen, off):
+        token_l = min(len(lit), 15)
+        token_m = min(mlen - 4, 15) if mlen else 0
+        out.append((token_l << 4) | token_m)
+        if len(lit) >= 15:
+            r = len(lit) - 15
+            out.extend(b"\xff" * (r // 255) + bytes([r % 255]))
+        out.extend(lit)
+        if mlen:
+            out.extend(off.to_bytes(2, "little"))
+            if mlen - 4 >= 15:
+                r = mlen - 4 - 15
+                out.extend(b"\xff" * (r // 255) + bytes([r % 255]))
+
+    while i + 4 <= n - 5:
+        key = bytes(data[i:i + 4])
+        cand = table.get(key)
+        table[key] = i
+        if cand is not None and i - cand <= 0xFFFF:
+            m = 4
+            while i + m < n - 5 and data[cand + m] == data[i + m]:
+                m += 1
+            emit(data[anchor:i], m, i - cand)
+            i += m
+            anchor = i
+        else:
+            i += 1
+    emit(data[anchor:], 0, 0)
+    return bytes(out)
+
+
+def _lz4_frame(data, block=1 << 16, stored=False, content_size=True, block_checksum=False):
+    flg = (1 << 6) | (1 << 5) | (int(block_checksum) << 4) | (int(content_size) << 3)
+    hdr = bytearray(b"\x04\x22\x4d\x18") + bytes([flg, 4 << 4])
+    if content_size:
+        hdr += len(data).to_bytes(8, "little")
+    hdr += b"\x00"                                            # header checksum (not verified by the reader)
+    body = bytearray()
+    for s in range(0, len(data), block):
+        chunk = data[s:s + block]
+        enc = chunk if stored else _lz4_block_encode(chunk)
+        body += (len(enc) | (0x80000000 if stored else 0)).to_bytes(4, "little") + enc
+        if block_checksum:
+            body += b"\x00\x00\x00\x00"
+    return bytes(hdr + body + b"\x00\x00\x00\x00")
+
+
+@pytest.mark.parametrize("kind", ["random", "runs", "zeros", "text"])
+@pytest.mark.parametrize("opts", [{}, {"stored": True}, {"content_size": False, "block_checksum": True}, {"block": 1000}])
+def test_lz4_frame_decoder(kind, opts):
+    rng = np.random.default_rng(5)
+    data = {"random": rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+            "runs": np.repeat(rng.integers(0, 256, 300, dtype=np.uint8), rng.integers(1, 700, 300)).tobytes(),
+            "zeros": bytes(100000),
+            "text": (b"the quick brown fox jumps over the lazy dog. " * 3000)[:123457]}[kind]
+    frame = _lz4_frame(data, **opts)
+    if kind in ("zeros", "text") and not opts.get("stored"):
+        assert len(frame) < len(data) // 4                    # the helper really compresses: matches are exercised
+    assert io.lz4_frame_decompress(frame) == data
+
+
+def test_lz4_framed_pth_motion(tmp_path):
+    """The reference's load_compressed_tensor format: LZ4 frame around pickle.dumps(ndarray)."""
+    import pickle
+    rng = np.random.default_rng(9)
+    flow = np.round(rng.standard_normal((1, 2, 40, 64)), 1).astype(np.float32)
+    p = str(tmp_path / "motion.pth")
+    open(p, "wb").write(_lz4_frame(pickle.dumps(flow)))
+    got = io.load_motion(p)
+    assert got.shape == (1, 2, 40, 64) and np.array_equal(got.numpy(), flow)
+    with pytest.raises(ValueError):
+        io.lz4_frame_decompress(b"\x04\x22\x4d\x18\x60\x40\x00" + b"\x10\x00\x00\x00" + b"\x00" * 3)   # truncated block
+
+
+def test_lz4_frame_from_system_liblz4(golden_dir):
+    """A frame written by the system liblz4 (tools/make_golden_lz4.py), i.e. by an implementation independent of
+    the reader: decodes to the pickled motion field the generator compressed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(golden_dir), "..", "tools", "make_golden_lz4.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)                                # (liblz4 is only loaded when the tool runs as a script)
+    want = mk.motion()
+    got = io.load_motion(os.path.join(golden_dir, "motion_lz4.pth"))
+    assert got.shape == want.shape and np.array_equal(got.numpy(), want)
