@@ -618,7 +618,7 @@ static int conv_launch(ConvArgs &a, float wscale, hipStream_t st) {
         else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false>), grid, dim3(CV_THREADS), 0, st, a);    \
     } while (0)
     if (ct == 128) CV_LAUNCH(2, 2);
-    else if (ct == 64) CV_LAUNCH(2, 1);
+    else if (ct == 64) CV_LAUNCH(1, 2);     // 1 tile x 4 rows per wave: half the weight-fragment loads of <2,1> (+4 %)
     else CV_LAUNCH(1, 1);
 #undef CV_LAUNCH
     SLR_CHECK_LAUNCH();
