@@ -25,8 +25,9 @@
 //   * the pre-split weights are stored in fragment order
 //     [co/32][ci/16][tap][half][ci group 2][co 32][ci 8]; a wave reads its A fragments straight from
 //     global memory one tap ahead (1 KiB contiguous per fragment, L2-resident);
-//   * wave (wc, wp) owns CPW 32-channel tiles x PT rows: CPW x PT accumulator tiles of 32x32
-//     (128 registers for the 128-channel variant), 3 MFMAs per tile, tap and chunk;
+//   * a wave owns CPW 32-channel tiles x PT rows: CPW x PT accumulator tiles of 32x32 (128-channel
+//     variant: wave wc = one channel tile x all 8 rows, 128 registers), 3 MFMAs per tile, tap and
+//     chunk; the B fragments of the rows are read in two batches of four against the same A;
 //   * epilogue on the accumulators: plain (+bias) or the partial-convolution one
 //     (o = (raw*ratio + b)*um, then + residual or the next layer's relu(bn(.))*um), same operations
 //     in the same order as csrc/pconv.hip.  The D layout (row = channel, column = pixel) makes every
@@ -263,17 +264,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             load_a(a_nxt, min(c * 9 + tap + 1, glast));
 #endif
             __builtin_amdgcn_sched_barrier(0);         // loads are issued HERE, a whole tap ahead of their use
-            h8 bh[PT], bl[PT];
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-#if CV_EXP & 1
-                const int p = (wp * PT + pt) * CV_HW + bcol;        // experiment: same fragments for every tap (CSE)
-#else
-                const int p = (wp * PT + pt + kh) * CV_HW + kw + bcol;
-#endif
-                bh[pt] = xh[p];
-                bl[pt] = xl[p];
-            }
             const bool stage_tap = !(CV_EXP & 4) && (tap == 2 || tap == 5 || tap == 8);
             Stage sg;
             sg.fresh = c + 1 < nchunk ? 1.0f : 0.0f;   // the last iteration re-stages its own chunk: not counted twice
@@ -286,19 +276,37 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             // consecutive MFMAs never touch the same accumulator.  In a staging tap the 8 values of the
             // round are converted BETWEEN groups of MFMAs (order pinned by scheduling barriers), so that
             // VALU work issues in the shadow of the matrix pipe instead of in front of it.
-            constexpr int NM = 3 * CPW * PT;
+            // B fragments are read in batches of <= 4 pixel tiles (32 registers): a wave with 8 rows
+            // (WCO = 4) makes two passes with the same A fragments.
+            constexpr int PB = PT > 4 ? 4 : PT, NB = PT / PB;
+            constexpr int NM = 3 * CPW * PT, NMB = 3 * CPW * PB;
 #pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                const int part = i / (CPW * PT), pt = (i / CPW) % PT, ct = i % CPW;
-                const h8 av = part == 0 ? a_cur[ct][1] : a_cur[ct][0];
-                const h8 bv = part == 1 ? bl[pt] : bh[pt];
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[ct][pt], 0, 0, 0);
-                if (stage_tap) {
-                    const int j0 = i * 8 / NM, j1 = (i + 1) * 8 / NM;
-                    if (j1 > j0) {
+            for (int hb = 0; hb < NB; ++hb) {
+                h8 bh[PB], bl[PB];
 #pragma unroll
-                        for (int j = j0; j < j1; ++j) stage_value(j, sg, st);
-                        __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < PB; ++k) {
+#if CV_EXP & 1
+                    const int p = (wp * PT + hb * PB + k) * CV_HW + bcol;   // experiment: same fragments for every tap (CSE)
+#else
+                    const int p = (wp * PT + hb * PB + k + kh) * CV_HW + kw + bcol;
+#endif
+                    bh[k] = xh[p];
+                    bl[k] = xl[p];
+                }
+#pragma unroll
+                for (int ib = 0; ib < NMB; ++ib) {
+                    const int part = ib / (CPW * PB), k = (ib / CPW) % PB, ct = ib % CPW;
+                    const int pt = hb * PB + k, i = hb * NMB + ib;
+                    const h8 av = part == 0 ? a_cur[ct][1] : a_cur[ct][0];
+                    const h8 bv = part == 1 ? bl[k] : bh[k];
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[ct][pt], 0, 0, 0);
+                    if (stage_tap) {
+                        const int j0 = i * 8 / NM, j1 = (i + 1) * 8 / NM;
+                        if (j1 > j0) {
+#pragma unroll
+                            for (int j = j0; j < j1; ++j) stage_value(j, sg, st);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
@@ -617,7 +625,8 @@ static int conv_launch(ConvArgs &a, float wscale, hipStream_t st) {
         if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true>), grid, dim3(CV_THREADS), 0, st, a);  \
         else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false>), grid, dim3(CV_THREADS), 0, st, a);    \
     } while (0)
-    if (ct == 128) CV_LAUNCH(2, 2);
+    if (ct == 128) CV_LAUNCH(1, 4);         // one 32-channel tile x all 8 rows per wave: a quarter of the weight-fragment
+                                            // traffic of 4 x 2 tiles per wave would need, half of <2,2> (+3..5 % measured)
     else if (ct == 64) CV_LAUNCH(1, 2);     // 1 tile x 4 rows per wave: half the weight-fragment loads of <2,1> (+4 %)
     else CV_LAUNCH(1, 1);
 #undef CV_LAUNCH
