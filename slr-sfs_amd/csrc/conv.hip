@@ -146,6 +146,10 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     auto load_round = [&](auto R, int c, float (&st)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+#if CV_EXP & 8
+            st[j] = (float)(c + j) * 0.01f + (float)offA * 1e-6f;      // experiment: staging arithmetic without the loads
+            continue;
+#endif
             if (R.value < 2) {
                 const float *pl = inb + (size_t)min(c * 16 + R.value * 8 + j, cmax) * HW;       // wave-uniform
                 st[j] = pl[(unsigned)offA];
@@ -254,14 +258,18 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             asm volatile("" ::: "memory");
 #endif
             // staging of the next chunk, one round per three taps: 8 registers in flight instead of 24.
-            // A round's loads are issued at the top of tap 0 / the end of taps 2 and 5 and consumed
+            // A round's loads are issued at the top of taps 0 / 3 / 6 (behind the weight loads) and consumed
             // (prologue, split, LDS store) in taps 2 / 5 / 8, where that VALU work is interleaved with
             // the tap's MFMAs (below).
-#if !(CV_EXP & 4)
-            if (tap == 0) load_round(R0{}, cn, st);
-#endif
 #if !(CV_EXP & 2)
             load_a(a_nxt, min(c * 9 + tap + 1, glast));
+#endif
+#if !(CV_EXP & 4)
+            // AFTER the weight loads: memory returns in order, so a staging load (HBM latency) issued in
+            // front of an A load (L2 latency) would make the next tap wait for HBM
+            if (tap == 0) load_round(R0{}, cn, st);
+            if (tap == 3) load_round(R1{}, cn, st);
+            if (tap == 6) load_round(R2{}, cn, st);
 #endif
             __builtin_amdgcn_sched_barrier(0);         // loads are issued HERE, a whole tap ahead of their use
             const bool stage_tap = !(CV_EXP & 4) && (tap == 2 || tap == 5 || tap == 8);
@@ -311,8 +319,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                 }
             }
             if (stage_tap) {
-                if (tap == 2) { stage_finish(R0{}, buf ^ 1, sg); load_round(R1{}, cn, st); }
-                if (tap == 5) { stage_finish(R1{}, buf ^ 1, sg); load_round(R2{}, cn, st); }
+                if (tap == 2) stage_finish(R0{}, buf ^ 1, sg);
+                if (tap == 5) stage_finish(R1{}, buf ^ 1, sg);
                 if (tap == 8) stage_finish(R2{}, buf ^ 1, sg);
             }
 #if !(CV_EXP & 2)
@@ -339,6 +347,15 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     const bool partial = a.partial != 0, has_bias = a.bias != nullptr, has_res = a.residual != nullptr,
                has_next = a.next_scale != nullptr;
     float *outp = a.out;
+    // Vector path of the stores: the finished 32-channel x 32-pixel tile takes a round trip through the wave's own
+    // LDS scratch (the staging buffers are free now) and comes back as [channel][4 consecutive pixels] per lane, so
+    // the residual is read and the result written with 16-byte accesses: 4 store instructions per tile instead
+    // of 16 (a VMEM instruction costs an in-order wave ~60-100 issue cycles).  Needs whole 32-pixel rows inside
+    // the image and 16-byte aligned rows; otherwise the 4-byte path below.
+    const bool vec = (a.W % 4 == 0) && (x0 + CV_W <= a.W) &&
+                     !(((uintptr_t)a.out | (uintptr_t)a.residual) & 15);
+    constexpr int SCR_STRIDE = 36;                     // floats per channel row: 16-byte aligned, conflict-free
+    float *scr = reinterpret_cast<float *>(&xs[0][0][0][0]) + wave * (32 * SCR_STRIDE);
     const int ox = x0 + bcol;
     const bool xin_img = ox < a.W;
     const int cout1 = a.Cout - 1;
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                     a.um_out[(size_t)n * HW + pix] = um;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = (o[r] * ratio + eb[r]) * um;                   // :72-74
-                if (has_res) {                                                                      // blocks.py:248
+                if (has_res && !vec) {                                                              // blocks.py:248
                     float rv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[r] += eb[r];
                 }
-                if (has_res) {
+                if (has_res && !vec) {
                     float rv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
@@ -402,9 +419,37 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                     for (int r = 0; r < 16; ++r) o[r] += rv[r];
                 }
             }
+            if (vec) {
+                // (the residual add is the LAST operation of both epilogues, so it moves behind the transpose unchanged)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok && co[r] <= cout1) outp[((size_t)n * a.Cout + co[r]) * HW + pix] = o[r];
+                for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * bgrp) * SCR_STRIDE + bcol] = o[r];
+                __builtin_amdgcn_wave_barrier();
+                const int quad = lane & 7;
+                float4 v[4], rv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4 *>(&scr[((lane >> 3) + 8 * k) * SCR_STRIDE + quad * 4]);
+                __builtin_amdgcn_wave_barrier();
+                const bool rowok = oy < a.H;
+                size_t vidx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cv = min((cot0 + ct) * 32 + (lane >> 3) + 8 * k, cout1);
+                    vidx[k] = ((size_t)n * a.Cout + cv) * HW + (rowok ? (size_t)oy * a.W + x0 + quad * 4 : 0);
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rv[k] = *reinterpret_cast<const float4 *>(&a.residual[vidx[k]]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[k].x += rv[k].x; v[k].y += rv[k].y; v[k].z += rv[k].z; v[k].w += rv[k].w; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (rowok && (cot0 + ct) * 32 + (lane >> 3) + 8 * k <= cout1) *reinterpret_cast<float4 *>(&outp[vidx[k]]) = v[k];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok && co[r] <= cout1) outp[((size_t)n * a.Cout + co[r]) * HW + pix] = o[r];
+            }
         }
     }
 }
