@@ -192,6 +192,13 @@ int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_b
  *   Weights are prepared once per layer with slr_conv3x3_split_weights into a buffer of
  *   slr_conv3x3_weight_bytes(Cout, Cin) bytes; `wscale` is a power of two that brings max|w|
  *   near 2^12 (f16 range) and must be passed unchanged to the forward calls. */
+/* `layout` flags of the forward calls: the activation BETWEEN two of these kernels may be kept channel-blocked,
+ * [N, C/8, H, W, 8] instead of [N, C, H, W] (C % 8 == 0): the consumer then stages an item's 8 channels with two
+ * 16-byte loads instead of eight 4-byte loads, the producer stores 16 bytes per lane without a transpose.
+ * Same values, same arithmetic; only the memory order of that one tensor differs. */
+#define SLR_CONV_IN_B8  1      /* `in` / `x` is channel-blocked */
+#define SLR_CONV_OUT_B8 2      /* `out` is written channel-blocked (not with `residual`) */
+
 size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
 int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit, int Cout, int Cin,
                               float wscale, void *stream);
@@ -202,7 +209,7 @@ int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit,
  * (the x_a + x_b of ResNet_Block, blocks.py:87). */
 int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual, float *out,
                         int N, int Cin, int Cout, int H, int W, float wscale,
-                        const float *pre_scale, const float *pre_shift, void *stream);
+                        const float *pre_scale, const float *pre_shift, int layout, void *stream);
 
 /* One partial convolution of ResNet_Block_Pconv2 in a single kernel
  * (models/layers/partialconv2d.py:41-81 with blocks.py:229-239,248):
@@ -220,7 +227,7 @@ int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, 
 int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
                          const void *wsplit, float wscale, const float *bias, const float *residual,
                          const float *next_scale, const float *next_shift, float *out, float *um_out,
-                         int N, int Cin, int Cout, int H, int W, void *stream);
+                         int N, int Cin, int Cout, int H, int W, int layout, void *stream);
 
 /* 1x1 convolution (skip branch of the residual blocks, models/layers/blocks.py:192-193,243-247) on the same
  * split-f16 arithmetic: out = conv1x1(in) + bias.  HBM-bound, no LDS.  Weights prepared once per layer with

@@ -70,6 +70,7 @@ struct ConvArgs {
     float mask_scale, winsize;   // conv(mask, ones) = box3x3(mask plane) * mask_scale; Cin * 9
     const float *residual, *next_scale, *next_shift;
     float *um_out;         // [N,1,H,W] or nullptr
+    int out_b8;            // output in the channel-blocked layout [N, Cout/8, H, W, 8] (Cout % 8 == 0)
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -79,7 +80,10 @@ __host__ __device__ inline int conv_cin_pad(int Cin) { return (Cin + 15) / 16 * 
 
 // CPW: 32-channel output tiles per wave; WCO: waves along the output channels (workgroup covers
 // 32*CPW*WCO channels); the other 4/WCO wave rows split the 8 block rows.
-template <int CPW, int WCO, bool PRE>
+// INB8: the input tensor is channel-blocked, [N, Cin/8, H, W, 8] (what a previous call wrote with out_b8): the 8 channels of
+// a staging item are 32 contiguous bytes = two 16-byte loads instead of eight 4-byte loads.  A VMEM instruction costs
+// an in-order wave ~60-100 issue cycles; the 24 staging loads per chunk of the NCHW scheme are 14 % of the kernel.
+template <int CPW, int WCO, bool PRE, bool INB8>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
     __shared__ h8 xs[2][2][2][CV_NPX];             // [buffer][hi|lo][8-channel group][halo pixel]
@@ -143,7 +147,16 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     const bool nonzero_mask = pre == PRE_BN_NONZERO;
     // R = staging round; c = chunk.  Channels past Cin re-read the last plane: finite values that meet
     // zero weights (and zero scale / shift with a prologue).
+    const int c8max = (a.Cin >> 3) - 1;               // INB8: last 8-channel group
     auto load_round = [&](auto R, int c, float (&st)[8]) {
+        if (INB8) {                                    // groups past Cin re-read the last one (zero weights)
+            const int grp = min(c * 2 + (R.value < 2 ? R.value : gB), c8max);
+            const float4 *q = reinterpret_cast<const float4 *>(inb) + ((size_t)grp * HW + (unsigned)(R.value < 2 ? offA : offB)) * 2;
+            const float4 u = q[0], v = q[1];
+            st[0] = u.x; st[1] = u.y; st[2] = u.z; st[3] = u.w;
+            st[4] = v.x; st[5] = v.y; st[6] = v.z; st[7] = v.w;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #if CV_EXP & 8
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                     a.um_out[(size_t)n * HW + pix] = um;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = (o[r] * ratio + eb[r]) * um;                   // :72-74
-                if (has_res && !vec) {                                                              // blocks.py:248
+                if (has_res && !vec) {                                                              // blocks.py:248 (never with out_b8)
                     float rv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
@@ -419,7 +432,17 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                     for (int r = 0; r < 16; ++r) o[r] += rv[r];
                 }
             }
-            if (vec) {
+            if (a.out_b8) {
+                // channel-blocked output: register group q = r >> 2 holds channels 8q + 4*bgrp + (0..3) of this pixel,
+                // i.e. 16 contiguous bytes of [N, Cout/8, H, W, 8]: 4 stores per tile, no transpose (residual: NCHW only)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c8 = (cot0 + ct) * 4 + q;
+                    if (ok && c8 * 8 + 4 * bgrp < a.Cout)
+                        *reinterpret_cast<float4 *>(&outp[(((size_t)n * (a.Cout >> 3) + c8) * HW + pix) * 8 + 4 * bgrp]) =
+                            make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                }
+            } else if (vec) {
                 // (the residual add is the LAST operation of both epilogues, so it moves behind the transpose unchanged)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * bgrp) * SCR_STRIDE + bcol] = o[r];
@@ -658,7 +681,7 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
     return 0;
 }
 
-static int conv_launch(ConvArgs &a, float wscale, hipStream_t st) {
+static int conv_launch(ConvArgs &a, float wscale, bool in_b8, hipStream_t st) {
     a.tiles_x = (a.W + CV_W - 1) / CV_W;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.unscale = 1.0f / (CV_XSCALE * wscale);
@@ -667,8 +690,10 @@ static int conv_launch(ConvArgs &a, float wscale, hipStream_t st) {
     const dim3 grid(tiles, conv_cout_pad(a.Cout) / ct, a.N);
 #define CV_LAUNCH(CPW, WCO)                                                                                     \
     do {                                                                                                       \
-        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true>), grid, dim3(CV_THREADS), 0, st, a);  \
-        else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false>), grid, dim3(CV_THREADS), 0, st, a);    \
+        if (a.pre != PRE_NONE && in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, true>), grid, dim3(CV_THREADS), 0, st, a);    \
+        else if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, false>), grid, dim3(CV_THREADS), 0, st, a);      \
+        else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, true>), grid, dim3(CV_THREADS), 0, st, a);                  \
+        else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, false>), grid, dim3(CV_THREADS), 0, st, a);                            \
     } while (0)
     if (ct == 128) CV_LAUNCH(1, 4);         // one 32-channel tile x all 8 rows per wave: a quarter of the weight-fragment
                                             // traffic of 4 x 2 tiles per wave would need, half of <2,2> (+3..5 % measured)
@@ -676,6 +701,16 @@ static int conv_launch(ConvArgs &a, float wscale, hipStream_t st) {
     else CV_LAUNCH(1, 1);
 #undef CV_LAUNCH
     SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
+                             bool derived_mask) {
+    SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8)) == 0, "layout flags");
+    SLR_CHECK_ARG(!(layout & SLR_CONV_IN_B8) || (Cin % 8 == 0 && !((uintptr_t)in & 15) && !derived_mask),
+                  "channel-blocked input needs Cin % 8 == 0, a 16-byte aligned tensor and an explicit mask");
+    SLR_CHECK_ARG(!(layout & SLR_CONV_OUT_B8) || (Cout % 8 == 0 && !((uintptr_t)out & 15) && !residual),
+                  "channel-blocked output needs Cout % 8 == 0, a 16-byte aligned tensor and no residual");
     return 0;
 }
 
@@ -687,8 +722,9 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
 
 SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual,
                                    float *out, int N, int Cin, int Cout, int H, int W, float wscale,
-                                   const float *pre_scale, const float *pre_shift, void *stream) {
+                                   const float *pre_scale, const float *pre_shift, int layout, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
+    if (int e = conv_check_layout(layout, in, out, Cin, Cout, residual, false)) return e;
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
     SLR_CHECK_ARG(!pre_scale || Cin <= CV_MAXCIN, "prologue supports Cin <= 1024");
     if (int e = conv_check_dims(N, Cin, Cout, H, W)) return e;
@@ -698,14 +734,16 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.pre = pre_scale ? PRE_BN : PRE_NONE;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.residual = residual;
-    return conv_launch(a, wscale, (hipStream_t)stream);
+    a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
+    return conv_launch(a, wscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
 }
 
 SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
                                     const void *wsplit, float wscale, const float *bias, const float *residual,
                                     const float *next_scale, const float *next_shift, float *out, float *um_out,
-                                    int N, int Cin, int Cout, int H, int W, void *stream) {
+                                    int N, int Cin, int Cout, int H, int W, int layout, void *stream) {
     SLR_CHECK_ARG(x && wsplit && bias && out, "null pointer");
+    if (int e = conv_check_layout(layout, x, out, Cin, Cout, residual, mask == nullptr)) return e;
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
     SLR_CHECK_ARG(!pre_scale || Cin <= CV_MAXCIN, "prologue supports Cin <= 1024");
     SLR_CHECK_ARG(mask || pre_scale, "mask = NULL (derived from x != 0) needs the raw input, i.e. pre_scale / pre_shift");
@@ -721,5 +759,6 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     a.mask_scale = mask ? (float)Cin : 1.0f;           // channel-uniform mask: Cin identical planes (partialconv2d.py:61)
     a.winsize = (float)Cin * 9.0f;
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
-    return conv_launch(a, wscale, (hipStream_t)stream);
+    a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
+    return conv_launch(a, wscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
 }

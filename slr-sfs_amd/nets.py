@@ -30,6 +30,13 @@ from . import _lib
 
 
 _CPU_REFERENCE = False
+IN_B8, OUT_B8 = 1, 2          # include/slr_splat.h: SLR_CONV_IN_B8 / SLR_CONV_OUT_B8
+
+
+def _b8(x, channels):
+    """Keep the activation between a block's two convolutions channel-blocked ([N,C/8,H,W,8]) on the device: it has
+    exactly one producer and one consumer, both our kernel (16-byte loads / stores instead of 4-byte ones)."""
+    return x.is_cuda and channels % 8 == 0
 
 
 class cpu_reference:
@@ -147,8 +154,8 @@ class Conv(nn.Module):
         self.cin, self.k = cin, k
         nn.init.normal_(self.weight, std=math.sqrt(1.0 / (cin * k * k)))
 
-    def forward(self, x, pre_bn=None, residual=None):
-        return self.conv(x, self.bias, pre_bn, residual)
+    def forward(self, x, pre_bn=None, residual=None, layout=0):
+        return self.conv(x, self.bias, pre_bn, residual, layout)
 
     def _split_weights(self):
         """Split-f16 weights of the matrix-core kernel (csrc/conv.hip), prepared once per device /
@@ -169,7 +176,7 @@ class Conv(nn.Module):
             c = self.__dict__["_wsplit"] = (key, buf, wscale)
         return c[1], c[2]
 
-    def conv(self, x, bias, pre_bn=None, residual=None):
+    def conv(self, x, bias, pre_bn=None, residual=None, layout=0):
         """conv(relu(bn(x))) + bias + residual (``pre_bn`` = (scale, shift) of the BN in front, or None).
         On a device 3x3 layers run on the matrix cores (split-f16 implicit GEMM of csrc/conv.hip, BN +
         ReLU fused into its prologue, bias / residual into its epilogue) and so do the 1x1 skips; CPU
@@ -184,8 +191,9 @@ class Conv(nn.Module):
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out),
                                                           N, cin, cout, H, W, wscale, _lib.ptr(sc), _lib.ptr(sh),
-                                                          _lib.stream_of(x)), "slr_conv3x3_forward")
+                                                          layout, _lib.stream_of(x)), "slr_conv3x3_forward")
             return out
+        assert layout == 0 or x.is_cuda        # the channel-blocked intermediate exists on the device path only
         if residual is not None:
             return self.conv(x, bias, pre_bn) + residual
         if pre_bn is not None:
@@ -227,7 +235,7 @@ class PartialConv(Conv):
     (slr_pconv3x3_forward, which also forms the box sum and the per-element mask from the staged
     input); on the CPU the torch composition that defines it."""
 
-    def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None):
+    def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None, layout=0):
         cin = x.shape[1]
         assert mask is not None or pre_bn is not None
         if self.k == 3 and _fused_ok(x, *([] if mask is None else [mask]), *([] if residual is None else [residual])):
@@ -242,8 +250,9 @@ class PartialConv(Conv):
                 _lib.check(_lib.lib().slr_pconv3x3_forward(
                     _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale,
                     _lib.ptr(self.bias), _lib.ptr(residual), _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um),
-                    N, cin, cout, H, W, _lib.stream_of(x)), "slr_pconv3x3_forward")
+                    N, cin, cout, H, W, layout, _lib.stream_of(x)), "slr_pconv3x3_forward")
             return out, um
+        assert layout == 0
         if mask is None:
             mplane, mscale = (x != 0).sum(1, keepdim=True).to(x.dtype), 1.0
         else:
@@ -305,9 +314,10 @@ class ResBlock(nn.Module):
         self.resample = _resample(resample)
 
     def forward(self, x):
-        a = self.conv_aa(x, self.bn1.scale_shift())            # BN + ReLU ride in the convolution's prologue
+        b8 = _b8(x, self.conv_aa.weight.shape[0])
+        a = self.conv_aa(x, self.bn1.scale_shift(), layout=OUT_B8 if b8 else 0)     # BN + ReLU ride in the prologue
         b = self.conv_b(x) if self.conv_b is not None else x
-        a = self.conv_ab(a, self.bn2.scale_shift(), residual=b)    # x_a + x_b (:87) joins the convolution's epilogue
+        a = self.conv_ab(a, self.bn2.scale_shift(), residual=b, layout=IN_B8 if b8 else 0)   # x_a + x_b (:87) in the epilogue
         return self.resample(a)              # == resample(x_a) + resample(x_b): both resamplers are linear
 
 
@@ -324,12 +334,14 @@ class PconvResBlock(nn.Module):
 
     def forward(self, x, mask):
         # mask: None = (x != 0) per channel (architectures.py:369), else [N,1,H,W] channel-uniform
-        a, m = self.conv_aa(x, mask, next_bn=self.bn2.scale_shift(), pre_bn=self.bn1.scale_shift())   # :229-236
+        b8 = _b8(x, self.conv_aa.weight.shape[0])
+        a, m = self.conv_aa(x, mask, next_bn=self.bn2.scale_shift(), pre_bn=self.bn1.scale_shift(),
+                            layout=OUT_B8 if b8 else 0)                              # :229-236
         # x_a + x_b (:248).  The reference resamples the two branches separately and adds; avg-pool
         # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
         # rounding, lets the residual join the epilogue, and halves the resampling work.
         skip = self.conv_b(x) if self.conv_b is not None else x                    # :243-247
-        a, m = self.conv_ab(a, m, residual=skip)                                   # :237-239
+        a, m = self.conv_ab(a, m, residual=skip, layout=IN_B8 if b8 else 0)        # :237-239
         return self.resample(a), self.resample_mask(m)                             # :240-241
 
 

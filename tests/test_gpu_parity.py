@@ -872,3 +872,37 @@ def test_conv_kernels_randomised_sweep(S):
                                             kw.get("residual"), kw.get("next_bn"))
             assert torch.equal(um, um2), ("um", case, mode, cin, cout, h, w)
             assert torch.equal(out, out2), ("pconv", case, mode, cin, cout, h, w, (out - out2).abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 16, 64), (32, 64, 9, 33), (128, 72, 11, 40)])
+def test_conv_channel_blocked_intermediate(S, cin, cout, h, w):
+    """The channel-blocked ([N,C/8,H,W,8]) layout of the activation between a block's two convolutions: writing it
+    (SLR_CONV_OUT_B8) and reading it (SLR_CONV_IN_B8) is bit-identical to the NCHW path -- plain and partial
+    convolution, with prologue / next-BN / residual."""
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin + w)
+
+    def to_b8(t):
+        n, c, hh, ww = t.shape
+        return t.view(n, c // 8, 8, hh, ww).permute(0, 1, 3, 4, 2).contiguous().view(n, c, hh, ww)
+
+    x = torch.randn(2, cin, h, w, device="cuda")
+    mask = (torch.rand(2, 1, h, w, device="cuda") > 0.3).float()
+    sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3
+    nsc, nsh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.3
+    with torch.no_grad():
+        conv = nets.Conv(cin, cout, 3).cuda()
+        conv.bias.data.normal_()
+        ref = conv(x, (sc, sh))
+        assert torch.equal(conv(x, (sc, sh), layout=nets.OUT_B8), to_b8(ref))                     # producer
+        res = torch.randn_like(ref)
+        assert torch.equal(conv(to_b8(x), (sc, sh), res, layout=nets.IN_B8), conv(x, (sc, sh), res))   # consumer
+        pc = nets.PartialConv(cin, cout, 3).cuda()
+        pc.bias.data.normal_()
+        o1, m1 = pc(x, mask, next_bn=(nsc, nsh), pre_bn=(sc, sh))
+        o2, m2 = pc(x, mask, next_bn=(nsc, nsh), pre_bn=(sc, sh), layout=nets.OUT_B8)
+        assert torch.equal(o2, to_b8(o1)) and torch.equal(m1, m2)
+        r2 = torch.randn_like(o1)
+        o3, m3 = pc(x, mask, residual=r2)
+        o4, m4 = pc(to_b8(x), mask, residual=r2, layout=nets.IN_B8)
+        assert torch.equal(o3, o4) and torch.equal(m3, m4)

@@ -29,7 +29,7 @@ def conv_hip(x, buf, wscale, cout):
     n, cin, h, w = x.shape
     out = torch.empty(n, cout, h, w, device=x.device)
     _lib.check(L.slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), None, None, _lib.ptr(out), n, cin, cout, h, w, wscale,
-                                     None, None, _lib.stream_of(x)), "conv")
+                                     None, None, 0, _lib.stream_of(x)), "conv")
     return out
 
 
