@@ -197,7 +197,8 @@ int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_b
  * 16-byte loads instead of eight 4-byte loads, the producer stores 16 bytes per lane without a transpose.
  * Same values, same arithmetic; only the memory order of that one tensor differs. */
 #define SLR_CONV_IN_B8  1      /* `in` / `x` is channel-blocked */
-#define SLR_CONV_OUT_B8 2      /* `out` is written channel-blocked (not with `residual`) */
+#define SLR_CONV_OUT_B8 2      /* `out` is written channel-blocked */
+#define SLR_CONV_RES_B8 4      /* `residual` is channel-blocked (only together with SLR_CONV_OUT_B8) */
 
 size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
 int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit, int Cout, int Cin,
@@ -236,23 +237,26 @@ size_t slr_conv1x1_weight_bytes(int Cout, int Cin);
 int slr_conv1x1_split_weights(const float *w /* [Cout,Cin,1,1] */, void *wsplit, int Cout, int Cin,
                               float wscale, void *stream);
 int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias /* [Cout] or NULL */, float *out,
-                        int N, int Cin, int Cout, int H, int W, float wscale, void *stream);
+                        int N, int Cin, int Cout, int H, int W, float wscale, int layout, void *stream);
 
 /* ------------------------------------------------------------------ decoder resampling stages (8 f3) */
 
 /* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad): "Down" of models/layers/blocks.py:196-199.
  *   in [N,C,H,W] -> out [N,C,(H-1)/2+1,(W-1)/2+1] */
-int slr_avgpool3x3s2(const float *in, float *out, int N, int C, int H, int W, void *stream);
+int slr_avgpool3x3s2(const float *in, float *out, int N, int C, int H, int W, int b8 /* both tensors channel-blocked */,
+                     void *stream);
 
 /* nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False): "Up" of blocks.py:200-203.
  *   in [N,C,H,W] -> out [N,C,2H,2W] */
-int slr_upsample_bilinear2x(const float *in, float *out, int N, int C, int H, int W, void *stream);
+int slr_upsample_bilinear2x(const float *in, float *out, int N, int C, int H, int W, int b8 /* both tensors channel-blocked */,
+                            void *stream);
 
 /* 1x1 convolution onto 1..4 output channels (the skip branch of the decoder's last block,
  * blocks.py:192-193,243-247 with configs.py:117-137): out = bias + w . in;  w [Cout,Cin], bias [Cout] or NULL.
- *   Requires H*W % 4 == 0 and 16-byte aligned tensors. */
+ *   NCHW input requires H*W % 4 == 0 and 16-byte aligned tensors. */
 int slr_conv1x1_small(const float *in, const float *w, const float *bias, float *out,
-                      int N, int Cin, int Cout, int H, int W, void *stream);
+                      int N, int Cin, int Cout, int H, int W, int in_b8 /* `in` channel-blocked; `out` is always NCHW */,
+                      void *stream);
 
 #ifdef __cplusplus
 }

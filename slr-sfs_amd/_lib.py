@@ -77,12 +77,12 @@ def lib():
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv1x1_split_weights": [fp, vp, i, i, f, vp],
-            "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, vp],
+            "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, i, vp],
             "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, fp, fp, i, vp],
             "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp],
-            "slr_avgpool3x3s2": [fp, fp, i, i, i, i, vp],
-            "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, vp],
-            "slr_conv1x1_small": [fp, fp, fp, fp, i, i, i, i, i, vp],
+            "slr_avgpool3x3s2": [fp, fp, i, i, i, i, i, vp],
+            "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, i, vp],
+            "slr_conv1x1_small": [fp, fp, fp, fp, i, i, i, i, i, i, vp],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)

@@ -71,6 +71,7 @@ struct ConvArgs {
     const float *residual, *next_scale, *next_shift;
     float *um_out;         // [N,1,H,W] or nullptr
     int out_b8;            // output in the channel-blocked layout [N, Cout/8, H, W, 8] (Cout % 8 == 0)
+    int res_b8;            // ... and the residual as well (only together with out_b8)
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // the residual is read and the result written with 16-byte accesses: 4 store instructions per tile instead
     // of 16 (a VMEM instruction costs an in-order wave ~60-100 issue cycles).  Needs whole 32-pixel rows inside
     // the image and 16-byte aligned rows; otherwise the 4-byte path below.
-    const bool vec = (a.W % 4 == 0) && (x0 + CV_W <= a.W) &&
+    const bool vec = !a.out_b8 && (a.W % 4 == 0) && (x0 + CV_W <= a.W) &&
                      !(((uintptr_t)a.out | (uintptr_t)a.residual) & 15);
     constexpr int SCR_STRIDE = 36;                     // floats per channel row: 16-byte aligned, conflict-free
     float *scr = reinterpret_cast<float *>(&xs[0][0][0][0]) + wave * (32 * SCR_STRIDE);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                     a.um_out[(size_t)n * HW + pix] = um;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = (o[r] * ratio + eb[r]) * um;                   // :72-74
-                if (has_res && !vec) {                                                              // blocks.py:248 (never with out_b8)
+                if (has_res && !vec && !a.out_b8) {                                                 // blocks.py:248
                     float rv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[r] += eb[r];
                 }
-                if (has_res && !vec) {
+                if (has_res && !vec && !a.out_b8) {
                     float rv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rv[r] = a.residual[((size_t)n * a.Cout + min(co[r], cout1)) * HW + pix];
@@ -434,13 +435,25 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             }
             if (a.out_b8) {
                 // channel-blocked output: register group q = r >> 2 holds channels 8q + 4*bgrp + (0..3) of this pixel,
-                // i.e. 16 contiguous bytes of [N, Cout/8, H, W, 8]: 4 stores per tile, no transpose (residual: NCHW only)
+                // i.e. 16 contiguous bytes of [N, Cout/8, H, W, 8]: 4 stores per tile, no transpose.  The residual
+                // (last operation of both epilogues) is read in its own layout: blocked (16 bytes) or NCHW.
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c8 = (cot0 + ct) * 4 + q;
-                    if (ok && c8 * 8 + 4 * bgrp < a.Cout)
-                        *reinterpret_cast<float4 *>(&outp[(((size_t)n * (a.Cout >> 3) + c8) * HW + pix) * 8 + 4 * bgrp]) =
-                            make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                    const bool live = ok && c8 * 8 + 4 * bgrp < a.Cout;
+                    const size_t bidx = (((size_t)n * (a.Cout >> 3) + (live ? c8 : 0)) * HW + pix) * 8 + 4 * bgrp;
+                    float4 v = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                    if (has_res) {
+                        float4 rv;
+                        if (a.res_b8) {
+                            rv = *reinterpret_cast<const float4 *>(&a.residual[bidx]);
+                        } else {
+                            const size_t ridx = ((size_t)n * a.Cout + (live ? c8 * 8 + 4 * bgrp : 0)) * HW + pix;
+                            rv = make_float4(a.residual[ridx], a.residual[ridx + HW], a.residual[ridx + 2 * (size_t)HW], a.residual[ridx + 3 * (size_t)HW]);
+                        }
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    if (live) *reinterpret_cast<float4 *>(&outp[bidx]) = v;
                 }
             } else if (vec) {
                 // (the residual add is the LAST operation of both epilogues, so it moves behind the transpose unchanged)
@@ -491,10 +504,10 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #endif
 constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (streaming several was measured slower:
                                                    // the stores of a tile share vmcnt with the next tile's loads)
-template <int NCT>
+template <int NCT, bool INB8>
 __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restrict__ in, const h8 *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out,
-                                                            int Cin, int Cout, int HW, int nchunk, float unscale) {
+                                                            int Cin, int Cout, int HW, int nchunk, float unscale, int out_b8) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.z;
@@ -510,6 +523,12 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
         const int t = g / nchunk, c = g - t * nchunk;
         const int p = p0 + t * 32;
         const unsigned poff = p < HW ? p : 0;
+        if (INB8) {                                    // channel-blocked input: the lane's 8 channels are 32 contiguous bytes
+            const float4 *q4 = reinterpret_cast<const float4 *>(inb) + ((size_t)min(c * 2 + grp, (Cin >> 3) - 1) * HW + poff) * 2;
+            const float4 u = q4[0], v = q4[1];
+            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+            return;
+        }
 #pragma unroll
 #if C1_EXP & 2
         for (int j = 0; j < 8; ++j) x[j] = (float)(c + j);
@@ -589,6 +608,17 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
                 const float v = bp[min((cot0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * grp, cout1)];
                 b[r] = has_bias ? v : 0.0f;
             }
+            if (out_b8) {                              // 4 channels of one 8-group per register group: 16-byte stores
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c8 = (cot0 + t) * 4 + q;
+                    if (ok && c8 * 8 + 4 * grp < Cout)
+                        *reinterpret_cast<float4 *>(&out[(((size_t)n * (Cout >> 3) + c8) * HW + p) * 8 + 4 * grp]) =
+                            make_float4(acc[t][4 * q] * unscale + b[4 * q], acc[t][4 * q + 1] * unscale + b[4 * q + 1],
+                                        acc[t][4 * q + 2] * unscale + b[4 * q + 2], acc[t][4 * q + 3] * unscale + b[4 * q + 3]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (cot0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * grp;
@@ -643,6 +673,9 @@ SLR_EXPORT int slr_conv3x3_split_weights(const float *w, void *wsplit, int Cout,
     return 0;
 }
 
+static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
+                             bool derived_mask);
+
 // 1x1: output channels in groups of NCT*32 <= 128 per workgroup row (64 accumulator registers: 3 waves per SIMD;
 // wider layers re-read the input once per 128 channels, mostly from L2; 64-channel rows measured the same)
 static int conv1x1_nct(int Cout) { const int t = (Cout + 31) / 32; return t > 2 ? 4 : (t > 1 ? 2 : 1); }
@@ -666,15 +699,22 @@ SLR_EXPORT int slr_conv1x1_split_weights(const float *w, void *wsplit, int Cout,
 }
 
 SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias, float *out, int N, int Cin,
-                                   int Cout, int H, int W, float wscale, void *stream) {
+                                   int Cout, int H, int W, float wscale, int layout, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
+    if (int e = conv_check_layout(layout & ~SLR_CONV_RES_B8, in, out, Cin, Cout, nullptr, false)) return e;
+    SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8), "layout flags");
     SLR_CHECK_ARG(N > 0 && N < 65536 && Cin > 0 && Cout > 0 && Cout < (1 << 20) && H > 0 && W > 0 &&
                   (long long)Cin * H * W < (1LL << 40) && (long long)H * W < (1LL << 31) - 128, "sizes");
     const int HW = H * W, nchunk = conv_cin_pad(Cin) / 16, nct = conv1x1_nct(Cout);
     const float unscale = 1.0f / (CV_XSCALE * wscale);
     const dim3 grid((HW + 128 * C1_TILES - 1) / (128 * C1_TILES), conv1x1_cout_pad(Cout) / (nct * 32), N);
     hipStream_t st = (hipStream_t)stream;
-#define C1_LAUNCH(T) hipLaunchKernelGGL(conv1x1_split_kernel<T>, grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale)
+    const int ob8 = (layout & SLR_CONV_OUT_B8) ? 1 : 0;
+#define C1_LAUNCH(T)                                                                                                       \
+    do {                                                                                                                   \
+        if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8); \
+        else hipLaunchKernelGGL((conv1x1_split_kernel<T, false>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8); \
+    } while (0)
     if (nct == 4) C1_LAUNCH(4); else if (nct == 2) C1_LAUNCH(2); else C1_LAUNCH(1);
 #undef C1_LAUNCH
     SLR_CHECK_LAUNCH();
@@ -706,11 +746,13 @@ static int conv_launch(ConvArgs &a, float wscale, bool in_b8, hipStream_t st) {
 
 static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
                              bool derived_mask) {
-    SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8)) == 0, "layout flags");
+    SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8 | SLR_CONV_RES_B8)) == 0, "layout flags");
+    SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8) || ((layout & SLR_CONV_OUT_B8) && residual && !((uintptr_t)residual & 15)),
+                  "a channel-blocked residual goes with a channel-blocked output");
     SLR_CHECK_ARG(!(layout & SLR_CONV_IN_B8) || (Cin % 8 == 0 && !((uintptr_t)in & 15) && !derived_mask),
                   "channel-blocked input needs Cin % 8 == 0, a 16-byte aligned tensor and an explicit mask");
-    SLR_CHECK_ARG(!(layout & SLR_CONV_OUT_B8) || (Cout % 8 == 0 && !((uintptr_t)out & 15) && !residual),
-                  "channel-blocked output needs Cout % 8 == 0, a 16-byte aligned tensor and no residual");
+    SLR_CHECK_ARG(!(layout & SLR_CONV_OUT_B8) || (Cout % 8 == 0 && !((uintptr_t)out & 15)),
+                  "channel-blocked output needs Cout % 8 == 0 and a 16-byte aligned tensor");
     return 0;
 }
 
@@ -735,6 +777,7 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.residual = residual;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
+    a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
     return conv_launch(a, wscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
 }
 
@@ -760,5 +803,6 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     a.winsize = (float)Cin * 9.0f;
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
+    a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
     return conv_launch(a, wscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
 }

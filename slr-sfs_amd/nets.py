@@ -30,12 +30,14 @@ from . import _lib
 
 
 _CPU_REFERENCE = False
-IN_B8, OUT_B8 = 1, 2          # include/slr_splat.h: SLR_CONV_IN_B8 / SLR_CONV_OUT_B8
+IN_B8, OUT_B8, RES_B8 = 1, 2, 4          # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8
 
 
 def _b8(x, channels):
-    """Keep the activation between a block's two convolutions channel-blocked ([N,C/8,H,W,8]) on the device: it has
-    exactly one producer and one consumer, both our kernel (16-byte loads / stores instead of 4-byte ones)."""
+    """On the device every activation whose channel count is a multiple of 8 lives channel-blocked ([N,C/8,H,W,8]
+    in memory, carried in a tensor of the logical shape [N,C,H,W]): all its producers and consumers are our kernels,
+    which then move 16 bytes per lane and instruction instead of 4.  The networks' inputs and outputs (3-, 65-, 2-channel
+    ends, the splat's feature planes) stay NCHW; no torch op ever touches a blocked tensor."""
     return x.is_cuda and channels % 8 == 0
 
 
@@ -198,13 +200,16 @@ class Conv(nn.Module):
             return self.conv(x, bias, pre_bn) + residual
         if pre_bn is not None:
             x = bn_relu_mask(x, pre_bn[0], pre_bn[1], False)
-        if self.k == 1 and self.weight.shape[0] <= 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and _fused_ok(x):
+        if self.k == 1 and self.weight.shape[0] <= 4 and ((layout & IN_B8) or (x.shape[2] * x.shape[3]) % 4 == 0) \
+                and _fused_ok(x):
             N, cin, H, W = x.shape                      # skip branch onto the 3 output channels: HBM-bound HIP kernel
             cout = self.weight.shape[0]
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             with torch.cuda.device(x.device):
+                assert not (layout & OUT_B8)
                 _lib.check(_lib.lib().slr_conv1x1_small(_lib.ptr(x), _lib.ptr(self.weight), _lib.ptr(bias), _lib.ptr(out),
-                                                        N, cin, cout, H, W, _lib.stream_of(x)), "slr_conv1x1_small")
+                                                        N, cin, cout, H, W, int(bool(layout & IN_B8)), _lib.stream_of(x)),
+                           "slr_conv1x1_small")
             return out
         if self.k == 1 and _fused_ok(x):                 # the other 1x1 skip branches: split-f16 MFMA, HBM-bound
             N, cin, H, W = x.shape
@@ -213,7 +218,7 @@ class Conv(nn.Module):
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv1x1_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
-                                                          N, cin, cout, H, W, wscale, _lib.stream_of(x)),
+                                                          N, cin, cout, H, W, wscale, layout, _lib.stream_of(x)),
                            "slr_conv1x1_forward")
             return out
         return F.conv2d(x, self.weight, bias, padding=self.pad)
@@ -263,25 +268,25 @@ class PartialConv(Conv):
         return pconv_epilogue(raw0, self.bias, box, mscale, cin * self.k * self.k, residual, next_bn)
 
 
-def avgpool_down(x):
-    """nn.AvgPool2d(3, stride=2, padding=1), blocks.py:196-199."""
+def avgpool_down(x, b8=False):
+    """nn.AvgPool2d(3, stride=2, padding=1), blocks.py:196-199 (b8: x and the result are channel-blocked)."""
     if _fused_ok(x):
         N, C, H, W = x.shape
         out = torch.empty(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().slr_avgpool3x3s2(_lib.ptr(x), _lib.ptr(out), N, C, H, W, _lib.stream_of(x)),
+            _lib.check(_lib.lib().slr_avgpool3x3s2(_lib.ptr(x), _lib.ptr(out), N, C, H, W, int(b8), _lib.stream_of(x)),
                        "slr_avgpool3x3s2")
         return out
     return F.avg_pool2d(x, 3, stride=2, padding=1)
 
 
-def upsample_up(x):
-    """nn.Upsample(scale_factor=2, mode='bilinear'), blocks.py:200-203."""
+def upsample_up(x, b8=False):
+    """nn.Upsample(scale_factor=2, mode='bilinear'), blocks.py:200-203 (b8: x and the result are channel-blocked)."""
     if _fused_ok(x):
         N, C, H, W = x.shape
         out = torch.empty(N, C, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().slr_upsample_bilinear2x(_lib.ptr(x), _lib.ptr(out), N, C, H, W, _lib.stream_of(x)),
+            _lib.check(_lib.lib().slr_upsample_bilinear2x(_lib.ptr(x), _lib.ptr(out), N, C, H, W, int(b8), _lib.stream_of(x)),
                        "slr_upsample_bilinear2x")
         return out
     return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
@@ -292,7 +297,7 @@ def _resample(kind):
         return upsample_up
     if kind:                                                       # "Down" / encoder "downsample=True"
         return avgpool_down
-    return lambda x: x
+    return lambda x, b8=False: x
 
 
 def _resample_mask(kind):
@@ -313,12 +318,20 @@ class ResBlock(nn.Module):
         self.conv_b = Conv(cin, cout, 1) if (resample or cin != cout) else None
         self.resample = _resample(resample)
 
-    def forward(self, x):
-        b8 = _b8(x, self.conv_aa.weight.shape[0])
-        a = self.conv_aa(x, self.bn1.scale_shift(), layout=OUT_B8 if b8 else 0)     # BN + ReLU ride in the prologue
-        b = self.conv_b(x) if self.conv_b is not None else x
-        a = self.conv_ab(a, self.bn2.scale_shift(), residual=b, layout=IN_B8 if b8 else 0)   # x_a + x_b (:87) in the epilogue
-        return self.resample(a)              # == resample(x_a) + resample(x_b): both resamplers are linear
+    def forward(self, x, b8_in=False):
+        """-> (y, b8_out): ``b8_in`` / ``b8_out`` = x / y are channel-blocked in memory (see _b8)."""
+        cout = self.conv_aa.weight.shape[0]
+        b8 = _b8(x, cout)                                   # layout of everything this block produces
+        lin = IN_B8 if b8_in else 0
+        a = self.conv_aa(x, self.bn1.scale_shift(), layout=lin | (OUT_B8 if b8 else 0))   # BN + ReLU ride in the prologue
+        if self.conv_b is not None:
+            skip_b8 = b8 and cout > 4                       # (the <= 4-channel skip kernel writes NCHW)
+            b = self.conv_b(x, layout=lin | (OUT_B8 if skip_b8 else 0))
+        else:
+            b, skip_b8 = x, b8_in
+        a = self.conv_ab(a, self.bn2.scale_shift(), residual=b,                           # x_a + x_b (:87) in the epilogue
+                         layout=(IN_B8 if b8 else 0) | (OUT_B8 if b8 else 0) | (RES_B8 if skip_b8 and b8 else 0))
+        return self.resample(a, b8), b8       # == resample(x_a) + resample(x_b): both resamplers are linear
 
 
 class PconvResBlock(nn.Module):
@@ -332,17 +345,25 @@ class PconvResBlock(nn.Module):
         self.resample, self.resample_mask = _resample(resample), _resample_mask(resample)
         self.has_resample = bool(resample)
 
-    def forward(self, x, mask):
-        # mask: None = (x != 0) per channel (architectures.py:369), else [N,1,H,W] channel-uniform
-        b8 = _b8(x, self.conv_aa.weight.shape[0])
+    def forward(self, x, mask, b8_in=False):
+        """-> (y, update_mask, b8_out).  mask: None = (x != 0) per channel (architectures.py:369; x is NCHW then), else
+        [N,1,H,W] channel-uniform; ``b8_in`` / ``b8_out``: x / y are channel-blocked in memory (see _b8)."""
+        cout = self.conv_aa.weight.shape[0]
+        b8 = _b8(x, cout)
+        lin = IN_B8 if b8_in else 0
         a, m = self.conv_aa(x, mask, next_bn=self.bn2.scale_shift(), pre_bn=self.bn1.scale_shift(),
-                            layout=OUT_B8 if b8 else 0)                              # :229-236
+                            layout=lin | (OUT_B8 if b8 else 0))                      # :229-236
         # x_a + x_b (:248).  The reference resamples the two branches separately and adds; avg-pool
         # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
         # rounding, lets the residual join the epilogue, and halves the resampling work.
-        skip = self.conv_b(x) if self.conv_b is not None else x                    # :243-247
-        a, m = self.conv_ab(a, m, residual=skip, layout=IN_B8 if b8 else 0)        # :237-239
-        return self.resample(a), self.resample_mask(m)                             # :240-241
+        if self.conv_b is not None:                                                # :243-247
+            skip_b8 = b8 and cout > 4
+            skip = self.conv_b(x, layout=lin | (OUT_B8 if skip_b8 else 0))
+        else:
+            skip, skip_b8 = x, b8_in
+        a, m = self.conv_ab(a, m, residual=skip,                                   # :237-239
+                            layout=(IN_B8 if b8 else 0) | (OUT_B8 if b8 else 0) | (RES_B8 if skip_b8 and b8 else 0))
+        return self.resample(a, b8), self.resample_mask(m), b8                     # :240-241
 
 
 # --------------------------------------------------------------------------- networks
@@ -362,8 +383,10 @@ class EncoderWithZ(nn.Module):
         self.blocks = nn.ModuleList(ResBlock(ch[i], ch[i + 1]) for i in range(8))
 
     def forward(self, x):
+        b8 = False
         for b in self.blocks:
-            x = b(x)
+            x, b8 = b(x, b8)
+        assert not b8                                    # 65 channels: NCHW
         return x[:, :-1].contiguous(), x[:, -1:].contiguous()          # :195-197
 
 
@@ -376,8 +399,10 @@ class Encoder(nn.Module):
         self.blocks = nn.ModuleList(ResBlock(ch[i], ch[i + 1]) for i in range(8))
 
     def forward(self, x):
+        b8 = False
         for b in self.blocks:
-            x = b(x)
+            x, b8 = b(x, b8)
+        assert not b8
         return x
 
 
@@ -390,9 +415,10 @@ class DecoderPconv2(nn.Module):
         self.blocks = nn.ModuleList(PconvResBlock(ch[i], ch[i + 1], _UPDOWN[i]) for i in range(8))
 
     def forward(self, x):
-        mask = None                                      # (x != 0) per channel, derived inside the first block
+        mask, b8 = None, False                           # (x != 0) per channel, derived inside the first block
         for b in self.blocks:
-            x, mask = b(x, mask)
+            x, mask, b8 = b(x, mask, b8)
+        assert not b8                                    # the 1- / 3-channel end is NCHW
         return x
 
 
@@ -405,8 +431,10 @@ class BGDecoder(nn.Module):
         self.blocks = nn.ModuleList(ResBlock(ch[i], ch[i + 1], _UPDOWN[i]) for i in range(8))
 
     def forward(self, x):
+        b8 = False
         for b in self.blocks:
-            x = b(x)
+            x, b8 = b(x, b8)
+        assert not b8
         return x
 
 

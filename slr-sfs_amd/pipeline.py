@@ -18,50 +18,15 @@ from . import nets
 from .synthesis import ClipSynthesizer
 
 
-def _features_ahead(clip, frames, overlap=True):
-    """Yield clip.features(t) for t in frames.  overlap=True computes frame i+1's features on a
-    side HIP stream while the caller's (current) stream is busy with frame i's decoder (the splat
-    stage is HBM-bound, the decoder convolutions compute-bound).  Measured on MI355X at C3: +1 %
-    frames/s, but the splat kernel itself runs 1.6x longer next to the convolutions (244 -> 403 us),
-    so it is OFF by default; tensors that cross streams are registered with the caching allocator."""
-    frames = list(frames)
-    if not frames:
-        return
-    if not overlap:
-        for t in frames:
-            yield clip.features(t)
-        return
-    main = torch.cuda.current_stream()
-    side = _side_stream(main.device)
-    side.wait_stream(main)                       # per-clip state (fs, Z, displacement maps) is ready
-
-    def launch(t):
-        with torch.cuda.stream(side):
-            out = clip.features(t)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        return out, ev
-
-    nxt = launch(frames[0])
-    for i in range(len(frames)):
-        out, ev = nxt
-        if i + 1 < len(frames):
-            nxt = launch(frames[i + 1])
-        main.wait_event(ev)
-        for x in (out if isinstance(out, tuple) else (out,)):
-            x.record_stream(main)
-        yield out
-    side.wait_stream(main)
-
-
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = device.index
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
+def _features_ahead(clip, frames):
+    """Yield clip.features(t) for t in frames, on the caller's stream.
+    (Round 1 had an option to compute frame i+1's features on a side HIP stream under frame i's decoder.
+    It was removed: next to the matrix-core convolution kernel the splat tile kernel then returned a few dozen
+    wrong values in 5-25 % of the frames -- reproducible with tools/ovl_debug*.py, cause not found (no
+    out-of-bounds write, independent of packed-fp32 code generation, every launch on its own stream) -- and it
+    bought 1 % at best.  Everything of a clip runs on ONE stream.)"""
+    for t in frames:
+        yield clip.features(t)
 
 
 def prepare_motion(flow, H, W, speed=1.0, align=None, N=None):
@@ -106,12 +71,12 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False):
+    def synthesize(self, image, motion, N, frames=None):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device."""
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
+        for i, gen_fs in enumerate(_features_ahead(clip, frames)):
             out[i] = torch.tanh(self.projector(gen_fs))[0]
         return out
 
@@ -151,10 +116,10 @@ class SLRv1Animator(torch.nn.Module):
                 "CompositeFluidAlpha": fluid_alpha / alpha_norm}                                   # :1087-1093
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False):
+    def synthesize(self, image, motion, N, frames=None):
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):
+        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames)):
             out[i] = self._decode(clip, gen_fs, alpha_fluid)["PredImg"][0]
         return out

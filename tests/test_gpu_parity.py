@@ -477,31 +477,25 @@ def test_softmax_splatter_variants_vs_oracle(S, oracle, variant):
             np.testing.assert_allclose(host(cs.features(t)), ref, rtol=2e-4, atol=2e-5)
 
 
-def test_synthesize_stream_overlap_equals_sequential(S):
-    """synthesize() computes frame i+1's features on a side stream under frame i's decoder.  The
-    features must match the plain per-frame path to summation-order noise (bins are filled in a
-    non-deterministic order, like the reference's atomics), the frames to that noise amplified by
-    the random-weight decoder."""
+def test_synthesize_is_reproducible(S):
+    """synthesize() twice on the same clip: the features agree to summation-order noise (bins are filled in a
+    non-deterministic order, like the reference's atomics), the frames to that noise through the decoder (measured
+    6e-6 on this random-weight decoder; 1e-4 is the north star's budget)."""
     H, W, N = 40, 72, 7
     torch.manual_seed(1)
     for an in (S.pipeline.BaselineAnimator().cuda().eval(), S.pipeline.SLRv1Animator().cuda().eval()):
         img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
         m = dev(smooth_motion(H, W, 5, amp=2.0))
         order = [0, 2, 3, 6]
-        for rep in range(2):
-            clip = an.begin_clip(img, m, N)
-            ahead = [tuple(x.clone() for x in (o if isinstance(o, tuple) else (o,)))
-                     for o in S.pipeline._features_ahead(clip, order)]
-            torch.cuda.synchronize()
-            for got, t in zip(ahead, order):
-                ref = clip.features(t)
-                for g, r in zip(got, ref if isinstance(ref, tuple) else (ref,)):
-                    assert torch.allclose(g, r, rtol=1e-5, atol=1e-5), (rep, t)
-            frames = an.synthesize(img, m, N, frames=order, overlap=bool(rep))
-            for i, t in enumerate(order):
-                f = an.frame(clip, t)
-                f = f["PredImg"] if isinstance(f, dict) else f
-                assert (frames[i] - f[0]).abs().max().item() < 5e-3, (rep, t)
+        a = an.synthesize(img, m, N, frames=order)
+        for rep in range(3):
+            b = an.synthesize(img, m, N, frames=order)
+            assert (a - b).abs().max().item() < 1e-4, rep
+        clip = an.begin_clip(img, m, N)
+        for i, t in enumerate(order):
+            f = an.frame(clip, t)
+            f = f["PredImg"] if isinstance(f, dict) else f
+            assert (a[i] - f[0]).abs().max().item() < 1e-4, t
 
 
 def test_c_abi_prebinned_reuse_and_errors(S, oracle):
@@ -906,3 +900,35 @@ def test_conv_channel_blocked_intermediate(S, cin, cout, h, w):
         o3, m3 = pc(x, mask, residual=r2)
         o4, m4 = pc(to_b8(x), mask, residual=r2, layout=nets.IN_B8)
         assert torch.equal(o3, o4) and torch.equal(m3, m4)
+
+
+def test_channel_blocked_resample_and_skip_kernels(S):
+    """The channel-blocked ([N,C/8,H,W,8]) variants of the stages between the blocks against their NCHW kernels:
+    3x3/2 average pooling, x2 bilinear up-sampling, the 1x1 skip convolutions (split-f16 and the <= 4-channel one),
+    and the 3x3 convolution writing a blocked output on top of a blocked / NCHW residual -- bit-identical."""
+    from slr_sfs_amd import nets
+    torch.manual_seed(17)
+
+    def to_b8(t):
+        n, c, hh, ww = t.shape
+        return t.view(n, c // 8, 8, hh, ww).permute(0, 1, 3, 4, 2).contiguous().view(n, c, hh, ww)
+
+    x = torch.randn(2, 24, 13, 34, device="cuda")
+    xb = to_b8(x)
+    with torch.no_grad():
+        assert torch.equal(nets.avgpool_down(xb, True), to_b8(nets.avgpool_down(x)))
+        assert torch.equal(nets.upsample_up(xb, True), to_b8(nets.upsample_up(x)))
+        c1 = nets.Conv(24, 72, 1, bias=False).cuda()
+        ref1 = c1(x)
+        assert torch.equal(c1(xb, layout=nets.IN_B8), ref1)
+        assert torch.equal(c1(x, layout=nets.OUT_B8), to_b8(ref1))
+        assert torch.equal(c1(xb, layout=nets.IN_B8 | nets.OUT_B8), to_b8(ref1))
+        x4 = torch.randn(2, 24, 12, 32, device="cuda")
+        c3 = nets.Conv(24, 3, 1, bias=True).cuda()
+        c3.bias.data.normal_()
+        assert torch.equal(c3(to_b8(x4), layout=nets.IN_B8), c3(x4))
+        conv = nets.Conv(24, 40, 3).cuda()
+        res = torch.randn(2, 40, 13, 34, device="cuda")
+        ref = conv(x, None, res)
+        assert torch.equal(conv(x, None, res, layout=nets.OUT_B8), to_b8(ref))                                  # NCHW residual
+        assert torch.equal(conv(xb, None, to_b8(res), layout=nets.IN_B8 | nets.OUT_B8 | nets.RES_B8), to_b8(ref))   # blocked residual
