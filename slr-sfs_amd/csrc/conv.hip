@@ -46,7 +46,8 @@ constexpr int CV_HW = CV_W + 2, CV_HH = CV_H + 2;  // input halo block
 constexpr int CV_NPX = CV_HW * CV_HH;              // 340 halo pixels
 constexpr int CV_THREADS = 256;
 #ifndef CV_EXP
-#define CV_EXP 0          // development experiments (tools/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging
+#define CV_EXP 0          // development experiments (tools/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging,
+                         // 8 staging without its loads, 32 no global writes (the "aggressor" of tools/ovl_debug4.py)
                          // (measured ceilings at 128->128, 768x1280: all three off 512 TFLOP/s; s_setprio around the MFMAs: -4 %)
 #endif
 constexpr float CV_XSCALE = 64.0f;                 // activations are scaled by 2^6 before the split
@@ -366,6 +367,9 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // the residual is read and the result written with 16-byte accesses: 4 store instructions per tile instead
     // of 16 (a VMEM instruction costs an in-order wave ~60-100 issue cycles).  Needs whole 32-pixel rows inside
     // the image and 16-byte aligned rows; otherwise the 4-byte path below.
+#if CV_EXP & 32
+    if (a.H > 0) return;                               // experiment: an aggressor that never writes global memory
+#endif
     const bool vec = !a.out_b8 && (a.W % 4 == 0) && (x0 + CV_W <= a.W) &&
                      !(((uintptr_t)a.out | (uintptr_t)a.residual) & 15);
     constexpr int SCR_STRIDE = 36;                     // floats per channel row: 16-byte aligned, conflict-free
