@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 1
+#define SLR_ABI_VERSION 2
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */

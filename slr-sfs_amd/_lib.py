@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/slr_splat.h declares
 SYMBOLS = (
