@@ -190,7 +190,7 @@ def conv_roofline(dev):
     avg = sum(us) / len(us)
     flops = 2.0 * 9 * cin * cout * H * W
     ach = flops / (avg * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "slr::conv3x3_split_kernel<2,2,true> (128->128, 768x1280, BN+mask prologue, "
+    return {"bound": "mfma", "kernel": "slr::conv3x3_split_kernel<1,4,true,false> (128->128, 768x1280, NCHW in/out, BN+mask prologue, "
                                        "partial-conv epilogue)",
             "achieved": round(ach, 1), "issued": round(3 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(ach / 2500.0, 4), "frac_issued": round(3 * ach / 2500.0, 4),
