@@ -33,7 +33,10 @@ constexpr int TILE_W   = 64;      // one wavefront of consecutive x
 constexpr int TILE_H   = SLR_TILE_H;
 constexpr int TILE_PIX = TILE_W * TILE_H;
 constexpr int SEG_ONE  = 2 * TILE_PIX;   // segment length, one flow per tile
-constexpr int SEG_TWO  = 3 * TILE_PIX;   // segment length, forward+backward flows per tile
+#ifndef SLR_EPT_TWO
+#define SLR_EPT_TWO 3
+#endif
+constexpr int SEG_TWO  = SLR_EPT_TWO * TILE_PIX;   // segment length, forward+backward flows per tile
 
 // Workspace layout (all offsets 256-byte aligned).  `hdr` is zeroed at the start of binning.
 struct WsLayout {

@@ -331,6 +331,12 @@ constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel
 #endif
 constexpr int XCD_GROUP = SLR_XCD_GROUP;                    // neighbouring tiles kept on one XCD (L2 halo reuse)
 constexpr int RB = 4;                          // records per batch in the gather loop
+#ifndef SLR_DBG
+#define SLR_DBG 0                              // development: 1 drain vmcnt before staging, 4 verify staged values (tools/ovl_debug6.py)
+#endif
+#ifndef SLR_LDS_PAD
+#define SLR_LDS_PAD 0                          // development: bytes of unused LDS in front of the staged values
+#endif
 #ifndef SLR_LMAX
 #define SLR_LMAX 16
 #endif
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     uint32_t *wsum = smem + T;                // [T/64] wave sums of the scan
     uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 16);            // [T] exclusive prefix (< 2^16)
     uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 16 + T / 2);          // [rec_cap] (entry index, weight bits)
-    float4 *val4 = reinterpret_cast<float4 *>(rec + rec_cap(EPT_MAX));     // [SEG][CHUNK/4] staged source values
+    float4 *val4 = reinterpret_cast<float4 *>(rec + rec_cap(EPT_MAX) + SLR_LDS_PAD / 8);     // [SEG][CHUNK/4] staged source values
 
     // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
     // Groups of XCD_GROUP consecutive work items (= horizontally neighbouring tiles) are placed on
@@ -623,6 +629,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
     if (!inside && single) op = trash;
     const size_t ostr = (!inside && single) ? (size_t)0 : ostride;
     auto chunk = [&](float (&pre)[EPT_MAX][CHUNK], int c0) {
+#if SLR_DBG & 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j)
 #pragma unroll
@@ -630,6 +639,21 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
                 val4[vslot<CHUNK>(tid + j * T, h)] = make_float4(pre[j][4 * h], pre[j][4 * h + 1], pre[j][4 * h + 2], pre[j][4 * h + 3]);
         SLR_STAMP(4 + 3 * (c0 / CHUNK));
         __syncthreads();
+#if SLR_DBG & 4
+        bool dbg_bad = false;                          // staged value != what global memory holds?
+        {
+            float fresh[EPT_MAX][CHUNK];
+            prefetch(fresh, c0);
+#pragma unroll
+            for (int j = 0; j < EPT_MAX; ++j)
+#pragma unroll
+                for (int u = 0; u < CHUNK; ++u) {
+                    const float4 q = val4[vslot<CHUNK>(tid + j * T, u / 4)];
+                    const float sv = (u & 3) == 0 ? q.x : (u & 3) == 1 ? q.y : (u & 3) == 2 ? q.z : q.w;
+                    dbg_bad |= __float_as_uint(sv) != __float_as_uint(fresh[j][u]);
+                }
+        }
+#endif
         SLR_STAMP(5 + 3 * (c0 / CHUNK));
         prefetch(pre, c0 + 2 * CHUNK);                 // two chunks ahead (three: no gain fused, -20 % one flow: registers)
         float acc[CHUNK];
@@ -716,6 +740,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
             float *dst = (c0 + u < a.C) ? op + (size_t)(c0 + u) * ostr : trash;
             if (whole && !first) r = MAXOP ? fmaxf(r, *dst) : r + *dst;      // earlier segments of this tile
             if (NORM && single && last) r = finish(r, nrm, a.norm_mode, a.eps);
+#if SLR_DBG & 4
+            if (dbg_bad) r = 12345.0f;
+#endif
             *dst = r;
         }
         SLR_STAMP(6 + 3 * (c0 / CHUNK));
@@ -879,7 +906,7 @@ template <bool NORM, bool MAXOP, int EPT, int CHUNK>
 static int launch_tile(const SplatArgs &a, uint32_t items_cap, uint32_t nt, hipStream_t st) {
     // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
     const size_t lds = (size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
-                       (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4;          // + the all-zero NULL entry
+                       (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;     // + the all-zero NULL entry
     const uint32_t grid = ((items_cap + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
     if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(a, grid, lds, st)) return e;

@@ -18,15 +18,48 @@ from . import nets
 from .synthesis import ClipSynthesizer
 
 
-def _features_ahead(clip, frames):
-    """Yield clip.features(t) for t in frames, on the caller's stream.
-    (Round 1 had an option to compute frame i+1's features on a side HIP stream under frame i's decoder.
-    It was removed: next to the matrix-core convolution kernel the splat tile kernel then returned a few dozen
-    wrong values in 5-25 % of the frames -- reproducible with tools/ovl_debug*.py, cause not found (no
-    out-of-bounds write, independent of packed-fp32 code generation, every launch on its own stream) -- and it
-    bought 1 % at best.  Everything of a clip runs on ONE stream.)"""
-    for t in frames:
-        yield clip.features(t)
+_side_streams = {}
+
+
+def _features_ahead(clip, frames, overlap=False):
+    """Yield clip.features(t) for t in frames.
+
+    overlap=False (default): everything on the caller's stream.
+    overlap=True: frame i+1's Euler lookup + splat run on a side HIP stream while the caller's stream runs frame
+    i's decoder (+1 % frames/s at 768x1280: the splat kernel itself takes 1.6x longer next to the convolutions).
+    Tensors that cross streams are registered with the caching allocator (record_stream).  This mode is what
+    exposed the packed-fp32 problem described in csrc/Makefile and DESIGN.md 3.2 (v_pk_fma_f32 next to a
+    concurrent MFMA kernel); the library is built without those instructions and
+    tests/test_gpu_parity.py::test_splat_next_to_concurrent_matrix_core_kernel keeps it that way."""
+    frames = list(frames)
+    if not overlap or not frames:
+        for t in frames:
+            yield clip.features(t)
+        return
+    main = torch.cuda.current_stream()
+    key = main.device.index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=main.device)
+    side = _side_streams[key]
+    side.wait_stream(main)                                          # the clip's frame-invariant tensors are ready
+
+    def launch(t):
+        with torch.cuda.stream(side):
+            out = clip.features(t)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return out, ev
+
+    nxt = launch(frames[0])
+    for i in range(len(frames)):
+        out, ev = nxt
+        if i + 1 < len(frames):
+            nxt = launch(frames[i + 1])
+        main.wait_event(ev)
+        for x in (out if isinstance(out, tuple) else (out,)):
+            x.record_stream(main)
+        yield out
+    side.wait_stream(main)
 
 
 def prepare_motion(flow, H, W, speed=1.0, align=None, N=None):
@@ -71,12 +104,12 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None):
-        """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device."""
+    def synthesize(self, image, motion, N, frames=None, overlap=False):
+        """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device (overlap: see _features_ahead)."""
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, gen_fs in enumerate(_features_ahead(clip, frames)):
+        for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = torch.tanh(self.projector(gen_fs))[0]
         return out
 
@@ -116,10 +149,10 @@ class SLRv1Animator(torch.nn.Module):
                 "CompositeFluidAlpha": fluid_alpha / alpha_norm}                                   # :1087-1093
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None):
+    def synthesize(self, image, motion, N, frames=None, overlap=False):
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames)):
+        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = self._decode(clip, gen_fs, alpha_fluid)["PredImg"][0]
         return out

@@ -93,3 +93,40 @@ def test_prepare_motion_and_alpha_semantics():
     assert m.shape == (1, 2, 8, 24)
     assert torch.allclose(m[:, 0], torch.full((1, 8, 24), 24 / 8 * 2.0 * 0.5))
     assert torch.allclose(m[:, 1], torch.full((1, 8, 24), 8 / 4 * 2.0 * 0.5))
+
+
+def test_device_code_has_no_packed_fp32_instructions(tmp_path):
+    """csrc/Makefile builds without packed-fp32 VALU instructions: with them the splat tile kernel returned wrong
+    low halves next to a concurrently running MFMA kernel on MI355X (tools/ovl_debug6.py).  Checked on
+    the ISA of every gfx950 code object bundled in the built library."""
+    import struct
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objcopy") and os.path.exists(f"{llvm}/llvm-objdump")):
+        pytest.skip("llvm-objcopy / llvm-objdump not available")
+    from slr_sfs_amd import _lib
+    fat = tmp_path / "fat.bin"
+    subprocess.check_call([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", _lib.LIB_PATH, str(tmp_path / "stripped")])
+    data = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    objects = mfma = 0
+    start = data.find(magic)
+    while start >= 0:
+        n = struct.unpack_from("<Q", data, start + 24)[0]
+        p = start + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and size:
+                co = tmp_path / f"dev{objects}.co"
+                co.write_bytes(data[start + off:start + off + size])
+                isa = subprocess.run([f"{llvm}/llvm-objdump", "-d", str(co)], capture_output=True, text=True, check=True).stdout
+                assert "s_endpgm" in isa
+                packed = re.findall(r"v_pk_(?:fma|add|mul)_f32", isa)
+                assert not packed, f"{len(packed)} packed-fp32 instructions in code object {objects} ({triple})"
+                mfma += isa.count("v_mfma_f32_32x32x16_f16")
+                objects += 1
+        start = data.find(magic, start + 24)
+    assert objects >= 6                      # one per source file of csrc/Makefile
+    assert mfma > 0                          # the disassembly really is the convolution's device code too

@@ -498,6 +498,39 @@ def test_synthesize_is_reproducible(S):
             assert (a[i] - f[0]).abs().max().item() < 1e-4, t
 
 
+def test_splat_next_to_concurrent_matrix_core_kernel(S):
+    """The splat on a side HIP stream while a large matrix-core convolution runs on the caller's stream gives the
+    sequential result.  Regression test of the round-1 finding: built WITH packed-fp32 instructions
+    the tile kernel returned a few dozen wrong values (low halves of the v_pk_fma_f32 pairs) in 1-4 % of such
+    launches -- 39 wrong frames of 4200, 0 of 4200 without them (csrc/Makefile NOPK); 280 frames here."""
+    from slr_sfs_amd import nets
+    from slr_sfs_amd.pipeline import _features_ahead
+    H, W, N = 40, 72, 7
+    torch.manual_seed(1)
+    an = S.pipeline.BaselineAnimator().cuda().eval()
+    img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+    m = dev(smooth_motion(H, W, 5, amp=2.0))
+    order = [0, 2, 3, 6, 1, 4, 5]
+    big = torch.randn(1, 64, 768, 1280, device="cuda")
+    bigconv = nets.Conv(64, 64, 3).cuda()
+    wrong = 0
+    with torch.no_grad():
+        for trial in range(40):
+            clip = an.begin_clip(img, m, N)
+            feats = []
+            for gen_fs in _features_ahead(clip, order, overlap=True):
+                feats.append(gen_fs.clone())
+                bigconv(big)                                        # ~0.4 ms of MFMA work under the next frame's splat
+            torch.cuda.synchronize()
+            for i, t in enumerate(order):
+                wrong += int((feats[i] - clip.features(t)).abs().max().item() > 1e-4)
+    assert wrong == 0
+    # and the whole pipeline with the option switched on
+    a = an.synthesize(img, m, N, frames=order)
+    b = an.synthesize(img, m, N, frames=order, overlap=True)
+    assert (a - b).abs().max().item() < 1e-4
+
+
 def test_c_abi_prebinned_reuse_and_errors(S, oracle):
     """Straight through ctypes: bin once, splat two tensors with the same bins (prebinned = 1);
     workspace too small / misaligned is refused with SLR_E_WORKSPACE."""
