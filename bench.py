@@ -83,8 +83,12 @@ def main():
     mine = parallel.shard_frames(NFRAMES, rank, world)
 
     def step():
-        loc = model.synthesize(image, motion, NFRAMES, frames=mine)
-        return parallel.gather_clip(loc, NFRAMES, rank, world)
+        if world == 1:
+            return model.synthesize(image, motion, NFRAMES, frames=mine)
+        # one small asynchronous all-gather per round of `world` frames, under the next round's rendering
+        asm = parallel.ClipAssembler(NFRAMES, rank, world)
+        model.synthesize(image, motion, NFRAMES, frames=mine, on_frame=asm.push)
+        return asm.finish(like=image[0])
 
     def fence():
         if world > 1:
@@ -152,7 +156,7 @@ def main():
                                     "C4 SLR-v1 2-layer pipeline (fluid + background + alpha)") +
                                    ", 768x1280, N=60, random-init weights of the reference architecture",
                        "frames_per_step": NFRAMES, "H": H, "W": W,
-                       "parallelism": f"frames sharded over {world} GPU(s), one all-gather per clip"},
+                       "parallelism": f"frames sharded over {world} GPU(s), all-gather per round of {world} frames under the next round"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -104,13 +104,15 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False):
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device (overlap: see _features_ahead)."""
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = torch.tanh(self.projector(gen_fs))[0]
+            if on_frame is not None:
+                on_frame(out[i])                                    # e.g. parallel.ClipAssembler.push
         return out
 
 
@@ -149,10 +151,12 @@ class SLRv1Animator(torch.nn.Module):
                 "CompositeFluidAlpha": fluid_alpha / alpha_norm}                                   # :1087-1093
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False):
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None):
         clip = self.begin_clip(image, motion, N)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = self._decode(clip, gen_fs, alpha_fluid)["PredImg"][0]
+            if on_frame is not None:
+                on_frame(out[i])
         return out

@@ -5,6 +5,8 @@ the golden fixtures generated from the reference.  Tolerances:
     is unspecified in the reference itself (racing fp32 atomicAdds, softsplat.py:187-199), so
     only rounding-noise-level agreement is meaningful; north_star's bound is 1e-4 max-abs.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -529,6 +531,38 @@ def test_splat_next_to_concurrent_matrix_core_kernel(S):
     a = an.synthesize(img, m, N, frames=order)
     b = an.synthesize(img, m, N, frames=order, overlap=True)
     assert (a - b).abs().max().item() < 1e-4
+
+
+def test_clip_assembler_on_rccl(S, tmp_path):
+    """parallel.ClipAssembler with backend nccl (= RCCL) in a child process: the asynchronous per-round collectives
+    on RCCL's stream, the frames rendered on the caller's stream in between, finish() -> the clip.  One GPU here, so
+    world_size 1 with the collective path forced; the 2-rank logic runs on gloo in tests/test_parallel_gloo.py."""
+    import subprocess
+    import sys
+    script = tmp_path / "asm.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import slr_sfs_amd as S\n"
+        "from slr_sfs_amd import parallel\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "torch.manual_seed(3)\n"
+        "an = S.pipeline.BaselineAnimator().cuda().eval()\n"
+        "img = torch.rand(1, 3, 40, 72, device='cuda') * 2 - 1\n"
+        "m = torch.randn(1, 2, 40, 72, device='cuda')\n"
+        "ref = an.synthesize(img, m, 6)\n"
+        "for rep in range(3):\n"
+        "    asm = parallel.ClipAssembler(6, 0, 1, always_collective=True)\n"
+        "    an.synthesize(img, m, 6, on_frame=asm.push)\n"
+        "    clip = asm.finish()\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert clip.shape == ref.shape and (clip - ref).abs().max().item() < 1e-4\n"
+        "dist.destroy_process_group()\n"
+        "print('ASSEMBLED')\n")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ASSEMBLED" in r.stdout, r.stderr[-2000:]
 
 
 def test_c_abi_prebinned_reuse_and_errors(S, oracle):

@@ -28,6 +28,12 @@ def _worker(rank, world, port, N, q):
     clip = parallel.gather_clip(local, N, rank, world)
     ok = clip.shape == (N, 3, 4, 5) and all(
         torch.equal(clip[t], torch.full((3, 4, 5), float(t)) + torch.arange(3).view(3, 1, 1) / 10) for t in range(N))
+    # round-wise asynchronous assembly (what bench.py uses): same clip
+    asm = parallel.ClipAssembler(N, rank, world)
+    for f in local:
+        asm.push(f)
+    clip2 = asm.finish(like=torch.zeros(3, 4, 5))
+    ok = ok and clip2.shape == clip.shape and torch.equal(clip2, clip)
     q.put((rank, bool(ok), mine))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,3 +70,7 @@ def test_gather_world1_is_identity():
     from slr_sfs_amd import parallel
     x = torch.randn(5, 3, 2, 2)
     assert parallel.gather_clip(x, 5, 0, 1) is x
+    asm = parallel.ClipAssembler(5, 0, 1)
+    for f in x:
+        asm.push(f)
+    assert torch.equal(asm.finish(), x)
