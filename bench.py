@@ -87,7 +87,7 @@ def main():
             return model.synthesize(image, motion, NFRAMES, frames=mine)
         # one small asynchronous all-gather per round of `world` frames, under the next round's rendering
         asm = parallel.ClipAssembler(NFRAMES, rank, world)
-        model.synthesize(image, motion, NFRAMES, frames=mine, on_frame=asm.push)
+        model.synthesize(image, motion, NFRAMES, frames=mine, on_frame=asm.push, shard=(rank, world))   # encoder in row bands
         return asm.finish(like=image[0])
 
     def fence():
@@ -156,7 +156,7 @@ def main():
                                     "C4 SLR-v1 2-layer pipeline (fluid + background + alpha)") +
                                    ", 768x1280, N=60, random-init weights of the reference architecture",
                        "frames_per_step": NFRAMES, "H": H, "W": W,
-                       "parallelism": f"frames sharded over {world} GPU(s), all-gather per round of {world} frames under the next round"},
+                       "parallelism": f"frames sharded over {world} GPU(s), all-gather per round of {world} frames under the next round; encoder in row bands + one all-gather"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

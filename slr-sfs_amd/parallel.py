@@ -88,3 +88,59 @@ class ClipAssembler:
             w.wait()
         self.work, self.keep = [], []
         return self.recv[:self.N]
+
+
+# ----------------------------------------------------------------------------------------------
+# The per-clip encoder, split by rows.  Every rank needs the frame-invariant features, and at 8 GPUs
+# repeating the encoder on every rank is 4.8 of the ~56 ms a rank spends on its 8 frames.  The
+# encoders on the path (ResNetEncoder / ResNetEncoder_with_Z, architectures.py:121-197) are 8
+# residual blocks of 3x3 / 1x1 convolutions at full resolution with pointwise BN + ReLU in between:
+# output row y depends on input rows y-16 .. y+16 only, so rank r runs the encoder on its band of
+# ceil(H/world) rows plus a 16-row halo (rows beyond the image are the convolution's own zero padding,
+# i.e. exact), cuts the halo off, and one all-gather (65 planes x H x W = 256 MB in total) gives every
+# rank the full tensors -- bit-identical to the unsplit encoder (every output pixel sums its channels and
+# taps in the same order wherever its tile lies; tests/test_gpu_parity.py::test_banded_encoder_is_exact).
+
+
+def band_rows(H, rank, world):
+    """Rows [y0, y1) of the image that ``rank`` encodes."""
+    rows = -(-H // world)
+    return min(rank * rows, H), min((rank + 1) * rows, H)
+
+
+def encoder_halo(encoder):
+    """Receptive-field radius in rows: two 3x3 convolutions per residual block."""
+    return 2 * len(encoder.blocks)
+
+
+def encode_band(encoder, image, rank, world, halo=None):
+    """This rank's band of the encoder outputs -> ([1,C,y1-y0,W] all outputs concatenated along C, [C_i])."""
+    H = image.shape[2]
+    halo = encoder_halo(encoder) if halo is None else halo
+    y0, y1 = band_rows(H, rank, world)
+    assert y1 > y0, f"rank {rank} of {world} has no rows of a {H}-row image"
+    a0, a1 = max(0, y0 - halo), min(H, y1 + halo)
+    outs = encoder(image[:, :, a0:a1].contiguous())
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    band = torch.cat([o[:, :, y0 - a0:y1 - a0] for o in outs], 1)
+    return band, [o.shape[1] for o in outs]
+
+
+def encode_banded(encoder, image, rank, world, group=None, halo=None):
+    """encoder(image) computed in row bands across the ranks + one all-gather; same return type as encoder(image)."""
+    if world == 1:
+        return encoder(image)
+    H, W = image.shape[2:]
+    rows = -(-H // world)
+    band, split = encode_band(encoder, image, rank, world, halo)
+    C = band.shape[1]
+    send = band.new_zeros(1, C, rows, W)
+    send[0, :, :band.shape[2]] = band[0]
+    recv = band.new_empty(world, C, rows, W)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    full = recv.permute(1, 0, 2, 3).reshape(1, C, world * rows, W)[:, :, :H]
+    outs, c0 = [], 0
+    for c in split:
+        outs.append(full[:, c0:c0 + c].contiguous())
+        c0 += c
+    return outs[0] if len(outs) == 1 else tuple(outs)

@@ -15,6 +15,7 @@ compositing.  Nothing syncs the host inside the loop; frames stay on the device.
 import torch
 
 from . import nets
+from . import parallel
 from .synthesis import ClipSynthesizer
 
 
@@ -62,6 +63,12 @@ def _features_ahead(clip, frames, overlap=False):
     side.wait_stream(main)
 
 
+def _encode(encoder, image, shard):
+    if shard is None:
+        return encoder(image)
+    return parallel.encode_banded(encoder, image, shard[0], shard[1], shard[2] if len(shard) > 2 else None)
+
+
 def prepare_motion(flow, H, W, speed=1.0, align=None, N=None):
     """Motion preparation of the test scripts (test_baseline_4eval_rawsize.py:173-184,222-226):
     scale a [1,2,h,w] field to the working grid, nearest-resize it, optional speed alignment."""
@@ -82,9 +89,10 @@ class BaselineAnimator(torch.nn.Module):
         self.projector = decoder if decoder is not None else nets.DecoderPconv2(64, 3)
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N):
-        """Frame-invariant part.  image [1,3,H,W] in [-1,1]; motion [1,2,H,W] px/frame."""
-        fs, Z = self.encoder(image)                                 # start_fs, Z_f (:779-786)
+    def begin_clip(self, image, motion, N, shard=None):
+        """Frame-invariant part.  image [1,3,H,W] in [-1,1]; motion [1,2,H,W] px/frame.
+        shard = (rank, world[, group]): the encoder runs in row bands across the ranks (parallel.encode_banded)."""
+        fs, Z = _encode(self.encoder, image, shard)                 # start_fs, Z_f (:779-786)
         return ClipSynthesizer(fs, Z, motion, N)
 
     @torch.no_grad()
@@ -104,9 +112,9 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None):
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device (overlap: see _features_ahead)."""
-        clip = self.begin_clip(image, motion, N)
+        clip = self.begin_clip(image, motion, N, shard)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
@@ -128,10 +136,10 @@ class SLRv1Animator(torch.nn.Module):
         self.use_alpha0 = use_alpha0
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N):
-        fs, Z = self.encoder(image)
+    def begin_clip(self, image, motion, N, shard=None):
+        fs, Z = _encode(self.encoder, image, shard)
         bg = torch.tanh(self.net_bg(image))                         # test_v1_4eval_rawsize.py:209, :925-927
-        a = self.net_alpha_encoder(image)                           # :938 (frame-invariant -> hoisted)
+        a = _encode(self.net_alpha_encoder, image, shard)           # :938 (frame-invariant -> hoisted)
         alpha_bg = torch.sigmoid(a[:, 0:1])                         # :943-946
         clip = ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=a[:, 1:2].contiguous(), alpha_bg=alpha_bg,
                                use_alpha0=self.use_alpha0)
@@ -151,8 +159,8 @@ class SLRv1Animator(torch.nn.Module):
                 "CompositeFluidAlpha": fluid_alpha / alpha_norm}                                   # :1087-1093
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None):
-        clip = self.begin_clip(image, motion, N)
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
+        clip = self.begin_clip(image, motion, N, shard)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):

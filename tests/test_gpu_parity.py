@@ -533,6 +533,29 @@ def test_splat_next_to_concurrent_matrix_core_kernel(S):
     assert (a - b).abs().max().item() < 1e-4
 
 
+def test_banded_encoder_is_exact(S):
+    """parallel.encode_band: the encoder on a band of rows + its 16-row halo gives, after the halo is cut off, the
+    same BITS as the encoder on the whole image (what lets the ranks of a multi-GPU job share the per-clip encoder);
+    with a halo that is too small it does not (the test can see the difference)."""
+    from slr_sfs_amd import nets, parallel
+    torch.manual_seed(11)
+    img = torch.rand(1, 3, 152, 136, device="cuda") * 2 - 1
+    with torch.no_grad():
+        for enc in (nets.EncoderWithZ().cuda().eval(), nets.Encoder(3, 2).cuda().eval()):
+            want = enc(img)
+            want = torch.cat(want, 1) if isinstance(want, tuple) else want
+            for world in (2, 4, 8):
+                got = torch.cat([parallel.encode_band(enc, img, r, world)[0] for r in range(world)], 2)
+                assert got.shape == want.shape and torch.equal(got, want), world
+            short = torch.cat([parallel.encode_band(enc, img, r, 4, halo=6)[0] for r in range(4)], 2)
+            assert not torch.equal(short, want)
+        an = S.pipeline.BaselineAnimator().cuda().eval()
+        m = torch.randn(1, 2, 152, 136, device="cuda")
+        a = an.synthesize(img, m, 4, frames=[1, 3])
+        b = an.synthesize(img, m, 4, frames=[1, 3], shard=(0, 1))
+        assert (a - b).abs().max().item() < 1e-4
+
+
 def test_clip_assembler_on_rccl(S, tmp_path):
     """parallel.ClipAssembler with backend nccl (= RCCL) in a child process: the asynchronous per-round collectives
     on RCCL's stream, the frames rendered on the caller's stream in between, finish() -> the clip.  One GPU here, so

@@ -74,3 +74,48 @@ def test_gather_world1_is_identity():
     for f in x:
         asm.push(f)
     assert torch.equal(asm.finish(), x)
+
+
+def _enc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slr_sfs_amd import nets, parallel
+    torch.manual_seed(5)                                  # same weights and image on every rank
+    ok = True
+    with nets.cpu_reference(), torch.no_grad():
+        img = torch.rand(1, 3, 45, 40) * 2 - 1            # 45 rows: bands of 23 + 22, padded for the gather
+        for enc in (nets.EncoderWithZ().eval(), nets.Encoder(3, 2).eval()):
+            want = enc(img)
+            got = parallel.encode_banded(enc, img, rank, world)
+            want = want if isinstance(want, tuple) else (want,)
+            got = got if isinstance(got, tuple) else (got,)
+            ok = ok and len(want) == len(got) and all(
+                g.shape == w.shape and g.is_contiguous() and torch.equal(g, w) for g, w in zip(got, want))
+    q.put((rank, bool(ok), []))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_banded_encoder_world2():
+    """The frame-invariant encoder in row bands + all-gather == the encoder on the whole image (CPU definition of the
+    networks; the device kernels: tests/test_gpu_parity.py::test_banded_encoder_is_exact)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_enc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+
+
+def test_band_rows_cover_the_image():
+    from slr_sfs_amd import parallel
+    for H in (768, 45, 8):
+        for world in (1, 2, 3, 8):
+            bands = [parallel.band_rows(H, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == H
+            assert all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
