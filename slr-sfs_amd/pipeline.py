@@ -31,7 +31,9 @@ def _features_ahead(clip, frames, overlap=False):
     Tensors that cross streams are registered with the caching allocator (record_stream).  This mode is what
     exposed the packed-fp32 problem described in csrc/Makefile and DESIGN.md 3.2 (v_pk_fma_f32 next to a
     concurrent MFMA kernel); the library is built without those instructions and
-    tests/test_gpu_parity.py::test_splat_next_to_concurrent_matrix_core_kernel keeps it that way."""
+    tests/test_gpu_parity.py::test_splat_next_to_concurrent_matrix_core_kernel keeps it that way.  (Kernels that
+    are not this library's -- torch's elementwise kernels -- keep their own code generation; on the side stream
+    the baseline pipeline launches none, the SLR-v1 features a few small ones.)  Off by default."""
     frames = list(frames)
     if not overlap or not frames:
         for t in frames:
