@@ -101,6 +101,11 @@ struct BinSet {
     const float *flow[2];
     uint32_t *count[2], *cursor[2], *listoff[2], *list[2];
 };
+__global__ __launch_bounds__(256) void zero_counts_kernel(BinSet b, uint32_t nt) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nt) b.count[blockIdx.y][i] = 0;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int tiles_x, int tiles) {
     const float *__restrict__ flow = b.flow[blockIdx.z];
@@ -876,8 +881,11 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
     for (int k = 0; k < nf; ++k) {
         b.flow[k] = fl[k];
         b.count[k] = ws[k]->count; b.cursor[k] = ws[k]->cursor; b.listoff[k] = ws[k]->listoff; b.list[k] = ws[k]->list;
-        SLR_CHECK_HIP(hipMemsetAsync(ws[k]->count, 0, (size_t)w0.L.nt * 4, st));
     }
+    // the per-tile counts of both flows are zeroed by one launch of our own (not hipMemsetAsync: one launch
+    // instead of two runtime fill kernels, and a captured hipMemsetAsync node made HIP-graph replays of the
+    // binning fault on ROCm 7.0 -- tools/graph_try.py, tests/test_gpu_parity.py::test_frame_is_graph_capturable)
+    hipLaunchKernelGGL(zero_counts_kernel, dim3((w0.L.nt + 255) / 256, nf), dim3(256), 0, st, b, w0.L.nt);
     dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), N, nf);
     hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, b, H, W, w0.L.tiles_x, w0.L.tiles);
     hipLaunchKernelGGL(offsets_kernel, dim3(nf), dim3(1024), 0, st, b, w0.L.nt);
