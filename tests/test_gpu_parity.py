@@ -500,6 +500,57 @@ def test_synthesize_is_reproducible(S):
             assert (a[i] - f[0]).abs().max().item() < 1e-4, t
 
 
+def test_operators_from_concurrent_host_threads(S):
+    """The boundary is re-entrant (DataParallel replicas call the operator from several Python threads):
+    four host threads, each on its own HIP stream with its own inputs, run forward + backward of the operator and the
+    fused synthesis at the same time; every result equals the one computed alone (workspaces are cached per stream,
+    the error string is thread-local, launches carry no shared mutable state)."""
+    import threading
+    rng = np.random.default_rng(77)
+    H, W, C = 37, 83, 6
+    cases = []
+    for i in range(4):
+        x = dev(rng.standard_normal((2, C, H, W)).astype(np.float32))
+        fl = dev(rng.uniform(-4, 4, (2, 2, H, W)).astype(np.float32))
+        m = dev(rng.standard_normal((2, 1, H, W)).astype(np.float32))
+        g = dev(rng.standard_normal((2, C, H, W)).astype(np.float32))
+        cases.append((x, fl, m, g))
+
+    def run(x, fl, m, g):
+        x = x.clone().requires_grad_(True)
+        fl = fl.clone().requires_grad_(True)
+        y = S.FunctionSoftsplat(x, fl, None, "summation")
+        y.backward(g)
+        z = S.FunctionSoftsplat(x.detach(), fl.detach(), m, "softmax")
+        return y.detach(), x.grad, fl.grad, z
+
+    alone = [run(*c) for c in cases]
+    torch.cuda.synchronize()
+    got, errs = [None] * 4, []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(st):
+                for _ in range(5):
+                    got[i] = run(*cases[i])
+            st.synchronize()
+        except Exception as e:                          # noqa: BLE001 -- reported below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        for a, b, name in zip(alone[i], got[i], ("forward", "grad input", "grad flow", "softmax")):
+            exact = name in ("grad input", "grad flow")                     # gathers: deterministic order
+            assert (torch.equal(a, b) if exact else (a - b).abs().max().item() < 1e-4), (i, name)
+
+
 def test_frame_is_graph_capturable(S):
     """One frame (Euler lookup, binning, fused splat, decoder) captured into a HIP graph and replayed: every launch
     goes to the caller's stream through the C ABI and nothing inside allocates or synchronises (workspaces and split
