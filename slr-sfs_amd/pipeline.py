@@ -65,6 +65,15 @@ def _features_ahead(clip, frames, overlap=False):
     side.wait_stream(main)
 
 
+def _check_grid(image):
+    """The decoders go through three stride-2 poolings and three 2x up-samplings (architectures.py:345-375): on a
+    grid that is not a multiple of 8 the reference's decoder returns a larger frame than it was given (and the
+    2-layer compositing fails on the shape mismatch); refuse it with a message instead."""
+    H, W = image.shape[2:]
+    if H % 8 or W % 8:
+        raise ValueError(f"working resolution {H}x{W}: height and width must be multiples of 8")
+
+
 def _encode(encoder, image, shard):
     if shard is None:
         return encoder(image)
@@ -116,6 +125,7 @@ class BaselineAnimator(torch.nn.Module):
     @torch.no_grad()
     def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device (overlap: see _features_ahead)."""
+        _check_grid(image)
         clip = self.begin_clip(image, motion, N, shard)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
@@ -162,6 +172,7 @@ class SLRv1Animator(torch.nn.Module):
 
     @torch.no_grad()
     def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
+        _check_grid(image)
         clip = self.begin_clip(image, motion, N, shard)
         frames = range(N) if frames is None else frames
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])

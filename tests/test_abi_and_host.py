@@ -130,3 +130,10 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
         start = data.find(magic, start + 24)
     assert objects >= 6                      # one per source file of csrc/Makefile
     assert mfma > 0                          # the disassembly really is the convolution's device code too
+
+
+def test_synthesize_refuses_grids_that_are_not_multiples_of_8():
+    from slr_sfs_amd import pipeline
+    an = pipeline.BaselineAnimator()
+    with pytest.raises(ValueError, match="multiples of 8"):
+        an.synthesize(torch.zeros(1, 3, 150, 136), torch.zeros(1, 2, 150, 136), 4)
