@@ -771,6 +771,34 @@ def test_randomised_shapes_flows_modes_vs_oracle(S, oracle):
                                                                        float(np.abs(out - ref).max()))
 
 
+def test_randomised_backward_vs_oracle(S, oracle):
+    """Seeded sweep of the operator's backward (grad input: bit-exact gather; grad flow: C-loop per work-item in the
+    reference's order, 1e-6) over shapes, batch sizes and flow families incl. out-of-range and integer flows
+    (softsplat.py:204-326 restated in oracle/slr_oracle.c)."""
+    rng = np.random.default_rng(int(os.environ.get("SLR_TEST_SEED", 99)))
+    for case in range(int(os.environ.get("SLR_TEST_CASES", 24))):
+        N, C = int(rng.integers(1, 3)), int(rng.integers(1, 12))
+        H, W = int(rng.integers(1, 70)), int(rng.integers(1, 150))
+        kind = case % 4
+        if kind == 0:
+            fl = rng.uniform(-3, 3, (N, 2, H, W))
+        elif kind == 1:
+            fl = rng.uniform(-80, 80, (N, 2, H, W))
+        elif kind == 2:
+            fl = rng.integers(-4, 5, (N, 2, H, W)).astype(np.float64)
+        else:
+            fl = rng.uniform(-1, 1, (N, 2, H, W)) + np.array([W / 3.0, -H / 4.0]).reshape(1, 2, 1, 1)
+        fl = fl.astype(np.float32)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        go = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        gi, gf = oracle.softsplat_backward(x, fl, go)
+        a, b = dev(x).requires_grad_(True), dev(fl).requires_grad_(True)
+        S.FunctionSoftsplat(a, b, None, "summation").backward(dev(go))
+        assert np.array_equal(host(a.grad), gi), (case, N, C, H, W, kind)
+        scale = max(1.0, float(np.abs(gf).max()))
+        np.testing.assert_allclose(host(b.grad), gf, rtol=1e-6, atol=1e-6 * scale, err_msg=str((case, N, C, H, W, kind)))
+
+
 def test_fused_synthesis_with_sink_motion_vs_oracle(S, oracle):
     """Motion field pointing at a sink: after a few Euler steps thousands of sources share a few
     output pixels in both splat directions (multi-segment tiles, long record lists, whole-tile
