@@ -276,6 +276,48 @@ def test_synthesis_vs_oracle_mid_size(S, oracle):
                                    rtol=1e-4, atol=1e-5)
 
 
+def test_randomised_synthesis_vs_oracle(S, oracle):
+    """Seeded sweep of the headline path itself -- all-frames Euler integration, two-direction exp-weighted splat,
+    normalisation (animating_softmax_splating.py:847-924; SLR v1: ..._2layers_alpha_seperate.py:950-1045) -- over
+    grids, clip lengths, frame indices and motion families, baseline and SLR-v1 packing, against the oracle."""
+    rng = np.random.default_rng(int(os.environ.get("SLR_TEST_SEED", 5)))
+    for case in range(int(os.environ.get("SLR_TEST_CASES", 12))):
+        H, W = int(rng.integers(3, 100)), int(rng.integers(3, 170))
+        N = int(rng.integers(2, 14))
+        C = int(rng.integers(1, 70))
+        y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        kind = case % 4
+        if kind == 0:
+            m = smooth_motion(H, W, case, amp=float(rng.uniform(0.5, 5)))
+        elif kind == 1:
+            m = rng.uniform(-6, 6, (1, 2, H, W)).astype(np.float32)
+        elif kind == 2:                                  # converging field: long record lists, multi-segment tiles
+            dx, dy = W * 0.5 - x, H * 0.5 - y
+            r = np.sqrt(dx * dx + dy * dy) + 1e-3
+            m = np.stack([dx / r * np.minimum(r, 3.0), dy / r * np.minimum(r, 3.0)])[None].astype(np.float32)
+        else:                                            # everything leaves the image after a few steps
+            m = np.full((1, 2, H, W), float(rng.uniform(2, 9)), np.float32)
+        fs = rng.standard_normal((1, C, H, W)).astype(np.float32)
+        Z = (rng.standard_normal((1, 1, H, W)) * float(rng.uniform(0.2, 3))).astype(np.float32)
+        ts = sorted({0, N - 1, int(rng.integers(0, N))})
+        cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+        for t in ts:
+            ref = oracle.synth_baseline(fs, Z, m, t, N)
+            scale = max(1.0, float(np.abs(ref).max()))
+            np.testing.assert_allclose(host(cs.features(t)), ref, rtol=2e-4, atol=2e-5 * scale,
+                                       err_msg=str((case, "baseline", H, W, N, C, kind, t)))
+        if case % 3 == 0:                                # SLR v1 packing (with alpha0 as blending weight)
+            afl = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+            abg = rng.uniform(0.05, 0.95, (1, 1, H, W)).astype(np.float32)
+            c1 = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, alpha_fluid_logit=dev(afl), alpha_bg=dev(abg))
+            for t in ts:
+                rg, ra = oracle.synth_v1(fs, Z, afl, abg, m, t, N)[:2]
+                g, a = c1.features(t)
+                scale = max(1.0, float(np.abs(rg).max()))
+                np.testing.assert_allclose(host(g), rg, rtol=2e-4, atol=2e-5 * scale, err_msg=str((case, "v1 fs", t)))
+                np.testing.assert_allclose(host(a), ra, rtol=2e-4, atol=2e-5, err_msg=str((case, "v1 alpha", t)))
+
+
 # ------------------------------------------------------------------------------ full-size properties
 
 def test_full_size_mass_conservation_and_linearity(S):
