@@ -713,6 +713,34 @@ def test_clip_assembler_on_rccl(S, tmp_path):
     assert r.returncode == 0 and "ASSEMBLED" in r.stdout, r.stderr[-2000:]
 
 
+def test_c_abi_from_a_plain_host_program(S, oracle, tmp_path):
+    """examples/cabi_demo.cpp: a C++ host program with hipMalloc'ed buffers and its own stream, linked against the
+    library through include/slr_splat.h only (no Python, no torch in the process) -- Euler integration, summation
+    splat, fused softmax mode with the bins reused; its outputs against the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "cabi_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "examples")])
+    rng = np.random.default_rng(123)
+    C, H, W, nsteps = 5, 61, 150, 7
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    m = smooth_motion(H, W, 4, amp=2.5)
+    met = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    for name, a in (("in", x), ("motion", m), ("metric", met)):
+        a.tofile(tmp_path / f"{name}.f32")
+    r = subprocess.run([exe, str(tmp_path / "in.f32"), str(tmp_path / "motion.f32"), str(tmp_path / "metric.f32"),
+                        str(C), str(H), str(W), str(nsteps), str(tmp_path / "out_")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr)
+    load = lambda n, shape: np.fromfile(tmp_path / f"out_{n}.f32", np.float32).reshape(shape)
+    disp, vis = oracle.euler_integration(m, nsteps)
+    assert np.array_equal(load("disp", (1, 2, H, W)), disp)
+    assert np.array_equal(load("visible", (1, 1, H, W)), vis.reshape(1, 1, H, W))
+    np.testing.assert_allclose(load("sum", (1, C, H, W)), oracle.softsplat_forward(x, disp), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(load("softmax", (1, C, H, W)), oracle.function_softsplat(x, disp, met, "softmax"),
+                               rtol=2e-4, atol=2e-5)
+
+
 def test_c_abi_prebinned_reuse_and_errors(S, oracle):
     """Straight through ctypes: bin once, splat two tensors with the same bins (prebinned = 1);
     workspace too small / misaligned is refused with SLR_E_WORKSPACE."""
