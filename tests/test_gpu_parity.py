@@ -676,6 +676,28 @@ def test_banded_encoder_is_exact(S):
         assert (a - b).abs().max().item() < 1e-4
 
 
+def test_two_ranks_one_clip(S):
+    """The multi-GPU job of bench.py end to end with two processes (tests/_two_rank_clip.py): frames round-robin over
+    the ranks, encoder in row bands + all-gather, round-wise asynchronous clip assembly -- every rank ends with the clip
+    a single process renders.  The test box has one GPU, so both ranks use cuda:0 and the collectives travel over gloo;
+    on N GPUs the same code runs over RCCL (test_clip_assembler_on_rccl covers that backend)."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_two_rank_clip.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"RANK{r} OK" in out, (r, out[-500:], err[-3000:])
+
+
 def test_clip_assembler_on_rccl(S, tmp_path):
     """parallel.ClipAssembler with backend nccl (= RCCL) in a child process: the asynchronous per-round collectives
     on RCCL's stream, the frames rendered on the caller's stream in between, finish() -> the clip.  One GPU here, so
