@@ -65,11 +65,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # development only (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): all ranks on cuda:0 with the
+    # collectives over gloo, to exercise this script's multi-rank control flow on a one-GPU box
+    one_gpu = os.environ.get("SLR_BENCH_ONE_GPU_GLOO") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import slr_sfs_amd as S
     from slr_sfs_amd import parallel, pipeline, synthesis

@@ -698,6 +698,34 @@ def test_two_ranks_one_clip(S):
         assert p.returncode == 0 and f"RANK{r} OK" in out, (r, out[-500:], err[-3000:])
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's own multi-rank path, launched the way the driver launches it (torch.distributed.run, 2 ranks):
+    warm-up, barrier-bracketed timed steps, MAX over ranks, rank 0's extra measurements while the other rank waits,
+    ONE JSON line from rank 0.  One GPU here: both ranks on cuda:0, collectives over gloo (SLR_BENCH_ONE_GPU_GLOO=1),
+    so the figure itself means nothing -- the control flow, the sharded clip and the JSON contract are what is checked."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLR_BENCH_ONE_GPU_GLOO="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["value"] > 0 and abs(d["value"] - 60 / (d["ms_per_step"] * 1e-3)) < 0.05 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"] is None                       # rank 0 at N=1 only
+
+
 def test_clip_assembler_on_rccl(S, tmp_path):
     """parallel.ClipAssembler with backend nccl (= RCCL) in a child process: the asynchronous per-round collectives
     on RCCL's stream, the frames rendered on the caller's stream in between, finish() -> the clip.  One GPU here, so
