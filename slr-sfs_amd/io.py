@@ -165,3 +165,19 @@ def speed_align(align_json, name):
         return None
     with open(align_json) as f:
         return json.load(f)[name]
+
+
+def encode_video(frame_dir, out_path, framerate=30):
+    """%06d.png -> mp4 / gif with the command line of the reference's test scripts
+    (test_baseline_4eval_rawsize.py:289: ``ffmpeg -loglevel quiet -framerate 30 -i DIR/%06d.png -framerate 30 OUT -y``).
+    Returns ``out_path``, or None when there is no ``ffmpeg`` on PATH (the reference's os.system call then fails
+    silently; here the caller is told)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("ffmpeg")
+    if exe is None:
+        return None
+    subprocess.check_call([exe, "-loglevel", "quiet", "-framerate", str(framerate), "-i", os.path.join(frame_dir, "%06d.png"),
+                           "-framerate", str(framerate), out_path, "-y"])
+    return out_path
+

@@ -161,3 +161,20 @@ def test_lz4_frame_from_system_liblz4(golden_dir):
     want = mk.motion()
     got = io.load_motion(os.path.join(golden_dir, "motion_lz4.pth"))
     assert got.shape == want.shape and np.array_equal(got.numpy(), want)
+
+
+def test_encode_video_command_line(tmp_path, monkeypatch):
+    """The ffmpeg step of the reference's test scripts (test_baseline_4eval_rawsize.py:289): same arguments; None
+    when ffmpeg is not installed (as in this image)."""
+    import shutil
+    import subprocess
+    from slr_sfs_amd import io
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert io.encode_video(str(tmp_path), str(tmp_path / "x.mp4")) is None
+    calls = []
+    monkeypatch.setattr(shutil, "which", lambda name: "/usr/bin/ffmpeg")
+    monkeypatch.setattr(subprocess, "check_call", lambda cmd: calls.append(cmd))
+    assert io.encode_video("/d/PredImg", "/d/out.mp4") == "/d/out.mp4"
+    assert calls == [["/usr/bin/ffmpeg", "-loglevel", "quiet", "-framerate", "30", "-i", "/d/PredImg/%06d.png",
+                      "-framerate", "30", "/d/out.mp4", "-y"]]
+

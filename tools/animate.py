@@ -44,6 +44,8 @@ def main():
     dt = time.perf_counter() - t0
     out = io.save_frames(io.frames_to_uint8(frames, (raw_h, raw_w)), os.path.join(a.outdir, a.name))
     print(f"{a.N} frames at {H}x{a.W} in {dt:.2f} s ({a.N / dt:.1f} frames/s) -> {out}")
+    video = io.encode_video(out, os.path.join(a.outdir, a.name, f"PredImg_{a.name}.mp4"))    # :289 (needs ffmpeg)
+    print(f"video: {video}" if video else "video: skipped (no ffmpeg on PATH)")
 
 
 if __name__ == "__main__":
