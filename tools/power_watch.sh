@@ -1,0 +1,16 @@
+#!/bin/bash
+# Clock and power of the GPU while the 128->128 3x3 convolution runs back to back (evidence for the
+# "clock(power)-limited" statement of DESIGN.md 3.4): rocm-smi sampled once a second next to tools/convloop.py.
+out=$1
+mkdir -p $out
+python tools/convloop.py 14 > $out/convloop.log 2>&1 &
+pid=$!
+sleep 3                                   # import + warm-up
+for i in 1 2 3 4 5 6 7 8; do
+  /opt/rocm/bin/rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|Power|Temperature \(Sensor (edge|junction)|hotspot" | tr -s ' ' | sed "s/^/t=$i /" >> $out/smi.log
+  sleep 1
+done
+wait $pid
+/opt/rocm/bin/rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | tr -s ' ' | sed "s/^/idle /" >> $out/smi.log
+cat $out/convloop.log | tail -3
+cat $out/smi.log
