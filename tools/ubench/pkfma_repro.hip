@@ -15,6 +15,9 @@
 #ifndef VARIANT
 #define VARIANT 0
 #endif
+#ifndef AGG
+#define AGG 0          // aggressor: 0 = MFMA loop, 1 = the same loop with scalar FMAs (control)
+#endif
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -37,7 +40,12 @@ __global__ __launch_bounds__(256, 2) void aggressor(float *out, int iters, int s
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const h8 b = frag[(it * 64 + 512 * (t & 3) + lane) & 2047];
+#if AGG == 0
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+#else                                                  // control: the same loop on the vector ALU only
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf((float)a[r & 7], (float)b[r & 7], acc[t][r]);
+#endif
         }
     }
     if (sink) {
