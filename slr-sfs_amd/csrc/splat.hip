@@ -883,8 +883,8 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
         b.count[k] = ws[k]->count; b.cursor[k] = ws[k]->cursor; b.listoff[k] = ws[k]->listoff; b.list[k] = ws[k]->list;
     }
     // the per-tile counts of both flows are zeroed by one launch of our own (not hipMemsetAsync: one launch
-    // instead of two runtime fill kernels, and a captured hipMemsetAsync node made HIP-graph replays of the
-    // binning fault on ROCm 7.0 -- tools/graph_try.py, tests/test_gpu_parity.py::test_frame_is_graph_capturable)
+    // instead of two runtime fill kernels, and a captured hipMemsetAsync node on a workspace from torch's graph-private
+    // pool made HIP-graph replays of the binning fault -- tools/graph_try.py, test_frame_is_graph_capturable)
     hipLaunchKernelGGL(zero_counts_kernel, dim3((w0.L.nt + 255) / 256, nf), dim3(256), 0, st, b, w0.L.nt);
     dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), N, nf);
     hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, b, H, W, w0.L.tiles_x, w0.L.tiles);
