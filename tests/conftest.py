@@ -41,3 +41,19 @@ def large_case(golden_dir, tag):
     motion = np.stack([u * msk, v * msk])[None].astype(np.float32)
     inp = r2.standard_normal((1, C, H, W)).astype(np.float32)
     return g, motion, inp, int(g[f"{tag}_steps"])
+
+
+def a6_large_inputs(H=768, W=1280):
+    """Seeded inputs of tests/golden/pipeline_a6_large.npz (same generator as tools/make_golden_pipeline.py
+    ::a6_large_inputs; only digests of the REFERENCE's forward_flow outputs are stored)."""
+    import numpy as np
+    rng = np.random.default_rng(2000 + H)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.5 * np.sin(2 * np.pi * (2 * x / W + y / H) + 0.9)
+    v = 1.5 * np.cos(2 * np.pi * (x / W - 1.5 * y / H) + 0.4)
+    m = (x >= 0.35 * W).astype(np.float32)
+    motion = np.stack([u * m, v * m])[None].astype(np.float32)
+    fs = rng.standard_normal((1, 64, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    alpha_out = rng.standard_normal((1, 2, H, W)).astype(np.float32)
+    return fs, Z, motion, alpha_out

@@ -963,6 +963,36 @@ def test_full_size_reference_digests(S, golden_dir, tag):
     assert int((out == 0).sum()) == int(g[f"{tag}_holes"])
 
 
+@pytest.mark.parametrize("tag,t", [("c3", 1), ("c3", 30), ("c3", 59), ("sq", 30)])
+def test_timed_fused_kernel_full_size_vs_oracle_and_reference(S, oracle, golden_dir, tag, t):
+    """The kernel bench.py times -- the fused two-flow instantiation behind ClipSynthesizer.features(t) with 64
+    features (C3) and its SLR-v1 packing (C4) -- at the size it is timed, 768x1280, N = 60, t in {1, 30, 59}:
+      * every element against the oracle (animating_softmax_splating.py:847-924,
+        ..._2layers_alpha_seperate.py:950-1045);
+      * against digests of the REFERENCE's own forward_flow on the same grid (4096 sampled positions, plane sums,
+        exact hole count; tests/golden/pipeline_a6_large.npz, tools/make_golden_pipeline.py)."""
+    from conftest import a6_large_inputs
+    from test_oracle_golden import check_a6_digest
+    g = load(golden_dir, "pipeline_a6_large")
+    _, _, H, W = [int(v) for v in g[f"{tag}_shape"]]
+    N = int(g["N"])
+    fs, Z, motion, a = a6_large_inputs(H, W)
+    cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(motion), N)
+    gen = host(cs.features(t))
+    ref = oracle.synth_baseline(fs, Z, motion, t, N)
+    np.testing.assert_allclose(gen, ref, rtol=1e-4, atol=1e-5)
+    assert np.array_equal(gen == 0, ref == 0)
+    check_a6_digest(g, tag, "baseline", t, gen, rtol=1e-4, atol=1e-5)
+    abg = torch.sigmoid(dev(a[:, 0:1]))
+    cv = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(motion), N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=abg)
+    gen, afl = cv.features(t)
+    gen, afl = host(gen), host(afl)
+    rg, ra, _ = oracle.synth_v1(fs, Z, a[:, 1:2], host(abg), motion, t, N)
+    np.testing.assert_allclose(gen, rg, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(afl, ra, rtol=1e-4, atol=2e-5)
+    check_a6_digest(g, tag, "v1", t, gen, afl, rtol=1e-4, atol=2e-5)
+
+
 def test_decoder_matrix_core_conv_vs_fp64(S):
     """Partial-conv decoder on the device (every 3x3 convolution = ONE fused split-f16 matrix-core kernel,
     csrc/conv.hip) vs the torch composition of the same modules evaluated in fp64 on the CPU (the

@@ -107,3 +107,36 @@ def test_full_size_digests(oracle, golden_dir, tag):
     assert np.array_equal(out.ravel()[g[f"{tag}_out_pos"]], g[f"{tag}_out_val"])      # same summation order: exact
     np.testing.assert_allclose(out.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_out_sum"], rtol=1e-12)
     assert int((out == 0).sum()) == int(g[f"{tag}_holes"])
+
+
+def check_a6_digest(g, tag, kind, t, gen, alpha=None, rtol=1e-5, atol=2e-6):
+    """Compare a decoder input [1,64,H,W] (and, for SLR v1, the warped alpha plane [1,1,H,W]) with the digests of
+    the REFERENCE's forward_flow output stored in pipeline_a6_large.npz.  Returns the largest sampled error."""
+    val = gen.ravel()[g[f"{tag}_pos"]]
+    ref = g[f"{tag}_{kind}_t{t}_val"]
+    np.testing.assert_allclose(val, ref, rtol=rtol, atol=atol, err_msg=f"{tag} {kind} t={t}")
+    np.testing.assert_allclose(gen.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_{kind}_t{t}_sum"],
+                               rtol=1e-5, atol=0.5)
+    assert int((gen == 0).sum()) == int(g[f"{tag}_{kind}_t{t}_holes"])       # holes exactly 0, and the same ones
+    err = float(np.abs(val - ref).max())
+    if alpha is not None:
+        av = alpha.ravel()[g[f"{tag}_apos"]]
+        np.testing.assert_allclose(av, g[f"{tag}_{kind}_t{t}_alpha_val"], rtol=rtol, atol=5e-6)
+        np.testing.assert_allclose(float(alpha.astype(np.float64).sum()), float(g[f"{tag}_{kind}_t{t}_alpha_sum"]),
+                                   rtol=1e-5, atol=0.5)
+        err = max(err, float(np.abs(av - g[f"{tag}_{kind}_t{t}_alpha_val"]).max()))
+    return err
+
+
+@pytest.mark.parametrize("tag,t", [("c3", 30), ("sq", 59)])
+def test_forward_flow_decoder_input_full_size_digests(oracle, golden_dir, tag, t):
+    """Oracle vs the reference's own forward_flow (baseline + SLR v1) at 768x1280 / 768x768, 64 features, N=60."""
+    from conftest import a6_large_inputs
+    g = _load(golden_dir, "pipeline_a6_large")
+    _, _, H, W = [int(v) for v in g[f"{tag}_shape"]]
+    fs, Z, motion, a = a6_large_inputs(H, W)
+    N = int(g["N"])
+    check_a6_digest(g, tag, "baseline", t, oracle.synth_baseline(fs, Z, motion, t, N))
+    abg = (1.0 / (1.0 + np.exp(-a[:, 0:1]))).astype(np.float32)
+    gen, afl, _ = oracle.synth_v1(fs, Z, a[:, 1:2], abg, motion, t, N)
+    check_a6_digest(g, tag, "v1", t, gen, afl)

@@ -139,9 +139,7 @@ def splat_flows(N, H, W, rng):
 
 def main():
     ss, eim = load_reference()
-    if os.path.isdir(OUT):
-        shutil.rmtree(OUT)
-    os.makedirs(OUT)
+    os.makedirs(OUT, exist_ok=True)       # files of other generators (make_golden_lz4.py, make_golden_nets.py) stay
     rng = np.random.default_rng(20260928)
 
     # ---- E1: euler_integration ------------------------------------------------------
@@ -256,8 +254,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "large_digests.npz"), **l1)
 
     if True:
-        from make_golden_pipeline import capture_pipeline
+        from make_golden_pipeline import capture_pipeline, capture_pipeline_large
         capture_pipeline(ss, eim, OUT, rng, cudalike)
+        capture_pipeline_large(ss, OUT, cudalike)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), f"{total / 1024:.0f} kB")

@@ -118,3 +118,87 @@ def capture_pipeline(ss, eim, out_dir, rng, cudalike):
             g[f"{tag}_t{t}_PredImg"] = _plain(pred["PredImg"])
             g[f"{tag}_t{t}_CompositeFluidAlpha"] = _plain(pred["CompositeFluidAlpha"])
     np.savez_compressed(os.path.join(out_dir, "pipeline_a6.npz"), **g)
+
+
+def a6_large_inputs(H=768, W=1280):
+    """Seeded inputs of the full-size a6 digests (regenerated identically by tests/conftest.py::a6_large_case and
+    by bench.py's parity check; only digests of the REFERENCE's outputs are stored)."""
+    rng = np.random.default_rng(2000 + H)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.5 * np.sin(2 * np.pi * (2 * x / W + y / H) + 0.9)
+    v = 1.5 * np.cos(2 * np.pi * (x / W - 1.5 * y / H) + 0.4)
+    m = (x >= 0.35 * W).astype(np.float32)
+    motion = np.stack([u * m, v * m])[None].astype(np.float32)
+    fs = rng.standard_normal((1, 64, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    alpha_out = rng.standard_normal((1, 2, H, W)).astype(np.float32)
+    return fs, Z, motion, alpha_out
+
+
+def capture_pipeline_large(ss, out_dir, cudalike):
+    """L2 fixtures: digests of the decoder input of the reference's own forward_flow (baseline and SLR v1),
+    64 features, N = 60, t in {1, 30, 59}, on two grids:
+      sq : 768x768  -- the reference's real working grid (test_baseline_4eval_rawsize.py:99,165), run as it is;
+      c3 : 768x1280 -- the grid BASELINE.json quotes and bench.py times.  The reference's forward_flow assumes a
+           square grid in three reshapes (Z_f.view(bs,1,W,W) animating_softmax_splating.py:786, and
+           forward_flow.view(bs,-1,W,W) ..._2layers_alpha_seperate.py:988,1025); for this grid Z and the motion are
+           handed over as a tensor subclass whose .view() to (..., W, W) keeps the [.,.,768,1280] shape they
+           already have.  Every arithmetic statement of the reference runs unmodified.
+    Must run after capture_pipeline (module stubs)."""
+    import models.animating_softmax_splating as A
+    import models.animating_softmax_splating_2layers_alpha_seperate as B
+    from options.train_options import ArgumentParser
+    N, SQ = 60, 768
+    base = ("--model_type softmax_splating --refine_model_type resnet_256W8UpDown64_de_resnet_pconv2_nonorm "
+            "--pconv pconv_pbn_woresbias --norm_G sync:spectral_batch --train_Z --use_softmax_splatter "
+            "--losses 1.0_l1 --W %d" % SQ)
+    v1 = base.replace("softmax_splating ", "softmax_splating_2layers_alpha_seperate ") + \
+        (" --bg_refine_model_type resnet_256W8UpDown64BG_nonorm "
+         "--alpha_refine_model_type resnet_256W8UpDown64Layers_de_resnet_pconv2_nonorm "
+         "--out_channel 65 --ngf 64 --train_bg --train_alpha --use_alpha0_as_blending_weight")
+    opt_base, _ = ArgumentParser().parse(base)
+    opt_v1, _ = ArgumentParser().parse(v1)
+    base_cls = type(cudalike(np.zeros(1, np.float32)))
+
+    class KeepGrid(base_cls):
+        def view(self, *shape):
+            shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+            if len(shape) == 4 and tuple(shape[-2:]) == (SQ, SQ) and self.dim() == 4 and self.shape[-2:] != (SQ, SQ):
+                return self
+            return super().view(*shape)
+
+    pos_rng = np.random.default_rng(77)
+    g = {"N": np.int32(N), "ts": np.array([1, 30, 59], np.int32)}
+    for tag, (H, W) in {"sq": (SQ, SQ), "c3": (768, 1280)}.items():
+        keep = (lambda a: cudalike(a).as_subclass(KeepGrid)) if W != H else cudalike
+        fs, Z, motion, alpha_out = a6_large_inputs(H, W)
+        img = np.zeros((1, 3, H, W), np.float32)
+        g[f"{tag}_shape"] = np.array([1, 64, H, W], np.int32)
+        pos = g[f"{tag}_pos"] = pos_rng.integers(0, 64 * H * W, 4096)
+        apos = g[f"{tag}_apos"] = pos_rng.integers(0, H * W, 4096)
+        for t in (1, 30, 59):
+            batch = {"features": [(cudalike(fs), keep(Z))], "images": [cudalike(img)],
+                     "motions": [keep(motion)], "index": torch.tensor([[0, t, N - 1]])}
+            rec = _Recorder(3)
+            me = types.SimpleNamespace(opt=opt_base, softsplater=ss.ModuleSoftsplat("summation"), projector=rec)
+            A.AnimatingSoftmaxSplating.forward_flow(me, batch)
+            gen = _plain(rec.seen[0])
+            assert gen.shape == (1, 64, H, W)
+            g[f"{tag}_baseline_t{t}_val"] = gen.ravel()[pos]
+            g[f"{tag}_baseline_t{t}_sum"] = gen.astype(np.float64).sum(axis=(2, 3))
+            g[f"{tag}_baseline_t{t}_holes"] = np.int64((gen == 0).sum())
+            rec_p, rec_a = _Recorder(3), _Recorder(1)
+            me = types.SimpleNamespace(opt=opt_v1, softsplater=ss.ModuleSoftsplat("summation"), projector=rec_p,
+                                       net_alpha_decoder=rec_a, net_alpha_encoder=_Fixed(cudalike(alpha_out)))
+            b = dict(batch)
+            b["BGImg"] = [cudalike(img)]
+            B.AnimatingSoftmaxSplatingJoint.forward_flow(me, b)
+            gen, ain = _plain(rec_p.seen[0]), _plain(rec_a.seen[0])
+            assert ain.shape == (1, 65, H, W)
+            g[f"{tag}_v1_t{t}_val"] = gen.ravel()[pos]
+            g[f"{tag}_v1_t{t}_sum"] = gen.astype(np.float64).sum(axis=(2, 3))
+            g[f"{tag}_v1_t{t}_holes"] = np.int64((gen == 0).sum())
+            g[f"{tag}_v1_t{t}_alpha_val"] = ain[0, 64].ravel()[apos]
+            g[f"{tag}_v1_t{t}_alpha_sum"] = np.float64(ain[0, 64].astype(np.float64).sum())
+            print(f"  a6 large {tag} t={t}: baseline holes {int(g[f'{tag}_baseline_t{t}_holes'])}", flush=True)
+    np.savez_compressed(os.path.join(out_dir, "pipeline_a6_large.npz"), **g)
