@@ -199,7 +199,7 @@ def _sigmoid32(x):
     return (1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.float32)
 
 
-def synth_v1(fs, Z, alpha_fluid_logit, alpha_bg, motion, t, N, use_alpha0=True):
+def synth_v1(fs, Z, alpha_fluid_logit, alpha_bg, motion, t, N, use_alpha0=True, variant=None):
     """Decoder inputs of AnimatingSoftmaxSplatingJoint.forward_flow for index=[0,t,N-1]
     -- animating_softmax_splating_2layers_alpha_seperate.py:921-922,950-1045.
     alpha_fluid_logit = alpha_output[:,1:2] (:944), alpha_bg = sigmoid(alpha_output[:,0:1]) (:946).
@@ -211,7 +211,12 @@ def synth_v1(fs, Z, alpha_fluid_logit, alpha_bg, motion, t, N, use_alpha0=True):
     disp_p, _ = euler_integration(-motion, N - t)                       # :922
     alpha = f32(1.0) - f32(t) / f32(N)                                  # :950
     alpha = np.clip(alpha, f32(1.0 / 600.0), f32(599.0 / 600.0))        # :952
-    Zn = Z - Z.max()                                                    # :961
+    if variant == "v2":                                                 # :955-957
+        Zn = Z - maximum_warp_norm_splat(Z, disp_f)
+    elif variant == "v1":                                               # :958-959
+        Zn = Z
+    else:
+        Zn = Z - Z.max()                                                # :961
     e = _exp32(Zn)
     if use_alpha0:                                                      # :963-972
         sg = _sigmoid32(af)

@@ -122,18 +122,30 @@ def require_device(*tensors):
         assert t.is_contiguous() is True
 
 
-# ---- scratch: caller-owned workspaces, cached per (device, stream, role, shape) -------------
-_ws_cache = {}
+# ---- scratch: caller-owned workspaces, cached per (device, stream, role, shape), least-recently-used eviction ----
+# A workspace is tied to the stream it was first used on (two streams must never share one), so the stream handle is
+# part of the key; the cache is bounded -- a service that animates many resolutions or creates and destroys streams
+# would otherwise pin ~300 MB of HBM per (stream, shape) for ever.  Evicted tensors go back to torch's stream-ordered
+# caching allocator (safe: they were only ever used on the stream they were allocated on).
+import collections
+
+WS_CACHE_MAX = int(os.environ.get("SLR_SFS_AMD_WS_CACHE", "8"))
+_ws_cache = collections.OrderedDict()
 
 
-def workspace(t, role, N, C, H, W):
+def workspace(t, role, N, C, H, W, nbytes=None):
     """A torch-allocated (stream-ordered) workspace for splatting [N,<=C,H,W] on t's device."""
-    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream, role, N, C, H, W)
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream, role, N, C, H, W, nbytes)
     ws = _ws_cache.get(key)
     if ws is None:
-        nbytes = int(lib().slr_splat_workspace_bytes(N, C, H, W))
+        if nbytes is None:
+            nbytes = int(lib().slr_splat_workspace_bytes(N, C, H, W))
+        while len(_ws_cache) >= max(1, WS_CACHE_MAX):
+            _ws_cache.popitem(last=False)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
         _ws_cache[key] = ws
+    else:
+        _ws_cache.move_to_end(key)
     return ws
 
 

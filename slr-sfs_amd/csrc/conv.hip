@@ -47,7 +47,7 @@ constexpr int CV_NPX = CV_HW * CV_HH;              // 340 halo pixels
 constexpr int CV_THREADS = 256;
 #ifndef CV_EXP
 #define CV_EXP 0          // development experiments (tools/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging,
-                         // 8 staging without its loads, 32 no global writes (the "aggressor" of tools/ovl_debug4.py)
+                         // 8 staging without its loads, 32 no global writes
                          // (measured ceilings at 128->128, 768x1280: all three off 512 TFLOP/s; s_setprio around the MFMAs: -4 %)
 #endif
 constexpr float CV_XSCALE = 64.0f;                 // activations are scaled by 2^6 before the split

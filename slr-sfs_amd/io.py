@@ -147,8 +147,23 @@ def frames_to_uint8(frames, raw_hw=None):
     return torch.clamp(torch.round(x), 0, 255).to(torch.uint8)
 
 
+def alpha_to_uint8(alpha, raw_hw=None):
+    """[n,1,H,W] in [0,1] -> uint8 [n,h,w] grey: bilinear resize, *255 (test_v1_4eval_rawsize.py:250-252,279-280)."""
+    if raw_hw is not None and tuple(alpha.shape[2:]) != tuple(raw_hw):
+        alpha = F.interpolate(alpha, raw_hw, mode="bilinear")
+    return torch.clamp(torch.round(alpha[:, 0] * 255.0), 0, 255).to(torch.uint8)
+
+
+def save_image(img_u8, path):
+    """uint8 [h,w,3] or [h,w] -> one PNG."""
+    from PIL import Image
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    Image.fromarray(img_u8.cpu().numpy()).save(path)
+    return path
+
+
 def save_frames(frames_u8, out_dir, key="PredImg"):
-    """uint8 [n,h,w,3] -> out_dir/key/%06d.png (:252-274)."""
+    """uint8 [n,h,w,3] (or [n,h,w] grey) -> out_dir/key/%06d.png (:252-274)."""
     from PIL import Image
     d = os.path.join(out_dir, key)
     os.makedirs(d, exist_ok=True)

@@ -132,6 +132,10 @@ def encode_banded(encoder, image, rank, world, group=None, halo=None):
         return encoder(image)
     H, W = image.shape[2:]
     rows = -(-H // world)
+    if (world - 1) * rows >= H:          # checked on EVERY rank before any work: a rank without rows must not leave the
+        raise ValueError(               # others waiting in the collective
+            f"encode_banded: {H} rows cannot be split into {world} non-empty bands of {rows} rows; use fewer ranks "
+            f"(or the redundant encoder)")
     band, split = encode_band(encoder, image, rank, world, halo)
     C = band.shape[1]
     send = band.new_zeros(1, C, rows, W)

@@ -12,6 +12,8 @@ the alpha encoder every frame although its input is frame-invariant, :938), Z.ma
 all-frames Euler passes.  Per frame: bin + fused splat (HIP), decoder(s) (PyTorch-ROCm), tanh /
 compositing.  Nothing syncs the host inside the loop; frames stay on the device.
 """
+import math
+
 import torch
 
 from . import nets
@@ -93,18 +95,53 @@ def prepare_motion(flow, H, W, speed=1.0, align=None, N=None):
     return flow.contiguous()
 
 
+def _flag(opts, name, default=False):
+    """``"name" in self.opt and self.opt.name`` of the reference, for an argparse.Namespace, a dict, or None."""
+    if opts is None:
+        return default
+    if isinstance(opts, dict):
+        return opts.get(name, default)
+    return getattr(opts, name, default)
+
+
+def _has(opts, name):
+    """``"name" in self.opt``: attribute EXISTENCE on the Namespace."""
+    if opts is None:
+        return False
+    return (name in opts) if isinstance(opts, dict) else hasattr(opts, name)
+
+
+def splat_options(opts, two_layer):
+    """Splat-weight options of a checkpoint's pickled ``opts`` -> ClipSynthesizer keyword arguments.
+
+    Baseline (animating_softmax_splating.py:849-859): use_softmax_splatter_v2 / _v1, and Z_f_norm is clamped to
+    [-20, 20] unless the Namespace HAS an attribute ``no_clamp_Z`` (whatever its value: checkpoints written by the
+    current option parser always have it, older ones do not).  2-layer model
+    (..._2layers_alpha_seperate.py:955-961): v2 / v1 only, never a clamp."""
+    kw = dict(softmax_v1=bool(_flag(opts, "use_softmax_splatter_v1")) and not _flag(opts, "use_softmax_splatter_v2"),
+              softmax_v2=bool(_flag(opts, "use_softmax_splatter_v2")), clamp_z=None)
+    if not two_layer and opts is not None and not _has(opts, "no_clamp_Z"):
+        kw["clamp_z"] = (-20.0, 20.0)
+    return kw
+
+
 class BaselineAnimator(torch.nn.Module):
-    def __init__(self, encoder=None, decoder=None):
+    def __init__(self, encoder=None, decoder=None, clamp_z=None, softmax_v1=False, softmax_v2=False, opts=None):
+        """clamp_z / softmax_v1 / softmax_v2: see ClipSynthesizer; ``opts`` (the checkpoint's pickled Namespace)
+        sets them the way the reference's forward_flow reads them (splat_options)."""
         super().__init__()
         self.encoder = encoder if encoder is not None else nets.EncoderWithZ()
         self.projector = decoder if decoder is not None else nets.DecoderPconv2(64, 3)
+        self.splat_kw = dict(clamp_z=clamp_z, softmax_v1=softmax_v1, softmax_v2=softmax_v2)
+        if opts is not None:
+            self.splat_kw = splat_options(opts, two_layer=False)
 
     @torch.no_grad()
     def begin_clip(self, image, motion, N, shard=None):
         """Frame-invariant part.  image [1,3,H,W] in [-1,1]; motion [1,2,H,W] px/frame.
         shard = (rank, world[, group]): the encoder runs in row bands across the ranks (parallel.encode_banded)."""
         fs, Z = _encode(self.encoder, image, shard)                 # start_fs, Z_f (:779-786)
-        return ClipSynthesizer(fs, Z, motion, N)
+        return ClipSynthesizer(fs, Z, motion, N, **self.splat_kw)
 
     @torch.no_grad()
     def frame(self, clip, t):
@@ -118,7 +155,7 @@ class BaselineAnimator(torch.nn.Module):
         start, middle, end = [int(v) for v in torch.as_tensor(batch["index"]).reshape(-1)[:3]]
         fs, Z = batch["features"][0][:2]
         clip = ClipSynthesizer(fs, Z.view(fs.shape[0], 1, fs.shape[2], fs.shape[3]), batch["motions"][0],
-                               end - start + 1)
+                               end - start + 1, **self.splat_kw)
         gen = clip.features(middle - start)
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
@@ -136,9 +173,33 @@ class BaselineAnimator(torch.nn.Module):
         return out
 
 
+def blur_alpha_region(alpha_region, W):
+    """The edit mask of ..._2layers_alpha_seperate.py:867-906: Gaussian blur with a (W // 20, made odd)-wide kernel,
+    sigma = W // 50, replicate padding.  An optional editing feature, once per clip: plain torch."""
+    k = W // 20
+    if k % 2 == 0:
+        k = k + 1
+    sigma = W // 50
+    xc = torch.arange(k)
+    xg = xc.repeat(k).view(k, k)
+    xy = torch.stack([xg, xg.t()], dim=-1)
+    mean, var = (k - 1) / 2.0, float(sigma ** 2)
+    g = (1.0 / (2.0 * math.pi * var)) * torch.exp(-torch.sum((xy - mean) ** 2.0, dim=-1).float() / (2.0 * var))
+    g = (g / torch.sum(g)).view(1, 1, k, k).to(alpha_region.device)
+    x = torch.nn.functional.pad(alpha_region, (k // 2,) * 4, mode="replicate")
+    return torch.nn.functional.conv2d(x, g)
+
+
 class SLRv1Animator(torch.nn.Module):
+    KEYS = ("PredImg", "BGImg", "FluidImg", "CompositeFluidAlpha")
+
     def __init__(self, encoder=None, decoder=None, net_bg=None, alpha_encoder=None, alpha_decoder=None,
-                 use_alpha0=True):
+                 use_alpha0=True, softmax_v1=False, softmax_v2=False, use_alpha_softmax=False, clamp_alpha=0.0,
+                 use_fluid_alpha_only=False, use_bg_alpha_only=False, opts=None):
+        """Compositing options of ..._2layers_alpha_seperate.py:1060-1085 (all off in the shipped scripts):
+        use_alpha_softmax, clamp_alpha (> 0: lower bound of the composited fluid alpha -- not the clamp of the time
+        weight, which this model always applies, :952), use_fluid_alpha_only, use_bg_alpha_only.  ``opts`` (the
+        checkpoint's pickled Namespace) sets all of them, use_alpha0 and the splat-weight variant."""
         super().__init__()
         self.encoder = encoder if encoder is not None else nets.EncoderWithZ()
         self.projector = decoder if decoder is not None else nets.DecoderPconv2(64, 3)
@@ -146,17 +207,34 @@ class SLRv1Animator(torch.nn.Module):
         self.net_alpha_encoder = alpha_encoder if alpha_encoder is not None else nets.Encoder(3, 2)
         self.net_alpha_decoder = alpha_decoder if alpha_decoder is not None else nets.DecoderPconv2(65, 1)
         self.use_alpha0 = use_alpha0
+        self.splat_kw = dict(softmax_v1=softmax_v1, softmax_v2=softmax_v2)
+        self.use_alpha_softmax, self.clamp_alpha = bool(use_alpha_softmax), float(clamp_alpha)
+        self.use_fluid_alpha_only, self.use_bg_alpha_only = bool(use_fluid_alpha_only), bool(use_bg_alpha_only)
+        if opts is not None:
+            kw = splat_options(opts, two_layer=True)
+            self.splat_kw = dict(softmax_v1=kw["softmax_v1"], softmax_v2=kw["softmax_v2"])
+            self.use_alpha0 = bool(_flag(opts, "use_alpha0_as_blending_weight"))
+            self.use_alpha_softmax = bool(_flag(opts, "use_alpha_softmax"))
+            self.clamp_alpha = float(_flag(opts, "clamp_alpha", 0.0) or 0.0)
+            self.use_fluid_alpha_only = bool(_flag(opts, "use_fluid_alpha_only"))
+            self.use_bg_alpha_only = bool(_flag(opts, "use_bg_alpha_only"))
+
+    def _clip(self, fs, Z, motion, N, alpha_out, bg, alpha_region=None):
+        alpha_bg_raw = alpha_out[:, 0:1]                            # :943-946
+        alpha_bg = torch.sigmoid(alpha_bg_raw)
+        clip = ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=alpha_out[:, 1:2].contiguous(), alpha_bg=alpha_bg,
+                               use_alpha0=self.use_alpha0, **self.splat_kw)
+        clip.bg, clip.alpha_bg, clip.alpha_bg_raw = bg, alpha_bg, alpha_bg_raw
+        clip.alpha_region = None if alpha_region is None else blur_alpha_region(alpha_region, fs.shape[3])
+        return clip
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N, shard=None):
+    def begin_clip(self, image, motion, N, shard=None, alpha_region=None):
+        """alpha_region [1,1,H,W]: optional edit mask (:867-906, 1079-1080): 1 = composite, 0 = fluid layer only."""
         fs, Z = _encode(self.encoder, image, shard)
         bg = torch.tanh(self.net_bg(image))                         # test_v1_4eval_rawsize.py:209, :925-927
         a = _encode(self.net_alpha_encoder, image, shard)           # :938 (frame-invariant -> hoisted)
-        alpha_bg = torch.sigmoid(a[:, 0:1])                         # :943-946
-        clip = ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=a[:, 1:2].contiguous(), alpha_bg=alpha_bg,
-                               use_alpha0=self.use_alpha0)
-        clip.bg, clip.alpha_bg = bg, alpha_bg
-        return clip
+        return self._clip(fs, Z, motion, N, a, bg, alpha_region)
 
     @torch.no_grad()
     def frame(self, clip, t):
@@ -164,20 +242,82 @@ class SLRv1Animator(torch.nn.Module):
 
     def _decode(self, clip, gen_fs, alpha_fluid):
         fluid = torch.tanh(self.projector(gen_fs))                  # :1048-1049
-        fluid_alpha = torch.sigmoid(self.net_alpha_decoder(torch.cat([gen_fs, alpha_fluid], 1)))   # :1052-1054
-        alpha_norm = torch.clamp(fluid_alpha + clip.alpha_bg, min=1e-8)                            # :1056-1057
-        pred = (fluid_alpha * fluid + clip.alpha_bg * clip.bg) / alpha_norm                        # :1077
-        return {"PredImg": pred, "BGImg": clip.bg, "FluidImg": fluid,
-                "CompositeFluidAlpha": fluid_alpha / alpha_norm}                                   # :1087-1093
+        fa_raw = self.net_alpha_decoder(torch.cat([gen_fs, alpha_fluid], 1))                       # :1052-1053
+        fluid_alpha = torch.sigmoid(fa_raw)                                                        # :1054
+        alpha_bg, bg = clip.alpha_bg, clip.bg
+        alpha_norm = torch.clamp(fluid_alpha + alpha_bg, min=1e-8)                                 # :1056-1057
+        if self.use_fluid_alpha_only or self.use_bg_alpha_only:                                    # :1060-1063
+            alpha_norm = 1
+        if self.use_alpha_softmax:                                                                 # :1066-1070
+            ca = torch.softmax(torch.cat([fa_raw, clip.alpha_bg_raw], 1), dim=1)
+            pred = ca[:, :1] * fluid + ca[:, 1:2] * bg
+        elif self.clamp_alpha > 0:                                                                 # :1071-1075
+            cfa = torch.clamp(fluid_alpha / alpha_norm, min=self.clamp_alpha)
+            pred = cfa * fluid + (1.0 - cfa) * bg
+        else:
+            pred = (fluid_alpha * fluid + alpha_bg * bg) / alpha_norm                              # :1077
+        region = getattr(clip, "alpha_region", None)
+        if region is not None:                                                                     # :1079-1080
+            pred = pred * region + fluid * (1.0 - region)
+        if self.use_fluid_alpha_only:                                                              # :1082-1083
+            pred = fluid_alpha * fluid + (1.0 - fluid_alpha) * bg
+        if self.use_bg_alpha_only:                                                                 # :1084-1085
+            pred = (1.0 - alpha_bg) * fluid + alpha_bg * bg
+        cfa = fluid_alpha / alpha_norm                                                             # :1088
+        out = {"PredImg": pred, "BGImg": bg, "FluidImg": fluid, "CompositeFluidAlpha": cfa}        # :1089-1093
+        if region is not None:                                                                     # :1100-1103
+            out["EditedCompositeFluidAlpha"] = cfa * region + 1.0 * (1.0 - region)
+            out["AlphaRegionMask"] = region
+        if self.use_fluid_alpha_only:
+            # :1104-1107 -- upstream assigns gen_fluid_alpha and then, under
+            # `"use_bg_alpha_only" in self.opt and self.opt.use_fluid_alpha_only` (the option EXISTS in every parsed
+            # Namespace, and the value tested is use_FLUID_alpha_only), overwrites it with alpha_bg_f.  Kept as it is
+            # (tests/golden/pipeline_v1_surface.npz holds the reference's output).
+            out["CompositeFluidAlpha"] = alpha_bg
+        return out
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
+    def forward_flow(self, batch):
+        """Reference-compatible single-frame entry: same batch keys and return dict as
+        AnimatingSoftmaxSplatingJoint.forward_flow (..._2layers_alpha_seperate.py:843-1108), as the runner calls it
+        (test_v1_4eval_rawsize.py:227-240): batch["features"] = [(start_fs, Z_f)], batch["BGImg"] = [net_bg(img)]
+        (before the tanh, :925-927), batch["images"], batch["motions"], batch["index"] = [[0, t, N-1]], optional
+        batch["alpha_region"].  Like the reference it re-runs the alpha encoder and the Euler integration on every
+        call; begin_clip / frame hoist them."""
+        idx = torch.as_tensor(batch["index"])
+        start, middle, end = [int(v) for v in idx.reshape(-1, 3)[0]]
+        assert idx.numel() == 3, "one frame per call (the reference's euler_integration is batch-1 only as well)"
+        image = batch["images"][0]
+        fs, Z = batch["features"][0][:2]
+        assert fs.shape[0] == 1
+        a = self.net_alpha_encoder(image)                           # :938
+        bg = torch.tanh(batch["BGImg"][0])                          # :925-927
+        clip = self._clip(fs, Z.view(1, 1, fs.shape[2], fs.shape[3]), batch["motions"][0], end - start + 1, a, bg,
+                          batch.get("alpha_region"))
+        return self._decode(clip, *clip.features(middle - start))
+
+    @torch.no_grad()
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None, keys=None,
+                   alpha_region=None):
+        """keys=None: PredImg frames [n,3,H,W] (as BaselineAnimator.synthesize).  keys=("PredImg", "FluidImg",
+        "CompositeFluidAlpha", "BGImg", ...): a dict of those outputs of forward_flow, stacked over the frames
+        ("BGImg" and "AlphaRegionMask" are frame-invariant: one [1,.,H,W] tensor) -- what
+        test_v1_4eval_rawsize.py:240-284 writes to disk."""
         _check_grid(image)
-        clip = self.begin_clip(image, motion, N, shard)
+        clip = self.begin_clip(image, motion, N, shard, alpha_region)
         frames = range(N) if frames is None else frames
-        out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
+        want = ("PredImg",) if keys is None else tuple(keys)
+        once = ("BGImg", "AlphaRegionMask")
+        outs = {}
         for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):
-            out[i] = self._decode(clip, gen_fs, alpha_fluid)["PredImg"][0]
+            d = self._decode(clip, gen_fs, alpha_fluid)
+            for k in want:
+                if k in once:
+                    outs[k] = d[k]
+                    continue
+                if k not in outs:
+                    outs[k] = d[k].new_empty(len(frames), *d[k].shape[1:])
+                outs[k][i] = d[k][0]
             if on_frame is not None:
-                on_frame(out[i])
-        return out
+                on_frame(outs["PredImg"][i])
+        return outs["PredImg"] if keys is None else outs

@@ -85,6 +85,11 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
             tenOutput = tenOutput[:, :-1, :, :] / tenNormalize
         return tenOutput
 
+    # The reference only asserts contiguity of what reaches _FunctionSoftsplat, and in these modes that is the result
+    # of torch.cat (:669-676), always contiguous: channel slices / permuted tensors are accepted like upstream.
+    tenInput = tenInput.contiguous()
+    if tenMetric is not None:
+        tenMetric = tenMetric.contiguous()
     _check_pair(tenInput, tenFlow)
     if strType != 'average':
         require_device(tenMetric)

@@ -57,3 +57,25 @@ def a6_large_inputs(H=768, W=1280):
     Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
     alpha_out = rng.standard_normal((1, 2, H, W)).astype(np.float32)
     return fs, Z, motion, alpha_out
+
+
+def v1_surface_inputs(W=60):
+    """Seeded inputs of tests/golden/pipeline_v1_surface.npz (same generator as tools/make_golden_pipeline.py)."""
+    import numpy as np
+    rng = np.random.default_rng(4100 + W)
+    y, x = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.2 * np.sin(2 * np.pi * (2 * x / W + y / W) + 0.2)
+    v = 1.2 * np.cos(2 * np.pi * (x / W - 1.5 * y / W) + 1.3)
+    motion = np.stack([u, v])[None].astype(np.float32)
+    d = {"motion": motion,
+         "fs": rng.standard_normal((1, 64, W, W)).astype(np.float32),
+         "Z": (rng.standard_normal((1, 1, W, W)) * 2).astype(np.float32),
+         "img": rng.uniform(-1, 1, (1, 3, W, W)).astype(np.float32),
+         "alpha_out": rng.standard_normal((1, 2, W, W)).astype(np.float32),
+         "bg_raw": rng.standard_normal((1, 3, W, W)).astype(np.float32),
+         "dec_out": rng.standard_normal((1, 3, W, W)).astype(np.float32),
+         "adec_out": (rng.standard_normal((1, 1, W, W)) * 2).astype(np.float32)}
+    region = np.zeros((1, 1, W, W), np.float32)
+    region[0, 0, W // 4: 3 * W // 4, W // 3:] = 1.0
+    d["alpha_region"] = region
+    return d

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -97,7 +98,7 @@ def test_prepare_motion_and_alpha_semantics():
 
 def test_device_code_has_no_packed_fp32_instructions(tmp_path):
     """csrc/Makefile builds without packed-fp32 VALU instructions: with them the splat tile kernel returned wrong
-    low halves next to a concurrently running MFMA kernel on MI355X (tools/ovl_debug6.py).  Checked on
+    low halves next to a concurrently running MFMA kernel on MI355X (tools/ubench/pkfma_repro.hip).  Checked on
     the ISA of every gfx950 code object bundled in the built library."""
     import struct
     import subprocess
@@ -137,3 +138,65 @@ def test_synthesize_refuses_grids_that_are_not_multiples_of_8():
     an = pipeline.BaselineAnimator()
     with pytest.raises(ValueError, match="multiples of 8"):
         an.synthesize(torch.zeros(1, 3, 150, 136), torch.zeros(1, 2, 150, 136), 4)
+
+
+class _FixedOut(torch.nn.Module):
+    def __init__(self, value):
+        super().__init__()
+        self.value = value
+
+    def forward(self, x):
+        return self.value
+
+
+V1_VARIANTS = {"plain": {}, "region": {}, "clamp": {"clamp_alpha": 0.6}, "softmax": {"use_alpha_softmax": True},
+               "fluidonly": {"use_fluid_alpha_only": True}, "bgonly": {"use_bg_alpha_only": True},
+               "v1weights": {"softmax_v1": True}}
+
+
+@pytest.mark.parametrize("tag", sorted(V1_VARIANTS))
+def test_v1_compositing_host_logic_vs_reference(oracle, golden_dir, tag):
+    """Host side of SLRv1Animator (everything after the splat: sigmoid / normalise / compositing variants /
+    alpha_region blur / return dict) against the return dict of the REFERENCE's forward_flow
+    (tests/golden/pipeline_v1_surface.npz), fed with the oracle's decoder inputs.  CPU only."""
+    import types
+    from conftest import v1_surface_inputs
+    from slr_sfs_amd import pipeline
+    g = np.load(f"{golden_dir}/pipeline_v1_surface.npz")
+    W, N, t = int(g["W"]), int(g["N"]), int(g["t"])
+    d = v1_surface_inputs(W)
+    T = lambda a: torch.from_numpy(a)
+    kw = dict(V1_VARIANTS[tag])
+    an = pipeline.SLRv1Animator(decoder=_FixedOut(T(d["dec_out"])), alpha_decoder=_FixedOut(T(d["adec_out"])),
+                                alpha_encoder=_FixedOut(T(d["alpha_out"])), **kw)
+    a = d["alpha_out"]
+    abg = (1.0 / (1.0 + np.exp(-a[:, 0:1]))).astype(np.float32)
+    gen, afl, _ = oracle.synth_v1(d["fs"], d["Z"], a[:, 1:2], abg, d["motion"], t, N,
+                                  variant="v1" if tag == "v1weights" else None)
+    clip = types.SimpleNamespace(bg=torch.tanh(T(d["bg_raw"])), alpha_bg=torch.sigmoid(T(a[:, 0:1])),
+                                 alpha_bg_raw=T(a[:, 0:1]),
+                                 alpha_region=pipeline.blur_alpha_region(T(d["alpha_region"]), W) if tag == "region" else None)
+    out = an._decode(clip, T(gen), T(afl))
+    assert sorted(out.keys()) == [str(k) for k in g[f"{tag}_keys"]]
+    for k, v in out.items():
+        ref = g[f"{tag}_{k}"] if f"{tag}_{k}" in g else g[f"plain_{k}"]
+        np.testing.assert_allclose(v.numpy(), ref, rtol=2e-5, atol=2e-6, err_msg=f"{tag} {k}")
+
+
+def test_splat_options_from_checkpoint_opts():
+    """How the reference's forward_flow reads the splat-weight options of a checkpoint's pickled Namespace
+    (animating_softmax_splating.py:849-859: clamp unless the Namespace HAS no_clamp_Z; 2-layer model: never)."""
+    import argparse
+    from slr_sfs_amd import pipeline
+    old = argparse.Namespace(use_softmax_splatter_v1=False)                 # written before --no_clamp_Z existed
+    new = argparse.Namespace(no_clamp_Z=False, use_softmax_splatter_v1=False, use_softmax_splatter_v2=False)
+    assert pipeline.splat_options(old, two_layer=False)["clamp_z"] == (-20.0, 20.0)
+    assert pipeline.splat_options(new, two_layer=False)["clamp_z"] is None
+    assert pipeline.splat_options(old, two_layer=True)["clamp_z"] is None
+    v2 = argparse.Namespace(no_clamp_Z=True, use_softmax_splatter_v1=True, use_softmax_splatter_v2=True)
+    kw = pipeline.splat_options(v2, two_layer=False)
+    assert kw["softmax_v2"] and not kw["softmax_v1"]                       # v2 is tested first (:849-853)
+    an = pipeline.SLRv1Animator(opts=argparse.Namespace(use_alpha0_as_blending_weight=True, clamp_alpha=0.25,
+                                                        use_alpha_softmax=False))
+    assert an.use_alpha0 and an.clamp_alpha == 0.25 and not an.use_fluid_alpha_only
+    assert pipeline.BaselineAnimator(opts=old).splat_kw["clamp_z"] == (-20.0, 20.0)

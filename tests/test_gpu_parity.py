@@ -36,6 +36,17 @@ def load(golden_dir, name):
     return np.load(f"{golden_dir}/{name}.npz")
 
 
+def assert_same_holes(gen, ref, slack=4):
+    """Holes (pixels no source reaches) are exactly 0.0 in every channel, and they are the same pixels.  Element-wise
+    the zero patterns may differ in a handful of places: a value whose contributions cancel to exactly 0.0 in one
+    summation order is ~1e-8 in another (the reference's own order is unspecified: racing atomicAdds)."""
+    assert np.array_equal((gen == 0).all(axis=1), (ref == 0).all(axis=1))
+    diff = (gen == 0) != (ref == 0)
+    assert int(diff.sum()) <= slack, int(diff.sum())
+    if diff.any():
+        assert float(np.abs(gen[diff]).max()) < 1e-6 and float(np.abs(ref[diff]).max()) < 1e-6
+
+
 def smooth_motion(H, W, seed=0, amp=1.5):
     rng = np.random.default_rng(seed)
     p1, p2 = rng.uniform(0, 2 * np.pi, 2)
@@ -391,6 +402,58 @@ def test_v1_compositing_golden(S, golden_dir, t):
     np.testing.assert_allclose(host(out["PredImg"]), g[f"v1_t{t}_PredImg"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(host(out["CompositeFluidAlpha"]), g[f"v1_t{t}_CompositeFluidAlpha"],
                                rtol=1e-5, atol=1e-6)
+
+
+class _FixedOut(torch.nn.Module):
+    def __init__(self, value):
+        super().__init__()
+        self.value = value
+
+    def forward(self, x):
+        return self.value
+
+
+@pytest.mark.parametrize("tag", ["plain", "region", "clamp", "softmax", "fluidonly", "bgonly", "v1weights"])
+def test_v1_forward_flow_batch_entry_vs_reference(S, golden_dir, tag):
+    """SLRv1Animator.forward_flow(batch) -- the reference's batch keys and return dict
+    (..._2layers_alpha_seperate.py:843-1108) -- against the return dict of the REFERENCE's forward_flow with the
+    optional compositing paths on (alpha_region, clamp_alpha, use_alpha_softmax, use_fluid_alpha_only,
+    use_bg_alpha_only, use_softmax_splatter_v1); the decoders / alpha encoder are the fixture's fixed maps."""
+    from conftest import v1_surface_inputs
+    from test_abi_and_host import V1_VARIANTS
+    g = load(golden_dir, "pipeline_v1_surface")
+    W, N, t = int(g["W"]), int(g["N"]), int(g["t"])
+    d = {k: dev(v) for k, v in v1_surface_inputs(W).items()}
+    an = S.pipeline.SLRv1Animator(decoder=_FixedOut(d["dec_out"]), alpha_decoder=_FixedOut(d["adec_out"]),
+                                  alpha_encoder=_FixedOut(d["alpha_out"]), **V1_VARIANTS[tag]).cuda()
+    batch = {"features": [(d["fs"], d["Z"])], "images": [d["img"]], "motions": [d["motion"]],
+             "index": torch.tensor([[0, t, N - 1]]), "BGImg": [d["bg_raw"]]}
+    if tag == "region":
+        batch["alpha_region"] = d["alpha_region"]
+    out = an.forward_flow(batch)
+    assert sorted(out.keys()) == [str(k) for k in g[f"{tag}_keys"]]
+    for k, v in out.items():
+        ref = g[f"{tag}_{k}"] if f"{tag}_{k}" in g else g[f"plain_{k}"]
+        np.testing.assert_allclose(host(v), ref, rtol=1e-4, atol=1e-5, err_msg=f"{tag} {k}")
+
+
+def test_v1_synthesize_returns_the_runner_outputs(S):
+    """synthesize(keys=...) stacks what test_v1_4eval_rawsize.py:240-284 writes (PredImg, FluidImg,
+    CompositeFluidAlpha per frame, BGImg once) and agrees with frame() / the PredImg-only form."""
+    H, W, N = 40, 72, 5
+    torch.manual_seed(1)
+    an = S.pipeline.SLRv1Animator().cuda().eval()
+    img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+    m = dev(smooth_motion(H, W, 2, amp=2.0))
+    outs = an.synthesize(img, m, N, keys=S.pipeline.SLRv1Animator.KEYS)
+    assert outs["PredImg"].shape == (N, 3, H, W) and outs["FluidImg"].shape == (N, 3, H, W)
+    assert outs["CompositeFluidAlpha"].shape == (N, 1, H, W) and outs["BGImg"].shape == (1, 3, H, W)
+    assert torch.equal(outs["PredImg"], an.synthesize(img, m, N))
+    clip = an.begin_clip(img, m, N)
+    f3 = an.frame(clip, 3)
+    for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
+        assert torch.equal(outs[k][3], f3[k][0])
+    assert all(bool(torch.isfinite(v).all()) for v in outs.values())
 
 
 def test_baseline_forward_flow_api_and_clip(S, oracle):
@@ -981,8 +1044,8 @@ def test_timed_fused_kernel_full_size_vs_oracle_and_reference(S, oracle, golden_
     gen = host(cs.features(t))
     ref = oracle.synth_baseline(fs, Z, motion, t, N)
     np.testing.assert_allclose(gen, ref, rtol=1e-4, atol=1e-5)
-    assert np.array_equal(gen == 0, ref == 0)
-    check_a6_digest(g, tag, "baseline", t, gen, rtol=1e-4, atol=1e-5)
+    assert_same_holes(gen, ref)
+    check_a6_digest(g, tag, "baseline", t, gen, rtol=1e-4, atol=1e-5, hole_slack=4)
     abg = torch.sigmoid(dev(a[:, 0:1]))
     cv = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(motion), N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=abg)
     gen, afl = cv.features(t)
@@ -990,7 +1053,8 @@ def test_timed_fused_kernel_full_size_vs_oracle_and_reference(S, oracle, golden_
     rg, ra, _ = oracle.synth_v1(fs, Z, a[:, 1:2], host(abg), motion, t, N)
     np.testing.assert_allclose(gen, rg, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(afl, ra, rtol=1e-4, atol=2e-5)
-    check_a6_digest(g, tag, "v1", t, gen, afl, rtol=1e-4, atol=2e-5)
+    assert_same_holes(gen, rg)
+    check_a6_digest(g, tag, "v1", t, gen, afl, rtol=1e-4, atol=2e-5, hole_slack=4)
 
 
 def test_decoder_matrix_core_conv_vs_fp64(S):

@@ -59,6 +59,15 @@ def test_image_and_frame_export(tmp_path):
     assert up.shape == (1, 30, 50, 3) and up.dtype == torch.uint8
     d = io.save_frames(up, str(tmp_path / "out"))
     assert sorted(os.listdir(d)) == ["000000.png"]
+    # SLR-v1 runner outputs (test_v1_4eval_rawsize.py:250-252,279-284): grey alpha frames, one background image
+    alpha = torch.linspace(0, 1, 2 * 16 * 24).view(2, 1, 16, 24)
+    a8 = io.alpha_to_uint8(alpha, (30, 50))
+    assert a8.shape == (2, 30, 50) and a8.dtype == torch.uint8 and int(a8.max()) == 255 and int(a8.min()) == 0
+    da = io.save_frames(a8, str(tmp_path / "out"), key="CompositeFluidAlpha")
+    assert sorted(os.listdir(da)) == ["000000.png", "000001.png"]
+    assert Image.open(os.path.join(da, "000001.png")).mode == "L"
+    pb = io.save_image(up[0], str(tmp_path / "out" / "BGImg.png"))
+    assert np.array_equal(np.asarray(Image.open(pb)), up[0].numpy())
 
 
 def test_prepare_motion_matches_script_arithmetic():

@@ -109,7 +109,7 @@ def test_full_size_digests(oracle, golden_dir, tag):
     assert int((out == 0).sum()) == int(g[f"{tag}_holes"])
 
 
-def check_a6_digest(g, tag, kind, t, gen, alpha=None, rtol=1e-5, atol=2e-6):
+def check_a6_digest(g, tag, kind, t, gen, alpha=None, rtol=1e-5, atol=2e-6, hole_slack=0):
     """Compare a decoder input [1,64,H,W] (and, for SLR v1, the warped alpha plane [1,1,H,W]) with the digests of
     the REFERENCE's forward_flow output stored in pipeline_a6_large.npz.  Returns the largest sampled error."""
     val = gen.ravel()[g[f"{tag}_pos"]]
@@ -117,7 +117,9 @@ def check_a6_digest(g, tag, kind, t, gen, alpha=None, rtol=1e-5, atol=2e-6):
     np.testing.assert_allclose(val, ref, rtol=rtol, atol=atol, err_msg=f"{tag} {kind} t={t}")
     np.testing.assert_allclose(gen.astype(np.float64).sum(axis=(2, 3)), g[f"{tag}_{kind}_t{t}_sum"],
                                rtol=1e-5, atol=0.5)
-    assert int((gen == 0).sum()) == int(g[f"{tag}_{kind}_t{t}_holes"])       # holes exactly 0, and the same ones
+    # holes are exactly 0, and the same ones.  hole_slack (GPU path only): an element that is 0.0 in one summation
+    # order through exact cancellation of its contributions and ~1e-8 in another is not a hole (1 of 37.7 M observed)
+    assert abs(int((gen == 0).sum()) - int(g[f"{tag}_{kind}_t{t}_holes"])) <= hole_slack
     err = float(np.abs(val - ref).max())
     if alpha is not None:
         av = alpha.ravel()[g[f"{tag}_apos"]]

@@ -254,9 +254,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "large_digests.npz"), **l1)
 
     if True:
-        from make_golden_pipeline import capture_pipeline, capture_pipeline_large
+        from make_golden_pipeline import capture_pipeline, capture_pipeline_large, capture_v1_surface
         capture_pipeline(ss, eim, OUT, rng, cudalike)
-        capture_pipeline_large(ss, OUT, cudalike)
+        if "--skip-large" not in sys.argv:
+            capture_pipeline_large(ss, OUT, cudalike)
+        capture_v1_surface(ss, OUT, cudalike)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), f"{total / 1024:.0f} kB")

@@ -202,3 +202,62 @@ def capture_pipeline_large(ss, out_dir, cudalike):
             g[f"{tag}_v1_t{t}_alpha_sum"] = np.float64(ain[0, 64].astype(np.float64).sum())
             print(f"  a6 large {tag} t={t}: baseline holes {int(g[f'{tag}_baseline_t{t}_holes'])}", flush=True)
     np.savez_compressed(os.path.join(out_dir, "pipeline_a6_large.npz"), **g)
+
+
+def v1_surface_inputs(W=60):
+    """Seeded inputs of tests/golden/pipeline_v1_surface.npz (regenerated by tests/conftest.py::v1_surface_inputs)."""
+    rng = np.random.default_rng(4100 + W)
+    y, x = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.2 * np.sin(2 * np.pi * (2 * x / W + y / W) + 0.2)
+    v = 1.2 * np.cos(2 * np.pi * (x / W - 1.5 * y / W) + 1.3)
+    motion = np.stack([u, v])[None].astype(np.float32)
+    d = {"motion": motion,
+         "fs": rng.standard_normal((1, 64, W, W)).astype(np.float32),
+         "Z": (rng.standard_normal((1, 1, W, W)) * 2).astype(np.float32),
+         "img": rng.uniform(-1, 1, (1, 3, W, W)).astype(np.float32),
+         "alpha_out": rng.standard_normal((1, 2, W, W)).astype(np.float32),
+         "bg_raw": rng.standard_normal((1, 3, W, W)).astype(np.float32),
+         "dec_out": rng.standard_normal((1, 3, W, W)).astype(np.float32),          # stand-in decoder outputs
+         "adec_out": (rng.standard_normal((1, 1, W, W)) * 2).astype(np.float32)}
+    region = np.zeros((1, 1, W, W), np.float32)
+    region[0, 0, W // 4: 3 * W // 4, W // 3:] = 1.0
+    d["alpha_region"] = region
+    return d
+
+
+def capture_v1_surface(ss, out_dir, cudalike):
+    """P2 fixtures: the full return dict of the reference's SLR-v1 forward_flow
+    (..._2layers_alpha_seperate.py:843-1108) with the optional compositing paths switched on one at a time --
+    alpha_region (:867-906,1079-1080,1100-1103), clamp_alpha, use_alpha_softmax, use_fluid_alpha_only,
+    use_bg_alpha_only (:1060-1085,1104-1107) -- and fixed random maps in place of the two decoders and the alpha
+    encoder.  Must run after capture_pipeline (module stubs)."""
+    import models.animating_softmax_splating_2layers_alpha_seperate as B
+    from options.train_options import ArgumentParser
+    W, N, t = 60, 24, 9
+    v1 = ("--model_type softmax_splating_2layers_alpha_seperate --refine_model_type resnet_256W8UpDown64_de_resnet_pconv2_nonorm "
+          "--pconv pconv_pbn_woresbias --norm_G sync:spectral_batch --train_Z --use_softmax_splatter "
+          "--losses 1.0_l1 --W %d --bg_refine_model_type resnet_256W8UpDown64BG_nonorm "
+          "--alpha_refine_model_type resnet_256W8UpDown64Layers_de_resnet_pconv2_nonorm "
+          "--out_channel 65 --ngf 64 --train_bg --train_alpha --use_alpha0_as_blending_weight" % W)
+    d = v1_surface_inputs(W)
+    variants = {"plain": "", "region": "", "clamp": " --clamp_alpha 0.6", "softmax": " --use_alpha_softmax",
+                "fluidonly": " --use_fluid_alpha_only", "bgonly": " --use_bg_alpha_only",
+                "v1weights": " --use_softmax_splatter_v1"}
+    g = {"W": np.int32(W), "N": np.int32(N), "t": np.int32(t)}
+    for tag, flags in variants.items():
+        opt, _ = ArgumentParser().parse(v1 + flags)
+        me = types.SimpleNamespace(opt=opt, softsplater=ss.ModuleSoftsplat("summation"),
+                                   projector=_Fixed(cudalike(d["dec_out"])),
+                                   net_alpha_decoder=_Fixed(cudalike(d["adec_out"])),
+                                   net_alpha_encoder=_Fixed(cudalike(d["alpha_out"])))
+        batch = {"features": [(cudalike(d["fs"]), cudalike(d["Z"]))], "images": [cudalike(d["img"])],
+                 "motions": [cudalike(d["motion"])], "index": torch.tensor([[0, t, N - 1]]),
+                 "BGImg": [cudalike(d["bg_raw"])]}
+        if tag == "region":
+            batch["alpha_region"] = cudalike(d["alpha_region"])
+        pred = B.AnimatingSoftmaxSplatingJoint.forward_flow(me, batch)
+        g[f"{tag}_keys"] = np.array(sorted(pred.keys()))
+        for k, v in pred.items():
+            if tag == "plain" or k not in ("BGImg", "FluidImg"):        # frame-/variant-invariant outputs: stored once
+                g[f"{tag}_{k}"] = _plain(v)
+    np.savez_compressed(os.path.join(out_dir, "pipeline_v1_surface.npz"), **g)
