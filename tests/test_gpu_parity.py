@@ -448,11 +448,12 @@ def test_v1_synthesize_returns_the_runner_outputs(S):
     outs = an.synthesize(img, m, N, keys=S.pipeline.SLRv1Animator.KEYS)
     assert outs["PredImg"].shape == (N, 3, H, W) and outs["FluidImg"].shape == (N, 3, H, W)
     assert outs["CompositeFluidAlpha"].shape == (N, 1, H, W) and outs["BGImg"].shape == (1, 3, H, W)
-    assert torch.equal(outs["PredImg"], an.synthesize(img, m, N))
+    # (two runs agree to rounding noise, not bit for bit: the order of a pixel's records depends on wave timing)
+    assert torch.allclose(outs["PredImg"], an.synthesize(img, m, N), rtol=1e-4, atol=1e-5)
     clip = an.begin_clip(img, m, N)
     f3 = an.frame(clip, 3)
     for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
-        assert torch.equal(outs[k][3], f3[k][0])
+        assert torch.allclose(outs[k][3], f3[k][0], rtol=1e-4, atol=1e-5)
     assert all(bool(torch.isfinite(v).all()) for v in outs.values())
 
 
