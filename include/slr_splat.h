@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 2
+#define SLR_ABI_VERSION 3
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -71,6 +71,15 @@ int slr_euler_integrate(const float *motion, int H, int W, int nsteps, float sig
  *   disp_all [nmax+1,2,H,W] out;  vis_all [nmax+1,H,W] out, may be NULL */
 int slr_euler_integrate_all(const float *motion, int H, int W, int nmax, float sign,
                             float *disp_all, float *vis_all, void *stream);
+
+/* Gradient of slr_euler_integrate w.r.t. the motion field: what torch autograd computes through the reference's
+ * differentiable loop (euler_integration_manipulator.py:36-55; the training path feeds it the motion regressor's
+ * output, animating_softmax_splating.py:515-580).  Each step of a still-valid pixel's path adds the pixel's
+ * displacement gradient to the cell it gathered from (:37-38); pixels that left the image contribute nothing
+ * (:45-46,55).
+ *   grad_disp [2,H,W] in;  grad_motion [2,H,W] out (zeroed here, then accumulated with fp32 atomics) */
+int slr_euler_backward(const float *motion, int H, int W, int nsteps, float sign, const float *grad_disp,
+                       float *grad_motion, void *stream);
 
 /* ------------------------------------------------------------------ splat: binning */
 

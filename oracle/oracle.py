@@ -39,6 +39,8 @@ def lib():
         i = ctypes.c_int
         _LIB.oracle_euler_integrate.argtypes = [_F, i, i, i, _F, _F]
         _LIB.oracle_euler_integrate_all.argtypes = [_F, i, i, i, _F, _F]
+        _LIB.oracle_euler_backward.argtypes = [_F, i, i, i, _F, _F]
+        _LIB.oracle_euler_backward.restype = None
         _LIB.oracle_softsplat_forward.argtypes = [_F, _F, _F, i, i, i, i]
         _LIB.oracle_softsplat_grad_input.argtypes = [_F, _F, _F, i, i, i, i]
         _LIB.oracle_softsplat_grad_flow.argtypes = [_F, _F, _F, _F, i, i, i, i]
@@ -93,6 +95,16 @@ def euler_integration_all(motion, nmax):
     vis = np.empty((nmax + 1, 1, H, W), np.float32)
     lib().oracle_euler_integrate_all(_p(motion), H, W, int(nmax), _p(disp), _p(vis))
     return disp, vis
+
+
+def euler_backward(motion, n, grad_disp):
+    """Gradient of euler_integration(motion, n)[0] w.r.t. motion (torch autograd through
+    euler_integration_manipulator.py:36-55).  motion, grad_disp [1,2,H,W] -> grad_motion [1,2,H,W]."""
+    motion, grad_disp = _c(motion), _c(grad_disp)
+    H, W = motion.shape[2:]
+    gm = np.empty((1, 2, H, W), np.float32)
+    lib().oracle_euler_backward(_p(motion), H, W, int(n), _p(grad_disp), _p(gm))
+    return gm
 
 
 # ----------------------------------------------------------------------------- splat

@@ -74,6 +74,35 @@ ORACLE_API void oracle_euler_integrate(const float *motion, int H, int W, int ns
         }
 }
 
+/* d loss / d motion of euler_integration(motion, n): what torch autograd computes through
+ * euler_integration_manipulator.py:36-55.  The gather `motion[0][:, round(y), round(x)]` (:37-38) is the only
+ * differentiable use of `motion` (the rounded indices carry no gradient), so every step of a pixel's path adds the
+ * pixel's output gradient to the cell it gathered from.  A pixel that goes out of bounds has its coordinate
+ * overwritten with a constant (:45-46) and its final displacement with max(H,W)+1 (:55): no gradient at all.
+ * grad_disp [2,H,W] -> grad_motion [2,H,W] (sequential accumulation in pixel order, then step order). */
+ORACLE_API void oracle_euler_backward(const float *motion, int H, int W, int nsteps,
+                                      const float *grad_disp, float *grad_motion)
+{
+    const size_t HW = (size_t)H * W;
+    const float *mx = motion, *my = motion + HW;
+    memset(grad_motion, 0, 2 * HW * sizeof(float));
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float ox = (float)x, oy = (float)y, px = ox, py = oy;
+            int inv = 0;
+            for (int s = 0; s < nsteps; ++s) euler_step(mx, my, H, W, ox, oy, &px, &py, &inv);
+            if (inv) continue;
+            size_t i = (size_t)y * W + x;
+            px = ox; py = oy;
+            for (int s = 0; s < nsteps; ++s) {
+                size_t g = (size_t)(long)rintf(py) * W + (size_t)(long)rintf(px);
+                grad_motion[g]      += grad_disp[i];
+                grad_motion[HW + g] += grad_disp[HW + i];
+                euler_step(mx, my, H, W, ox, oy, &px, &py, &inv);
+            }
+        }
+}
+
 /* All frames 0..nmax in one pass: disp_all[t] == euler_integration(motion, t)[0],
  * vis_all[t] == ...[1].  The reference's own return_all_frames=True branch is broken
  * (euler_integration_manipulator.py:31,50); this is the equivalent of calling :7-56

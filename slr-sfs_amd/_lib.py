@@ -7,12 +7,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/slr_splat.h declares
 SYMBOLS = (
     "slr_abi_version", "slr_last_error", "slr_splat_time_next",
-    "slr_euler_integrate", "slr_euler_integrate_all",
+    "slr_euler_integrate", "slr_euler_integrate_all", "slr_euler_backward",
     "slr_splat_workspace_bytes", "slr_splat_bin", "slr_splat_bin_pair",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
@@ -63,6 +63,7 @@ def lib():
         sig = {
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
+            "slr_euler_backward": [fp, i, i, i, f, fp, fp, vp],
             "slr_splat_bin": [fp, i, i, i, i, vp, sz, vp],
             "slr_splat_bin_pair": [fp, fp, i, i, i, i, vp, vp, sz, vp],
             "slr_softsplat_forward": [fp, fp, fp, i, i, i, i, vp, sz, i, vp],

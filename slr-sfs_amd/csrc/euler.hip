@@ -72,6 +72,41 @@ __global__ __launch_bounds__(256) void euler_all_kernel(const float *__restrict_
     }
 }
 
+// Backward of euler_kernel w.r.t. the motion field -- what torch autograd computes through the reference's loop
+// (euler_integration_manipulator.py:36-55): the gather at the rounded coordinate (:37-38) is the only differentiable
+// use of `motion`, so each step of a pixel's path receives the pixel's output gradient; a pixel that ever leaves the
+// image has its coordinate and its displacement overwritten with constants (:45-46, :55) -> no gradient.
+// One work-item per pixel: pass 1 finds out whether the path stays valid, pass 2 re-walks it and scatters (global fp32
+// atomics: many paths cross the same cell; training-only path, HBM-atomic-bound, order as unspecified as torch's own
+// index_put_(accumulate=True) backward).
+__global__ __launch_bounds__(256) void euler_backward_kernel(const float *__restrict__ motion, int H, int W, int nsteps,
+                                                             float sign, const float *__restrict__ gdisp,
+                                                             float *__restrict__ gmotion) {
+    const int HW = H * W;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float *mx = motion, *my = motion + HW;
+    const int y = i / W, x = i - y * W;
+    const float ox = (float)x, oy = (float)y;
+    float px = ox, py = oy;
+    bool inv = false;
+    for (int s = 0; s < nsteps && !inv; ++s) euler_step(mx, my, H, W, sign, ox, oy, px, py, inv);
+    if (inv) return;
+    const float gx = sign * gdisp[i], gy = sign * gdisp[HW + i];
+    px = ox; py = oy;
+    for (int s = 0; s < nsteps; ++s) {
+        const int g = (int)rintf(py) * W + (int)rintf(px);
+        atomicAdd(&gmotion[g], gx);
+        atomicAdd(&gmotion[HW + g], gy);
+        euler_step(mx, my, H, W, sign, ox, oy, px, py, inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_f32_kernel(float *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+
 }  // namespace slr
 
 SLR_EXPORT int slr_euler_integrate(const float *motion, int H, int W, int nsteps, float sign,
@@ -96,6 +131,21 @@ SLR_EXPORT int slr_euler_integrate_all(const float *motion, int H, int W, int nm
     int blocks = (H * W + 255) / 256;
     hipLaunchKernelGGL(slr::euler_all_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        motion, H, W, nmax, sign, disp_all, vis_all);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_euler_backward(const float *motion, int H, int W, int nsteps, float sign, const float *grad_disp,
+                                  float *grad_motion, void *stream) {
+    SLR_CHECK_ARG(motion && grad_disp && grad_motion, "null pointer");
+    SLR_CHECK_ARG(H > 0 && W > 0 && nsteps >= 0, "sizes");
+    SLR_CHECK_ARG((long long)H * W < (1LL << 30), "H*W too large");
+    SLR_CHECK_ARG(sign == 1.0f || sign == -1.0f, "sign must be +1 or -1");
+    const int blocks = (H * W + 255) / 256;
+    hipLaunchKernelGGL(slr::zero_f32_kernel, dim3(2 * blocks), dim3(256), 0, (hipStream_t)stream, grad_motion,
+                       (size_t)2 * H * W);
+    hipLaunchKernelGGL(slr::euler_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, motion, H, W, nsteps,
+                       sign, grad_disp, grad_motion);
     SLR_CHECK_LAUNCH();
     return 0;
 }

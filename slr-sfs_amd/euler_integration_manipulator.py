@@ -37,6 +37,15 @@ def euler_integration(motion, destination_frame, return_all_frames=False):
         return euler_integration_all(motion, n)
     motion = motion.contiguous()
     require_device(motion)
+    if torch.is_grad_enabled() and motion.requires_grad:
+        # joint training feeds the motion regressor's output through here (animating_softmax_splating.py:515-580):
+        # the reference's loop is differentiable w.r.t. `motion`, so is this
+        return _EulerIntegrate.apply(motion, n)
+    return _integrate(motion, n)
+
+
+def _integrate(motion, n):
+    _, _, height, width = motion.shape
     disp = torch.empty_like(motion)
     vis = motion.new_empty(1, 1, height, width)
     with torch.cuda.device(motion.device):
@@ -45,10 +54,39 @@ def euler_integration(motion, destination_frame, return_all_frames=False):
     return disp, vis
 
 
+class _EulerIntegrate(torch.autograd.Function):
+    """euler_integration with the gradient torch autograd derives from the reference's loop (:36-55): every step of
+    a pixel that stays inside the image passes the pixel's displacement gradient to the motion cell it gathered
+    from; pixels that left the image (constant displacement, :55) and `visible_pixels` carry none."""
+
+    @staticmethod
+    def forward(ctx, motion, n):
+        ctx.save_for_backward(motion)
+        ctx.n = n
+        disp, vis = _integrate(motion, n)
+        ctx.mark_non_differentiable(vis)
+        return disp, vis
+
+    @staticmethod
+    def backward(ctx, grad_disp, _grad_vis):
+        motion, = ctx.saved_tensors
+        grad_disp = grad_disp.contiguous()
+        require_device(grad_disp)
+        _, _, height, width = motion.shape
+        grad_motion = torch.empty_like(motion)
+        with torch.cuda.device(motion.device):
+            check(lib().slr_euler_backward(ptr(motion), height, width, ctx.n, 1.0, ptr(grad_disp), ptr(grad_motion),
+                                           stream_of(motion)), "slr_euler_backward")
+        return grad_motion, None
+
+
 def euler_integration_all(motion, nmax, sign=1.0, want_visible=True):
     """Displacement maps to every frame t = 0..nmax in one pass:
     out[t] == euler_integration(sign*motion, t).  -> ([nmax+1,2,H,W], [nmax+1,1,H,W] or None)"""
     assert motion.dim() == 4 and motion.shape[0] == 1 and motion.shape[1] == 2
+    if torch.is_grad_enabled() and motion.requires_grad:
+        raise RuntimeError("euler_integration_all has no backward (inference pipeline); use euler_integration per "
+                           "frame when gradients w.r.t. the motion field are needed")
     motion = motion.contiguous()
     require_device(motion)
     _, _, H, W = motion.shape

@@ -28,7 +28,8 @@ def test_header_symbols_exported(L):
     raw = ctypes.CDLL(slr_sfs_amd._lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert L.slr_abi_version() == slr_sfs_amd._lib.ABI_VERSION == 2
+    m = re.search(r"#define\s+SLR_ABI_VERSION\s+(\d+)", hdr)
+    assert L.slr_abi_version() == slr_sfs_amd._lib.ABI_VERSION == int(m.group(1))
 
 
 def test_workspace_size_and_argument_errors(L):

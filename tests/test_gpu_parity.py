@@ -98,6 +98,30 @@ def test_euler_full_size_vs_oracle(S, oracle):
     assert np.array_equal(host(dn)[0], host(dn2)[17])
 
 
+def test_euler_backward_golden_and_oracle(S, oracle, golden_dir):
+    """The drop-in euler_integration is differentiable w.r.t. the motion field like the reference's loop
+    (euler_integration_manipulator.py:36-55): gradients vs torch autograd through the REFERENCE (golden), vs the
+    oracle on a larger field, through EulerIntegration too; visible_pixels carries no gradient."""
+    g = load(golden_dir, "euler_grad")
+    for i in range(int(g["count"])):
+        m = dev(g[f"c{i}_motion"]).requires_grad_(True)
+        d, v = S.euler_integration(m, int(g[f"c{i}_n"]))
+        assert d.requires_grad and not v.requires_grad
+        (gm,) = torch.autograd.grad(d, m, dev(g[f"c{i}_gout"]))
+        np.testing.assert_allclose(host(gm), g[f"c{i}_gmotion"], rtol=1e-5, atol=1e-5, err_msg=str(g[f"c{i}_tag"]))
+    H, W, n = 96, 160, 23
+    mo = smooth_motion(H, W, 7, amp=2.0)
+    go = np.random.default_rng(3).standard_normal((1, 2, H, W)).astype(np.float32)
+    m = dev(mo).requires_grad_(True)
+    d = S.EulerIntegration()(m, torch.tensor([n]))
+    d.backward(dev(go))
+    np.testing.assert_allclose(host(m.grad), oracle.euler_backward(mo, n, go), rtol=1e-4, atol=1e-4)
+    with torch.no_grad():                                     # inference path unchanged: no graph
+        assert not S.euler_integration(m, n)[0].requires_grad
+    with pytest.raises(RuntimeError):
+        S.euler_integration_all(m, n)
+
+
 def test_euler_asserts(S):
     with pytest.raises(AssertionError):
         S.euler_integration(torch.zeros(2, 2, 4, 4).cuda(), 1)        # batch must be 1 (:20)

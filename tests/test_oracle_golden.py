@@ -142,3 +142,12 @@ def test_forward_flow_decoder_input_full_size_digests(oracle, golden_dir, tag, t
     abg = (1.0 / (1.0 + np.exp(-a[:, 0:1]))).astype(np.float32)
     gen, afl, _ = oracle.synth_v1(fs, Z, a[:, 1:2], abg, motion, t, N)
     check_a6_digest(g, tag, "v1", t, gen, afl)
+
+
+def test_euler_backward_vs_reference_autograd(oracle, golden_dir):
+    """d euler_integration / d motion: the oracle's restatement vs torch autograd through the reference's own loop
+    (tests/golden/euler_grad.npz).  Accumulation order differs (index_put backward), hence 1e-5."""
+    g = _load(golden_dir, "euler_grad")
+    for i in range(int(g["count"])):
+        gm = oracle.euler_backward(g[f"c{i}_motion"], int(g[f"c{i}_n"]), g[f"c{i}_gout"])
+        np.testing.assert_allclose(gm, g[f"c{i}_gmotion"], rtol=1e-5, atol=1e-5, err_msg=str(g[f"c{i}_tag"]))

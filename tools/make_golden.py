@@ -225,6 +225,28 @@ def main():
     m1["count"] = np.int32(idx)
     np.savez_compressed(os.path.join(OUT, "splat_max.npz"), **m1)
 
+    # ---- E2: gradient of euler_integration w.r.t. the motion field (torch autograd through the reference's loop,
+    # euler_integration_manipulator.py:36-55; the joint-training path, animating_softmax_splating.py:515-580)
+    e2 = {}
+    rg = np.random.default_rng(31)
+    idx = 0
+    for (H, W) in ((16, 24), (33, 47)):
+        fields = motion_fields(H, W, rg)
+        for fname in ("smooth", "random3", "exit"):
+            for n in (1, 5, 17):
+                m = torch.from_numpy(fields[fname]).clone().requires_grad_(True)
+                disp, vis = eim.euler_integration(m, n)
+                gout = torch.from_numpy(rg.standard_normal((1, 2, H, W)).astype(np.float32))
+                (gm,) = torch.autograd.grad(disp, m, gout)
+                e2[f"c{idx}_motion"] = fields[fname]
+                e2[f"c{idx}_n"] = np.int32(n)
+                e2[f"c{idx}_gout"] = gout.numpy()
+                e2[f"c{idx}_gmotion"] = gm.numpy().astype(np.float32)
+                e2[f"c{idx}_tag"] = np.array(f"{fname}_{H}x{W}_n{n}")
+                idx += 1
+    e2["count"] = np.int32(idx)
+    np.savez_compressed(os.path.join(OUT, "euler_grad.npz"), **e2)
+
     # ---- L1: full-size digests (config C3 grid 768x1280; C2 grid 256x480) ------------------
     # inputs are regenerated from seeds by the tests; only digests of the reference's outputs are stored
     l1 = {}
