@@ -138,6 +138,26 @@ int slr_synth_group(const float *values, const float *wlogit, const float *wmax,
                     float *out, float *norm_out, int C, int H, int W, float eps,
                     void *ws_f, void *ws_p, size_t ws_bytes, void *stream);
 
+/* ---- clip plans: all frames of a clip binned and planned by one set of launches ----
+ * forward_flow integrates and splats per frame (animating_softmax_splating.py:847-848,884-921); every displacement
+ * map of a clip exists before its first frame (slr_euler_integrate_all), and binning is latency-bound, so the 2 x n
+ * maps of n frames are binned (count, scan, fill) and planned by ONE launch each instead of n x 6 launches.
+ * Frame i uses disp_f[idx_f[i]] and disp_p[idx_p[i]] (idx_*: DEVICE int arrays; for frame t of an N-frame clip
+ * idx_f = t, idx_p = N - t).  8*nframes*H*W must stay below 2^32 (plan longer clips in chunks).
+ * slr_clip_plan_totals: where the per-frame totals sit inside the plan buffer (stride_words uint32 per frame:
+ * [0] work items, [3] multi-segment tiles, [4] whole-tile items) -- read them back once per clip to pass exact
+ * grids to slr_synth_group_clip (n_items / n_multi / n_whole; -1 = unknown: upper-bound grids, surplus exits). */
+size_t slr_clip_plan_bytes(int nframes, int H, int W);
+size_t slr_splat_scratch_bytes(int C, int H, int W);      /* partial-tile scratch of one slr_synth_group_clip call */
+int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words);
+int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp_p, const int *idx_p, int nframes,
+                        int H, int W, void *plan, size_t plan_bytes, void *stream);
+/* slr_synth_group for frame `frame` of a built clip plan (disp_f / disp_p: that frame's two maps). */
+int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                         const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
+                         int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes, int frame,
+                         void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole, void *stream);
+
 /* Global max of a tensor (Z.max(), animating_softmax_splating.py:855) -> result[0].
  * scratch: 1024 floats of device memory. */
 int slr_global_max(const float *x, size_t n, float *result, float *scratch, void *stream);

@@ -16,6 +16,7 @@ SYMBOLS = (
     "slr_splat_workspace_bytes", "slr_splat_bin", "slr_splat_bin_pair",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
+    "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
@@ -56,6 +57,10 @@ def lib():
         L.slr_splat_time_next.argtypes = [vp, vp]
         L.slr_splat_workspace_bytes.restype = sz
         L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
+        L.slr_clip_plan_bytes.restype = sz
+        L.slr_clip_plan_bytes.argtypes = [i, i, i]
+        L.slr_splat_scratch_bytes.restype = sz
+        L.slr_splat_scratch_bytes.argtypes = [i, i, i]
         L.slr_conv3x3_weight_bytes.restype = sz
         L.slr_conv3x3_weight_bytes.argtypes = [i, i]
         L.slr_conv1x1_weight_bytes.restype = sz
@@ -71,6 +76,9 @@ def lib():
             "slr_splat_normalize": [fp, fp, i, i, i, i, i, f, vp],
             "slr_synth_group": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, vp, sz, vp],
             "slr_global_max": [fp, sz, fp, fp, vp],
+            "slr_clip_plan_totals": [i, i, i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)],
+            "slr_clip_plan_build": [fp, vp, fp, vp, i, i, i, vp, sz, vp],
+            "slr_synth_group_clip": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, sz, i, i, vp, sz, i, i, i, vp],
             "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],

@@ -107,13 +107,10 @@ __global__ __launch_bounds__(256) void zero_counts_kernel(BinSet b, uint32_t nt)
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int tiles_x, int tiles) {
-    const float *__restrict__ flow = b.flow[blockIdx.z];
-    uint32_t *__restrict__ counter = FILL ? b.cursor[blockIdx.z] : b.count[blockIdx.z];
-    const uint32_t *__restrict__ listoff = b.listoff[blockIdx.z];
-    uint32_t *__restrict__ list = b.list[blockIdx.z];
+__device__ __forceinline__ void bin_body(const float *__restrict__ flow, uint32_t *__restrict__ counter,
+                                         const uint32_t *__restrict__ listoff, uint32_t *__restrict__ list,
+                                         int n, int H, int W, int tiles_x, int tiles) {
     const int HW = H * W;
-    const int n = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const float *f = flow + (size_t)n * 2 * HW;
     const int tb = n * tiles;
@@ -167,6 +164,39 @@ __global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int ti
         }
 }
 
+template <bool FILL>
+__global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int tiles_x, int tiles) {
+    bin_body<FILL>(b.flow[blockIdx.z], FILL ? b.cursor[blockIdx.z] : b.count[blockIdx.z], b.listoff[blockIdx.z],
+                   b.list[blockIdx.z], blockIdx.y, H, W, tiles_x, tiles);
+}
+
+// ---- a whole clip at once ---------------------------------------------------------------------------------------
+// All displacement maps of a clip exist before its first frame (one all-frames Euler pass per direction), and the
+// binning kernels are latency-bound (flow load -> footprint -> reservation atomic -> list store): binning the 2 x n
+// maps of n frames in ONE launch each (count, scan, fill) costs about what a handful of per-frame launches cost.
+// Map m = d * nframes + i is the direction-d map of frame i: disp[d] + idx[d][i] * 2*H*W.  Per map: count[nt],
+// cursor[nt], listoff[nt + 1] (local exclusive prefix), mapbase[m] = where the map's lists start in the shared list
+// array (a second scan over the map totals): the lists of all maps are packed back to back.
+struct ClipMaps {
+    const float *disp[2];        // [*, 2, H, W] displacement maps of the two directions
+    const int *idx[2];           // [nframes] device arrays: which map of disp[d] frame i uses
+    uint32_t *count, *cursor, *listoff, *mapbase, *list;
+    uint32_t nframes, nt;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bin_clip_kernel(ClipMaps c, int H, int W, int tiles_x, int tiles) {
+    const uint32_t m = blockIdx.z, d = m >= c.nframes ? 1u : 0u, i = m - d * c.nframes;
+    const float *flow = c.disp[d] + (size_t)c.idx[d][i] * 2 * H * W;
+    bin_body<FILL>(flow, (FILL ? c.cursor : c.count) + (size_t)m * c.nt, c.listoff + (size_t)m * (c.nt + 1),
+                   FILL ? c.list + c.mapbase[m] : nullptr, 0, H, W, tiles_x, tiles);
+}
+
+__global__ __launch_bounds__(256) void zero_u32_kernel(uint32_t *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 // Block-wide exclusive scan helper (1024 threads), returns the block total.
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *excl, uint32_t *wsum /*[16]*/) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -207,6 +237,41 @@ __global__ __launch_bounds__(1024) void offsets_kernel(BinSet b, uint32_t nt) {
     if (threadIdx.x == 0) listoff[nt] = run;
 }
 
+// One workgroup per map: local exclusive prefix of its tile counts, zeroed cursors, and the map's total.
+__global__ __launch_bounds__(1024) void offsets_clip_kernel(ClipMaps c, uint32_t *__restrict__ maptotal) {
+    const uint32_t m = blockIdx.x, nt = c.nt;
+    const uint32_t *__restrict__ count = c.count + (size_t)m * nt;
+    uint32_t *__restrict__ listoff = c.listoff + (size_t)m * (nt + 1);
+    uint32_t *__restrict__ cursor = c.cursor + (size_t)m * nt;
+    __shared__ uint32_t wsum[16];
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < nt; b0 += 1024) {
+        uint32_t t = b0 + threadIdx.x;
+        uint32_t v = t < nt ? count[t] : 0;
+        uint32_t ex;
+        uint32_t tot = block_exscan(v, &ex, wsum);
+        if (t < nt) { listoff[t] = run + ex; cursor[t] = 0; }
+        run += tot;
+    }
+    if (threadIdx.x == 0) { listoff[nt] = run; maptotal[m] = run; }
+}
+
+// mapbase = exclusive prefix of the map totals (single workgroup; mapbase[nmaps] = all entries of the clip).
+__global__ __launch_bounds__(1024) void mapbase_kernel(const uint32_t *__restrict__ maptotal, uint32_t *__restrict__ mapbase,
+                                                       uint32_t nmaps) {
+    __shared__ uint32_t wsum[16];
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < nmaps; b0 += 1024) {
+        uint32_t m = b0 + threadIdx.x;
+        uint32_t v = m < nmaps ? maptotal[m] : 0;
+        uint32_t ex;
+        uint32_t tot = block_exscan(v, &ex, wsum);
+        if (m < nmaps) mapbase[m] = run + ex;
+        run += tot;
+    }
+    if (threadIdx.x == 0) mapbase[nmaps] = run;
+}
+
 // Everything a tile workgroup needs to know about its work item, in ONE 32-byte record (one scalar
 // load instead of a chain of dependent lookups through items -> count/listoff/nseg/partoff).
 struct ItemDesc {
@@ -231,15 +296,16 @@ constexpr uint32_t PLAN_SX = 4, PLAN_SY = SLR_PLAN_SY;   // super-tile of the wo
 // nseg[t] = segments of the concatenated bin, items[] = (tile, segment) work list, partoff[t] =
 // first partial slot of a multi-segment tile.  A tile that does not fit into the partial
 // budget is left in one piece (correct, just slower).  Single workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ count0,
-                                                    const uint32_t *__restrict__ count1,
-                                                    const uint32_t *__restrict__ listoff0,
-                                                    const uint32_t *__restrict__ listoff1, uint32_t nt,
-                                                    uint32_t tiles_x, uint32_t tiles_y,
-                                                    uint32_t seg, uint32_t part_slots,
-                                                    uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
-                                                    ItemDesc *__restrict__ items, uint32_t *__restrict__ multi,
-                                                    uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals) {
+// (base0 / base1: where the two bins' lists start in list[0] / list[1], added to ItemDesc.off0 / off1)
+__device__ __forceinline__ void plan_body(const uint32_t *__restrict__ count0,
+                                          const uint32_t *__restrict__ count1,
+                                          const uint32_t *__restrict__ listoff0,
+                                          const uint32_t *__restrict__ listoff1, uint32_t base0, uint32_t base1, uint32_t nt,
+                                          uint32_t tiles_x, uint32_t tiles_y,
+                                          uint32_t seg, uint32_t part_slots,
+                                          uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
+                                          ItemDesc *__restrict__ items, uint32_t *__restrict__ multi,
+                                          uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals) {
     __shared__ uint32_t wsum[16];
     uint32_t run_items = 0, run_parts = 0, run_multi = 0, run_whole = 0;
     // Work items are emitted in the order of "super-tiles" of PLAN_SY x PLAN_SX tiles (not row-major):
@@ -281,7 +347,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
             partoff[t] = run_parts + pex;
             ItemDesc d;
             d.tile = t; d.cnt0 = count0[t]; d.cnt1 = count1 ? count1[t] : 0u;
-            d.off0 = listoff0[t]; d.off1 = listoff1 ? listoff1[t] : 0u;
+            d.off0 = base0 + listoff0[t]; d.off1 = listoff1 ? base1 + listoff1[t] : 0u;
             d.nseg = whole ? 0u : ns; d.partoff = run_parts + pex;
             for (uint32_t s = 0; s < ns; ++s) { d.seg = s; items[run_items + iex + s] = d; }
         }
@@ -289,6 +355,36 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         run_parts += ptot;
     }
     if (threadIdx.x == 0) { totals[0] = run_items; totals[1] = run_parts; totals[3] = run_multi; totals[4] = run_whole; }
+}
+
+__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ count0,
+                                                    const uint32_t *__restrict__ count1,
+                                                    const uint32_t *__restrict__ listoff0,
+                                                    const uint32_t *__restrict__ listoff1, uint32_t nt,
+                                                    uint32_t tiles_x, uint32_t tiles_y,
+                                                    uint32_t seg, uint32_t part_slots,
+                                                    uint32_t *__restrict__ nseg, uint32_t *__restrict__ partoff,
+                                                    ItemDesc *__restrict__ items, uint32_t *__restrict__ multi,
+                                                    uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals) {
+    plan_body(count0, count1, listoff0, listoff1, 0u, 0u, nt, tiles_x, tiles_y, seg, part_slots, nseg, partoff, items, multi,
+              whole_items, totals);
+}
+
+// The work plans of all frames of a clip in one launch: workgroup i plans frame i (its forward + backward bins).
+struct ClipPlan {
+    uint32_t *nseg, *partoff, *multi, *whole_items, *totals;      // [nframes][nt] ... totals [nframes][CLIP_TOTALS]
+    ItemDesc *items;                                               // [nframes][items_cap]
+    uint32_t items_cap, part_slots;
+};
+constexpr uint32_t CLIP_TOTALS = 8;
+
+__global__ __launch_bounds__(1024) void plan_clip_kernel(ClipMaps c, ClipPlan p, uint32_t tiles_x, uint32_t tiles_y,
+                                                         uint32_t seg) {
+    const uint32_t i = blockIdx.x, nt = c.nt, m0 = i, m1 = c.nframes + i;
+    plan_body(c.count + (size_t)m0 * nt, c.count + (size_t)m1 * nt, c.listoff + (size_t)m0 * (nt + 1),
+              c.listoff + (size_t)m1 * (nt + 1), c.mapbase[m0], c.mapbase[m1], nt, tiles_x, tiles_y, seg, p.part_slots,
+              p.nseg + (size_t)i * nt, p.partoff + (size_t)i * nt, p.items + (size_t)i * p.items_cap,
+              p.multi + (size_t)i * nt, p.whole_items + (size_t)i * nt, p.totals + (size_t)i * CLIP_TOTALS);
 }
 
 // =========================================================================== splat
@@ -910,18 +1006,47 @@ static int launch_tile_variant(const SplatArgs &a, uint32_t grid, size_t lds, hi
     return 0;
 }
 
+// n_items / n_whole: what the plan holds, when the host knows it (a clip plan's totals read back once per clip);
+// < 0 = unknown -> the grid covers the upper bound and surplus workgroups exit at once.
 template <bool NORM, bool MAXOP, int EPT, int CHUNK>
-static int launch_tile(const SplatArgs &a, uint32_t items_cap, uint32_t nt, hipStream_t st) {
+static int launch_tile(const SplatArgs &a, uint32_t items_cap, uint32_t nt, int n_items, int n_whole, hipStream_t st) {
     // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
     const size_t lds = (size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
                        (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;     // + the all-zero NULL entry
-    const uint32_t grid = ((items_cap + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+    const uint32_t cover = n_items >= 0 && (uint32_t)n_items < items_cap ? (uint32_t)n_items : items_cap;
+    const uint32_t grid = ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
-    if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(a, grid, lds, st)) return e;
+    if (grid)
+        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(a, grid, lds, st)) return e;
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));         // the dominant kernel only
     g_ev_start = g_ev_stop = nullptr;                                                // one-shot
     // tiles that did not fit the partial-slot budget (none for ordinary flows: the workgroups exit at once)
-    return launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(a, nt < 256u ? nt : 256u, lds, st);
+    if (n_whole == 0) return 0;
+    const uint32_t wg = n_whole > 0 ? (uint32_t)n_whole : nt;
+    return launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(a, wg < 256u ? wg : 256u, lds, st);
+}
+
+// tile kernel(s) + combine for a plan that is already in `a`.
+template <bool NORM, bool MAXOP>
+static int run_plan(SplatArgs &a, bool two_flows, uint32_t items_cap, uint32_t nt, uint32_t part_slots, int n_items,
+                    int n_multi, int n_whole, hipStream_t st) {
+    a.ndir = two_flows ? 2 : 1;
+    a.seg = two_flows ? SEG_TWO : SEG_ONE;
+#ifdef SLR_TRACE
+    a.trace = g_trace;
+#endif
+    if (two_flows) {
+        if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, items_cap, nt, n_items, n_whole, st)) return e;
+    } else {
+        if (int e = launch_tile<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(a, items_cap, nt, n_items, n_whole, st)) return e;
+    }
+    // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
+    if (n_multi != 0)
+        hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>),
+                           dim3(n_multi > 0 ? (uint32_t)n_multi : part_slots / 2, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
+                           dim3(SPLAT_THREADS), 0, st, a);
+    SLR_CHECK_LAUNCH();
+    return 0;
 }
 
 // plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
@@ -929,31 +1054,62 @@ template <bool NORM, bool MAXOP>
 static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     a.tiles_x = w0.L.tiles_x;
     a.tiles = w0.L.tiles;
-    a.ndir = w1 ? 2 : 1;
-    a.seg = w1 ? SEG_TWO : SEG_ONE;
     a.count[0] = w0.count; a.listoff[0] = w0.listoff; a.list[0] = w0.list;
     a.count[1] = w1 ? w1->count : nullptr; a.listoff[1] = w1 ? w1->listoff : nullptr; a.list[1] = w1 ? w1->list : nullptr;
     a.nseg = w0.nseg; a.partoff = w0.partoff; a.items = w0.items; a.totals = w0.totals; a.multi = w0.multi; a.whole_items = w0.whole_items;
     a.partial = w0.partial;
     a.trash = w0.trash;
-#ifdef SLR_TRACE
-    a.trace = g_trace;
-#endif
     a.part_stride = w0.L.part_stride;
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)w0.count,
                        (const uint32_t *)(w1 ? w1->count : nullptr), (const uint32_t *)w0.listoff,
                        (const uint32_t *)(w1 ? w1->listoff : nullptr), w0.L.nt, (uint32_t)w0.L.tiles_x,
-                       (uint32_t)w0.L.tiles_y, (uint32_t)a.seg,
+                       (uint32_t)w0.L.tiles_y, (uint32_t)(w1 ? SEG_TWO : SEG_ONE),
                        w0.L.part_slots, w0.nseg, w0.partoff, w0.items, w0.multi, w0.whole_items, w0.totals);
-    if (w1) {
-        if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, w0.L.items_cap, w0.L.nt, st)) return e;
-    } else {
-        if (int e = launch_tile<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(a, w0.L.items_cap, w0.L.nt, st)) return e;
+    return run_plan<NORM, MAXOP>(a, w1 != nullptr, w0.L.items_cap, w0.L.nt, w0.L.part_slots, -1, -1, -1, st);
+}
+
+// ---- clip plans (all frames of a clip binned and planned by one set of launches) ---------------------------------
+struct ClipLayout {
+    int tiles_x, tiles_y, tiles;
+    uint32_t nt, nframes, nmaps, part_slots, items_cap;
+    size_t off_count, off_cursor, off_listoff, off_maptotal, off_mapbase, off_nseg, off_partoff, off_multi, off_whole,
+        off_items, off_totals, off_list, total;
+};
+
+static ClipLayout clip_layout(int nframes, int H, int W) {
+    ClipLayout L;
+    L.tiles_x = (W + TILE_W - 1) / TILE_W;
+    L.tiles_y = (H + TILE_H - 1) / TILE_H;
+    L.tiles = L.tiles_x * L.tiles_y;
+    L.nt = (uint32_t)L.tiles;
+    L.nframes = (uint32_t)nframes;
+    L.nmaps = 2u * L.nframes;
+    L.part_slots = L.nt < 64 ? 64 : L.nt;
+    L.items_cap = L.nt + L.part_slots;
+    size_t o = 0;
+    L.off_count = o;    o += al256((size_t)L.nmaps * L.nt * 4);
+    L.off_cursor = o;   o += al256((size_t)L.nmaps * L.nt * 4);
+    L.off_listoff = o;  o += al256((size_t)L.nmaps * (L.nt + 1) * 4);
+    L.off_maptotal = o; o += al256((size_t)L.nmaps * 4);
+    L.off_mapbase = o;  o += al256(((size_t)L.nmaps + 1) * 4);
+    L.off_nseg = o;     o += al256((size_t)L.nframes * L.nt * 4);
+    L.off_partoff = o;  o += al256((size_t)L.nframes * L.nt * 4);
+    L.off_multi = o;    o += al256((size_t)L.nframes * L.nt * 4);
+    L.off_whole = o;    o += al256((size_t)L.nframes * L.nt * 4);
+    L.off_items = o;    o += al256((size_t)L.nframes * L.items_cap * sizeof(ItemDesc));
+    L.off_totals = o;   o += al256((size_t)L.nframes * CLIP_TOTALS * 4);
+    L.off_list = o;     o += al256((size_t)4 * H * W * L.nmaps * 4);        // worst case: 4 bins per source pixel
+    L.total = o;
+    return L;
+}
+
+static int clip_check(int nframes, int H, int W, const char *who) {
+    // list offsets are 32-bit: 4 entries per source pixel and map must stay below 2^32 (plan longer clips in chunks)
+    if (nframes <= 0 || H <= 0 || W <= 0 || (long long)H * W >= (1LL << 29) ||
+        (long long)8 * nframes * H * W >= (1LL << 32)) {
+        set_error("%s: bad sizes nframes=%d H=%d W=%d (8*nframes*H*W must stay below 2^32)", who, nframes, H, W);
+        return SLR_E_BADARG;
     }
-    // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
-    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(w0.L.part_slots / 2, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
-                       dim3(SPLAT_THREADS), 0, st, a);
-    SLR_CHECK_LAUNCH();
     return 0;
 }
 
@@ -1090,4 +1246,107 @@ SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *o
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out; a.init = init;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
     return do_splat<false, true>(a, w, nullptr, st);
+}
+
+// ------------------------------------------------------------------------------------------ clip plans (C ABI)
+
+SLR_EXPORT size_t slr_clip_plan_bytes(int nframes, int H, int W) {
+    if (nframes <= 0 || H <= 0 || W <= 0 || (long long)8 * nframes * H * W >= (1LL << 32)) return 0;
+    return clip_layout(nframes, H, W).total;
+}
+
+SLR_EXPORT size_t slr_splat_scratch_bytes(int C, int H, int W) {
+    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    const ClipLayout L = clip_layout(1, H, W);
+    const size_t stride = (size_t)(C + 1) * TILE_PIX * 4;
+    return al256(stride) + al256((size_t)L.part_slots * stride);
+}
+
+SLR_EXPORT int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words) {
+    if (int e = clip_check(nframes, H, W, __func__)) return e;
+    SLR_CHECK_ARG(offset_bytes && stride_words, "null pointer");
+    *offset_bytes = clip_layout(nframes, H, W).off_totals;
+    *stride_words = (int)CLIP_TOTALS;
+    return 0;
+}
+
+SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp_p, const int *idx_p, int nframes,
+                                   int H, int W, void *plan, size_t plan_bytes, void *stream) {
+    SLR_CHECK_ARG(disp_f && idx_f && disp_p && idx_p && plan, "null pointer");
+    if (int e = clip_check(nframes, H, W, __func__)) return e;
+    const ClipLayout L = clip_layout(nframes, H, W);
+    if (((uintptr_t)plan & 15) || plan_bytes < L.total) {
+        set_error("%s: plan buffer needs %zu bytes (16-byte aligned), got %zu", __func__, L.total, plan_bytes);
+        return SLR_E_WORKSPACE;
+    }
+    char *b = (char *)plan;
+    hipStream_t st = (hipStream_t)stream;
+    ClipMaps c = {};
+    c.disp[0] = disp_f; c.disp[1] = disp_p; c.idx[0] = idx_f; c.idx[1] = idx_p;
+    c.count = (uint32_t *)(b + L.off_count); c.cursor = (uint32_t *)(b + L.off_cursor);
+    c.listoff = (uint32_t *)(b + L.off_listoff); c.mapbase = (uint32_t *)(b + L.off_mapbase);
+    c.list = (uint32_t *)(b + L.off_list);
+    c.nframes = L.nframes; c.nt = L.nt;
+    uint32_t *maptotal = (uint32_t *)(b + L.off_maptotal);
+    ClipPlan p = {};
+    p.nseg = (uint32_t *)(b + L.off_nseg); p.partoff = (uint32_t *)(b + L.off_partoff);
+    p.multi = (uint32_t *)(b + L.off_multi); p.whole_items = (uint32_t *)(b + L.off_whole);
+    p.totals = (uint32_t *)(b + L.off_totals); p.items = (ItemDesc *)(b + L.off_items);
+    p.items_cap = L.items_cap; p.part_slots = L.part_slots;
+    const size_t ncount = (size_t)L.nmaps * L.nt;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ncount + 255) / 256)), dim3(256), 0, st, c.count, ncount);
+    // blockIdx.z carries the map: at most 65535 maps per launch (the 2^32 entry bound above is far tighter)
+    const dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), 1, L.nmaps);
+    hipLaunchKernelGGL(bin_clip_kernel<false>, grid, dim3(256), 0, st, c, H, W, L.tiles_x, L.tiles);
+    hipLaunchKernelGGL(offsets_clip_kernel, dim3(L.nmaps), dim3(1024), 0, st, c, maptotal);
+    hipLaunchKernelGGL(mapbase_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)maptotal, c.mapbase, L.nmaps);
+    hipLaunchKernelGGL(bin_clip_kernel<true>, grid, dim3(256), 0, st, c, H, W, L.tiles_x, L.tiles);
+    hipLaunchKernelGGL(plan_clip_kernel, dim3(L.nframes), dim3(1024), 0, st, c, p, (uint32_t)L.tiles_x, (uint32_t)L.tiles_y,
+                       (uint32_t)SEG_TWO);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                                    const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
+                                    int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes,
+                                    int frame, void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole,
+                                    void *stream) {
+    SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && out && plan && scratch, "null pointer");
+    if (int e = check_dims(1, C, H, W, __func__)) return e;
+    if (int e = clip_check(nframes, H, W, __func__)) return e;
+    SLR_CHECK_ARG(frame >= 0 && frame < nframes, "frame index");
+    const ClipLayout L = clip_layout(nframes, H, W);
+    const size_t stride = (size_t)(C + 1) * TILE_PIX;
+    const size_t need = al256(stride * 4) + al256((size_t)L.part_slots * stride * 4);
+    if (((uintptr_t)plan & 15) || plan_bytes < L.total || ((uintptr_t)scratch & 15) || scratch_bytes < need) {
+        set_error("%s: plan needs %zu bytes (got %zu), scratch %zu (got %zu), both 16-byte aligned", __func__, L.total,
+                  plan_bytes, need, scratch_bytes);
+        return SLR_E_WORKSPACE;
+    }
+    const char *b = (const char *)plan;
+    const size_t i = (size_t)frame;
+    SplatArgs a = {};
+    a.in = values; a.mul = wlogit; a.mulmax = wmax;
+    a.flow[0] = disp_f; a.flow[1] = disp_p;
+    a.scale[0] = alpha; a.scale[1] = 1.0f - alpha;
+    a.out = out; a.norm_out = norm_out;
+    a.N = 1; a.C = C; a.H = H; a.W = W;
+    a.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
+    a.norm_mode = SLR_NORM_CLAMP_EPS;
+    a.eps = eps;
+    a.tiles_x = L.tiles_x; a.tiles = L.tiles;
+    a.count[0] = (const uint32_t *)(b + L.off_count) + i * L.nt;
+    a.count[1] = (const uint32_t *)(b + L.off_count) + ((size_t)L.nframes + i) * L.nt;
+    a.list[0] = a.list[1] = (const uint32_t *)(b + L.off_list);       // ItemDesc.off0 / off1 are absolute (mapbase included)
+    a.nseg = (const uint32_t *)(b + L.off_nseg) + i * L.nt;
+    a.partoff = (const uint32_t *)(b + L.off_partoff) + i * L.nt;
+    a.multi = (const uint32_t *)(b + L.off_multi) + i * L.nt;
+    a.whole_items = (const uint32_t *)(b + L.off_whole) + i * L.nt;
+    a.items = (const ItemDesc *)(b + L.off_items) + i * L.items_cap;
+    a.totals = (const uint32_t *)(b + L.off_totals) + i * CLIP_TOTALS;
+    a.trash = (float *)scratch;
+    a.partial = (float *)((char *)scratch + al256(stride * 4));
+    a.part_stride = stride;
+    return run_plan<true, false>(a, true, L.items_cap, L.nt, L.part_slots, n_items, n_multi, n_whole, (hipStream_t)stream);
 }

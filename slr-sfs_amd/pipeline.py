@@ -18,7 +18,7 @@ import torch
 
 from . import nets
 from . import parallel
-from .synthesis import ClipSynthesizer
+from .synthesis import ClipSynthesizer, MotionPlan
 
 
 _side_streams = {}
@@ -137,11 +137,13 @@ class BaselineAnimator(torch.nn.Module):
             self.splat_kw = splat_options(opts, two_layer=False)
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N, shard=None):
+    def begin_clip(self, image, motion, N, shard=None, frames=None):
         """Frame-invariant part.  image [1,3,H,W] in [-1,1]; motion [1,2,H,W] px/frame.
-        shard = (rank, world[, group]): the encoder runs in row bands across the ranks (parallel.encode_banded)."""
-        fs, Z = _encode(self.encoder, image, shard)                 # start_fs, Z_f (:779-786)
-        return ClipSynthesizer(fs, Z, motion, N, **self.splat_kw)
+        shard = (rank, world[, group]): the encoder runs in row bands across the ranks (parallel.encode_banded).
+        frames: the frames that will be rendered (default all): bins / work plans are prepared for those."""
+        plan = MotionPlan(motion, N, frames)                        # motion-only work first (its totals reach the host
+        fs, Z = _encode(self.encoder, image, shard)                 # under the encoder); start_fs, Z_f (:779-786)
+        return ClipSynthesizer(fs, Z, motion, N, plan=plan, **self.splat_kw)
 
     @torch.no_grad()
     def frame(self, clip, t):
@@ -155,7 +157,7 @@ class BaselineAnimator(torch.nn.Module):
         start, middle, end = [int(v) for v in torch.as_tensor(batch["index"]).reshape(-1)[:3]]
         fs, Z = batch["features"][0][:2]
         clip = ClipSynthesizer(fs, Z.view(fs.shape[0], 1, fs.shape[2], fs.shape[3]), batch["motions"][0],
-                               end - start + 1, **self.splat_kw)
+                               end - start + 1, frames=[middle - start], **self.splat_kw)
         gen = clip.features(middle - start)
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
@@ -163,8 +165,8 @@ class BaselineAnimator(torch.nn.Module):
     def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device (overlap: see _features_ahead)."""
         _check_grid(image)
-        clip = self.begin_clip(image, motion, N, shard)
         frames = range(N) if frames is None else frames
+        clip = self.begin_clip(image, motion, N, shard, frames)
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
             out[i] = torch.tanh(self.projector(gen_fs))[0]
@@ -219,22 +221,23 @@ class SLRv1Animator(torch.nn.Module):
             self.use_fluid_alpha_only = bool(_flag(opts, "use_fluid_alpha_only"))
             self.use_bg_alpha_only = bool(_flag(opts, "use_bg_alpha_only"))
 
-    def _clip(self, fs, Z, motion, N, alpha_out, bg, alpha_region=None):
+    def _clip(self, fs, Z, motion, N, alpha_out, bg, alpha_region=None, plan=None, frames=None):
         alpha_bg_raw = alpha_out[:, 0:1]                            # :943-946
         alpha_bg = torch.sigmoid(alpha_bg_raw)
         clip = ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=alpha_out[:, 1:2].contiguous(), alpha_bg=alpha_bg,
-                               use_alpha0=self.use_alpha0, **self.splat_kw)
+                               use_alpha0=self.use_alpha0, plan=plan, frames=frames, **self.splat_kw)
         clip.bg, clip.alpha_bg, clip.alpha_bg_raw = bg, alpha_bg, alpha_bg_raw
         clip.alpha_region = None if alpha_region is None else blur_alpha_region(alpha_region, fs.shape[3])
         return clip
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N, shard=None, alpha_region=None):
+    def begin_clip(self, image, motion, N, shard=None, alpha_region=None, frames=None):
         """alpha_region [1,1,H,W]: optional edit mask (:867-906, 1079-1080): 1 = composite, 0 = fluid layer only."""
+        plan = MotionPlan(motion, N, frames)
         fs, Z = _encode(self.encoder, image, shard)
         bg = torch.tanh(self.net_bg(image))                         # test_v1_4eval_rawsize.py:209, :925-927
         a = _encode(self.net_alpha_encoder, image, shard)           # :938 (frame-invariant -> hoisted)
-        return self._clip(fs, Z, motion, N, a, bg, alpha_region)
+        return self._clip(fs, Z, motion, N, a, bg, alpha_region, plan=plan)
 
     @torch.no_grad()
     def frame(self, clip, t):
@@ -293,7 +296,7 @@ class SLRv1Animator(torch.nn.Module):
         a = self.net_alpha_encoder(image)                           # :938
         bg = torch.tanh(batch["BGImg"][0])                          # :925-927
         clip = self._clip(fs, Z.view(1, 1, fs.shape[2], fs.shape[3]), batch["motions"][0], end - start + 1, a, bg,
-                          batch.get("alpha_region"))
+                          batch.get("alpha_region"), frames=[middle - start])
         return self._decode(clip, *clip.features(middle - start))
 
     @torch.no_grad()
@@ -304,8 +307,8 @@ class SLRv1Animator(torch.nn.Module):
         ("BGImg" and "AlphaRegionMask" are frame-invariant: one [1,.,H,W] tensor) -- what
         test_v1_4eval_rawsize.py:240-284 writes to disk."""
         _check_grid(image)
-        clip = self.begin_clip(image, motion, N, shard, alpha_region)
         frames = range(N) if frames is None else frames
+        clip = self.begin_clip(image, motion, N, shard, alpha_region, frames)
         want = ("PredImg",) if keys is None else tuple(keys)
         once = ("BGImg", "AlphaRegionMask")
         outs = {}

@@ -12,6 +12,8 @@ Index semantics: batch["index"] = [start, middle, end] = [0, t
 forward steps = middle-start = t, backward steps = end-middle+1 = N-t,
 alpha = 1 - (middle-start)/(end-start+1) = 1 - t/N.
 """
+import ctypes
+
 import torch
 
 from ._lib import check, lib, ptr, require_device, stream_of, workspace
@@ -83,16 +85,99 @@ def synth_group(values, wlogit, disp_f, disp_p, alpha, ws_f, ws_p, wmax=None, ex
     return (out, norm) if return_norm else out
 
 
+PLAN_CHUNK = 64      # frames per clip plan (bounds the plan buffer: ~16 MB of bin lists per map at 768x1280, worst case)
+
+
+class MotionPlan:
+    """Everything of a clip that depends on the motion field only: the two all-frames Euler passes and, for the frames
+    that will be rendered, the tile bins + work plans of both directions -- built by ONE set of launches per chunk of
+    PLAN_CHUNK frames (slr_clip_plan_build) instead of six latency-bound launches per frame.  Independent of the image,
+    so the animators build it BEFORE the encoder runs: the per-frame totals (work items, multi-segment tiles) are
+    copied to the host asynchronously and have long arrived when the first frame is launched.
+
+    frame t of an N-frame clip: t forward steps of +motion, N - t backward steps of -motion."""
+
+    def __init__(self, motion, N, frames=None):
+        require_device(motion)
+        assert motion.shape[0] == 1 and motion.shape[1] == 2
+        self.N = int(N)
+        self.H, self.W = motion.shape[2:]
+        self.frames = list(range(self.N)) if frames is None else [int(t) for t in frames]
+        # all-frames Euler passes: forward t = 0..N-1 steps of +motion, backward 1..N steps of -motion
+        self.disp_f, _ = euler_integration_all(motion, self.N - 1, +1.0, want_visible=False)
+        self.disp_p, _ = euler_integration_all(motion, self.N, -1.0, want_visible=False)
+        self._where = {}                                   # t -> (chunk record, index inside the chunk)
+        for c0 in range(0, len(self.frames), PLAN_CHUNK):
+            self._build(self.frames[c0:c0 + PLAN_CHUNK])
+
+    def _build(self, ts):
+        n, dev = len(ts), self.disp_f.device
+        L = lib()
+        nbytes = int(L.slr_clip_plan_bytes(n, self.H, self.W))
+        if nbytes == 0:
+            raise RuntimeError(f"slr_sfs_amd: no clip plan for {n} frames of {self.H}x{self.W}")
+        plan = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        idx_f = torch.tensor(ts, dtype=torch.int32, device=dev)
+        idx_p = (self.N - idx_f).to(torch.int32)
+        with torch.cuda.device(dev):
+            check(L.slr_clip_plan_build(ptr(self.disp_f), ctypes.c_void_p(idx_f.data_ptr()), ptr(self.disp_p),
+                                        ctypes.c_void_p(idx_p.data_ptr()), n, self.H, self.W, ptr(plan), nbytes,
+                                        stream_of(plan)), "slr_clip_plan_build")
+        off, stride = ctypes.c_size_t(), ctypes.c_int()
+        check(L.slr_clip_plan_totals(n, self.H, self.W, ctypes.byref(off), ctypes.byref(stride)), "slr_clip_plan_totals")
+        totals = plan[off.value:off.value + n * stride.value * 4].view(torch.int32).view(n, stride.value)
+        host = torch.empty(totals.shape, dtype=torch.int32, pin_memory=True)
+        host.copy_(totals, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        rec = {"plan": plan, "n": n, "host": host, "event": ev, "keep": (idx_f, idx_p)}
+        for i, t in enumerate(ts):
+            self._where[t] = (rec, i)
+
+    def lookup(self, t):
+        """-> (plan buffer, frames in it, index of t, (n_items, n_multi, n_whole))."""
+        if t not in self._where:
+            self._build([t])                               # a frame outside the announced set: its own one-frame plan
+        rec, i = self._where[t]
+        if rec["event"] is not None:
+            rec["event"].synchronize()                     # long done unless this is the clip's very first launch
+            rec["event"] = None
+        row = rec["host"][i]
+        return rec["plan"], rec["n"], i, (int(row[0]), int(row[3]), int(row[4]))
+
+
+def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, eps=1e-8, return_norm=False, timed=False):
+    """synth_group for frame t of a MotionPlan (bins and work plan prepared per clip)."""
+    require_device(values, wlogit, wmax)
+    assert values.shape[0] == 1 and wlogit.shape[1] == 1
+    _, C, H, W = values.shape
+    plan, n, i, (n_items, n_multi, n_whole) = mp.lookup(t)
+    disp_f, disp_p = mp.disp_f[t], mp.disp_p[mp.N - t]
+    out = torch.empty_like(values)
+    norm = values.new_empty(1, 1, H, W) if return_norm else None
+    scratch = workspace(values, "clip", 1, C, H, W, nbytes=int(lib().slr_splat_scratch_bytes(C, H, W)))
+    with torch.cuda.device(values.device):
+        if timed and kernel_timing is not None:
+            _arm_timer(values)
+        check(lib().slr_synth_group_clip(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0,
+                                         ptr(disp_f), ptr(disp_p), float(alpha), ptr(out), ptr(norm), C, H, W,
+                                         float(eps), ptr(plan), plan.numel(), n, i, ptr(scratch), scratch.numel(),
+                                         n_items, n_multi, n_whole, stream_of(values)), "slr_synth_group_clip")
+    return (out, norm) if return_norm else out
+
+
 class ClipSynthesizer:
     """Frame-invariant state of one clip + per-frame decoder-input synthesis.
 
     baseline:  ClipSynthesizer(fs, Z, motion, N).features(t)                     -> gen_fs
     SLR v1:    ClipSynthesizer(fs, Z, motion, N, alpha_fluid_logit=..., alpha_bg=...,
                                use_alpha0=True, clamp_alpha=True).features(t)   -> gen_fs, alpha_fluid
+    ``plan``: a MotionPlan built earlier for the same motion / N (the animators build it before the encoder);
+    ``frames``: the frames that will be asked for (default all; a rank of a sharded job passes its share).
     """
 
     def __init__(self, fs, Z, motion, N, alpha_fluid_logit=None, alpha_bg=None, use_alpha0=True,
-                 clamp_alpha=None, softmax_v1=False, softmax_v2=False, clamp_z=None):
+                 clamp_alpha=None, softmax_v1=False, softmax_v2=False, clamp_z=None, plan=None, frames=None):
         require_device(fs, Z, motion)
         assert fs.shape[0] == 1 and Z.shape[1] == 1 and motion.shape[1] == 2
         self.N = int(N)
@@ -106,14 +191,16 @@ class ClipSynthesizer:
         self.clamp_z = clamp_z
         if self.softmax_v2:
             self.Z, self.zmax = Z, None
-        elif clamp_z is not None:                                        # :856-859 (not the shipped behaviour)
+        elif clamp_z is not None:                                        # :856-859 (checkpoints without no_clamp_Z)
             Zn = Z if softmax_v1 else Z - Z.max()
             self.Z, self.zmax = torch.clamp(Zn, min=clamp_z[0], max=clamp_z[1]).contiguous(), None
         else:
             self.Z, self.zmax = Z, (None if softmax_v1 else global_max(Z))
-        # all-frames Euler passes: forward t = 0..N-1 steps of +motion, backward 1..N steps of -motion
-        self.disp_f, _ = euler_integration_all(motion, self.N - 1, +1.0, want_visible=False)
-        self.disp_p, _ = euler_integration_all(motion, self.N, -1.0, want_visible=False)
+        if plan is None:
+            plan = MotionPlan(motion, self.N, frames)
+        assert plan.N == self.N and (plan.H, plan.W) == tuple(fs.shape[2:])
+        self.plan = plan
+        self.disp_f, self.disp_p = plan.disp_f, plan.disp_p
         self.C = self.fs.shape[1]
         if self.v1:
             af = alpha_fluid_logit.contiguous()
@@ -137,23 +224,19 @@ class ClipSynthesizer:
         """Decoder input for frame t (index = [0, t, N-1])."""
         t = int(t)
         assert 0 <= t < self.N
-        disp_f = self.disp_f[t:t + 1]                # t forward steps
-        disp_p = self.disp_p[self.N - t:self.N - t + 1]   # N - t backward steps
-        ws_f, ws_p = bin_flow_pair(disp_f, disp_p, self.C)
         a = self.alpha(t)
         Zt = self.Z
         if self.softmax_v2:                      # Z_f_max = maximum_warp_norm_splater(Z_f, forward_flow)  (:849-851)
             from .softsplat import _FunctionMaximumWarpNormsplat
-            Zt = self.Z - _FunctionMaximumWarpNormsplat(self.Z, disp_f.contiguous())
+            Zt = self.Z - _FunctionMaximumWarpNormsplat(self.Z, self.disp_f[t:t + 1].contiguous())
             if self.clamp_z is not None:
                 Zt = torch.clamp(Zt, min=self.clamp_z[0], max=self.clamp_z[1])
-        res = synth_group(self.fs, Zt, disp_f, disp_p, a, ws_f, ws_p, wmax=self.zmax,
-                          return_norm=return_norm, timed=True)
+        res = synth_group_clip(self.fs, Zt, self.plan, t, a, wmax=self.zmax, return_norm=return_norm, timed=True)
         gen, norm = res if return_norm else (res, None)
         if not self.v1:
             return (gen, norm) if return_norm else gen
         if self.use_alpha0:
-            afl = synth_group(self.af, self.A0, disp_f, disp_p, a, ws_f, ws_p, wmax=None, exp_weights=True)
+            afl = synth_group_clip(self.af, self.A0, self.plan, t, a, wmax=None, exp_weights=True)
         else:
             gen, afl = gen[:, :-1], gen[:, -1:]
         return (gen, afl, norm) if return_norm else (gen, afl)
