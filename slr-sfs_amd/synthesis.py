@@ -23,6 +23,26 @@ from .euler_integration_manipulator import euler_integration_all
 # bench.py sets this to a list to collect (start, stop) torch events around the tile kernel of
 # every synth_group call with timed=True (through slr_splat_time_next); None = no timing.
 kernel_timing = None
+# bench.py sets this to a list to collect ("prep" | "frame", start, stop) torch events around the WHOLE splat stage:
+# "prep" = the per-clip motion work (Euler passes, binning, planning), "frame" = one features(t) call.
+stage_timing = None
+
+
+class _stage:
+    def __init__(self, kind, device):
+        self.kind, self.device = kind, device
+
+    def __enter__(self):
+        if stage_timing is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if stage_timing is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            stage_timing.append((self.kind, self.e0, e1))
+        return False
 
 
 def _arm_timer(t):
@@ -103,12 +123,13 @@ class MotionPlan:
         self.N = int(N)
         self.H, self.W = motion.shape[2:]
         self.frames = list(range(self.N)) if frames is None else [int(t) for t in frames]
-        # all-frames Euler passes: forward t = 0..N-1 steps of +motion, backward 1..N steps of -motion
-        self.disp_f, _ = euler_integration_all(motion, self.N - 1, +1.0, want_visible=False)
-        self.disp_p, _ = euler_integration_all(motion, self.N, -1.0, want_visible=False)
         self._where = {}                                   # t -> (chunk record, index inside the chunk)
-        for c0 in range(0, len(self.frames), PLAN_CHUNK):
-            self._build(self.frames[c0:c0 + PLAN_CHUNK])
+        with _stage("prep", motion.device):
+            # all-frames Euler passes: forward t = 0..N-1 steps of +motion, backward 1..N steps of -motion
+            self.disp_f, _ = euler_integration_all(motion, self.N - 1, +1.0, want_visible=False)
+            self.disp_p, _ = euler_integration_all(motion, self.N, -1.0, want_visible=False)
+            for c0 in range(0, len(self.frames), PLAN_CHUNK):
+                self._build(self.frames[c0:c0 + PLAN_CHUNK])
 
     def _build(self, ts):
         n, dev = len(ts), self.disp_f.device
@@ -224,6 +245,10 @@ class ClipSynthesizer:
         """Decoder input for frame t (index = [0, t, N-1])."""
         t = int(t)
         assert 0 <= t < self.N
+        with _stage("frame", self.fs.device):
+            return self._features(t, return_norm)
+
+    def _features(self, t, return_norm):
         a = self.alpha(t)
         Zt = self.Z
         if self.softmax_v2:                      # Z_f_max = maximum_warp_norm_splater(Z_f, forward_flow)  (:849-851)
