@@ -444,10 +444,23 @@ constexpr int RB = 4;                          // records per batch in the gathe
 constexpr int LMAX = SLR_LMAX;                       // records a work-item walks alone (longer lists: wave-cooperative)
 constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 // Per-variant shape: EPT bin entries per work-item (segment = EPT*TILE_PIX entries), CHUNK planes
-// staged in LDS / accumulated in registers per pass.  Chosen so that two workgroups fit one CU's
-// 160 KiB of LDS:  one flow  EPT 2, CHUNK 8 -> 3.1 + 36 + 32 = 71 KiB
-//                  two flows EPT 3, CHUNK 4 -> 3.1 + 52 + 24 = 79 KiB
-constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = 8;     // (CHUNK 4 measures the same: the chunk count /
+// staged in LDS / accumulated in registers per pass.  LDS per workgroup (6-byte records):
+//   one flow  EPT 2, CHUNK 4 -> 3.1 + 27.0 + 16 = 46 KiB, 80 VGPRs -> THREE workgroups per CU
+//   two flows EPT 3, CHUNK 4 -> 3.1 + 39.0 + 24 = 66 KiB            -> two   workgroups per CU
+// Measured (768x1280, C = 65, tile kernel alone, identity / Euler t=30 / t=59 / incoherent flow, us):
+//   8-byte records, CHUNK 8, 2 workgroups per CU (round 1): 152 / 196 / 244 / 228
+//   6-byte records, CHUNK 4, 3 workgroups per CU          : 144 / 178 / 223 / 208
+// (6-byte records alone: no change; CHUNK 4 alone, still 2 per CU: 148 / 188 / 236 / 218.)
+#ifndef SLR_CHUNK_ONE
+#define SLR_CHUNK_ONE 4
+#endif
+#ifndef SLR_REC6
+#define SLR_REC6 1             // records as (u16 entry, f32 weight) in two LDS arrays: 6 instead of 8 bytes each
+#endif
+#ifndef SLR_WAVES_ONE
+#define SLR_WAVES_ONE 6        // __launch_bounds__ waves per SIMD of the one-flow instantiation: 80 VGPRs, three workgroups per CU
+#endif
+constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = SLR_CHUNK_ONE;     // (CHUNK 4 measures the same: the chunk count /
                                                                     // barrier count is not what bounds the kernel)
 constexpr int EPT_TWO = SEG_TWO / SPLAT_THREADS, CHUNK_TWO = 4;
 // records per segment: <= 4 per entry, + 1 pad per output pixel (list lengths are made odd so the
@@ -481,16 +494,33 @@ __device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
 //            byte is written exactly once, coalesced, never read, never zeroed.
 //
 // Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
+// bytes of LDS in front of the staged values: counts, wave sums, offsets, records (16-byte aligned)
+__host__ __device__ constexpr size_t lds_head_bytes(int ept) {
+    return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (SLR_REC6 ? 6 : 8) + 15) & ~(size_t)15;
+}
+constexpr int tile_min_waves(int ept) { return (ept == EPT_ONE && SLR_WAVES_ONE > 0) ? SLR_WAVES_ONE : 1; }
+
 template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE>
-__global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) {
+__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX)) void splat_tile_kernel(SplatArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int T = SPLAT_THREADS;
     constexpr int SEG = EPT_MAX * T;
     uint32_t *cnt = smem;                     // [T]   records per output pixel
     uint32_t *wsum = smem + T;                // [T/64] wave sums of the scan
     uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 16);            // [T] exclusive prefix (< 2^16)
+#if SLR_REC6
+    float *rec_w = reinterpret_cast<float *>(smem + T + 16 + T / 2);        // [rec_cap] weights
+    uint16_t *rec_e = reinterpret_cast<uint16_t *>(rec_w + rec_cap(EPT_MAX));   // [rec_cap] entry indices (< SEG <= 2^16)
+#define REC_PUT(i, e, w) do { rec_e[i] = (uint16_t)(e); rec_w[i] = (w); } while (0)
+#define REC_E(i) ((uint32_t)rec_e[i])
+#define REC_W(i) (rec_w[i])
+#else
     uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 16 + T / 2);          // [rec_cap] (entry index, weight bits)
-    float4 *val4 = reinterpret_cast<float4 *>(rec + rec_cap(EPT_MAX) + SLR_LDS_PAD / 8);     // [SEG][CHUNK/4] staged source values
+#define REC_PUT(i, e, w) (rec[i] = make_uint2((uint32_t)(e), __float_as_uint(w)))
+#define REC_E(i) (rec[i].x)
+#define REC_W(i) (__uint_as_float(rec[i].y))
+#endif
+    float4 *val4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem) + lds_head_bytes(EPT_MAX) + SLR_LDS_PAD);     // [SEG][CHUNK/4] staged source values
 
     // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
     // Groups of XCD_GROUP consecutive work items (= horizontally neighbouring tiles) are placed on
@@ -643,7 +673,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
         for (int k = 0; k < 4; ++k) {
             const uint32_t ts = e_ts[j][k];
             if (ts != 0xffffffffu) {
-                rec[off[ts >> 16] + (ts & 0xffffu)] = make_uint2((uint32_t)(tid + j * T), __float_as_uint(e_w[j][k]));
+                REC_PUT(off[ts >> 16] + (ts & 0xffffu), tid + j * T, e_w[j][k]);
             }
         }
     __syncthreads();
@@ -691,9 +721,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
     for (int k = 0; k < KREG; ++k) {
         const bool on = r0 + k < rl;
-        const uint2 q = rec[on ? r0 + k : 0u];
-        ce[k] = on ? q.x : NULL_E;
-        cw[k] = on ? __uint_as_float(q.y) : 0.0f;
+        const uint32_t qi = on ? r0 + k : 0u;
+        ce[k] = on ? REC_E(qi) : NULL_E;
+        cw[k] = on ? REC_W(qi) : 0.0f;
     }
 #pragma unroll
     for (int h = 0; h < CHUNK / 4; ++h)
@@ -701,12 +731,12 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 
     float nrm = 0.0f;
     if (NORM) {
-        for (uint32_t r = r0; r < rl; ++r) nrm += __uint_as_float(rec[r].y);
+        for (uint32_t r = r0; r < rl; ++r) nrm += REC_W(r);
         for (unsigned long long hv = heavy; hv; hv &= hv - 1) {        // long lists: the wave walks them together
             const int src = __ffsll((long long)hv) - 1;
             const uint32_t hb = __shfl(rl, src), he = __shfl(r1, src);
             float part = 0.0f;
-            for (uint32_t r = hb + lane; r < he; r += 64) part += __uint_as_float(rec[r].y);
+            for (uint32_t r = hb + lane; r < he; r += 64) part += REC_W(r);
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
             if (lane == src) nrm += part;
@@ -787,9 +817,9 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const bool on = r + k < rl;
-                const uint2 q = rec[on ? r + k : r];
-                e[k] = on ? q.x : NULL_E;
-                w[k] = on ? __uint_as_float(q.y) : 0.0f;
+                const uint32_t qi = on ? r + k : r;
+                e[k] = on ? REC_E(qi) : NULL_E;
+                w[k] = on ? REC_W(qi) : 0.0f;
             }
             float v[RB][CHUNK];
 #pragma unroll
@@ -814,11 +844,11 @@ __global__ __launch_bounds__(SPLAT_THREADS) void splat_tile_kernel(SplatArgs a) 
 #pragma unroll
             for (int u = 0; u < CHUNK; ++u) part[u] = MAXOP ? -INFINITY : 0.0f;
             for (uint32_t r = hb + lane; r < he; r += 64) {
-                const uint2 q = rec[r];
-                const float w = __uint_as_float(q.y);
+                const uint32_t qe = REC_E(r);
+                const float w = REC_W(r);
 #pragma unroll
                 for (int h = 0; h < CHUNK / 4; ++h) {
-                    const float4 x = val4[vslot<CHUNK>(q.x, h)];
+                    const float4 x = val4[vslot<CHUNK>(qe, h)];
                     const float xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -1011,8 +1041,7 @@ static int launch_tile_variant(const SplatArgs &a, uint32_t grid, size_t lds, hi
 template <bool NORM, bool MAXOP, int EPT, int CHUNK>
 static int launch_tile(const SplatArgs &a, uint32_t items_cap, uint32_t nt, int n_items, int n_whole, hipStream_t st) {
     // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
-    const size_t lds = (size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(EPT) * 8 +
-                       (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;     // + the all-zero NULL entry
+    const size_t lds = lds_head_bytes(EPT) + (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;     // + the all-zero NULL entry
     const uint32_t cover = n_items >= 0 && (uint32_t)n_items < items_cap ? (uint32_t)n_items : items_cap;
     const uint32_t grid = ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
