@@ -211,6 +211,13 @@ int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_b
                        const float *residual, const float *next_scale, const float *next_shift,
                        float *out, float *um_out, float winsize, int N, int C, int H, int W, void *stream);
 
+/* The split-f16 convolution kernels below represent an activation x as two f16 halves of x * 2^6: exact-domain for
+ * |x| < 1023 (post-BN activations are O(1 .. 10^2)).  A larger activation is CLAMPED there (no inf / NaN), which makes
+ * the frame wrong rather than inexact -- the reference's fp32 convolution has no such limit -- so every wave that had to
+ * clamp adds to a per-device counter.  *count = the counter of the CURRENT device (synchronises with the device: call
+ * it once per clip, not per layer); reset != 0 zeroes it.  The Python networks raise on a non-zero count. */
+int slr_conv_saturation_count(unsigned long long *count, int reset);
+
 /* ------------------------------------------------------------------ decoder convolution on the matrix cores (8 f3) */
 
 /* 3x3 / stride 1 / zero-pad 1 convolution, fp32 in / fp32 out: implicit GEMM on

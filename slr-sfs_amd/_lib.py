@@ -18,7 +18,7 @@ SYMBOLS = (
     "slr_synth_group", "slr_global_max",
     "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
-    "slr_bn_relu_mask", "slr_pconv_epilogue",
+    "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
@@ -84,6 +84,7 @@ def lib():
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
+            "slr_conv_saturation_count": [ctypes.POINTER(ctypes.c_ulonglong), i],
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv1x1_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, i, vp],

@@ -73,6 +73,7 @@ struct ConvArgs {
     float *um_out;         // [N,1,H,W] or nullptr
     int out_b8;            // output in the channel-blocked layout [N, Cout/8, H, W, 8] (Cout % 8 == 0)
     int res_b8;            // ... and the residual as well (only together with out_b8)
+    unsigned *sat;         // device counter: incremented by every wave that had to saturate an activation (see stage_value)
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // commutes with the roundings) + split + LDS store: straight-line code, no selects on validity.
     // In three pieces (begin / one value / finish) so the main loop can slot the values between MFMAs.
     struct Stage { int cb; float mk0, fresh, cnt; h8 hi, lo; };
+    unsigned long long sat = 0ull;
     const float *pss = reinterpret_cast<const float *>(&pss4[0][0]);
     auto stage_begin = [&](auto R, int c, Stage &g) {
         g.cb = c * 16 + (R.value < 2 ? R.value * 8 : gB * 8);
@@ -195,8 +197,11 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             v = x * g.mk0;
         }
         // f16 range guard (one v_med3): the split is exact-domain for |activation| < 2^16 / 2^6 = 1023;
-        // larger values saturate there instead of becoming inf -> NaN (post-BN activations are O(1..10^2))
+        // larger values saturate there instead of becoming inf -> NaN (post-BN activations are O(1..10^2)).
+        // A saturated value makes the frame WRONG, not just inexact: it is counted (one compare into a lane mask
+        // held in SGPRs, one atomic per affected wave at the end) and surfaced by slr_conv_saturation_count.
         v = __builtin_amdgcn_fmed3f(v, -65472.0f, 65472.0f);
+        sat |= __ballot(fabsf(v) >= 65472.0f);            // tested AFTER the clamp (no second live copy of v); lane mask in SGPRs
         const _Float16 h = (_Float16)v;
         g.hi[j] = h;
         g.lo[j] = (_Float16)(v - (float)h);
@@ -345,6 +350,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         }
         __syncthreads();
     }
+
+    if (a.sat && sat != 0ull && lane == 0) atomicAdd(a.sat, 1u);   // an activation left the f16 range (stage_value)
 
     if (pre == PRE_BN_NONZERO) {                       // mask plane = channel sum of (x != 0)  (architectures.py:369,
         mpl[tid] = cnt[0] + cnt[1];                    // partialconv2d.py:61 with a per-element mask)
@@ -511,7 +518,8 @@ constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (s
 template <int NCT, bool INB8>
 __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restrict__ in, const h8 *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out,
-                                                            int Cin, int Cout, int HW, int nchunk, float unscale, int out_b8) {
+                                                            int Cin, int Cout, int HW, int nchunk, float unscale, int out_b8,
+                                                            unsigned *__restrict__ sat_count) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.z;
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
     f16v acc[NCT];
     float x0[8], x1[8], x2[8];
     h8 a_cur[NCT][2], a_nxt[NCT][2];
+    bool sat = false;                                  // an activation left the f16 range of the split (see conv3x3_split_kernel)
     load_x(x0, 0);
     load_a(a_cur, 0);
     load_x(x1, 1);
@@ -581,6 +590,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             h8 bh, bl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                sat |= fabsf(x0[j] * okf) > 65472.0f;
                 const float v = __builtin_amdgcn_fmed3f(x0[j] * okf, -65472.0f, 65472.0f);
                 const _Float16 h = (_Float16)v;
                 bh[j] = h;
@@ -635,6 +645,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             }
         }
     }
+    if (sat_count && __ballot(sat) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(sat_count, 1u);
 }
 
 // w [Cout,Cin,k,k] fp32 (taps = k*k = 9 or 1) -> split f16 weights in fragment order over the PADDED
@@ -656,9 +667,44 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float *__
     }
 }
 
+// Saturation counter of the split-f16 kernels, one per device (lazily allocated, zeroed): the kernels add to it when an
+// activation exceeds the f16 range of the split (|x| * 2^6 > 65472, i.e. |x| >= 1023) and had to be clamped.
+static unsigned *g_sat[64];
+static int sat_counter(unsigned **p) {
+    int dev = 0;
+    SLR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { *p = nullptr; return 0; }
+    if (!g_sat[dev]) {
+        unsigned *q = nullptr;
+        hipError_t e = hipMalloc((void **)&q, 256);
+        if (e != hipSuccess) {       // e.g. first convolution of a device inside a stream capture
+            set_error("conv: cannot allocate the saturation counter (%s); call slr_conv_saturation_count once before "
+                      "capturing a graph", hipGetErrorString(e));
+            return (int)e;
+        }
+        SLR_CHECK_HIP(hipMemset(q, 0, 256));
+        g_sat[dev] = q;
+    }
+    *p = g_sat[dev];
+    return 0;
+}
+
 }  // namespace slr
 
 using namespace slr;
+
+SLR_EXPORT int slr_conv_saturation_count(unsigned long long *count, int reset) {
+    SLR_CHECK_ARG(count, "null pointer");
+    unsigned *p = nullptr;
+    if (int e = sat_counter(&p)) return e;
+    unsigned v = 0;
+    if (p) {
+        SLR_CHECK_HIP(hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost));      // synchronises with the device
+        if (reset && v) SLR_CHECK_HIP(hipMemset(p, 0, sizeof(v)));
+    }
+    *count = v;
+    return 0;
+}
 
 SLR_EXPORT size_t slr_conv3x3_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
@@ -714,10 +760,12 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
     const dim3 grid((HW + 128 * C1_TILES - 1) / (128 * C1_TILES), conv1x1_cout_pad(Cout) / (nct * 32), N);
     hipStream_t st = (hipStream_t)stream;
     const int ob8 = (layout & SLR_CONV_OUT_B8) ? 1 : 0;
+    unsigned *satp = nullptr;
+    if (int e = sat_counter(&satp)) return e;
 #define C1_LAUNCH(T)                                                                                                       \
     do {                                                                                                                   \
-        if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8); \
-        else hipLaunchKernelGGL((conv1x1_split_kernel<T, false>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8); \
+        if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8, satp); \
+        else hipLaunchKernelGGL((conv1x1_split_kernel<T, false>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8, satp); \
     } while (0)
     if (nct == 4) C1_LAUNCH(4); else if (nct == 2) C1_LAUNCH(2); else C1_LAUNCH(1);
 #undef C1_LAUNCH
@@ -729,8 +777,14 @@ static int conv_launch(ConvArgs &a, float wscale, bool in_b8, hipStream_t st) {
     a.tiles_x = (a.W + CV_W - 1) / CV_W;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.unscale = 1.0f / (CV_XSCALE * wscale);
+    if (int e = sat_counter(&a.sat)) return e;
     const int tiles = a.tiles_x * ((a.H + CV_H - 1) / CV_H);
-    const int ct = conv_cout_tile(a.Cout);
+    int ct = conv_cout_tile(a.Cout);
+    // NCHW input WITH a prologue and > 64 output channels: 24 scalar staging loads + the prologue table + 128
+    // accumulator registers do not fit 256 VGPRs (the <1,4,true,false> instantiation spilled 14-27 of them); that
+    // combination runs as two 64-channel workgroup rows instead (no network on the path uses it: wide layers read
+    // channel-blocked activations).  The weight buffer is indexed by 32-channel tiles, so any row width reads it.
+    if (ct == 128 && a.pre != PRE_NONE && !in_b8) ct = 64;
     const dim3 grid(tiles, conv_cout_pad(a.Cout) / ct, a.N);
 #define CV_LAUNCH(CPW, WCO)                                                                                     \
     do {                                                                                                       \
@@ -739,8 +793,12 @@ static int conv_launch(ConvArgs &a, float wscale, bool in_b8, hipStream_t st) {
         else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, true>), grid, dim3(CV_THREADS), 0, st, a);                  \
         else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, false>), grid, dim3(CV_THREADS), 0, st, a);                            \
     } while (0)
-    if (ct == 128) CV_LAUNCH(1, 4);         // one 32-channel tile x all 8 rows per wave: a quarter of the weight-fragment
+    if (ct == 128) {                        // one 32-channel tile x all 8 rows per wave: a quarter of the weight-fragment
                                             // traffic of 4 x 2 tiles per wave would need, half of <2,2> (+3..5 % measured)
+        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true>), grid, dim3(CV_THREADS), 0, st, a);   // (in_b8)
+        else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true>), grid, dim3(CV_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, false>), grid, dim3(CV_THREADS), 0, st, a);
+    }
     else if (ct == 64) CV_LAUNCH(1, 2);     // 1 tile x 4 rows per wave: half the weight-fragment loads of <2,1> (+4 %)
     else CV_LAUNCH(1, 1);
 #undef CV_LAUNCH

@@ -498,10 +498,11 @@ __device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
 __host__ __device__ constexpr size_t lds_head_bytes(int ept) {
     return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (SLR_REC6 ? 6 : 8) + 15) & ~(size_t)15;
 }
-constexpr int tile_min_waves(int ept) { return (ept == EPT_ONE && SLR_WAVES_ONE > 0) ? SLR_WAVES_ONE : 1; }
+// (the rare whole-tile instantiation carries a segment loop and would spill under the 80-register cap)
+constexpr int tile_min_waves(int ept, bool whole) { return (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1; }
 
 template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE>
-__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX)) void splat_tile_kernel(SplatArgs a) {
+__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void splat_tile_kernel(SplatArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int T = SPLAT_THREADS;
     constexpr int SEG = EPT_MAX * T;

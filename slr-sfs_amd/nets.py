@@ -438,6 +438,22 @@ class BGDecoder(nn.Module):
         return x
 
 
+def check_saturation(device, what="convolution", reset=True):
+    """Raise if a split-f16 kernel on ``device`` had to clamp an activation since the last check (|x| >= 1023: outside the
+    exact domain of the split, csrc/conv.hip).  The result of such a launch is wrong, not merely inexact, and the
+    reference's fp32 convolution has no such limit -- so it is an error, never silent.  Synchronises with the device:
+    the pipelines call it once per clip."""
+    import ctypes
+    n = ctypes.c_ulonglong(0)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().slr_conv_saturation_count(ctypes.byref(n), 1 if reset else 0), "slr_conv_saturation_count")
+    if n.value:
+        raise RuntimeError(f"slr_sfs_amd: {n.value} wave(s) of the {what} kernels met activations >= 1023 in magnitude, "
+                           f"outside the exact range of the split-f16 matrix-core convolution; the frames of this clip "
+                           f"are not valid (check the checkpoint's BN statistics / the input range)")
+    return 0
+
+
 # --------------------------------------------------------------------------- checkpoints
 
 def _fold_sn(sd, key):

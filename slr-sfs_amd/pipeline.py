@@ -172,6 +172,8 @@ class BaselineAnimator(torch.nn.Module):
             out[i] = torch.tanh(self.projector(gen_fs))[0]
             if on_frame is not None:
                 on_frame(out[i])                                    # e.g. parallel.ClipAssembler.push
+        if image.is_cuda:
+            nets.check_saturation(image.device, "encoder / decoder")   # once per clip: no silent clamping (csrc/conv.hip)
         return out
 
 
@@ -323,4 +325,6 @@ class SLRv1Animator(torch.nn.Module):
                 outs[k][i] = d[k][0]
             if on_frame is not None:
                 on_frame(outs["PredImg"][i])
+        if image.is_cuda:
+            nets.check_saturation(image.device, "encoder / decoder")
         return outs["PredImg"] if keys is None else outs

@@ -128,6 +128,11 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
                 packed = re.findall(r"v_pk_(?:fma|add|mul)_f32", isa)
                 assert not packed, f"{len(packed)} packed-fp32 instructions in code object {objects} ({triple})"
                 mfma += isa.count("v_mfma_f32_32x32x16_f16")
+                # no kernel of the library spills to scratch memory (round 1 shipped a convolution variant with 60 bytes
+                # of scratch per lane): every kernel descriptor's private segment size is 0
+                notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+                sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)]
+                assert sizes and not any(sizes), f"scratch in code object {objects} ({triple}): {sizes}"
                 objects += 1
         start = data.find(magic, start + 24)
     assert objects >= 6                      # one per source file of csrc/Makefile

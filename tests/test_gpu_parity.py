@@ -1201,16 +1201,47 @@ def test_conv1x1_small(S, cin, cout, bias):
 
 
 def test_conv3x3_saturates_instead_of_nan(S):
-    """Activations beyond the f16 range of the split (|x| * 2^6 > 65504) saturate; no inf / NaN escapes."""
+    """Activations beyond the f16 range of the split (|x| * 2^6 > 65504) saturate; no inf / NaN escapes -- and the
+    clamp is never silent: the device counter behind slr_conv_saturation_count moves and nets.check_saturation raises
+    (the reference's fp32 convolution has no such limit, so a clamped frame is an error, not a result)."""
     from slr_sfs_amd import nets
     torch.manual_seed(1)
+    dev0 = torch.device("cuda", torch.cuda.current_device())
     conv = nets.Conv(16, 64, 3, bias=False).cuda()
     x = torch.randn(1, 16, 8, 32, device="cuda")
+    with torch.no_grad():
+        conv(x)
+    assert nets.check_saturation(dev0) == 0                 # O(1) activations: nothing clamped (also resets the counter)
     x[0, 3, 4, 7] = 5.0e4
     x[0, 5, 2, 9] = -3.0e38
     with torch.no_grad():
         y = conv(x)
     assert bool(torch.isfinite(y).all())
+    with pytest.raises(RuntimeError, match="1023"):
+        nets.check_saturation(dev0)
+    assert nets.check_saturation(dev0) == 0                 # the check reset the counter
+    # activations of ~1e4 through every kernel family: 3x3 with the BN prologue (NCHW and channel-blocked), partial
+    # convolution, 1x1 skip -- each must report
+    big = torch.randn(1, 64, 16, 40, device="cuda") * 1.0e4
+    mask = torch.ones(1, 1, 16, 40, device="cuda")
+    sc, sh = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    with torch.no_grad():
+        for run in (lambda: nets.Conv(64, 128, 3).cuda()(big, pre_bn=(sc, sh)),
+                    lambda: nets.Conv(64, 128, 3).cuda()(big, layout=nets.IN_B8 | nets.OUT_B8),
+                    lambda: nets.PartialConv(64, 64, 3).cuda()(big, mask, pre_bn=(sc, sh)),
+                    lambda: nets.Conv(64, 128, 1).cuda()(big)):
+            out = run()
+            out = out[0] if isinstance(out, tuple) else out
+            assert bool(torch.isfinite(out).all())
+            with pytest.raises(RuntimeError):
+                nets.check_saturation(dev0)
+        # 1000 is inside the range: exact-domain, no report, and the result is right
+        ok = torch.full((1, 16, 8, 32), 1000.0, device="cuda")
+        c2 = nets.Conv(16, 32, 3, bias=False).cuda()
+        y = c2(ok)
+        ref = torch.nn.functional.conv2d(ok.double(), c2.weight.double(), padding=1)
+        assert nets.check_saturation(dev0) == 0
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("cin,cout,h,w,bias", [(64, 128, 16, 40, False), (128, 256, 9, 33, True), (3, 32, 7, 19, True),
