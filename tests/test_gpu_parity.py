@@ -786,7 +786,8 @@ def test_two_ranks_one_clip(S):
         assert p.returncode == 0 and f"RANK{r} OK" in out, (r, out[-500:], err[-3000:])
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("form", [(), ("--assembly", "final", "--encoder", "redundant")])
+def test_bench_two_ranks_on_one_gpu(form):
     """bench.py's own multi-rank path, launched the way the driver launches it (torch.distributed.run, 2 ranks):
     warm-up, barrier-bracketed timed steps, MAX over ranks, rank 0's extra measurements while the other rank waits,
     ONE JSON line from rank 0.  One GPU here: both ranks on cuda:0, collectives over gloo (SLR_BENCH_ONE_GPU_GLOO=1),
@@ -803,7 +804,8 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, SLR_BENCH_ONE_GPU_GLOO="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", *form], env=env, capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -812,6 +814,16 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["value"] > 0 and abs(d["value"] - 60 / (d["ms_per_step"] * 1e-3)) < 0.05 * d["value"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"] is None                       # rank 0 at N=1 only
+    # the line says which multi-GPU form ran and what it moved: default = per-round all-gathers + banded encoder,
+    # the north_star form = redundant encoder + ONE all-gather of the finished clip
+    cfg = d["config"]
+    frame = 3 * 768 * 1280 * 4
+    if form:
+        assert cfg["assembly"] == "final" and cfg["encoder"] == "redundant"
+        assert cfg["collective_bytes_received_per_rank_per_clip"] == 30 * frame
+    else:
+        assert cfg["assembly"] == "rounds" and cfg["encoder"] == "banded"
+        assert cfg["collective_bytes_received_per_rank_per_clip"] == 30 * frame + 65 * 768 * 1280 * 4 // 2
 
 
 def test_clip_assembler_on_rccl(S, tmp_path):

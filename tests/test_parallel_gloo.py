@@ -1,5 +1,6 @@
-"""Frame sharding + clip assembly on 2 CPU processes (gloo); the GPU path uses the same code
-with backend nccl (= RCCL)."""
+"""Frame sharding + clip assembly on 2, 4 and 8 CPU processes (gloo); the GPU path uses the same code
+with backend nccl (= RCCL).  World 8 / 4 with N = 60 is config C5's shape: 60 = 7 * 8 + 4, so ranks 4-7 have no frame in
+the last round (their padding must land behind frame 59 and be cut off)."""
 import os
 import socket
 
@@ -39,17 +40,17 @@ def _worker(rank, world, port, N, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N", [60, 7, 1])
-def test_shard_and_gather_world2(N):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,N", [(2, 60), (2, 7), (2, 1), (4, 60), (8, 60), (8, 5)])
+def test_shard_and_gather(world, N):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, N, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     covered = sorted(t for _, _, mine in res for t in mine)
@@ -76,14 +77,15 @@ def test_gather_world1_is_identity():
     assert torch.equal(asm.finish(), x)
 
 
-def _enc_worker(rank, world, port, q):
+def _enc_worker(rank, world, port, q, hw=(45, 40)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
     from slr_sfs_amd import nets, parallel
     torch.manual_seed(5)                                  # same weights and image on every rank
     ok = True
     with nets.cpu_reference(), torch.no_grad():
-        img = torch.rand(1, 3, 45, 40) * 2 - 1            # 45 rows: bands of 23 + 22, padded for the gather
+        img = torch.rand(1, 3, *hw) * 2 - 1               # 45 rows: bands of 23 + 22, padded for the gather
         for enc in (nets.EncoderWithZ().eval(), nets.Encoder(3, 2).eval()):
             want = enc(img)
             got = parallel.encode_banded(enc, img, rank, world)
@@ -96,20 +98,33 @@ def _enc_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_banded_encoder_world2():
+@pytest.mark.parametrize("world,hw", [(2, (45, 40)), (4, (768, 8)), (8, (768, 8))])
+def test_banded_encoder(world, hw):
     """The frame-invariant encoder in row bands + all-gather == the encoder on the whole image (CPU definition of the
-    networks; the device kernels: tests/test_gpu_parity.py::test_banded_encoder_is_exact)."""
-    world, port = 2, _free_port()
+    networks; the device kernels: tests/test_gpu_parity.py::test_banded_encoder_is_exact).  768 rows over 8 / 4 ranks:
+    bands of 96 / 192 rows with the 16-row halo, the working height of config C5."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_enc_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_enc_worker, args=(r, world, port, q, hw)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
+
+
+def test_banded_encoder_refuses_empty_bands_on_every_rank():
+    """More ranks than bands of ceil(H/world) rows: EVERY rank raises before any work or collective (a rank that
+    asserted alone would leave the others waiting in the all-gather)."""
+    from slr_sfs_amd import nets, parallel
+    img = torch.zeros(1, 3, 72, 8)
+    enc = nets.Encoder(3, 2)
+    for rank in (0, 7, 15):
+        with pytest.raises(ValueError, match="non-empty bands"):
+            parallel.encode_banded(enc, img, rank, 16)
 
 
 def test_band_rows_cover_the_image():
