@@ -379,7 +379,7 @@ def dropin_roofline(dev, motion):
     C = 65
     x = torch.randn(1, C, H, W, device=dev)
     alg = (2 * C + 2) * H * W * 4
-    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,8>", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,4>", "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "alg_bytes_per_call": alg, "flows": {}}
     worst = None
     for name, steps in (("euler_t30", 30), ("euler_t59", 59)):

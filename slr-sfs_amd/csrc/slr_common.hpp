@@ -32,7 +32,10 @@ void set_error(const char *fmt, ...);
 constexpr int TILE_W   = 64;      // one wavefront of consecutive x
 constexpr int TILE_H   = SLR_TILE_H;
 constexpr int TILE_PIX = TILE_W * TILE_H;
-constexpr int SEG_ONE  = 2 * TILE_PIX;   // segment length, one flow per tile
+#ifndef SLR_EPT_ONE
+#define SLR_EPT_ONE 2
+#endif
+constexpr int SEG_ONE  = SLR_EPT_ONE * TILE_PIX;   // segment length, one flow per tile
 #ifndef SLR_EPT_TWO
 #define SLR_EPT_TWO 3
 #endif

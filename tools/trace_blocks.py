@@ -13,7 +13,7 @@ H, W, C = 768, 1280, 65
 x = torch.randn(1, C, H, W, device="cuda")
 m = smooth_motion(H, W)
 dall, _ = S.euler_integration_all(m, 60)
-for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", dall[30:31].contiguous())):
+for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", dall[30:31].contiguous()), ("t59", dall[59:60].contiguous())):
     S.FunctionSoftsplat(x, fl, None, "summation")
     nb = 4096
     buf = torch.zeros(nb * 40, dtype=torch.int64, device="cuda")
@@ -33,6 +33,8 @@ for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", d
         print(f"  chunk {c}: barrier wait {np.median(t[:, b+1]-t[:, b]):8.0f}  gather+store {np.median(t[:, b+2]-t[:, b+1]):8.0f}" +
               (f"  barrier+stage {np.median(t[:, b+3]-t[:, b+2]):8.0f}" if c < 8 else ""))
     tot = t[:, 30] - t[:, 0]
+    print("  sum of block totals / 1e6:", tot.sum() / 1e6, " blocks slower than 1.5x median:", int((tot > 1.5 * np.median(tot)).sum()),
+          " their share of the sum:", float(tot[tot > 1.5 * np.median(tot)].sum() / tot.sum()))
     print("  block total percentiles 50/90/99/max:", np.percentile(tot, [50, 90, 99, 100]))
     idx = np.argsort(tot)[-8:]
     for i in idx:
