@@ -119,10 +119,10 @@ def splat_roofline(kev, sev, c_splat, kernel):
     prep = [e0.elapsed_time(e1) * 1e3 for k, e0, e1 in sev if k == "prep"]
     stage_us = (sum(frames) + sum(prep)) / max(1, len(frames))
     traffic, src = None, None
-    tf = os.path.join(ROOT, "profiles", "r1_splat_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "r2_splat_traffic.json")
     if c_splat == 65 and os.path.exists(tf):
         traffic = json.load(open(tf))["traffic_bytes_per_launch"]
-        src = "static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/r1_splat_traffic.json, not measured in this run"
+        src = "static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/r2_splat_traffic.json, not measured in this run"
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "alg_bytes_per_launch": alg, "avg_us": round(k_avg, 1), "min_us": round(kus[0], 1),
