@@ -716,7 +716,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
     // register-resident head of this pixel's record list (see the gather loop)
     constexpr uint32_t NULL_E = SEG;                   // staged-entry index of the all-zero slot
-    constexpr int KREG = 2 * EPT_MAX;                  // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
+#ifndef SLR_KREG_ONE
+#define SLR_KREG_ONE 4
+#endif
+#ifndef SLR_KREG_TWO
+#define SLR_KREG_TWO 6
+#endif
+    constexpr int KREG = EPT_MAX == EPT_ONE ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
     float cw[KREG];
     uint32_t ce[KREG];
 #pragma unroll

@@ -63,6 +63,24 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+def _splat_by_composition(values, flow, metric, mode):
+    """The differentiable route: one summation splat of [values * w, w] through _FunctionSoftsplat (whose backward is
+    the reference's), then the division -- the arithmetic of models/softsplat.py:669-688, so gradients flow as upstream:
+    w = 1 (average) | metric (linear) | exp(metric) (softmax); an exact-zero normaliser divides by 1 (:684)."""
+    if mode == 'summation':
+        return _FunctionSoftsplat.apply(values, flow)
+    if mode == 'average':
+        weight = values.new_ones(values.shape[0], 1, values.shape[2], values.shape[3])
+        stacked = torch.cat([values, weight], 1)
+    else:
+        weight = metric.exp() if mode == 'softmax' else metric
+        stacked = torch.cat([values * weight, weight], 1)
+    splatted = _FunctionSoftsplat.apply(stacked, flow)
+    norm = splatted[:, -1:, :, :]
+    norm[norm == 0.0] = 1.0                 # in place on the view, like upstream (the zeros carry no gradient)
+    return splatted[:, :-1, :, :] / norm
+
+
 def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
     """models/softsplat.py:665-690.  Without autograd (the inference scripts run under
     torch.no_grad(), test_animating/test_baseline_4eval_rawsize.py:244) weighting, splat and
@@ -72,18 +90,7 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
     assert(strType in ['summation', 'average', 'linear', 'softmax'])
 
     if strType == 'summation' or _needs_grad(tenInput, tenFlow, tenMetric):
-        if strType == 'average':
-            tenInput = torch.cat([ tenInput, tenInput.new_ones(tenInput.shape[0], 1, tenInput.shape[2], tenInput.shape[3]) ], 1)
-        elif strType == 'linear':
-            tenInput = torch.cat([ tenInput * tenMetric, tenMetric ], 1)
-        elif strType == 'softmax':
-            tenInput = torch.cat([ tenInput * tenMetric.exp(), tenMetric.exp() ], 1)
-        tenOutput = _FunctionSoftsplat.apply(tenInput, tenFlow)
-        if strType != 'summation':
-            tenNormalize = tenOutput[:, -1:, :, :]
-            tenNormalize[tenNormalize == 0.0] = 1.0
-            tenOutput = tenOutput[:, :-1, :, :] / tenNormalize
-        return tenOutput
+        return _splat_by_composition(tenInput, tenFlow, tenMetric, strType)
 
     # The reference only asserts contiguity of what reaches _FunctionSoftsplat, and in these modes that is the result
     # of torch.cat (:669-676), always contiguous: channel slices / permuted tensors are accepted like upstream.

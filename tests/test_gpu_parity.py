@@ -311,6 +311,28 @@ def test_synthesis_vs_oracle_mid_size(S, oracle):
                                    rtol=1e-4, atol=1e-5)
 
 
+def test_clip_plans_in_chunks_and_for_unannounced_frames(S, oracle, monkeypatch):
+    """MotionPlan bins / plans a clip in chunks of PLAN_CHUNK frames (32-bit list offsets; bounds the plan buffer): with
+    a chunk of 3 frames an 8-frame clip takes three plans; a rank that announced only some frames (sharded job) gets a
+    one-frame plan built on demand for any other frame.  Every frame against the oracle, and plan-independent."""
+    H, W, N = 48, 136, 8
+    rng = np.random.default_rng(21)
+    fs = rng.standard_normal((1, 9, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    m = smooth_motion(H, W, 5, amp=3.0)
+    whole = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+    monkeypatch.setattr(S.synthesis, "PLAN_CHUNK", 3)
+    chunked = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+    assert len({id(rec["plan"]) for rec, _ in chunked.plan._where.values()}) == 3
+    sharded = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, frames=[1, 5])
+    assert sorted(sharded.plan._where) == [1, 5]
+    for t in range(N):
+        ref = oracle.synth_baseline(fs, Z, m, t, N)
+        for cs in (whole, chunked, sharded):
+            np.testing.assert_allclose(host(cs.features(t)), ref, rtol=1e-4, atol=1e-5, err_msg=str(t))
+    assert sorted(sharded.plan._where) == list(range(N))             # the other six were planned on demand
+
+
 def test_randomised_synthesis_vs_oracle(S, oracle):
     """Seeded sweep of the headline path itself -- all-frames Euler integration, two-direction exp-weighted splat,
     normalisation (animating_softmax_splating.py:847-924; SLR v1: ..._2layers_alpha_seperate.py:950-1045) -- over
