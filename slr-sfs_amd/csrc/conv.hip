@@ -34,6 +34,8 @@
 //     accumulator register a pair of 128-byte row segments of the NCHW output.
 #include "slr_common.hpp"
 
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 namespace slr {
@@ -669,12 +671,15 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float *__
 
 // Saturation counter of the split-f16 kernels, one per device (lazily allocated, zeroed): the kernels add to it when an
 // activation exceeds the f16 range of the split (|x| * 2^6 > 65472, i.e. |x| >= 1023) and had to be clamped.
-static unsigned *g_sat[64];
+static std::atomic<unsigned *> g_sat[64];
+static std::mutex g_sat_lock;
 static int sat_counter(unsigned **p) {
     int dev = 0;
     SLR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) { *p = nullptr; return 0; }
-    if (!g_sat[dev]) {
+    if (!g_sat[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> guard(g_sat_lock);           // host threads may issue their first convolution together
+        if (g_sat[dev].load(std::memory_order_relaxed)) { *p = g_sat[dev].load(); return 0; }
         unsigned *q = nullptr;
         hipError_t e = hipMalloc((void **)&q, 256);
         if (e != hipSuccess) {       // e.g. first convolution of a device inside a stream capture
@@ -683,9 +688,9 @@ static int sat_counter(unsigned **p) {
             return (int)e;
         }
         SLR_CHECK_HIP(hipMemset(q, 0, 256));
-        g_sat[dev] = q;
+        g_sat[dev].store(q, std::memory_order_release);
     }
-    *p = g_sat[dev];
+    *p = g_sat[dev].load(std::memory_order_acquire);
     return 0;
 }
 
