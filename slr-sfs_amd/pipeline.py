@@ -67,6 +67,25 @@ def _features_ahead(clip, frames, overlap=False):
     side.wait_stream(main)
 
 
+import os as _os
+DECODE_BATCH = int(_os.environ.get("SLR_SFS_AMD_DECODE_BATCH", "4"))      # frames decoded per launch of the decoder networks (measured at 768x1280: 6.04 / 5.95 / 5.87 ms per
+                      # frame at 1 / 2 / 4 -- fewer kernel tails; the splat writes straight into the batch buffer)
+
+
+def _feature_batches(clip, frames, batch):
+    """Yield (first index, gen_fs [b,C,H,W], alpha_fluid [b,1,H,W] or None) for consecutive groups of <= batch frames:
+    every frame's features are written by the splat kernels directly into one sample of the batch tensors."""
+    frames = list(frames)
+    H, W = clip.fs.shape[2:]
+    for i0 in range(0, len(frames), batch):
+        ts = frames[i0:i0 + batch]
+        gen = clip.fs.new_empty(len(ts), clip.C, H, W)
+        afl = clip.fs.new_empty(len(ts), 1, H, W) if clip.v1 else None
+        for j, t in enumerate(ts):
+            clip.features(t, out=gen[j:j + 1], out_alpha=None if afl is None else afl[j:j + 1])
+        yield i0, gen, afl
+
+
 def _check_grid(image):
     """The decoders go through three stride-2 poolings and three 2x up-samplings (architectures.py:345-375): on a
     grid that is not a multiple of 8 the reference's decoder returns a larger frame than it was given (and the
@@ -162,16 +181,25 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None):
-        """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device (overlap: see _features_ahead)."""
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None, batch=None):
+        """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device.  batch (default DECODE_BATCH):
+        frames per decoder launch; overlap=True (see _features_ahead) decodes frame by frame."""
         _check_grid(image)
         frames = range(N) if frames is None else frames
         clip = self.begin_clip(image, motion, N, shard, frames)
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
-        for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
-            out[i] = torch.tanh(self.projector(gen_fs))[0]
-            if on_frame is not None:
-                on_frame(out[i])                                    # e.g. parallel.ClipAssembler.push
+        batch = DECODE_BATCH if batch is None else max(1, int(batch))
+        if overlap or batch == 1:
+            for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
+                out[i] = torch.tanh(self.projector(gen_fs))[0]
+                if on_frame is not None:
+                    on_frame(out[i])                                # e.g. parallel.ClipAssembler.push
+        else:
+            for i0, gen, _ in _feature_batches(clip, frames, batch):
+                out[i0:i0 + gen.shape[0]] = torch.tanh(self.projector(gen))
+                if on_frame is not None:
+                    for i in range(i0, i0 + gen.shape[0]):
+                        on_frame(out[i])
         if image.is_cuda:
             nets.check_saturation(image.device, "encoder / decoder")   # once per clip: no silent clamping (csrc/conv.hip)
         return out
@@ -303,7 +331,7 @@ class SLRv1Animator(torch.nn.Module):
 
     @torch.no_grad()
     def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None, keys=None,
-                   alpha_region=None):
+                   alpha_region=None, batch=None):
         """keys=None: PredImg frames [n,3,H,W] (as BaselineAnimator.synthesize).  keys=("PredImg", "FluidImg",
         "CompositeFluidAlpha", "BGImg", ...): a dict of those outputs of forward_flow, stacked over the frames
         ("BGImg" and "AlphaRegionMask" are frame-invariant: one [1,.,H,W] tensor) -- what
@@ -314,17 +342,24 @@ class SLRv1Animator(torch.nn.Module):
         want = ("PredImg",) if keys is None else tuple(keys)
         once = ("BGImg", "AlphaRegionMask")
         outs = {}
-        for i, (gen_fs, alpha_fluid) in enumerate(_features_ahead(clip, frames, overlap)):
-            d = self._decode(clip, gen_fs, alpha_fluid)
+        batch = DECODE_BATCH if batch is None else max(1, int(batch))
+        if overlap or batch == 1 or not clip.use_alpha0:
+            groups = ((i, g, a) for i, (g, a) in enumerate(_features_ahead(clip, frames, overlap)))
+        else:
+            groups = _feature_batches(clip, frames, batch)
+        for i0, gen_fs, alpha_fluid in groups:
+            d = self._decode(clip, gen_fs, alpha_fluid)              # every stage works on a batch of frames
+            b = gen_fs.shape[0]
             for k in want:
                 if k in once:
                     outs[k] = d[k]
                     continue
                 if k not in outs:
                     outs[k] = d[k].new_empty(len(frames), *d[k].shape[1:])
-                outs[k][i] = d[k][0]
+                outs[k][i0:i0 + b] = d[k]
             if on_frame is not None:
-                on_frame(outs["PredImg"][i])
+                for i in range(i0, i0 + b):
+                    on_frame(outs["PredImg"][i])
         if image.is_cuda:
             nets.check_saturation(image.device, "encoder / decoder")
         return outs["PredImg"] if keys is None else outs

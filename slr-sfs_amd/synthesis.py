@@ -167,14 +167,20 @@ class MotionPlan:
         return rec["plan"], rec["n"], i, (int(row[0]), int(row[3]), int(row[4]))
 
 
-def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, eps=1e-8, return_norm=False, timed=False):
-    """synth_group for frame t of a MotionPlan (bins and work plan prepared per clip)."""
+def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, eps=1e-8, return_norm=False, timed=False,
+                     out=None):
+    """synth_group for frame t of a MotionPlan (bins and work plan prepared per clip).
+    out: optional [1,C,H,W] destination (e.g. one sample of a batch buffer the decoder will read)."""
     require_device(values, wlogit, wmax)
     assert values.shape[0] == 1 and wlogit.shape[1] == 1
     _, C, H, W = values.shape
     plan, n, i, (n_items, n_multi, n_whole) = mp.lookup(t)
     disp_f, disp_p = mp.disp_f[t], mp.disp_p[mp.N - t]
-    out = torch.empty_like(values)
+    if out is None:
+        out = torch.empty_like(values)
+    else:
+        require_device(out)
+        assert out.shape == values.shape and out.device == values.device
     norm = values.new_empty(1, 1, H, W) if return_norm else None
     scratch = workspace(values, "clip", 1, C, H, W, nbytes=int(lib().slr_splat_scratch_bytes(C, H, W)))
     with torch.cuda.device(values.device):
@@ -241,14 +247,17 @@ class ClipSynthesizer:
             a = torch.clamp(a, min=1.0 / 600.0, max=599.0 / 600.0)
         return float(a)
 
-    def features(self, t, return_norm=False):
-        """Decoder input for frame t (index = [0, t, N-1])."""
+    def features(self, t, return_norm=False, out=None, out_alpha=None):
+        """Decoder input for frame t (index = [0, t, N-1]).  out / out_alpha: optional [1,C,H,W] / [1,1,H,W]
+        destinations (samples of the batch buffers the decoders read; not for the 2-layer model without alpha0,
+        whose alpha plane is a slice of the feature splat)."""
         t = int(t)
         assert 0 <= t < self.N
+        assert (out is None and out_alpha is None) or not (self.v1 and not self.use_alpha0)
         with _stage("frame", self.fs.device):
-            return self._features(t, return_norm)
+            return self._features(t, return_norm, out, out_alpha)
 
-    def _features(self, t, return_norm):
+    def _features(self, t, return_norm, out=None, out_alpha=None):
         a = self.alpha(t)
         Zt = self.Z
         if self.softmax_v2:                      # Z_f_max = maximum_warp_norm_splater(Z_f, forward_flow)  (:849-851)
@@ -256,12 +265,12 @@ class ClipSynthesizer:
             Zt = self.Z - _FunctionMaximumWarpNormsplat(self.Z, self.disp_f[t:t + 1].contiguous())
             if self.clamp_z is not None:
                 Zt = torch.clamp(Zt, min=self.clamp_z[0], max=self.clamp_z[1])
-        res = synth_group_clip(self.fs, Zt, self.plan, t, a, wmax=self.zmax, return_norm=return_norm, timed=True)
+        res = synth_group_clip(self.fs, Zt, self.plan, t, a, wmax=self.zmax, return_norm=return_norm, timed=True, out=out)
         gen, norm = res if return_norm else (res, None)
         if not self.v1:
             return (gen, norm) if return_norm else gen
         if self.use_alpha0:
-            afl = synth_group_clip(self.af, self.A0, self.plan, t, a, wmax=None, exp_weights=True)
+            afl = synth_group_clip(self.af, self.A0, self.plan, t, a, wmax=None, exp_weights=True, out=out_alpha)
         else:
             gen, afl = gen[:, :-1], gen[:, -1:]
         return (gen, afl, norm) if return_norm else (gen, afl)
