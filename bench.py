@@ -111,22 +111,30 @@ def timed_clips(step, steps, warmup, world, dev):
 
 def splat_roofline(kev, sev, c_splat, kernel):
     """Tile kernel (HIP events recorded by the library around that launch) and the whole stage per frame."""
-    kus = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in kev)
-    k_avg = sum(kus) / len(kus)
+    # one launch of the tile kernel does the work of `nf` frames (pipeline.DECODE_BATCH of them share a launch)
+    launches = [(e0.elapsed_time(e1) * 1e3, nf) for e0, e1, nf in kev]
+    per_frame = sorted(us / nf for us, nf in launches)
+    nframes = sum(nf for _, nf in launches)
+    k_avg = sum(us for us, _ in launches) / nframes                     # launch duration per frame of work
+    l_avg = sum(us for us, _ in launches) / len(launches)
+    fpl = nframes / len(launches)
     alg = splat_alg_bytes(c_splat)
     ach = alg / (k_avg * 1e-6) / 1e9
-    frames = [e0.elapsed_time(e1) * 1e3 for k, e0, e1 in sev if k == "frame"]
-    prep = [e0.elapsed_time(e1) * 1e3 for k, e0, e1 in sev if k == "prep"]
-    stage_us = (sum(frames) + sum(prep)) / max(1, len(frames))
+    frames = [(e0.elapsed_time(e1) * 1e3, nf) for k, e0, e1, nf in sev if k == "frame"]
+    prep = [e0.elapsed_time(e1) * 1e3 for k, e0, e1, nf in sev if k == "prep"]
+    stage_us = (sum(us for us, _ in frames) + sum(prep)) / max(1, sum(nf for _, nf in frames))
     traffic, src = None, None
     tf = os.path.join(ROOT, "profiles", "r2_splat_traffic.json")
     if c_splat == 65 and os.path.exists(tf):
-        traffic = json.load(open(tf))["traffic_bytes_per_launch"]
-        src = "static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/r2_splat_traffic.json, not measured in this run"
+        traffic = round(json.load(open(tf))["traffic_bytes_per_launch"] * fpl)
+        src = ("static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/r2_splat_traffic.json (per frame of work) x "
+               "frames_per_launch, not measured in this run")
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "alg_bytes_per_launch": alg, "avg_us": round(k_avg, 1), "min_us": round(kus[0], 1),
-            "max_us": round(kus[-1], 1), "launches": len(kus),
+            "alg_bytes_per_launch": round(alg * fpl), "frames_per_launch": round(fpl, 2), "launch_avg_us": round(l_avg, 1),
+            "alg_bytes_per_frame": alg, "avg_us": round(k_avg, 1), "min_us": round(per_frame[0], 1),
+            "max_us": round(per_frame[-1], 1), "launches": len(launches),
+            "note": "avg/min/max_us = launch duration / frames in the launch; achieved = alg_bytes_per_launch / launch_avg_us",
             "stage_us": round(stage_us, 1), "stage_frac": round(alg / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "stage_prep_us_per_clip": round(sum(prep) / max(1, len(prep)), 1),
             "stage": "per frame: fused tile kernel + combine (+ the 2nd weight group for C4); per clip / frames: both "
@@ -341,10 +349,10 @@ def context_measurements(workload, image, motion, dev):
         torch.manual_seed(0)
         m3 = pipeline.BaselineAnimator().to(dev).eval()
         with torch_convolutions():
-            m3.synthesize(image, motion, NFRAMES, frames=range(0, 6))        # MIOpen picks its kernels
+            m3.synthesize(image, motion, NFRAMES, frames=range(0, 6), batch=1)        # MIOpen picks its kernels
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3))
+            m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
             torch.cuda.synchronize()
             out["fps_fp32_convs"] = {"value": round(20 / (time.perf_counter() - t1), 2), "unit": "frames/s",
                                      "what": "same C3 clip (20 of its 60 frames) with every convolution of the "
@@ -388,7 +396,7 @@ def dropin_roofline(dev, motion):
         call_avg, call_min = _time_calls(lambda: (synthesis._arm_timer(x), S.FunctionSoftsplat(x, flow, None, "summation")), 20)
         kev, synthesis.kernel_timing = synthesis.kernel_timing, None
         torch.cuda.synchronize()
-        kus = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in kev[3:])
+        kus = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1, _ in kev[3:])
         k_avg = sum(kus) / len(kus)
         r = {"tile_us": round(k_avg, 1), "tile_gbs": round(alg / k_avg / 1e3, 1), "tile_frac": round(alg / k_avg / 1e3 / HBM_PEAK_GBS, 4),
              "call_us": round(call_avg, 1), "call_frac": round(alg / call_avg / 1e3 / HBM_PEAK_GBS, 4)}

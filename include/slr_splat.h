@@ -152,6 +152,18 @@ size_t slr_splat_scratch_bytes(int C, int H, int W);      /* partial-tile scratc
 int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words);
 int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp_p, const int *idx_p, int nframes,
                         int H, int W, void *plan, size_t plan_bytes, void *stream);
+/* slr_synth_group for nb <= 8 frames of a built clip plan in ONE launch of the tile kernel (and one of combine):
+ * consecutive kernels of a stream do not overlap, and the last round of a frame's ~2100 work items runs on a half-empty
+ * chip; with the frames of a decoder batch in one grid the splat of a frame takes 190-200 us instead of 243.
+ * Arrays of nb entries: disp_f / disp_p / out / norm_out (device pointers per frame; norm_out may be NULL), alpha,
+ * frame (index into the plan); hints = nb x {n_items, n_multi, n_whole} or NULL (all unknown).
+ * scratch: slr_splat_scratch_bytes_batch(C, H, W, nb) bytes (one partial-tile area per frame of the batch). */
+size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb);
+int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                               const float *const *disp_f, const float *const *disp_p, const float *alpha,
+                               float *const *out, float *const *norm_out, int C, int H, int W, float eps,
+                               const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                               void *scratch, size_t scratch_bytes, const int *hints, void *stream);
 /* slr_synth_group for frame `frame` of a built clip plan (disp_f / disp_p: that frame's two maps). */
 int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                          const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,

@@ -411,6 +411,31 @@ struct SplatArgs {
     long long *trace;
 };
 
+// Several frames of a clip in ONE launch: kernels on a stream run one after the other, so with one launch per frame
+// the last round of a frame's work items runs on a half-empty chip (2100 items for 512 workgroup slots: 4.1 rounds)
+// before the next frame's first round may start; measured with two streams, letting consecutive frames overlap takes
+// the splat of a frame from 243 to 190-200 us.  The arguments of up to MAXB frames travel as kernel arguments; a
+// workgroup finds its frame from its block index (ranges end[] for the tile kernel, cend[] for combine), wave-uniform.
+#ifndef SLR_MAXB
+#define SLR_MAXB 8
+#endif
+constexpr int MAXB = SLR_MAXB;
+struct SplatBatch {
+    SplatArgs f[MAXB];
+    uint32_t end[MAXB];      // tile kernel: blocks [end[i-1], end[i]) belong to frame i (multiples of 8 * XCD_GROUP)
+    uint32_t cend[MAXB];     // combine kernel: the same for its grid.x
+    uint32_t nb;
+};
+
+__device__ __forceinline__ uint32_t batch_frame(const uint32_t (&end)[MAXB], uint32_t nb, uint32_t bx, uint32_t &start) {
+    uint32_t f = 0;
+    start = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < MAXB; ++i)
+        if (i + 1 < (int)nb && bx >= end[i]) { f = i + 1; start = end[i]; }
+    return f;
+}
+
 __device__ __forceinline__ float finish(float s, float nrm, int norm_mode, float eps) {
     if (norm_mode == SLR_NORM_ZERO_TO_ONE) return s / (nrm == 0.0f ? 1.0f : nrm);   // softsplat.py:684-686
     return s / fmaxf(nrm, eps);                                                      // ...splating.py:923-924
@@ -458,7 +483,8 @@ constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 #define SLR_REC6 1             // records as (u16 entry, f32 weight) in two LDS arrays: 6 instead of 8 bytes each
 #endif
 #ifndef SLR_WAVES_ONE
-#define SLR_WAVES_ONE 6        // __launch_bounds__ waves per SIMD of the one-flow instantiation: 80 VGPRs, three workgroups per CU
+#define SLR_WAVES_ONE 5        // __launch_bounds__ waves per SIMD of the one-flow instantiation: <= 96 VGPRs (6 = 80 VGPRs
+                               // measures the same -- the table below -- but leaves the NORM variant 2 registers short: spills)
 #endif
 constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = SLR_CHUNK_ONE;     // (CHUNK 4 measures the same: the chunk count /
                                                                     // barrier count is not what bounds the kernel)
@@ -502,8 +528,11 @@ __host__ __device__ constexpr size_t lds_head_bytes(int ept) {
 constexpr int tile_min_waves(int ept, bool whole) { return (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1; }
 
 template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE>
-__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void splat_tile_kernel(SplatArgs a) {
+__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void splat_tile_kernel(SplatBatch batch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t bstart;
+    const SplatArgs &a = batch.f[batch_frame(batch.end, batch.nb, blockIdx.x, bstart)];     // scalar loads, dynamic offset
+    const uint32_t bx = blockIdx.x - bstart;               // block index inside this frame's range
     constexpr int T = SPLAT_THREADS;
     constexpr int SEG = EPT_MAX * T;
     uint32_t *cnt = smem;                     // [T]   records per output pixel
@@ -531,14 +560,14 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     uint32_t item;
     if (!WHOLE) {
         const uint32_t total = a.totals[0];
-        const uint32_t slot = blockIdx.x >> 3;
-        item = ((slot / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + slot % XCD_GROUP;
+        const uint32_t slot = bx >> 3;
+        item = ((slot / XCD_GROUP) * 8u + (bx & 7u)) * XCD_GROUP + slot % XCD_GROUP;
         if (item >= total) return;
     } else {                                           // the (rare) whole-tile items, grid-strided
-        if (blockIdx.x >= a.totals[4]) return;
-        item = a.whole_items[blockIdx.x];
+        if (bx >= a.totals[4]) return;
+        item = a.whole_items[bx];
     }
-  for (uint32_t wi = blockIdx.x;;) {                   // one pass unless WHOLE
+  for (uint32_t wi = bx;;) {                           // one pass unless WHOLE
     const ItemDesc it = a.items[item];
     const uint32_t t = it.tile;
     // Normally one workgroup = one segment.  A tile whose segments did not fit into the partial-slot
@@ -902,9 +931,12 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
 // grid (max multi-segment tiles, ceil(C/COMBINE_CHUNK)); TILE_PIX threads; workgroups past the
 // number of multi-segment tiles of this plan (totals[3]) exit at once.
 template <bool NORM, bool MAXOP>
-__global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatArgs a) {
-    if (blockIdx.x >= a.totals[3]) return;
-    const uint32_t t = a.multi[blockIdx.x];
+__global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatBatch batch) {
+    uint32_t bstart;
+    const SplatArgs &a = batch.f[batch_frame(batch.cend, batch.nb, blockIdx.x, bstart)];
+    const uint32_t bx = blockIdx.x - bstart;
+    if (bx >= a.totals[3]) return;
+    const uint32_t t = a.multi[bx];
     const uint32_t ns = a.nseg[t];
     const int c0 = blockIdx.y * COMBINE_CHUNK;
     const int n = t / a.tiles, tl = t - n * a.tiles;
@@ -1028,7 +1060,7 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
 }
 
 template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE>
-static int launch_tile_variant(const SplatArgs &a, uint32_t grid, size_t lds, hipStream_t st) {
+static int launch_tile_variant(const SplatBatch &b, uint32_t grid, size_t lds, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
     // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
     static bool attr_set[64] = {};
@@ -1039,50 +1071,76 @@ static int launch_tile_variant(const SplatArgs &a, uint32_t grid, size_t lds, hi
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>), dim3(grid), dim3(SPLAT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>), dim3(grid), dim3(SPLAT_THREADS), lds, st, b);
     return 0;
 }
 
-// n_items / n_whole: what the plan holds, when the host knows it (a clip plan's totals read back once per clip);
-// < 0 = unknown -> the grid covers the upper bound and surplus workgroups exit at once.
+// What the host knows about the plan of one frame (a clip plan's totals read back once per clip); < 0 = unknown ->
+// the grids cover the upper bounds and surplus workgroups exit at once.
+struct PlanHint { int n_items, n_multi, n_whole; };
+
+// Tile kernel, whole-tile kernel and combine for nb frames whose plans are already in b.f[]: the main tile kernel
+// and combine as ONE launch each over all frames.
 template <bool NORM, bool MAXOP, int EPT, int CHUNK>
-static int launch_tile(const SplatArgs &a, uint32_t items_cap, uint32_t nt, int n_items, int n_whole, hipStream_t st) {
-    // counts (T words) + wave sums (16) + offsets (T halfwords) | records (8 B) | CHUNK staged planes
-    const size_t lds = lds_head_bytes(EPT) + (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;     // + the all-zero NULL entry
-    const uint32_t cover = n_items >= 0 && (uint32_t)n_items < items_cap ? (uint32_t)n_items : items_cap;
-    const uint32_t grid = ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+static int launch_batch(SplatBatch &b, const PlanHint *hint, uint32_t items_cap, uint32_t nt, uint32_t part_slots,
+                        hipStream_t st) {
+    // counts (T words) + wave sums (16) + offsets (T halfwords) | records | CHUNK staged planes + the all-zero NULL entry
+    const size_t lds = lds_head_bytes(EPT) + (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
+    uint32_t grid = 0, cgrid = 0;
+    for (uint32_t i = 0; i < b.nb; ++i) {
+        const int ni = hint[i].n_items, nm = hint[i].n_multi;
+        const uint32_t cover = ni >= 0 && (uint32_t)ni < items_cap ? (uint32_t)ni : items_cap;
+        grid += ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+        b.end[i] = grid;
+        // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
+        cgrid += nm >= 0 ? (uint32_t)nm : part_slots / 2;
+        b.cend[i] = cgrid;
+    }
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
     if (grid)
-        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(a, grid, lds, st)) return e;
+        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(b, grid, lds, st)) return e;
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));         // the dominant kernel only
     g_ev_start = g_ev_stop = nullptr;                                                // one-shot
-    // tiles that did not fit the partial-slot budget (none for ordinary flows: the workgroups exit at once)
-    if (n_whole == 0) return 0;
-    const uint32_t wg = n_whole > 0 ? (uint32_t)n_whole : nt;
-    return launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(a, wg < 256u ? wg : 256u, lds, st);
+    // tiles that did not fit the partial-slot budget (none for ordinary flows), frame by frame
+    for (uint32_t i = 0; i < b.nb; ++i) {
+        if (hint[i].n_whole == 0) continue;
+        SplatBatch one = {};
+        one.f[0] = b.f[i];
+        one.nb = 1;
+        const uint32_t wg = hint[i].n_whole > 0 ? (uint32_t)hint[i].n_whole : nt;
+        one.end[0] = wg < 256u ? wg : 256u;
+        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(one, one.end[0], lds, st)) return e;
+    }
+    if (cgrid)
+        hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(cgrid, (b.f[0].C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
+                           dim3(SPLAT_THREADS), 0, st, b);
+    SLR_CHECK_LAUNCH();
+    return 0;
 }
 
-// tile kernel(s) + combine for a plan that is already in `a`.
+template <bool NORM, bool MAXOP>
+static int run_batch(SplatBatch &b, const PlanHint *hint, bool two_flows, uint32_t items_cap, uint32_t nt,
+                     uint32_t part_slots, hipStream_t st) {
+    for (uint32_t i = 0; i < b.nb; ++i) {
+        b.f[i].ndir = two_flows ? 2 : 1;
+        b.f[i].seg = two_flows ? SEG_TWO : SEG_ONE;
+#ifdef SLR_TRACE
+        b.f[i].trace = g_trace;
+#endif
+    }
+    if (two_flows) return launch_batch<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(b, hint, items_cap, nt, part_slots, st);
+    return launch_batch<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(b, hint, items_cap, nt, part_slots, st);
+}
+
+// tile kernel(s) + combine for ONE frame whose plan is already in `a`.
 template <bool NORM, bool MAXOP>
 static int run_plan(SplatArgs &a, bool two_flows, uint32_t items_cap, uint32_t nt, uint32_t part_slots, int n_items,
                     int n_multi, int n_whole, hipStream_t st) {
-    a.ndir = two_flows ? 2 : 1;
-    a.seg = two_flows ? SEG_TWO : SEG_ONE;
-#ifdef SLR_TRACE
-    a.trace = g_trace;
-#endif
-    if (two_flows) {
-        if (int e = launch_tile<NORM, MAXOP, EPT_TWO, CHUNK_TWO>(a, items_cap, nt, n_items, n_whole, st)) return e;
-    } else {
-        if (int e = launch_tile<NORM, MAXOP, EPT_ONE, CHUNK_ONE>(a, items_cap, nt, n_items, n_whole, st)) return e;
-    }
-    // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
-    if (n_multi != 0)
-        hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>),
-                           dim3(n_multi > 0 ? (uint32_t)n_multi : part_slots / 2, (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),
-                           dim3(SPLAT_THREADS), 0, st, a);
-    SLR_CHECK_LAUNCH();
-    return 0;
+    SplatBatch b = {};
+    b.f[0] = a;
+    b.nb = 1;
+    const PlanHint h = {n_items, n_multi, n_whole};
+    return run_batch<NORM, MAXOP>(b, &h, two_flows, items_cap, nt, part_slots, st);
 }
 
 // plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
@@ -1343,34 +1401,12 @@ SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const 
     return 0;
 }
 
-SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
-                                    const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
-                                    int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes,
-                                    int frame, void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole,
-                                    void *stream) {
-    SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && out && plan && scratch, "null pointer");
-    if (int e = check_dims(1, C, H, W, __func__)) return e;
-    if (int e = clip_check(nframes, H, W, __func__)) return e;
-    SLR_CHECK_ARG(frame >= 0 && frame < nframes, "frame index");
-    const ClipLayout L = clip_layout(nframes, H, W);
-    const size_t stride = (size_t)(C + 1) * TILE_PIX;
-    const size_t need = al256(stride * 4) + al256((size_t)L.part_slots * stride * 4);
-    if (((uintptr_t)plan & 15) || plan_bytes < L.total || ((uintptr_t)scratch & 15) || scratch_bytes < need) {
-        set_error("%s: plan needs %zu bytes (got %zu), scratch %zu (got %zu), both 16-byte aligned", __func__, L.total,
-                  plan_bytes, need, scratch_bytes);
-        return SLR_E_WORKSPACE;
-    }
+// SplatArgs of frame `frame` of a clip plan (everything but the per-call tensors).
+static void clip_frame_args(SplatArgs &a, const ClipLayout &L, const void *plan, int frame, void *scratch, int slot, int C) {
     const char *b = (const char *)plan;
     const size_t i = (size_t)frame;
-    SplatArgs a = {};
-    a.in = values; a.mul = wlogit; a.mulmax = wmax;
-    a.flow[0] = disp_f; a.flow[1] = disp_p;
-    a.scale[0] = alpha; a.scale[1] = 1.0f - alpha;
-    a.out = out; a.norm_out = norm_out;
-    a.N = 1; a.C = C; a.H = H; a.W = W;
-    a.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
-    a.norm_mode = SLR_NORM_CLAMP_EPS;
-    a.eps = eps;
+    const size_t stride = (size_t)(C + 1) * TILE_PIX;
+    const size_t slot_bytes = al256((size_t)L.part_slots * stride * 4);
     a.tiles_x = L.tiles_x; a.tiles = L.tiles;
     a.count[0] = (const uint32_t *)(b + L.off_count) + i * L.nt;
     a.count[1] = (const uint32_t *)(b + L.off_count) + ((size_t)L.nframes + i) * L.nt;
@@ -1381,8 +1417,67 @@ SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, co
     a.whole_items = (const uint32_t *)(b + L.off_whole) + i * L.nt;
     a.items = (const ItemDesc *)(b + L.off_items) + i * L.items_cap;
     a.totals = (const uint32_t *)(b + L.off_totals) + i * CLIP_TOTALS;
-    a.trash = (float *)scratch;
-    a.partial = (float *)((char *)scratch + al256(stride * 4));
+    a.trash = (float *)scratch;                                        // shared by the frames of a batch (write-only sink)
+    a.partial = (float *)((char *)scratch + al256(stride * 4) + (size_t)slot * slot_bytes);
     a.part_stride = stride;
-    return run_plan<true, false>(a, true, L.items_cap, L.nt, L.part_slots, n_items, n_multi, n_whole, (hipStream_t)stream);
+}
+
+static size_t clip_scratch_need(const ClipLayout &L, int C, int nb) {
+    const size_t stride = (size_t)(C + 1) * TILE_PIX;
+    return al256(stride * 4) + (size_t)nb * al256((size_t)L.part_slots * stride * 4);
+}
+
+SLR_EXPORT size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb) {
+    if (C <= 0 || H <= 0 || W <= 0 || nb <= 0 || nb > MAXB) return 0;
+    return clip_scratch_need(clip_layout(1, H, W), C, nb);
+}
+
+SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                                          const float *const *disp_f, const float *const *disp_p, const float *alpha,
+                                          float *const *out, float *const *norm_out, int C, int H, int W, float eps,
+                                          const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                          void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+    SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && alpha && out && plan && scratch && frame, "null pointer");
+    SLR_CHECK_ARG(nb >= 1 && nb <= MAXB, "1 <= nb <= 8 frames per launch");
+    if (int e = check_dims(1, C, H, W, __func__)) return e;
+    if (int e = clip_check(nframes, H, W, __func__)) return e;
+    const ClipLayout L = clip_layout(nframes, H, W);
+    const size_t need = clip_scratch_need(L, C, nb);
+    if (((uintptr_t)plan & 15) || plan_bytes < L.total || ((uintptr_t)scratch & 15) || scratch_bytes < need) {
+        set_error("%s: plan needs %zu bytes (got %zu), scratch %zu (got %zu), both 16-byte aligned", __func__, L.total,
+                  plan_bytes, need, scratch_bytes);
+        return SLR_E_WORKSPACE;
+    }
+    SplatBatch b = {};
+    PlanHint h[MAXB];
+    b.nb = (uint32_t)nb;
+    for (int k = 0; k < nb; ++k) {
+        SLR_CHECK_ARG(frame[k] >= 0 && frame[k] < nframes, "frame index");
+        SLR_CHECK_ARG(disp_f[k] && disp_p[k] && out[k], "null pointer");
+        SplatArgs &a = b.f[k];
+        a.in = values; a.mul = wlogit; a.mulmax = wmax;
+        a.flow[0] = disp_f[k]; a.flow[1] = disp_p[k];
+        a.scale[0] = alpha[k]; a.scale[1] = 1.0f - alpha[k];
+        a.out = out[k]; a.norm_out = norm_out ? norm_out[k] : nullptr;
+        a.N = 1; a.C = C; a.H = H; a.W = W;
+        a.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
+        a.norm_mode = SLR_NORM_CLAMP_EPS;
+        a.eps = eps;
+        clip_frame_args(a, L, plan, frame[k], scratch, k, C);
+        h[k].n_items = hints ? hints[3 * k] : -1;
+        h[k].n_multi = hints ? hints[3 * k + 1] : -1;
+        h[k].n_whole = hints ? hints[3 * k + 2] : -1;
+    }
+    return run_batch<true, false>(b, h, true, L.items_cap, L.nt, L.part_slots, (hipStream_t)stream);
+}
+
+SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                                    const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
+                                    int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes,
+                                    int frame, void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole,
+                                    void *stream) {
+    const int hints[3] = {n_items, n_multi, n_whole};
+    return slr_synth_group_clip_batch(values, wlogit, wmax, exp_weights, &disp_f, &disp_p, &alpha, &out,
+                                      norm_out ? &norm_out : nullptr, C, H, W, eps, plan, plan_bytes, nframes, &frame, 1,
+                                      scratch, scratch_bytes, hints, stream);
 }

@@ -75,15 +75,17 @@ DECODE_BATCH = int(_os.environ.get("SLR_SFS_AMD_DECODE_BATCH", "4"))      # fram
 def _feature_batches(clip, frames, batch):
     """Yield (first index, gen_fs [b,C,H,W], alpha_fluid [b,1,H,W] or None) for consecutive groups of <= batch frames:
     every frame's features are written by the splat kernels directly into one sample of the batch tensors."""
+    from .synthesis import MAX_BATCH
     frames = list(frames)
     H, W = clip.fs.shape[2:]
-    for i0 in range(0, len(frames), batch):
-        ts = frames[i0:i0 + batch]
+    sb = max(batch, MAX_BATCH // batch * batch)      # frames splatted together: whole decoder batches, <= MAX_BATCH
+    for s0 in range(0, len(frames), sb):
+        ts = frames[s0:s0 + sb]
         gen = clip.fs.new_empty(len(ts), clip.C, H, W)
         afl = clip.fs.new_empty(len(ts), 1, H, W) if clip.v1 else None
-        for j, t in enumerate(ts):
-            clip.features(t, out=gen[j:j + 1], out_alpha=None if afl is None else afl[j:j + 1])
-        yield i0, gen, afl
+        clip.features_batch(ts, gen, afl)            # one launch of the tile kernel per weight group for (up to 8 of) them
+        for j in range(0, len(ts), batch):
+            yield s0 + j, gen[j:j + batch], None if afl is None else afl[j:j + batch]
 
 
 def _check_grid(image):

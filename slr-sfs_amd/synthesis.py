@@ -13,6 +13,7 @@ forward steps = middle-start = t, backward steps = end-middle+1 = N-t,
 alpha = 1 - (middle-start)/(end-start+1) = 1 - t/N.
 """
 import ctypes
+import os
 
 import torch
 
@@ -23,14 +24,15 @@ from .euler_integration_manipulator import euler_integration_all
 # bench.py sets this to a list to collect (start, stop) torch events around the tile kernel of
 # every synth_group call with timed=True (through slr_splat_time_next); None = no timing.
 kernel_timing = None
-# bench.py sets this to a list to collect ("prep" | "frame", start, stop) torch events around the WHOLE splat stage:
-# "prep" = the per-clip motion work (Euler passes, binning, planning), "frame" = one features(t) call.
+# bench.py sets this to a list to collect ("prep" | "frame", start, stop, frames) torch events around the WHOLE splat
+# stage: "prep" = the per-clip motion work (Euler passes, binning, planning), "frame" = one features(t) call or one
+# features_batch group (`frames` of them in one launch).
 stage_timing = None
 
 
 class _stage:
-    def __init__(self, kind, device):
-        self.kind, self.device = kind, device
+    def __init__(self, kind, device, frames=1):
+        self.kind, self.device, self.frames = kind, device, frames
 
     def __enter__(self):
         if stage_timing is not None:
@@ -41,16 +43,18 @@ class _stage:
         if stage_timing is not None and exc[0] is None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.device))
-            stage_timing.append((self.kind, self.e0, e1))
+            stage_timing.append((self.kind, self.e0, e1, self.frames))
         return False
 
 
-def _arm_timer(t):
+def _arm_timer(t, frames=1):
+    """Ask the library to record events around the next tile-kernel launch; kernel_timing gets (start, stop, frames in
+    that launch) -- a batched launch does the work of several frames."""
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     for e in ev:
         e.record(torch.cuda.current_stream(t.device))      # materialises the hipEvent_t handle
     lib().slr_splat_time_next(ev[0].cuda_event, ev[1].cuda_event)
-    kernel_timing.append(ev)
+    kernel_timing.append((ev[0], ev[1], frames))
 
 
 def bin_flow(flow, C, role):
@@ -155,6 +159,12 @@ class MotionPlan:
         for i, t in enumerate(ts):
             self._where[t] = (rec, i)
 
+    def chunk_of(self, t):
+        """The plan chunk frame t lives in (built on demand for an unannounced frame)."""
+        if t not in self._where:
+            self._build([t])
+        return self._where[t][0]
+
     def lookup(self, t):
         """-> (plan buffer, frames in it, index of t, (n_items, n_multi, n_whole))."""
         if t not in self._where:
@@ -191,6 +201,39 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
                                          float(eps), ptr(plan), plan.numel(), n, i, ptr(scratch), scratch.numel(),
                                          n_items, n_multi, n_whole, stream_of(values)), "slr_synth_group_clip")
     return (out, norm) if return_norm else out
+
+
+MAX_BATCH = int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "8"))     # frames per launch of slr_synth_group_clip_batch (csrc: MAXB = 8)
+
+
+def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_weights=True, eps=1e-8, timed=False):
+    """synth_group_clip for up to MAX_BATCH frames `ts` of ONE chunk of a MotionPlan in one launch of the tile kernel:
+    outs[k] ([1,C,H,W], e.g. the samples of a decoder batch) receives frame ts[k]."""
+    require_device(values, wlogit, wmax, *outs)
+    assert values.shape[0] == 1 and wlogit.shape[1] == 1 and 1 <= len(ts) <= MAX_BATCH and len(outs) == len(ts)
+    _, C, H, W = values.shape
+    look = [mp.lookup(t) for t in ts]
+    plan, n = look[0][0], look[0][1]
+    assert all(lk[0] is plan for lk in look), "frames of one launch must come from one chunk of the plan"
+    nb = len(ts)
+    L = lib()
+    scratch = workspace(values, "clipb", nb, C, H, W, nbytes=int(L.slr_splat_scratch_bytes_batch(C, H, W, nb)))
+    PP = ctypes.c_void_p * nb
+    df = PP(*[mp.disp_f[t].data_ptr() for t in ts])
+    dp = PP(*[mp.disp_p[mp.N - t].data_ptr() for t in ts])
+    op = PP(*[o.data_ptr() for o in outs])
+    al = (ctypes.c_float * nb)(*[float(a) for a in alphas])
+    fr = (ctypes.c_int * nb)(*[lk[2] for lk in look])
+    hints = (ctypes.c_int * (3 * nb))(*[v for lk in look for v in lk[3]])
+    for o in outs:
+        assert o.shape == values.shape and o.device == values.device
+    with torch.cuda.device(values.device):
+        if timed and kernel_timing is not None:
+            _arm_timer(values, nb)
+        check(L.slr_synth_group_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, df, dp, al, op,
+                                           None, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb, ptr(scratch),
+                                           scratch.numel(), hints, stream_of(values)), "slr_synth_group_clip_batch")
+    return outs
 
 
 class ClipSynthesizer:
@@ -256,6 +299,34 @@ class ClipSynthesizer:
         assert (out is None and out_alpha is None) or not (self.v1 and not self.use_alpha0)
         with _stage("frame", self.fs.device):
             return self._features(t, return_norm, out, out_alpha)
+
+    def features_batch(self, ts, out, out_alpha=None):
+        """Decoder inputs of the frames `ts` into the samples of the batch tensors out [b,C,H,W] (and out_alpha [b,1,H,W]
+        for the 2-layer model): the frames of one plan chunk go through ONE launch of the tile kernel per weight group
+        (up to MAX_BATCH at a time).  Falls back to frame-by-frame calls where a frame needs its own weights
+        (use_softmax_splatter_v2) or the alpha plane rides in the feature splat (no alpha0)."""
+        ts = [int(t) for t in ts]
+        assert out.shape[0] == len(ts)
+        if self.softmax_v2 or (self.v1 and not self.use_alpha0):
+            assert not (self.v1 and not self.use_alpha0), "no batch buffers for the 2-layer model without alpha0"
+            for k, t in enumerate(ts):
+                self.features(t, out=out[k:k + 1], out_alpha=None if out_alpha is None else out_alpha[k:k + 1])
+            return
+        k0 = 0
+        while k0 < len(ts):
+            chunk = self.plan.chunk_of(ts[k0])
+            k1 = k0 + 1
+            while k1 < len(ts) and k1 - k0 < MAX_BATCH and self.plan.chunk_of(ts[k1]) is chunk:
+                k1 += 1
+            grp = ts[k0:k1]
+            al = [self.alpha(t) for t in grp]
+            with _stage("frame", self.fs.device, frames=len(grp)):
+                synth_group_clip_batch(self.fs, self.Z, self.plan, grp, al, [out[k:k + 1] for k in range(k0, k1)],
+                                       wmax=self.zmax, timed=True)
+                if self.v1:
+                    synth_group_clip_batch(self.af, self.A0, self.plan, grp, al,
+                                           [out_alpha[k:k + 1] for k in range(k0, k1)], wmax=None, exp_weights=True)
+            k0 = k1
 
     def _features(self, t, return_norm, out=None, out_alpha=None):
         a = self.alpha(t)

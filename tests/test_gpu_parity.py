@@ -333,6 +333,50 @@ def test_clip_plans_in_chunks_and_for_unannounced_frames(S, oracle, monkeypatch)
     assert sorted(sharded.plan._where) == list(range(N))             # the other six were planned on demand
 
 
+def test_batched_frames_in_one_launch_vs_oracle(S, oracle):
+    """features_batch: the frames of a decoder batch go through ONE launch of the tile kernel (and one of combine) per
+    weight group -- baseline and SLR v1, batches of 1-4 and a ragged tail, a converging field (multi-segment tiles in
+    several frames of the same launch: one partial-tile area per frame), frames from two plan chunks in one call."""
+    H, W, N = 56, 200, 11
+    rng = np.random.default_rng(33)
+    fs = rng.standard_normal((1, 16, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    dx, dy = W * 0.5 - x, H * 0.5 - y
+    r = np.sqrt(dx * dx + dy * dy) + 1e-3
+    conv = np.stack([dx / r * np.minimum(r, 2.0), dy / r * np.minimum(r, 2.0)])[None].astype(np.float32)
+    afl = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    abg = rng.uniform(0.05, 0.95, (1, 1, H, W)).astype(np.float32)
+    for m in (smooth_motion(H, W, 2, amp=3.0), conv):
+        base = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+        ts = [0, 3, 4, 10, 7, 1, 9]                                   # 4 + 3 frames, any order
+        out = torch.empty(len(ts), 16, H, W, device="cuda")
+        base.features_batch(ts, out)
+        for k, t in enumerate(ts):
+            np.testing.assert_allclose(host(out[k:k + 1]), oracle.synth_baseline(fs, Z, m, t, N), rtol=2e-4, atol=2e-5,
+                                       err_msg=str(t))
+        v1 = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, alpha_fluid_logit=dev(afl), alpha_bg=dev(abg))
+        out = torch.empty(3, 16, H, W, device="cuda")
+        oa = torch.empty(3, 1, H, W, device="cuda")
+        v1.features_batch([2, 5, 8], out, oa)
+        for k, t in enumerate([2, 5, 8]):
+            rg, ra, _ = oracle.synth_v1(fs, Z, afl, abg, m, t, N)
+            np.testing.assert_allclose(host(out[k:k + 1]), rg, rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(host(oa[k:k + 1]), ra, rtol=2e-4, atol=2e-5)
+    # frames that live in different chunks of the plan are split into separate launches
+    import slr_sfs_amd.synthesis as syn
+    old = syn.PLAN_CHUNK
+    syn.PLAN_CHUNK = 2
+    try:
+        cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(conv), N)
+    finally:
+        syn.PLAN_CHUNK = old
+    out = torch.empty(4, 16, H, W, device="cuda")
+    cs.features_batch([1, 2, 3, 4], out)
+    for k, t in enumerate([1, 2, 3, 4]):
+        np.testing.assert_allclose(host(out[k:k + 1]), oracle.synth_baseline(fs, Z, conv, t, N), rtol=2e-4, atol=2e-5)
+
+
 def test_randomised_synthesis_vs_oracle(S, oracle):
     """Seeded sweep of the headline path itself -- all-frames Euler integration, two-direction exp-weighted splat,
     normalisation (animating_softmax_splating.py:847-924; SLR v1: ..._2layers_alpha_seperate.py:950-1045) -- over

@@ -20,7 +20,7 @@ for name, fl in flows.items():
         synthesis._arm_timer(x)
         S.FunctionSoftsplat(x, fl, None, "summation")
     torch.cuda.synchronize()
-    us = sorted(a.elapsed_time(b) * 1e3 for a, b in synthesis.kernel_timing[5:])
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b, _ in synthesis.kernel_timing[5:])
     synthesis.kernel_timing = None
     out.append(f"{name} {sum(us)/len(us):6.1f} us ({alg/ (sum(us)/len(us)) / 1e3 / 8000:.3f})")
 print(os.path.basename(os.environ.get("SLR_SFS_AMD_LIB", "default")), " | ".join(out))
