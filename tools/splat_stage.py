@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The splat stage of bench.py's workload alone (no networks): both Euler passes + 60 x
-(bin + fused two-direction splat + normalise) at 768x1280 -- the command the PMC passes
+(fused two-direction splat + normalise, 8 frames per launch) at 768x1280, bins and plans per clip -- the command the PMC passes
 (FETCH_SIZE / WRITE_SIZE) are collected on (rocprofv3 --pmc crashes with the MIOpen pipeline)."""
 import os, sys
 import numpy as np, torch
@@ -13,8 +13,11 @@ fs = torch.randn(1, 64, H, W, device=dev, generator=g)
 Z = torch.randn(1, 1, H, W, device=dev, generator=g)
 motion = torch.from_numpy(smooth_motion(H, W)).to(dev)
 cs = S.synthesis.ClipSynthesizer(fs, Z, motion, NFRAMES)
+B = S.synthesis.MAX_BATCH                     # frames per launch of the tile kernel, as the pipelines use it
+out = torch.empty(B, 64, H, W, device=dev)
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1):
-    for t in range(NFRAMES):
-        out = cs.features(t)
+    for t0 in range(0, NFRAMES, B):
+        ts = list(range(t0, min(t0 + B, NFRAMES)))
+        cs.features_batch(ts, out[:len(ts)])
 torch.cuda.synchronize()
 print("ok", float(out.abs().mean()))
