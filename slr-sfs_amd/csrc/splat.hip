@@ -486,12 +486,13 @@ constexpr int LMAX = SLR_LMAX;                       // records a work-item walk
 constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 // Per-variant shape: EPT bin entries per work-item (segment = EPT*TILE_PIX entries), CHUNK planes
 // staged in LDS / accumulated in registers per pass.  LDS per workgroup (6-byte records):
-//   one flow  EPT 2, CHUNK 4 -> 3.1 + 27.0 + 16 = 46 KiB, 80 VGPRs -> THREE workgroups per CU
-//   two flows EPT 3, CHUNK 4 -> 3.1 + 39.0 + 24 = 66 KiB            -> two   workgroups per CU
+//   one flow  EPT 2, CHUNK 4 -> 3.1 + 27.0 + 16 = 46 KiB
+//   two flows EPT 3, CHUNK 4 -> 3.1 + 39.0 + 24 = 66 KiB  -> two workgroups per CU
 // Measured (768x1280, C = 65, tile kernel alone, identity / Euler t=30 / t=59 / incoherent flow, us):
-//   8-byte records, CHUNK 8, 2 workgroups per CU (round 1): 152 / 196 / 244 / 228
-//   6-byte records, CHUNK 4, 3 workgroups per CU          : 144 / 178 / 223 / 208
-// (6-byte records alone: no change; CHUNK 4 alone, still 2 per CU: 148 / 188 / 236 / 218.)
+//   8-byte records, CHUNK 8 (round 1)   : 152 / 196 / 244 / 228
+//   6-byte records, CHUNK 4             : 144 / 178 / 223 / 208
+// (6-byte records alone: no change; CHUNK 4 alone: 148 / 188 / 236 / 218.  The register cap does not matter: 4 / 5 / 6
+// waves per SIMD = 2 / 2 / 3 workgroups per CU measure the same within 1 %.)
 #ifndef SLR_CHUNK_ONE
 #define SLR_CHUNK_ONE 4
 #endif
