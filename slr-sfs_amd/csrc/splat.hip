@@ -497,8 +497,9 @@ constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 #define SLR_CHUNK_ONE 4
 #endif
 #ifndef SLR_REC6
-#define SLR_REC6 1             // records as (u16 entry, f32 weight) in two LDS arrays: 6 instead of 8 bytes each
-#endif
+#define SLR_REC6 1             // ONE-FLOW variant: records as (u16 entry, f32 weight) in two LDS arrays, 6 instead of 8 bytes.
+#endif                         // The two-flow variant keeps 8-byte records (one ds_read_b64 per record instead of two reads:
+                               // its lists are longer; measured 201 vs 206 us per frame)
 #ifndef SLR_WAVES_ONE
 #define SLR_WAVES_ONE 5        // __launch_bounds__ waves per SIMD of the one-flow instantiation: <= 96 VGPRs (6 = 80 VGPRs
                                // measures the same -- the table below -- but leaves the NORM variant 2 registers short: spills)
@@ -538,8 +539,9 @@ __device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
 //
 // Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
 // bytes of LDS in front of the staged values: counts, wave sums, offsets, records (16-byte aligned)
+__host__ __device__ constexpr bool rec6(int ept) { return SLR_REC6 && ept * SPLAT_THREADS == SEG_ONE; }
 __host__ __device__ constexpr size_t lds_head_bytes(int ept) {
-    return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (SLR_REC6 ? 6 : 8) + 15) & ~(size_t)15;
+    return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (rec6(ept) ? 6 : 8) + 15) & ~(size_t)15;
 }
 // (the rare whole-tile instantiation carries a segment loop and would spill under the 80-register cap)
 constexpr int tile_min_waves(int ept, bool whole) { return (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1; }
@@ -555,18 +557,15 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     uint32_t *cnt = smem;                     // [T]   records per output pixel
     uint32_t *wsum = smem + T;                // [T/64] wave sums of the scan
     uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 16);            // [T] exclusive prefix (< 2^16)
-#if SLR_REC6
-    float *rec_w = reinterpret_cast<float *>(smem + T + 16 + T / 2);        // [rec_cap] weights
-    uint16_t *rec_e = reinterpret_cast<uint16_t *>(rec_w + rec_cap(EPT_MAX));   // [rec_cap] entry indices (< SEG <= 2^16)
-#define REC_PUT(i, e, w) do { rec_e[i] = (uint16_t)(e); rec_w[i] = (w); } while (0)
-#define REC_E(i) ((uint32_t)rec_e[i])
-#define REC_W(i) (rec_w[i])
-#else
-    uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 16 + T / 2);          // [rec_cap] (entry index, weight bits)
-#define REC_PUT(i, e, w) (rec[i] = make_uint2((uint32_t)(e), __float_as_uint(w)))
-#define REC_E(i) (rec[i].x)
-#define REC_W(i) (__uint_as_float(rec[i].y))
-#endif
+    constexpr bool R6 = rec6(EPT_MAX);
+    float *rec_w = reinterpret_cast<float *>(smem + T + 16 + T / 2);        // R6: [rec_cap] weights ...
+    uint16_t *rec_e = reinterpret_cast<uint16_t *>(rec_w + rec_cap(EPT_MAX));   // ... and [rec_cap] entry indices (< SEG <= 2^16)
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 16 + T / 2);          // !R6: [rec_cap] (entry index, weight bits)
+    auto REC_PUT = [&](uint32_t i, uint32_t e, float w) {
+        if constexpr (R6) { rec_e[i] = (uint16_t)e; rec_w[i] = w; } else rec[i] = make_uint2(e, __float_as_uint(w));
+    };
+    auto REC_E = [&](uint32_t i) -> uint32_t { if constexpr (R6) return rec_e[i]; else return rec[i].x; };
+    auto REC_W = [&](uint32_t i) -> float { if constexpr (R6) return rec_w[i]; else return __uint_as_float(rec[i].y); };
     float4 *val4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem) + lds_head_bytes(EPT_MAX) + SLR_LDS_PAD);     // [SEG][CHUNK/4] staged source values
 
     // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
