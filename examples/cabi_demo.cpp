@@ -1,5 +1,6 @@
 // Host program on the C ABI alone (include/slr_splat.h): no Python, no torch -- hipMalloc'ed buffers, one HIP
-// stream, Euler integration of a motion field followed by the summation splat and the fused softmax mode,
+// stream, Euler integration of a motion field followed by the summation splat and the fused softmax mode, then
+// the per-clip path (all-frames Euler passes -> clip plan -> three frames of the clip synthesised by ONE launch),
 // results written as raw float32 files.  tests/test_gpu_parity.py::test_c_abi_from_a_plain_host_program builds
 // and runs it and compares the files with the CPU oracle.
 //
@@ -84,7 +85,47 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "a 16-byte workspace was accepted\n");
         return 4;
     }
+    // ---- the frame-synthesis block of forward_flow for a clip of N frames (a6): features = the C input planes, weight
+    // logits = the metric plane, frames t = 1, N/2, N-1 in one launch of the tile kernel
+    const int N = nsteps + 3, NB = 3;
+    const int ts[NB] = {1, N / 2, N - 1};
+    float *disp_f, *disp_p, *zmax, *zscratch, *frames_out;
+    HIP_OK(hipMalloc(&disp_f, (size_t)N * 2 * hw * 4));                 // forward maps of t = 0 .. N-1
+    HIP_OK(hipMalloc(&disp_p, (size_t)(N + 1) * 2 * hw * 4));           // backward maps of 0 .. N steps
+    HIP_OK(hipMalloc(&zmax, 4));
+    HIP_OK(hipMalloc(&zscratch, 1024 * 4));
+    HIP_OK(hipMalloc(&frames_out, (size_t)NB * C * hw * 4));
+    SLR_OK(slr_euler_integrate_all(motion, H, W, N - 1, +1.0f, disp_f, nullptr, st));
+    SLR_OK(slr_euler_integrate_all(motion, H, W, N, -1.0f, disp_p, nullptr, st));
+    SLR_OK(slr_global_max(metric, hw, zmax, zscratch, st));                                         // Z.max()
+    int h_idx_f[NB], h_idx_p[NB], *idx_f, *idx_p;
+    for (int k = 0; k < NB; ++k) { h_idx_f[k] = ts[k]; h_idx_p[k] = N - ts[k]; }                   // t forward, N - t backward steps
+    HIP_OK(hipMalloc(&idx_f, sizeof h_idx_f));
+    HIP_OK(hipMalloc(&idx_p, sizeof h_idx_p));
+    HIP_OK(hipMemcpyAsync(idx_f, h_idx_f, sizeof h_idx_f, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(idx_p, h_idx_p, sizeof h_idx_p, hipMemcpyHostToDevice, st));
+    const size_t plan_bytes = slr_clip_plan_bytes(NB, H, W), scratch_bytes = slr_splat_scratch_bytes_batch(C, H, W, NB);
+    void *plan, *scratch;
+    HIP_OK(hipMalloc(&plan, plan_bytes));
+    HIP_OK(hipMalloc(&scratch, scratch_bytes));
+    SLR_OK(slr_clip_plan_build(disp_f, idx_f, disp_p, idx_p, NB, H, W, plan, plan_bytes, st));      // bins + plans of all frames
+    const float *pf[NB], *pp[NB];
+    float *po[NB], alpha[NB];
+    int frame[NB];
+    for (int k = 0; k < NB; ++k) {
+        pf[k] = disp_f + (size_t)ts[k] * 2 * hw;
+        pp[k] = disp_p + (size_t)(N - ts[k]) * 2 * hw;
+        po[k] = frames_out + (size_t)k * C * hw;
+        alpha[k] = 1.0f - (float)ts[k] / (float)N;                                                  // :860
+        frame[k] = k;
+    }
+    SLR_OK(slr_synth_group_clip_batch(in, metric, zmax, 1, pf, pp, alpha, po, nullptr, C, H, W, 1e-8f, plan, plan_bytes,
+                                      NB, frame, NB, scratch, scratch_bytes, nullptr /* totals not read back */, st));
     HIP_OK(hipStreamSynchronize(st));
+    if (!write_f32(prefix, "frames", frames_out, (size_t)NB * C * hw)) {
+        std::fprintf(stderr, "cannot write the outputs\n");
+        return 1;
+    }
     if (!write_f32(prefix, "disp", disp, 2 * hw) || !write_f32(prefix, "visible", vis, hw) ||
         !write_f32(prefix, "sum", out_sum, C * hw) || !write_f32(prefix, "softmax", out_soft, C * hw)) {
         std::fprintf(stderr, "cannot write the outputs\n");

@@ -932,7 +932,8 @@ def test_clip_assembler_on_rccl(S, tmp_path):
 def test_c_abi_from_a_plain_host_program(S, oracle, tmp_path):
     """examples/cabi_demo.cpp: a C++ host program with hipMalloc'ed buffers and its own stream, linked against the
     library through include/slr_splat.h only (no Python, no torch in the process) -- Euler integration, summation
-    splat, fused softmax mode with the bins reused; its outputs against the oracle."""
+    splat, fused softmax mode with the bins reused, and the per-clip path (clip plan + three frames in one launch); its
+    outputs against the oracle."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "cabi_demo")
@@ -955,6 +956,12 @@ def test_c_abi_from_a_plain_host_program(S, oracle, tmp_path):
     np.testing.assert_allclose(load("sum", (1, C, H, W)), oracle.softsplat_forward(x, disp), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(load("softmax", (1, C, H, W)), oracle.function_softsplat(x, disp, met, "softmax"),
                                rtol=2e-4, atol=2e-5)
+    # the per-clip entry points from C: slr_euler_integrate_all x 2 -> slr_clip_plan_build -> three frames of the clip by ONE
+    # slr_synth_group_clip_batch launch (N = nsteps + 3 frames; t = 1, N/2, N-1)
+    N = nsteps + 3
+    frames = load("frames", (3, C, H, W))
+    for k, t in enumerate((1, N // 2, N - 1)):
+        np.testing.assert_allclose(frames[k:k + 1], oracle.synth_baseline(x, met, m, t, N), rtol=2e-4, atol=2e-5, err_msg=str(t))
 
 
 def test_c_abi_prebinned_reuse_and_errors(S, oracle):
