@@ -433,12 +433,17 @@ struct SplatArgs {
 #ifndef SLR_MAXB
 #define SLR_MAXB 8
 #endif
+#ifndef SLR_BATCH_INTERLEAVE
+#define SLR_BATCH_INTERLEAVE 1
+#endif
 constexpr int MAXB = SLR_MAXB;
 struct SplatBatch {
     SplatArgs f[MAXB];
-    uint32_t end[MAXB];      // tile kernel: blocks [end[i-1], end[i]) belong to frame i (multiples of 8 * XCD_GROUP)
+    uint32_t end[MAXB];      // tile kernel: blocks [end[i-1], end[i]) belong to frame i (multiples of 8 * XCD_GROUP) ...
     uint32_t cend[MAXB];     // combine kernel: the same for its grid.x
     uint32_t nb;
+    uint32_t interleave;     // ... or (tile kernel, nb > 1): groups of 8 * XCD_GROUP blocks round-robin over the frames,
+                             // end[i] = frame i's OWN grid size (see launch_batch)
 };
 
 static_assert(sizeof(SplatBatch) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -549,9 +554,18 @@ constexpr int tile_min_waves(int ept, bool whole) { return (ept == EPT_ONE && SL
 template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE>
 __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void splat_tile_kernel(SplatBatch batch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t bstart;
-    const SplatArgs &a = batch.f[batch_frame(batch.end, batch.nb, blockIdx.x, bstart)];     // scalar loads, dynamic offset
-    const uint32_t bx = blockIdx.x - bstart;               // block index inside this frame's range
+    uint32_t bstart, bf, bx;                               // frame of this block, block index inside the frame's own grid
+    if (batch.interleave) {
+        constexpr uint32_t G = 8 * XCD_GROUP;
+        const uint32_t gg = blockIdx.x / G;
+        bf = gg % batch.nb;
+        bx = (gg / batch.nb) * G + blockIdx.x % G;
+        if (bx >= batch.end[bf]) return;                   // this frame has fewer groups than the longest of the batch
+    } else {
+        bf = batch_frame(batch.end, batch.nb, blockIdx.x, bstart);
+        bx = blockIdx.x - bstart;
+    }
+    const SplatArgs &a = batch.f[bf];                      // scalar loads with a dynamic offset
     constexpr int T = SPLAT_THREADS;
     constexpr int SEG = EPT_MAX * T;
     uint32_t *cnt = smem;                     // [T]   records per output pixel
@@ -1102,16 +1116,25 @@ static int launch_batch(SplatBatch &b, const PlanHint *hint, uint32_t items_cap,
                         hipStream_t st) {
     // counts (T words) + wave sums (16) + offsets (T halfwords) | records | CHUNK staged planes + the all-zero NULL entry
     const size_t lds = lds_head_bytes(EPT) + (size_t)CHUNK * (EPT * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
-    uint32_t grid = 0, cgrid = 0;
+    // Frames of a batch are consecutive frames of a clip: tile T of frame k+1 gathers from almost the same source region
+    // as tile T of frame k (the displacement maps differ by one Euler step).  With the block ranges of the frames laid
+    // end to end, those two workgroups run a whole frame apart and both fetch the region from HBM; with the groups of
+    // 8 * XCD_GROUP blocks dealt round-robin over the frames they run side by side on the same XCD and share its L2.
+    const bool interleave = SLR_BATCH_INTERLEAVE && b.nb > 1;
+    b.interleave = interleave ? 1u : 0u;
+    uint32_t grid = 0, cgrid = 0, gmax = 0;
     for (uint32_t i = 0; i < b.nb; ++i) {
         const int ni = hint[i].n_items, nm = hint[i].n_multi;
         const uint32_t cover = ni >= 0 && (uint32_t)ni < items_cap ? (uint32_t)ni : items_cap;
-        grid += ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
-        b.end[i] = grid;
+        const uint32_t own = ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+        grid += own;
+        gmax = own > gmax ? own : gmax;
+        b.end[i] = interleave ? own : grid;
         // every multi-segment tile owns >= 2 partial slots -> at most part_slots / 2 of them
         cgrid += nm >= 0 ? (uint32_t)nm : part_slots / 2;
         b.cend[i] = cgrid;
     }
+    if (interleave) grid = gmax * b.nb;              // (frames with fewer groups leave a few empty blocks)
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
     if (grid)
         if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(b, grid, lds, st)) return e;
