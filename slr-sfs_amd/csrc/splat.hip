@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void zero_counts_kernel(BinSet b, uint32_t nt)
     if (i < nt) b.count[blockIdx.y][i] = 0;
 }
 
+// Wave-aggregated binning: one global atomic per wave, pixel group and footprint slot.  Used for the COUNT pass (nothing
+// comes back from its atomics, so it never waits: 470 us for a clip's 120 maps against 870 with the LDS table below).
 template <bool FILL>
-__device__ __forceinline__ void bin_body(const float *__restrict__ flow, uint32_t *__restrict__ counter,
+__device__ __forceinline__ void bin_body_wave(const float *__restrict__ flow, uint32_t *__restrict__ counter,
                                          const uint32_t *__restrict__ listoff, uint32_t *__restrict__ list,
                                          int n, int H, int W, int tiles_x, int tiles) {
     const int HW = H * W;
@@ -162,6 +164,107 @@ __device__ __forceinline__ void bin_body(const float *__restrict__ flow, uint32_
             if (tile[p][k] == lt[p][k]) tile[p][k] = -1;                       // served
             wave_append<FILL>(tile[p][k], (uint32_t)pix[p], counter, listoff, list);   // lanes that disagree (rare)
         }
+}
+
+// Workgroup-level aggregation of the bin reservations, for the FILL pass.  The wave-aggregated version above issues
+// one RETURNING global atomic per wave, pixel group and footprint slot and then waits for all of them: 1.26 ms for a
+// clip's 120 maps whatever else was changed, 25-45 us for the one map of a stand-alone call.  A workgroup's
+// 256 x BIN_PPT consecutive pixels land in a handful of tiles, so they are first counted in a small LDS hash table
+// (tile -> entries of this workgroup; integer LDS atomics, fast) and ONE global atomic per distinct tile and
+// workgroup reserves the whole chunk.  Inside the chunk an entry's place is the value its LDS atomic returned: the
+// lanes of one wave instruction (64 consecutive pixels) keep their order, as before.
+constexpr int BIN_HASH = 128;                      // table slots (power of two); > distinct tiles of any sane workgroup
+
+template <bool FILL>
+__device__ __forceinline__ void bin_body(const float *__restrict__ flow, uint32_t *__restrict__ counter,
+                                         const uint32_t *__restrict__ listoff, uint32_t *__restrict__ list,
+                                         int n, int H, int W, int tiles_x, int tiles) {
+    if (!FILL) {                                   // (compile-time) counting: the wave-aggregated form is the faster one
+        bin_body_wave<false>(flow, counter, listoff, list, n, H, W, tiles_x, tiles);
+        return;
+    }
+    __shared__ int h_key[BIN_HASH];                // tile id, -1 = free
+    __shared__ uint32_t h_cnt[BIN_HASH];           // entries of this workgroup for that tile
+    __shared__ uint32_t h_dst[BIN_HASH];           // FILL: where this workgroup's chunk starts in the tile's list
+    const int HW = H * W;
+    const float *f = flow + (size_t)n * 2 * HW;
+    const int tb = n * tiles;
+    for (int i = threadIdx.x; i < BIN_HASH; i += 256) { h_key[i] = -1; h_cnt[i] = 0; }
+    int pix[BIN_PPT];
+    float fx[BIN_PPT], fy[BIN_PPT];
+#pragma unroll
+    for (int p = 0; p < BIN_PPT; ++p) {
+        pix[p] = (blockIdx.x * BIN_PPT + p) * 256 + threadIdx.x;
+        const int q = pix[p] < HW ? pix[p] : 0;
+        fx[p] = f[q];
+        fy[p] = f[HW + q];
+    }
+    __syncthreads();
+    // (slot << 16 | rank in the workgroup's chunk) per footprint slot; 0xffffffff: nothing; 0xfffffffe: table full ->
+    // that entry takes the wave-aggregated path on global memory below
+    uint32_t where[BIN_PPT][4];
+    int tile[BIN_PPT][4];
+#pragma unroll
+    for (int p = 0; p < BIN_PPT; ++p) {
+        TileSet s = {};
+        if (pix[p] < HW) {
+            const int y = pix[p] / W, x = pix[p] - y * W;
+            s = footprint_tiles(make_corners(fx[p], fy[p], x, y), H, W);
+        }
+        tile[p][0] = (s.vya & s.vxa) ? tb + s.tya * tiles_x + s.txa : -1;
+        tile[p][1] = (s.vya & s.vxb) ? tb + s.tya * tiles_x + s.txb : -1;
+        tile[p][2] = (s.vyb & s.vxa) ? tb + s.tyb * tiles_x + s.txa : -1;
+        tile[p][3] = (s.vyb & s.vxb) ? tb + s.tyb * tiles_x + s.txb : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            where[p][k] = 0xffffffffu;
+            const int t = tile[p][k];
+            if (t >= 0) {
+                uint32_t slot = ((uint32_t)t * 2654435761u) >> (32 - 7);          // 7 = log2(BIN_HASH)
+                where[p][k] = 0xfffffffeu;
+                for (int probe = 0; probe < BIN_HASH; ++probe) {
+                    const int prev = atomicCAS(&h_key[slot], -1, t);
+                    if (prev == -1 || prev == t) {
+                        where[p][k] = (slot << 16) | atomicAdd(&h_cnt[slot], 1u);  // < 2^16 entries per workgroup
+                        break;
+                    }
+                    slot = (slot + 1) & (BIN_HASH - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // one reservation per distinct tile of the workgroup
+    for (int i = threadIdx.x; i < BIN_HASH; i += 256) {
+        const int t = h_key[i];
+        if (t >= 0) {
+            const uint32_t b = atomicAdd(&counter[t], h_cnt[i]);
+            if (FILL) h_dst[i] = listoff[t] + b;
+        }
+    }
+    if (FILL) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < BIN_PPT; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w = where[p][k];
+                if (w < 0xfffffffeu) list[h_dst[w >> 16] + (w & 0xffffu)] = (uint32_t)pix[p];
+            }
+    }
+    // overflow of the table (a workgroup whose pixels scatter over more than ~100 tiles: huge incoherent flows)
+    bool any_over = false;
+#pragma unroll
+    for (int p = 0; p < BIN_PPT; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any_over |= where[p][k] == 0xfffffffeu;
+    if (__ballot(any_over)) {                                                  // wave-uniform
+#pragma unroll
+        for (int p = 0; p < BIN_PPT; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                wave_append<FILL>(where[p][k] == 0xfffffffeu ? tile[p][k] : -1, (uint32_t)pix[p], counter, listoff, list);
+    }
 }
 
 template <bool FILL>
