@@ -993,6 +993,70 @@ def test_c_abi_prebinned_reuse_and_errors(S, oracle):
     assert float(res) == float(big.max())
 
 
+def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
+    """The per-clip entry points straight through ctypes: slr_clip_plan_bytes / _build / _totals,
+    slr_synth_group_clip with and without the totals read back (exact grids vs upper-bound grids: same result),
+    slr_synth_group_clip_batch; and their argument errors (codes + slr_last_error, nothing launched)."""
+    import ctypes
+    from slr_sfs_amd._lib import lib, ptr, stream_of
+    L = lib()
+    rng = np.random.default_rng(41)
+    C, H, W, N = 6, 40, 136, 7
+    fs = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    m = smooth_motion(H, W, 9, amp=3.0)
+    dfs, dZ, dm = dev(fs), dev(Z), dev(m)
+    st = stream_of(dfs)
+    disp_f = torch.empty(N, 2, H, W, device="cuda")
+    disp_p = torch.empty(N + 1, 2, H, W, device="cuda")
+    assert L.slr_euler_integrate_all(ptr(dm), H, W, N - 1, 1.0, ptr(disp_f), None, st) == 0
+    assert L.slr_euler_integrate_all(ptr(dm), H, W, N, -1.0, ptr(disp_p), None, st) == 0
+    ts = [0, 2, 6]
+    idx_f = torch.tensor(ts, dtype=torch.int32, device="cuda")
+    idx_p = torch.tensor([N - t for t in ts], dtype=torch.int32, device="cuda")
+    nb = len(ts)
+    pbytes = int(L.slr_clip_plan_bytes(nb, H, W))
+    assert pbytes > 0 and int(L.slr_clip_plan_bytes(0, H, W)) == 0
+    assert int(L.slr_clip_plan_bytes(70000, 768, 1280)) == 0              # 8 * nframes * H * W must stay below 2^32
+    plan = torch.empty(pbytes, dtype=torch.uint8, device="cuda")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.slr_clip_plan_build(ptr(disp_f), vp(idx_f), ptr(disp_p), vp(idx_p), nb, H, W, ptr(plan), pbytes // 2, st) == -2
+    assert b"plan buffer" in L.slr_last_error()
+    assert L.slr_clip_plan_build(ptr(disp_f), vp(idx_f), ptr(disp_p), vp(idx_p), nb, H, W, ptr(plan), pbytes, st) == 0
+    off, stride = ctypes.c_size_t(), ctypes.c_int()
+    assert L.slr_clip_plan_totals(nb, H, W, ctypes.byref(off), ctypes.byref(stride)) == 0
+    totals = plan[off.value:off.value + nb * stride.value * 4].view(torch.int32).view(nb, stride.value).cpu()
+    tiles = ((H + 7) // 8) * ((W + 63) // 64)
+    assert all(int(totals[i, 0]) >= tiles for i in range(nb))             # at least one work item per tile
+    zmax = dZ.max().reshape(1).contiguous()
+    sbytes = int(L.slr_splat_scratch_bytes_batch(C, H, W, nb))
+    assert sbytes >= int(L.slr_splat_scratch_bytes(C, H, W)) and int(L.slr_splat_scratch_bytes_batch(C, H, W, 9)) == 0
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device="cuda")
+    refs = [oracle.synth_baseline(fs, Z, m, t, N) for t in ts]
+    alphas = [1.0 - t / N for t in ts]
+    for k, t in enumerate(ts):                                             # one frame per call, exact and upper-bound grids
+        for hints in ((int(totals[k, 0]), int(totals[k, 3]), int(totals[k, 4])), (-1, -1, -1)):
+            out = torch.empty(1, C, H, W, device="cuda")
+            assert L.slr_synth_group_clip(ptr(dfs), ptr(dZ), ptr(zmax), 1, ptr(disp_f[t]), ptr(disp_p[N - t]), alphas[k],
+                                          ptr(out), None, C, H, W, 1e-8, ptr(plan), pbytes, nb, k, ptr(scratch), sbytes,
+                                          *hints, st) == 0
+            np.testing.assert_allclose(host(out), refs[k], rtol=2e-4, atol=2e-5)
+    outs = torch.empty(nb, C, H, W, device="cuda")                        # all three frames in one launch
+    PP = ctypes.c_void_p * nb
+    df, dp = PP(*[disp_f[t].data_ptr() for t in ts]), PP(*[disp_p[N - t].data_ptr() for t in ts])
+    po = PP(*[outs[k].data_ptr() for k in range(nb)])
+    al = (ctypes.c_float * nb)(*alphas)
+    fr = (ctypes.c_int * nb)(*range(nb))
+    call = lambda n_, fr_, sb_: L.slr_synth_group_clip_batch(ptr(dfs), ptr(dZ), ptr(zmax), 1, df, dp, al, po, None, C, H, W, 1e-8,
+                                                             ptr(plan), pbytes, nb, fr_, n_, ptr(scratch), sb_, None, st)
+    assert call(nb, fr, sbytes) == 0
+    for k in range(nb):
+        np.testing.assert_allclose(host(outs[k:k + 1]), refs[k], rtol=2e-4, atol=2e-5)
+    assert call(9, fr, sbytes) == -1 and b"frames per launch" in L.slr_last_error()
+    assert call(nb, (ctypes.c_int * nb)(0, 1, 5), sbytes) == -1 and b"frame index" in L.slr_last_error()
+    assert call(nb, fr, 1024) == -2 and b"scratch" in L.slr_last_error()
+
+
 def test_splat_over_budget_tiles_whole_tile_path(S, oracle):
     """More segments than partial-tile slots (everything converges into one tile of a larger
     image): the over-budget tile is walked segment by segment by one workgroup (WHOLE kernel)."""
