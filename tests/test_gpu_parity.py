@@ -377,6 +377,28 @@ def test_batched_frames_in_one_launch_vs_oracle(S, oracle):
         np.testing.assert_allclose(host(out[k:k + 1]), oracle.synth_baseline(fs, Z, conv, t, N), rtol=2e-4, atol=2e-5)
 
 
+def test_batched_launch_with_whole_tile_items(S, oracle):
+    """A motion field that puts every source pixel onto the corner shared by four tiles after one step: 4 x H x W bin
+    entries in four tiles, more segments than partial-tile slots -> whole-tile items.  In a batched launch each such
+    frame gets its own whole-tile kernel behind the shared main launch; the other frames of the batch are ordinary."""
+    H, W, N = 320, 640, 3
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    m = np.stack([W / 2 - x - 0.5, H / 2 - y - 0.5])[None].astype(np.float32)
+    rng = np.random.default_rng(8)
+    fs = rng.standard_normal((1, 5, H, W)).astype(np.float32)
+    Z = (rng.standard_normal((1, 1, H, W)) * 0.3).astype(np.float32)
+    cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
+    ts = [1, 0, 2]
+    hints = [cs.plan.lookup(t)[3] for t in ts]
+    assert hints[0][2] > 0 and hints[1][2] == 0, hints              # frame 1 has whole-tile items, frame 0 has none
+    out = torch.empty(len(ts), 5, H, W, device="cuda")
+    cs.features_batch(ts, out)
+    for k, t in enumerate(ts):
+        ref = oracle.synth_baseline(fs, Z, m, t, N)
+        np.testing.assert_allclose(host(out[k:k + 1]), ref, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(ref).max())), err_msg=str(t))
+        np.testing.assert_allclose(host(cs.features(t)), host(out[k:k + 1]), rtol=1e-3, atol=1e-4)
+
+
 def test_randomised_synthesis_vs_oracle(S, oracle):
     """Seeded sweep of the headline path itself -- all-frames Euler integration, two-direction exp-weighted splat,
     normalisation (animating_softmax_splating.py:847-924; SLR v1: ..._2layers_alpha_seperate.py:950-1045) -- over
