@@ -421,6 +421,7 @@ __device__ __forceinline__ void plan_body(const uint32_t *__restrict__ count0,
     const uint32_t sup_x = (tiles_x + PLAN_SX - 1) / PLAN_SX, sup_y = (tiles_y + PLAN_SY - 1) / PLAN_SY;
     const uint32_t slots_per_sample = sup_x * sup_y * PLAN_SX * PLAN_SY;
     const uint32_t nslots = (nt / tiles) * slots_per_sample;
+    const uint32_t nslots_r = (nslots + 1023u) / 1024u * 1024u;        // passes start on a 1024-slot boundary
     // Heavy tiles first: a launch ends when its last workgroup ends, and the tiles that take 2-3x the median (the
     // ridges of an Euler-integrated field: many entries, long record lists) used to start wherever the spatial order
     // put them -- in the last round as often as in the first.  Two passes over the same spatial order: tiles with
@@ -430,8 +431,9 @@ __device__ __forceinline__ void plan_body(const uint32_t *__restrict__ count0,
     // whose frames share a launch: the tail of a frame is covered by the next frame's head) keeps the one-pass order.
     const uint32_t all_entries = listoff0[nt] + (listoff1 ? listoff1[nt] : 0u);
     const uint32_t heavy_thr = (uint32_t)(((unsigned long long)all_entries * heavy) / (4ull * (nt ? nt : 1u)));
-  for (int pass = 0; pass < (heavy ? 2 : 1); ++pass)
-    for (uint32_t b = 0; b < nslots; b += 1024) {
+    for (uint32_t pb = 0; pb < (heavy ? 2u : 1u) * nslots_r; pb += 1024) {
+        const int pass = (int)(pb / nslots_r);
+        const uint32_t b = pb - (uint32_t)pass * nslots_r;
         const uint32_t slot = b + threadIdx.x;
         uint32_t t = nt;                                 // nt = no tile in this slot (ragged edge of the super-tile grid)
         if (slot < nslots) {

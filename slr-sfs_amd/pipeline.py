@@ -198,7 +198,7 @@ class BaselineAnimator(torch.nn.Module):
                     on_frame(out[i])                                # e.g. parallel.ClipAssembler.push
         else:
             for i0, gen, _ in _feature_batches(clip, frames, batch):
-                out[i0:i0 + gen.shape[0]] = torch.tanh(self.projector(gen))
+                torch.tanh(self.projector(gen), out=out[i0:i0 + gen.shape[0]])     # (no temporary + copy)
                 if on_frame is not None:
                     for i in range(i0, i0 + gen.shape[0]):
                         on_frame(out[i])

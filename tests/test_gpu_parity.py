@@ -157,6 +157,31 @@ def test_splat_needs_input_grad_subsets(S, golden_dir):
     np.testing.assert_allclose(host(b.grad), g["c3_gflow"], rtol=1e-6, atol=1e-6)
 
 
+def test_backward_one_launch_equals_separate_launches(S, oracle):
+    """slr_softsplat_backward with both gradients requested runs ONE kernel that gathers gradOutput once for both
+    (csrc/grad.hip); each gradient is bit-identical to the launch that computes it alone (same terms, same order),
+    and gradInput to the oracle, on an Euler-integrated flow with non-finite and far-away entries, C = 65 (channel
+    tail of the 4-channel passes), batch 2."""
+    from slr_sfs_amd._lib import check, lib, ptr, stream_of
+    N, C, H, W = 2, 65, 96, 200
+    rng = np.random.default_rng(12)
+    flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=3.0), 35 + n)[0] for n in range(N)])
+    flow[0, 0, 5, 7] = np.nan
+    flow[1, 1, 50, 60] = np.inf
+    flow[0, :, 20, 30] = (3.0e9, -2.0e9)
+    x, go = rng.standard_normal((N, C, H, W)).astype(np.float32), rng.standard_normal((N, C, H, W)).astype(np.float32)
+    X, F, G = dev(x), dev(flow), dev(go)
+    gi1, gf1, gi2, gf2 = torch.empty_like(X), torch.empty_like(F), torch.empty_like(X), torch.empty_like(F)
+    L, st = lib(), stream_of(X)
+    check(L.slr_softsplat_backward(ptr(X), ptr(F), ptr(G), ptr(gi1), ptr(gf1), N, C, H, W, st), "both")
+    check(L.slr_softsplat_backward(ptr(X), ptr(F), ptr(G), ptr(gi2), None, N, C, H, W, st), "input")
+    check(L.slr_softsplat_backward(ptr(X), ptr(F), ptr(G), None, ptr(gf2), N, C, H, W, st), "flow")
+    assert torch.equal(gi1, gi2) and torch.equal(gf1, gf2)
+    ogi, ogf = oracle.softsplat_backward(x, flow, go)
+    assert np.array_equal(host(gi1), ogi)
+    np.testing.assert_allclose(host(gf1), ogf, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("shape", [(1, 65, 256, 480), (2, 7, 45, 131), (1, 16, 100, 64), (3, 1, 17, 70)])
 def test_splat_sum_vs_oracle_euler_flow(S, oracle, shape):
     """Euler-integrated fluid flow (piles sources up -> multi-segment tiles + combine path),

@@ -9,8 +9,10 @@ x = torch.randn(1, C, H, W, device="cuda"); go = torch.randn(1, C, H, W, device=
 m = smooth_motion(H, W); dall, _ = S.euler_integration_all(m, 60)
 gi = torch.empty_like(x); gf = torch.empty(1, 2, H, W, device="cuda")
 L = lib(); st = stream_of(x)
-for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", dall[30:31].contiguous())):
+for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", dall[30:31].contiguous()), ("t59", dall[59:60].contiguous())):
     t1 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), None, 1, C, H, W, st), "b"), 10)
     t2 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), None, ptr(gf), 1, C, H, W, st), "b"), 10)
+    t3 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), 1, C, H, W, st), "b"), 10)
     B = 2 * C * H * W * 4
-    print(name, "grad_input us", t1, f"{B/t1[1]/1e6:.2f} TB/s", " grad_flow us", t2, f"{B/t2[1]/1e6:.2f} TB/s")
+    print(name, "grad_input us", t1, f"{B/t1[1]/1e6:.2f} TB/s", " grad_flow us", t2, f"{B/t2[1]/1e6:.2f} TB/s",
+          " both (one launch) us", t3, f"{1.5*B/t3[1]/1e6:.2f} TB/s")
