@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void zero_counts_kernel(BinSet b, uint32_t nt)
     if (i < nt) b.count[blockIdx.y][i] = 0;
 }
 
-// Wave-aggregated binning: one global atomic per wave, pixel group and footprint slot.  Used for the COUNT pass (nothing
-// comes back from its atomics, so it never waits: 470 us for a clip's 120 maps against 870 with the LDS table below).
+// Wave-aggregated binning: one global atomic per wave, pixel group and footprint slot.  Used for the COUNT pass of a
+// clip (nothing comes back from its atomics, so it never waits: 470 us for a clip's 120 maps against 870 with the LDS
+// table below), and for entries that overflow that table.
 template <bool FILL>
 __device__ __forceinline__ void bin_body_wave(const float *__restrict__ flow, uint32_t *__restrict__ counter,
                                          const uint32_t *__restrict__ listoff, uint32_t *__restrict__ list,
@@ -175,11 +176,15 @@ __device__ __forceinline__ void bin_body_wave(const float *__restrict__ flow, ui
 // lanes of one wave instruction (64 consecutive pixels) keep their order, as before.
 constexpr int BIN_HASH = 128;                      // table slots (power of two); > distinct tiles of any sane workgroup
 
-template <bool FILL>
+// WAVE_COUNT (compile-time): the COUNT pass in the wave-aggregated form.  Its atomics return nothing, so it never waits,
+// and with the 120 maps of a clip in one launch it is the faster one (470 vs 870 us).  The ONE map of a stand-alone call
+// is bound by something else: every wave adds to the same few hundred tile counters (~500 atomics per counter at
+// 256x480, serialised in L2: 23 us); aggregated per workgroup first, they are 16-64x fewer.
+template <bool FILL, bool WAVE_COUNT>
 __device__ __forceinline__ void bin_body(const float *__restrict__ flow, uint32_t *__restrict__ counter,
                                          const uint32_t *__restrict__ listoff, uint32_t *__restrict__ list,
                                          int n, int H, int W, int tiles_x, int tiles) {
-    if (!FILL) {                                   // (compile-time) counting: the wave-aggregated form is the faster one
+    if (!FILL && WAVE_COUNT) {
         bin_body_wave<false>(flow, counter, listoff, list, n, H, W, tiles_x, tiles);
         return;
     }
@@ -269,7 +274,7 @@ __device__ __forceinline__ void bin_body(const float *__restrict__ flow, uint32_
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int tiles_x, int tiles) {
-    bin_body<FILL>(b.flow[blockIdx.z], FILL ? b.cursor[blockIdx.z] : b.count[blockIdx.z], b.listoff[blockIdx.z],
+    bin_body<FILL, false>(b.flow[blockIdx.z], FILL ? b.cursor[blockIdx.z] : b.count[blockIdx.z], b.listoff[blockIdx.z],
                    b.list[blockIdx.z], blockIdx.y, H, W, tiles_x, tiles);
 }
 
@@ -291,7 +296,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void bin_clip_kernel(ClipMaps c, int H, int W, int tiles_x, int tiles) {
     const uint32_t m = blockIdx.z, d = m >= c.nframes ? 1u : 0u, i = m - d * c.nframes;
     const float *flow = c.disp[d] + (size_t)c.idx[d][i] * 2 * H * W;
-    bin_body<FILL>(flow, (FILL ? c.cursor : c.count) + (size_t)m * c.nt, c.listoff + (size_t)m * (c.nt + 1),
+    bin_body<FILL, true>(flow, (FILL ? c.cursor : c.count) + (size_t)m * c.nt, c.listoff + (size_t)m * (c.nt + 1),
                    FILL ? c.list + c.mapbase[m] : nullptr, 0, H, W, tiles_x, tiles);
 }
 
@@ -713,6 +718,11 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     // those items, so its code carries no loop.
     constexpr bool whole = WHOLE;
     if ((it.nseg == 0) != WHOLE) return;
+    // Channel groups (gridDim.y > 1: small grids, see launch_batch): this workgroup builds the tile's records like
+    // any other and gathers the planes [cb, cend) only.  Groups start on a multiple of 2 * CHUNK planes.
+    const int cper = (((a.C + (int)gridDim.y - 1) / (int)gridDim.y + 2 * CHUNK - 1) / (2 * CHUNK)) * (2 * CHUNK);
+    const int cb = (int)blockIdx.y * cper, cend = min(a.C, cb + cper);
+    if (cb >= a.C) return;
     const uint32_t nloop = WHOLE ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;
     float nrm_total = 0.0f;
     const int n = t / a.tiles, tl = t - n * a.tiles;
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         for (int k = 0; k < 4; ++k) { e_ts[j][k] = 0xffffffffu; e_w[j][k] = 0.0f; }
     }
     const float *ip = a.in + (size_t)n * a.C * HW;
-    const int cmax = a.C - 1;
+    const int cmax = cend - 1;                       // (prefetches past the group's last plane re-read it)
     auto prefetch = [&](float (&pre)[EPT_MAX][CHUNK], int c0) {
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
@@ -771,8 +781,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         SLR_STAMP(28);
         // the plane loads of the first two chunks only need the source indices: issue them now,
         // they complete under the footprint math, the LDS atomics and the scan
-        prefetch(preA, 0);
-        prefetch(preB, CHUNK);
+        prefetch(preA, cb);
+        prefetch(preB, cb + CHUNK);
         float fx[EPT_MAX], fy[EPT_MAX], mm[EPT_MAX];
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j) {
@@ -915,8 +925,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         nrm_total += nrm;
         nrm = nrm_total;                                  // all segments seen so far (whole-tile items)
         if (single) {
-            if (a.norm_out && inside && last) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
-        } else {
+            if (a.norm_out && inside && last && cb == 0) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
+        } else if (cb == 0) {
             a.partial[(size_t)(it.partoff + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid] = nrm;
         }
     }
@@ -1039,7 +1049,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
             float r = acc[u];
-            float *dst = (c0 + u < a.C) ? op + (size_t)(c0 + u) * ostr : trash;
+            float *dst = (c0 + u < cend) ? op + (size_t)(c0 + u) * ostr : trash;
             if (whole && !first) r = MAXOP ? fmaxf(r, *dst) : r + *dst;      // earlier segments of this tile
             if (NORM && single && last) r = finish(r, nrm, a.norm_mode, a.eps);
 #if SLR_DBG & 4
@@ -1050,9 +1060,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         SLR_STAMP(6 + 3 * (c0 / CHUNK));
         __syncthreads();                               // val[] is overwritten by the next chunk
     };
-    for (int c0 = 0; c0 < a.C; c0 += 2 * CHUNK) {
+    for (int c0 = cb; c0 < cend; c0 += 2 * CHUNK) {
         chunk(preA, c0);
-        if (c0 + CHUNK < a.C) chunk(preB, c0 + CHUNK);
+        if (c0 + CHUNK < cend) chunk(preB, c0 + CHUNK);
     }
   }
     if (!WHOLE) break;
@@ -1195,7 +1205,7 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
 }
 
 template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE>
-static int launch_tile_variant(const SplatBatch &b, uint32_t grid, size_t lds, hipStream_t st) {
+static int launch_tile_variant(const SplatBatch &b, uint32_t grid, uint32_t groups, size_t lds, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
     // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
     static bool attr_set[64] = {};
@@ -1206,13 +1216,19 @@ static int launch_tile_variant(const SplatBatch &b, uint32_t grid, size_t lds, h
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>), dim3(grid), dim3(SPLAT_THREADS), lds, st, b);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>), dim3(grid, groups), dim3(SPLAT_THREADS), lds, st, b);
     return 0;
 }
 
 // What the host knows about the plan of one frame (a clip plan's totals read back once per clip); < 0 = unknown ->
 // the grids cover the upper bounds and surplus workgroups exit at once.
 struct PlanHint { int n_items, n_multi, n_whole; };
+#ifndef SLR_CSPLIT_MAX
+#define SLR_CSPLIT_MAX 4          // channel groups per tile on small grids (1 = off)
+#endif
+#ifndef SLR_CSPLIT_SLOTS
+#define SLR_CSPLIT_SLOTS 512      // workgroup slots of the chip the groups may fill
+#endif
 
 // Tile kernel, whole-tile kernel and combine for nb frames whose plans are already in b.f[]: the main tile kernel
 // and combine as ONE launch each over all frames.
@@ -1241,8 +1257,18 @@ static int launch_batch(SplatBatch &b, const PlanHint *hint, uint32_t items_cap,
     }
     if (interleave) grid = gmax * b.nb;              // (frames with fewer groups leave a few empty blocks)
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));       // slr_splat_time_next:
+    // Small grids (fewer tiles than the chip has workgroup slots: 256 CUs x 2): a tile is one workgroup whose chunk
+    // pipeline nothing overlaps with, so the planes are dealt to 2-4 workgroups per tile (gridDim.y; each builds the
+    // tile's records itself, phase 1 is the cheap part).  256x480, C = 64 (config C2): 32 -> ... us.
+    uint32_t groups = 1;
+    if (b.nb == 1 && SLR_CSPLIT_MAX > 1) {
+        const uint32_t fit = SLR_CSPLIT_SLOTS / (nt ? nt : 1u), byc = (uint32_t)b.f[0].C / (2u * CHUNK);
+        groups = fit < (uint32_t)SLR_CSPLIT_MAX ? fit : (uint32_t)SLR_CSPLIT_MAX;
+        groups = groups < byc ? groups : byc;
+        groups = groups < 1u ? 1u : groups;
+    }
     if (grid)
-        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(b, grid, lds, st)) return e;
+        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(b, grid, groups, lds, st)) return e;
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));         // the dominant kernel only
     g_ev_start = g_ev_stop = nullptr;                                                // one-shot
     // tiles that did not fit the partial-slot budget (none for ordinary flows), frame by frame
@@ -1253,7 +1279,7 @@ static int launch_batch(SplatBatch &b, const PlanHint *hint, uint32_t items_cap,
         one.nb = 1;
         const uint32_t wg = hint[i].n_whole > 0 ? (uint32_t)hint[i].n_whole : nt;
         one.end[0] = wg < 256u ? wg : 256u;
-        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(one, one.end[0], lds, st)) return e;
+        if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, true>(one, one.end[0], 1u, lds, st)) return e;
     }
     if (cgrid)
         hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(cgrid, (b.f[0].C + COMBINE_CHUNK - 1) / COMBINE_CHUNK),

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import slr_sfs_amd as S
 from slr_sfs_amd import synthesis
 from bench import smooth_motion, H, W
+from kbench import timeit
 dev = torch.device("cuda:0")
 motion = torch.from_numpy(smooth_motion(H, W)).to(dev)
 x = torch.randn(1, 65, H, W, device=dev)
@@ -22,5 +23,6 @@ for name, fl in flows.items():
     torch.cuda.synchronize()
     us = sorted(a.elapsed_time(b) * 1e3 for a, b, _ in synthesis.kernel_timing[5:])
     synthesis.kernel_timing = None
-    out.append(f"{name} {sum(us)/len(us):6.1f} us ({alg/ (sum(us)/len(us)) / 1e3 / 8000:.3f})")
+    call = timeit(lambda: S.FunctionSoftsplat(x, fl, None, "summation"), 20)[0]
+    out.append(f"{name} {sum(us)/len(us):6.1f} us ({alg/ (sum(us)/len(us)) / 1e3 / 8000:.3f}) call {call:6.1f}")
 print(os.path.basename(os.environ.get("SLR_SFS_AMD_LIB", "default")), " | ".join(out))
