@@ -71,3 +71,16 @@ def net_input(net):
     x[:, 3, 0, 0] = 0.0
     x[:, :, :, 47] = 0.0
     return torch.from_numpy(x)
+
+
+def e2e_inputs(W=64, N=8):
+    """Inputs of the end-to-end fixture (tests/golden/pipeline_e2e.npz): an image in [-1, 1] and a motion field
+    (px / frame at the working resolution, zero outside the 'fluid' region like the data set's masks), seeded."""
+    r = _rng("e2e", W, N)
+    img = r.uniform(-1, 1, (1, 3, W, W)).astype(np.float32)
+    y, x = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = 1.2 * np.sin(2 * np.pi * (1.5 * x / W + y / W) + 0.5)
+    v = 1.2 * np.cos(2 * np.pi * (x / W - 1.2 * y / W) + 1.3)
+    m = ((x >= 0.3 * W) & (y >= 0.2 * W)).astype(np.float32)
+    motion = np.stack([u * m, v * m])[None].astype(np.float32)
+    return img, motion, N
