@@ -289,6 +289,28 @@ def parity_check(model, image, motion, workload, dev, t=30):
         out["reference_forward_flow_digest_max_abs"] = float(np.abs(gen.ravel()[g["c3_pos"]] - g[f"c3_{kind}_t{t}_val"]).max())
         out["reference_holes"] = int(g[f"c3_{kind}_t{t}_holes"])
         out["holes"] = int((gen == 0).sum())
+    # (3) FRAMES: the whole pipeline (encoder -> Euler -> splat -> decoder, HIP kernels throughout) on the seeded weights /
+    # image / motion of tests/golden/pipeline_e2e.npz against the frames the reference's own models produced from them
+    # (tools/make_golden_e2e.py; 64x64, N = 8) -- the north star's parity statement on the frames themselves.
+    epath = os.path.join(ROOT, "tests", "golden", "pipeline_e2e.npz")
+    if os.path.exists(epath):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import nets_fixture as NF
+        from slr_sfs_amd import nets, pipeline
+        g, gn = np.load(epath), np.load(os.path.join(ROOT, "tests", "golden", "nets_reference.npz"))
+        img, mo, n = NF.e2e_inputs(int(g["W"]), int(g["N"]))
+        v1 = workload != "c3"
+        an = (pipeline.SLRv1Animator() if v1 else pipeline.BaselineAnimator())
+        for name in (("encoder", "projector", "net_bg", "net_alpha_encoder", "net_alpha_decoder") if v1 else ("encoder", "projector")):
+            keys = [str(k) for k in gn[f"{name}_keys"]]
+            pre = NF.NETS[name][0]
+            sd = {pre + k: v for k, v in NF.state_dict(name, keys, gn[f"{name}_shapes"]).items()}
+            nets.load_reference_state_dict(getattr(an, name), sd, pre)
+        an = an.to(dev).eval()
+        ts = [int(t) for t in g["v1_ts"]] if v1 else list(range(n))
+        fr = an.synthesize(torch.from_numpy(img).to(dev), torch.from_numpy(mo).to(dev), n, frames=ts).cpu().numpy()
+        ref = g["v1_PredImg"] if v1 else g["baseline_PredImg"]
+        out["frames_vs_reference_models_max_abs"] = float(np.abs(fr - ref).max())
     out["ok"] = bool(max(v for k, v in out.items() if k.endswith("max_abs")) < out["tolerance"])
     return out
 
