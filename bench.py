@@ -493,11 +493,25 @@ def cpu_baseline(motion):
         o.synth_baseline(fs, Z, motion, t, NFRAMES)
     dt1 = time.perf_counter() - t0
     o.set_threads(cores)
+    # the networks either side of the path on the same cores: the reference's decoder formulation through torch's CPU
+    # convolutions (the package's torch definition of the nets, which the tests hold against the reference's classes)
+    from slr_sfs_amd import nets
+    gen = torch.from_numpy(o.synth_baseline(fs, Z, motion, 30, NFRAMES))
+    with nets.cpu_reference(), torch.no_grad():
+        dec = nets.DecoderPconv2(64, 3).eval()
+        t0 = time.perf_counter()
+        torch.tanh(dec(gen))
+        ddec = time.perf_counter() - t0
+    whole = 1.0 / (dt / len(frames) + ddec)
     return {"value": round(len(frames) / dt, 4), "unit": "frames/s (splat stage: Euler + 2x65-plane splat + normalise; "
             "no encoder/decoder)", "cores": cores, "kind": "port",
             "sample": f"{len(frames)} frames (every 2nd) of the same 768x1280 N=60 clip, {dt:.1f} s of CPU work",
             "one_thread": {"value": round(len(one) / dt1, 4), "cores": 1,
-                           "sample": f"frames {one} of the same clip, {dt1:.1f} s of CPU work"}}
+                           "sample": f"frames {one} of the same clip, {dt1:.1f} s of CPU work"},
+            "with_decoder": {"value": round(whole, 4), "unit": "frames/s (splat stage + partial-conv decoder per frame; encoder "
+                             "once per clip not counted)", "decoder_s_per_frame": round(ddec, 3),
+                             "torch_threads": torch.get_num_threads(),
+                             "sample": "one frame through the decoder (torch CPU convolutions, fp32)"}}
 
 
 if __name__ == "__main__":
