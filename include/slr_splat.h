@@ -178,7 +178,8 @@ int slr_global_max(const float *x, size_t n, float *result, float *scratch, void
 
 /* _FunctionSoftsplat.backward.  Replaces kernel_Softsplat_updateGradInput / updateGradFlow
  * and their launcher, softsplat.py:204-255, 257-326, 427-478.
- *   grad_in [N,C,H,W] and/or grad_flow [N,2,H,W]; either may be NULL (needs_input_grad). */
+ *   grad_in [N,C,H,W] and/or grad_flow [N,2,H,W]; either may be NULL (needs_input_grad).  With both requested ONE kernel
+ *   gathers grad_out once for both; each result is bit-identical to the call that asks for it alone. */
 int slr_softsplat_backward(const float *in, const float *flow, const float *grad_out,
                            float *grad_in, float *grad_flow,
                            int N, int C, int H, int W, void *stream);
