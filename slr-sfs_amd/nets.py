@@ -45,7 +45,8 @@ class cpu_reference:
     """Context manager for the TESTS that validate these module definitions against the reference's own
     classes (which only exist where the reference checkout is, on the CPU): inside it, CPU tensors run
     the torch composition that defines every fused stage.  Outside it CPU tensors raise, like the
-    reference's operators do (models/softsplat.py:418-419): the product has no CPU path."""
+    reference's operators do (models/softsplat.py:418-419): the product has no CPU path.  (bench.py's `cpu_baseline` leg
+    also enters it, to TIME the decoder on the host cores next to the oracle -- a reported baseline, never a product path.)"""
 
     def __enter__(self):
         global _CPU_REFERENCE
