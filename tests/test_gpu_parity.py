@@ -1040,6 +1040,56 @@ def test_c_abi_prebinned_reuse_and_errors(S, oracle):
     assert float(res) == float(big.max())
 
 
+def test_prebinned_pair_and_single_splats_share_their_bins_in_any_order(S, oracle):
+    """Bins are reusable: bin a pair of flows once (slr_splat_bin_pair), then run the fused two-direction group on the
+    pair AND the one-flow summation splat on each bin with prebinned = 1, in both orders -- the work plan of a splat
+    (one bin: SEG_ONE segments, two bins: SEG_TWO) is rebuilt per call and must not depend on what ran before.  All
+    three results against the oracle, on an Euler flow whose tiles split into several segments."""
+    from slr_sfs_amd._lib import lib, ptr, stream_of
+    L = lib()
+    rng = np.random.default_rng(57)
+    C, H, W = 5, 72, 200
+    m = smooth_motion(H, W, 4, amp=3.0)
+    ff = oracle.euler_integration(m, 45)[0]
+    fp = oracle.euler_integration(-m, 30)[0]
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    dff, dfp, dx, dZ = dev(ff), dev(fp), dev(x), dev(Z)
+    st = stream_of(dx)
+    nbytes = int(L.slr_splat_workspace_bytes(1, C, H, W))
+    wsf, wsp = (torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2))
+    zmax = dZ.max().reshape(1)
+    e = np.exp(Z - Z.max())
+    alpha = 0.3
+    S_f = oracle.softsplat_forward(np.concatenate([x * e * np.float32(alpha), e * np.float32(alpha)], 1), ff)
+    S_p = oracle.softsplat_forward(np.concatenate([x * e * np.float32(1 - alpha), e * np.float32(1 - alpha)], 1), fp)
+    nrm = S_f[:, -1:] + S_p[:, -1:]
+    ref_pair = (S_f[:, :-1] + S_p[:, :-1]) / np.maximum(nrm, np.float32(1e-8))
+    for order in (0, 1):
+        assert L.slr_splat_bin_pair(ptr(dff), ptr(dfp), 1, C, H, W, ptr(wsf), ptr(wsp), nbytes, st) == 0
+        outs = {}
+
+        def pair():
+            o = torch.empty(1, C, H, W, device="cuda")
+            assert L.slr_synth_group(ptr(dx), ptr(dZ), ptr(zmax), 1, ptr(dff), ptr(dfp), alpha, ptr(o), None, C, H, W, 1e-8,
+                                     ptr(wsf), ptr(wsp), nbytes, st) == 0, L.slr_last_error()
+            outs["pair"] = o
+
+        def singles():
+            for tag, fl, ws in (("f", dff, wsf), ("p", dfp, wsp)):
+                o = torch.empty(1, C, H, W, device="cuda")
+                assert L.slr_softsplat_forward(ptr(dx), ptr(fl), ptr(o), 1, C, H, W, ptr(ws), nbytes, 1, st) == 0
+                outs[tag] = o
+        (pair, singles)[order]()
+        (singles, pair)[order]()
+        np.testing.assert_allclose(host(outs["f"]), oracle.softsplat_forward(x, ff), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(host(outs["p"]), oracle.softsplat_forward(x, fp), rtol=1e-5, atol=2e-5)
+        got = host(outs["pair"])
+        mask = nrm[0, 0] > 1e-3                               # (tiny normalisers amplify the rounding of the sums)
+        assert mask.mean() > 0.2
+        np.testing.assert_allclose(got[:, :, mask], ref_pair[:, :, mask], rtol=2e-4, atol=2e-5)
+
+
 def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
     """The per-clip entry points straight through ctypes: slr_clip_plan_bytes / _build / _totals,
     slr_synth_group_clip with and without the totals read back (exact grids vs upper-bound grids: same result),
