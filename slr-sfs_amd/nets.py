@@ -46,7 +46,7 @@ class cpu_reference:
     classes (which only exist where the reference checkout is, on the CPU): inside it, CPU tensors run
     the torch composition that defines every fused stage.  Outside it CPU tensors raise, like the
     reference's operators do (models/softsplat.py:418-419): the product has no CPU path.  (bench.py's `cpu_baseline` leg
-    also enters it, to TIME the decoder on the host cores next to the oracle -- a reported baseline, never a product path.)"""
+    also enters it, to TIME the decoder on the host cores for its reported CPU figure -- never a product path.)"""
 
     def __enter__(self):
         global _CPU_REFERENCE
