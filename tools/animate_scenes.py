@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Animate every scene of a directory -- counterpart of the reference's
+    python test_animating/CLAW/test_all_CLAW_scenes.py IMAGE_DIR FLOW_DIR SAVE_DIR CKPT NAME W N SPEED PYFILE SCENE ALIGNFILE START END
+(:1-96: ``<scene>_input.jpg`` + ``<scene>.flo`` pairs, one run of the per-scene script each) with the same leading
+arguments.  One process: the reference's flow.  Under torchrun --nproc-per-node G: config C5 of BASELINE.json -- the
+frames of every clip sharded over the G GPUs of the node, one all-gather per clip, rank 0 writes
+SAVE_DIR/<scene>/<scene>/PredImg/%06d.png (the reference's nesting: save_dir/name, then /name inside the per-scene script).
+The model is built and the checkpoint read once, not once per scene."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from animate import init_ranks  # noqa: E402
+from slr_sfs_amd import runner  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("image_dir"), ap.add_argument("flow_dir"), ap.add_argument("save_dir"), ap.add_argument("ckpt")
+    ap.add_argument("name", nargs="?", default="Demo")          # (the reference overwrites it with the scene name, :80)
+    ap.add_argument("W", nargs="?", type=int, default=256), ap.add_argument("N", nargs="?", type=int, default=60)
+    ap.add_argument("speed", nargs="?", type=float, default=0.25)
+    ap.add_argument("align", nargs="?", default="None"), ap.add_argument("start", nargs="?", type=int, default=-1)
+    ap.add_argument("end", nargs="?", type=int, default=-1)
+    ap.add_argument("--H", type=int, default=None), ap.add_argument("--v1", action="store_true")
+    ap.add_argument("--no-video", action="store_true")
+    a = ap.parse_args()
+    rank, world, dev = init_ranks()
+    model = runner.load_model(a.ckpt, a.v1, dev)
+    scenes = runner.list_scenes(a.image_dir, a.flow_dir, a.align, a.start, a.end)
+    busy, t0 = 0.0, time.perf_counter()
+    for scene, img, flo in scenes:
+        dt, out = runner.animate_scene(model, img, flo, os.path.join(a.save_dir, scene), scene, a.H or a.W, a.W, a.N, a.speed,
+                                       a.align, rank, world, video=not a.no_video)
+        busy += dt
+        if rank == 0:
+            print(f"{scene}: {a.N} frames in {dt:.2f} s ({a.N / dt:.1f} frames/s) -> {out}", flush=True)
+    if rank == 0:
+        n = len(scenes) * a.N
+        print(f"{len(scenes)} scenes, {n} frames on {world} GPU(s): {n / max(busy, 1e-9):.1f} frames/s rendering, "
+              f"{time.perf_counter() - t0:.1f} s with loading and PNG writing")
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
