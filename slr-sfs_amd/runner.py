@@ -33,13 +33,16 @@ def load_model(ckpt, v1, dev):
 
 
 def animate_scene(model, image_path, flow_path, out_dir, name, H, W, N, speed, align=None, rank=0, world=1, group=None,
-                  video=True):
+                  video=True, half_size=False):
     """One scene -> out_dir/name/PredImg/%06d.png (2-layer model: + FluidImg/, CompositeFluidAlpha/, BGImg.png;
-    test_v1_4eval_rawsize.py:240-284), written by rank 0.  Returns (seconds of device work for the clip, frame dir)."""
+    test_v1_4eval_rawsize.py:240-284), written by rank 0, at the raw size of the image (the *_rawsize scripts) or at half
+    of it (half_size: test_baseline_4eval.py / test_v1_4eval.py:160-161).  Returns (seconds of device work, frame dir)."""
     v1 = isinstance(model, pipeline.SLRv1Animator)
     dev = next(model.parameters()).device
     image, (raw_w, raw_h) = io.load_image(image_path, H, W)
     motion = pipeline.prepare_motion(io.load_motion(flow_path), H, W, speed, io.speed_align(align, name), N)
+    if half_size:
+        raw_w, raw_h = raw_w // 2, raw_h // 2
     image, motion = image.to(dev), motion.to(dev)
     mine = parallel.shard_frames(N, rank, world)
     shard = (rank, world, group) if world > 1 else None

@@ -84,6 +84,10 @@ def test_one_scene_with_a_reference_format_checkpoint(tmp_path, golden_dir):
         assert got.shape == (50, 70, 3)
         assert np.abs(got.astype(int) - ref[t].astype(int)).max() <= 1           # (record order -> last-bit differences)
     assert np.abs(np.diff(ref.astype(int), axis=0)).max() > 0                    # the clip moves
+    # the non-rawsize scripts write half-size frames (test_baseline_4eval.py:160-161)
+    _, hdir = runner.animate_scene(model, os.path.join(d, "00007_input.jpg"), os.path.join(d, "00007.flo"),
+                                   os.path.join(d, "half"), "00007", H, W, N, 0.5, align, video=False, half_size=True)
+    assert np.asarray(Image.open(os.path.join(hdir, "000003.png"))).shape == (25, 35, 3)
 
 
 @pytest.mark.gpu

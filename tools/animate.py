@@ -38,10 +38,12 @@ def main():
     ap.add_argument("speed", type=float), ap.add_argument("align", nargs="?", default="None")
     ap.add_argument("--H", type=int, default=None, help="working height (default: W, square like the reference)")
     ap.add_argument("--v1", action="store_true")
+    ap.add_argument("--half-size", action="store_true", help="write frames at half the raw size (test_baseline_4eval.py / test_v1_4eval.py)")
     a = ap.parse_args()
     rank, world, dev = init_ranks()
     model = runner.load_model(a.ckpt, a.v1, dev)
-    dt, out = runner.animate_scene(model, a.image, a.flow, a.outdir, a.name, a.H or a.W, a.W, a.N, a.speed, a.align, rank, world)
+    dt, out = runner.animate_scene(model, a.image, a.flow, a.outdir, a.name, a.H or a.W, a.W, a.N, a.speed, a.align, rank, world,
+                                   half_size=a.half_size)
     if rank == 0:
         print(f"{a.N} frames at {a.H or a.W}x{a.W} on {world} GPU(s) in {dt:.2f} s ({a.N / dt:.1f} frames/s) -> {out}")
     if world > 1:

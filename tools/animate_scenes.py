@@ -29,6 +29,7 @@ def main():
     ap.add_argument("end", nargs="?", type=int, default=-1)
     ap.add_argument("--H", type=int, default=None), ap.add_argument("--v1", action="store_true")
     ap.add_argument("--no-video", action="store_true")
+    ap.add_argument("--half-size", action="store_true", help="write frames at half the raw size (test_baseline_4eval.py / test_v1_4eval.py)")
     a = ap.parse_args()
     rank, world, dev = init_ranks()
     model = runner.load_model(a.ckpt, a.v1, dev)
@@ -36,7 +37,7 @@ def main():
     busy, t0 = 0.0, time.perf_counter()
     for scene, img, flo in scenes:
         dt, out = runner.animate_scene(model, img, flo, os.path.join(a.save_dir, scene), scene, a.H or a.W, a.W, a.N, a.speed,
-                                       a.align, rank, world, video=not a.no_video)
+                                       a.align, rank, world, video=not a.no_video, half_size=a.half_size)
         busy += dt
         if rank == 0:
             print(f"{scene}: {a.N} frames in {dt:.2f} s ({a.N / dt:.1f} frames/s) -> {out}", flush=True)
