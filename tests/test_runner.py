@@ -91,8 +91,8 @@ def test_one_scene_with_a_reference_format_checkpoint(tmp_path, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("v1", [False, True])
-def test_directory_on_two_ranks_matches_one_rank(tmp_path, golden_dir, v1):
+@pytest.mark.parametrize("v1,shard", [(False, "frames"), (True, "frames"), (False, "scenes")])
+def test_directory_on_two_ranks_matches_one_rank(tmp_path, golden_dir, v1, shard):
     from PIL import Image
     d = str(tmp_path)
     for i, n in enumerate(("00001", "00002")):
@@ -100,7 +100,7 @@ def test_directory_on_two_ranks_matches_one_rank(tmp_path, golden_dir, v1):
     ck = os.path.join(d, "ck.pth")
     _checkpoint(ck, golden_dir, ("encoder", "projector", "net_bg", "net_alpha_encoder", "net_alpha_decoder") if v1 else
                 ("encoder", "projector"))
-    args = [d, d, None, ck, "Demo", "64", "7", "0.5", "None", "-1", "-1", "--no-video"] + (["--v1"] if v1 else [])
+    args = [d, d, None, ck, "Demo", "64", "7", "0.5", "None", "-1", "-1", "--no-video", "--shard", shard] + (["--v1"] if v1 else [])
     env = dict(os.environ, SLR_ONE_GPU_GLOO="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29713")
     outs = []
     for world in (1, 2):

@@ -29,24 +29,34 @@ def main():
     ap.add_argument("end", nargs="?", type=int, default=-1)
     ap.add_argument("--H", type=int, default=None), ap.add_argument("--v1", action="store_true")
     ap.add_argument("--no-video", action="store_true")
+    ap.add_argument("--shard", default="frames", choices=["frames", "scenes"],
+                    help="under torchrun: frames of every clip over the ranks + one all-gather per clip (default; config C5), or "
+                         "whole scenes per rank, no collective (the reference's own parallelism: one process per scene, test_sbatch_2.sh)")
     ap.add_argument("--half-size", action="store_true", help="write frames at half the raw size (test_baseline_4eval.py / test_v1_4eval.py)")
     a = ap.parse_args()
     rank, world, dev = init_ranks()
     model = runner.load_model(a.ckpt, a.v1, dev)
     scenes = runner.list_scenes(a.image_dir, a.flow_dir, a.align, a.start, a.end)
     busy, t0 = 0.0, time.perf_counter()
-    for scene, img, flo in scenes:
+    by_scene = a.shard == "scenes" and world > 1
+    for i, (scene, img, flo) in enumerate(scenes):
+        if by_scene and i % world != rank:
+            continue                                             # another rank's scene
+        r, w = (0, 1) if by_scene else (rank, world)             # a scene of one's own is rendered and written alone
         dt, out = runner.animate_scene(model, img, flo, os.path.join(a.save_dir, scene), scene, a.H or a.W, a.W, a.N, a.speed,
-                                       a.align, rank, world, video=not a.no_video, half_size=a.half_size)
+                                       a.align, r, w, video=not a.no_video, half_size=a.half_size)
         busy += dt
-        if rank == 0:
+        if r == 0:
             print(f"{scene}: {a.N} frames in {dt:.2f} s ({a.N / dt:.1f} frames/s) -> {out}", flush=True)
-    if rank == 0:
-        n = len(scenes) * a.N
-        print(f"{len(scenes)} scenes, {n} frames on {world} GPU(s): {n / max(busy, 1e-9):.1f} frames/s rendering, "
-              f"{time.perf_counter() - t0:.1f} s with loading and PNG writing")
     if world > 1:
         torch.distributed.barrier()
+    if rank == 0:
+        n = len(scenes) * a.N
+        wall = time.perf_counter() - t0
+        print(f"{len(scenes)} scenes, {n} frames on {world} GPU(s) ({a.shard} sharded): "
+              + (f"{n / max(busy, 1e-9):.1f} frames/s rendering, " if not by_scene else "")
+              + f"{wall:.1f} s with loading and PNG writing ({n / wall:.1f} frames/s)")
+    if world > 1:
         torch.distributed.destroy_process_group()
 
 
