@@ -18,7 +18,8 @@ V1_NETS = ("encoder", "projector", "net_bg", "net_alpha_encoder", "net_alpha_dec
 
 def load_model(ckpt, v1, dev):
     """BaselineAnimator / SLRv1Animator on ``dev``; ``ckpt``: a reference checkpoint (``state_dict`` with
-    ``model.module.<net>.`` keys, ``opts`` = the training Namespace) or None / 'None' for random-init networks."""
+    ``model.module.<net>.`` keys, ``opts`` = the training Namespace) or None / 'None' for random-init networks.
+    (Like the reference's scripts, this unpickles the file -- the Namespace is a pickled object: only load checkpoints you trust.)"""
     opts, sd = None, None
     if ckpt not in (None, "None", "none", ""):
         blob = torch.load(ckpt, map_location="cpu", weights_only=False)
