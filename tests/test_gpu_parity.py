@@ -821,6 +821,41 @@ def test_frame_is_graph_capturable(S):
             assert (out - ref).abs().max().item() < 1e-4
 
 
+def test_batched_frames_are_graph_capturable(S):
+    """The batched path -- 7 frames through ONE launch of the tile kernel (their arguments travel as kernel arguments,
+    no host memory is read at replay) and the decoder on the batch -- captured into a HIP graph and replayed."""
+    H, W, N = 40, 72, 7
+    torch.manual_seed(3)
+    an = S.pipeline.BaselineAnimator().cuda().eval()
+    img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+    m = dev(smooth_motion(H, W, 5, amp=2.0))
+    ts = list(range(N))
+    with torch.no_grad():
+        clip = an.begin_clip(img, m, N)
+        buf = torch.empty(N, 64, H, W, device="cuda")
+
+        def run():
+            clip.features_batch(ts, buf)
+            return torch.tanh(an.projector(buf))
+        ref = run().clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = run()
+        for _ in range(3):
+            out.zero_()
+            buf.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert (out - ref).abs().max().item() < 1e-4
+        for t in ts:                                         # and the batch equals the frames one at a time
+            assert (ref[t:t + 1] - an.frame(clip, t)).abs().max().item() < 1e-4
+
+
 def test_splat_next_to_concurrent_matrix_core_kernel(S):
     """The splat on a side HIP stream while a large matrix-core convolution runs on the caller's stream gives the
     sequential result.  Regression test of the round-1 finding: built WITH packed-fp32 instructions
