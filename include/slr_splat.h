@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 3
+#define SLR_ABI_VERSION 4
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -97,6 +97,16 @@ int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_
  * displacement map of a frame): same launches, about the time of one. */
 int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W,
                        void *ws_a, void *ws_b, size_t ws_bytes, void *stream);
+
+/* Front end of the one-flow calls below (slr_softsplat_forward, slr_softsplat_mode_forward, slr_maxsplat_forward,
+ * slr_max_warp_norm with prebinned == 0).  Two exact front ends exist:
+ *   bins : slr_splat_bin + a work plan + the tile kernel + combine (8 launches) -- sized for large grids;
+ *   scan : one kernel writes the destination box of every 8x64 block of source pixels, then every output tile's
+ *          workgroup scans the flow of the blocks whose box touches it (2 launches, no bins, no plan, no combine).
+ * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64)); default 512,
+ * 0 = always bins, INT_MAX = always scan.  Process-wide; returns the previous value.
+ * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199.) */
+int slr_splat_set_scan_max_tiles(int max_tiles);
 
 /* ------------------------------------------------------------------ splat: forward */
 

@@ -57,6 +57,10 @@ struct WsLayout {
     size_t off_whole;     // uint32[nt]   work items that cover a whole over-budget tile (plan)
     size_t off_items;     // ItemDesc[items_cap] (32 B per work item)           (plan)
     size_t off_totals;    // uint32[4]    total items, total partial slots (plan)
+    size_t off_box;       // SrcBox[nt]   destination box of every source tile (scan front end: no bins, no plan)
+    size_t off_ctl;       // uint32[4]    scan front end, segment sharing: queue head, tail, partial slots used
+    size_t off_queue;     // uint64[part_slots] work words (tile, segment, segments, first slot, channel group)
+    size_t off_arrive;    // uint32[part_slots] arrivals per shared tile
     size_t off_trash;     // float[planes][TILE_PIX]  sink for work-items outside the image
     size_t off_partial;   // float[part_slots][planes][TILE_PIX]           (main -> combine)
     size_t part_stride;   // floats per partial slot = planes * TILE_PIX
@@ -85,8 +89,12 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_whole = o;   o += al256((size_t)L.nt * 4);
     L.off_items = o;   o += al256((size_t)L.items_cap * 32);
     L.off_totals = o;  o += 256;
-    // C value planes + the normaliser plane
-    L.part_stride = (size_t)(C + 1) * TILE_PIX;
+    L.off_box = o;     o += al256((size_t)L.nt * 16);
+    L.off_ctl = o;     o += 256;
+    L.off_queue = o;   o += al256((size_t)L.part_slots * 8);
+    L.off_arrive = o;  o += al256((size_t)L.part_slots * 4);
+    // C value planes (rounded up to whole chunks of 4: the scan front end stores a chunk per 16-byte word) + the normaliser plane
+    L.part_stride = (size_t)((C + 3) / 4 * 4 + 1) * TILE_PIX;
     L.off_trash = o;   o += al256(L.part_stride * 4);
     L.off_partial = o;
     o += al256((size_t)L.part_slots * L.part_stride * 4);

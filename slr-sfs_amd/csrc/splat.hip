@@ -28,6 +28,8 @@
 #include "slr_common.hpp"
 
 #include <stdarg.h>
+#include <atomic>
+#include <type_traits>
 
 namespace slr {
 
@@ -512,6 +514,51 @@ __global__ __launch_bounds__(1024) void plan_clip_kernel(ClipMaps c, ClipPlan p,
               p.multi + (size_t)i * nt, p.whole_items + (size_t)i * nt, p.totals + (size_t)i * CLIP_TOTALS);
 }
 
+// =========================================================================== scan front end (no bins)
+// Small grids (config C2 of BASELINE.json: 256x480) spend their time in the latency chains of seven tiny dependent
+// launches (zero, count, scan, fill, plan, whole, combine: ~35 us around a 30 us tile kernel, profiles/r2_c2_kernel_stats.txt).
+// The scan front end replaces all of them by ONE small kernel: every 8x64 block of SOURCE pixels ("source tile") gets
+// the bounding box of the NW corners its pixels splat to.  The tile kernel (SCAN instantiation) then needs no bins:
+// an output tile's workgroup tests all boxes (16 bytes each, L2-resident), scans the flow of the few source tiles
+// whose box touches the tile (wave w = row w of the source tile: coalesced 256-byte loads) and builds its entry list
+// in LDS itself.  Any flow is handled exactly: a box that covers everything just means more candidates to scan.
+struct SrcBox { int x0, x1, y0, y1; };      // inclusive range of the footprints' NW corners; x0 > x1: no pixel splats into the image
+
+__global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restrict__ flow, SrcBox *__restrict__ box,
+                                                            int H, int W, int tiles_x, int tiles, uint32_t *__restrict__ ctl,
+                                                            unsigned long long *__restrict__ q_items, uint32_t *__restrict__ arrive,
+                                                            uint32_t part_slots) {
+    const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // the segment-sharing state of the tile kernel that follows (a kernel boundary makes the zeros visible to it)
+    for (uint32_t i = (uint32_t)t * TILE_PIX + tid; i < part_slots; i += gridDim.x * TILE_PIX) { q_items[i] = 0ull; arrive[i] = 0u; }
+    if (t == 0 && tid < 64) ctl[tid] = 0u;      // (ctl[3], tickets on offer, is signed: draws may race ahead of the publisher's add)
+    const int y = (tl / tiles_x) * TILE_H + wid, x = (tl % tiles_x) * TILE_W + lane;
+    int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
+    if (y < H && x < W) {
+        const float *f = flow + (size_t)n * 2 * H * W + (size_t)y * W + x;
+        const Corners c = make_corners(f[0], f[(size_t)H * W], x, y);
+        // some corner of the footprint lies inside the image (the same test as footprint_tiles)
+        if (c.ok && c.x0 >= -1 && c.x0 <= W - 1 && c.y0 >= -1 && c.y0 <= H - 1) { bx0 = bx1 = c.x0; by0 = by1 = c.y0; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
+        by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
+    }
+    __shared__ int red[TILE_H][4];
+    if (lane == 0) { red[wid][0] = bx0; red[wid][1] = bx1; red[wid][2] = by0; red[wid][3] = by1; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < TILE_H; ++w) {
+            bx0 = min(bx0, red[w][0]); bx1 = max(bx1, red[w][1]); by0 = min(by0, red[w][2]); by1 = max(by1, red[w][3]);
+        }
+        SrcBox b; b.x0 = bx0; b.x1 = bx1; b.y0 = by0; b.y1 = by1;
+        box[t] = b;
+    }
+}
+
 // =========================================================================== splat
 
 enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
@@ -534,6 +581,11 @@ struct SplatArgs {
     int mulmode, norm_mode;
     float eps, init;
     long long *trace;
+    const SrcBox *box;      // SCAN front end: destination boxes of the source tiles [N * tiles]
+    uint32_t nt, part_slots;  // SCAN front end: N * tiles (there is no plan to read a total from); partial-tile slots
+    uint32_t *ctl;          // SCAN front end, segment sharing (see ScanCtl): head / tail / slots used; nullptr = off
+    unsigned long long *q_items;   // [part_slots] queue of (tile, segment) work, one 8-byte word each, 0 = not written yet
+    uint32_t *arrive;       // [part_slots] arrival counter of a shared tile, indexed by its first partial slot
 };
 
 // Several frames of a clip in ONE launch: kernels on a stream run one after the other, so with one launch per frame
@@ -578,9 +630,13 @@ __device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps)
 }
 
 #ifdef SLR_TRACE      // development aid: per-workgroup phase timestamps (s_memtime) into a.trace
-#define SLR_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 40 + (slot)] = clock64(); } while (0)
+#define SLR_TRACE_SLOTS 64      // 0-3, 28: phase 1; 4..30: the first 9 chunks (3 stamps each); 32..: specials
+#define SLR_STAMP(slot) do { if (a.trace && threadIdx.x == 0 && (slot) < SLR_TRACE_SLOTS) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SLR_TRACE_SLOTS + (slot)] = clock64(); } while (0)
+// (clock64 counters differ between XCDs: chip-wide timelines use the 100 MHz real-time counter)
+#define SLR_STAMP_RT(slot) do { if (a.trace && threadIdx.x == 0) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SLR_TRACE_SLOTS + (slot)] = wall_clock64(); } while (0)
 #else
 #define SLR_STAMP(slot) do { } while (0)
+#define SLR_STAMP_RT(slot) do { } while (0)
 #endif
 
 constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
@@ -655,15 +711,96 @@ __device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
 //
 // Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
 // bytes of LDS in front of the staged values: counts, wave sums, offsets, records (16-byte aligned)
-__host__ __device__ constexpr bool rec6(int ept) { return SLR_REC6 && ept * SPLAT_THREADS == SEG_ONE; }
-__host__ __device__ constexpr size_t lds_head_bytes(int ept) {
-    return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (rec6(ept) ? 6 : 8) + 15) & ~(size_t)15;
+#ifndef SLR_EPT_SCAN
+#define SLR_EPT_SCAN 2         // entries per work-item of the SCAN instantiation (segment = EPT * 512 entries)
+#endif
+constexpr int EPT_SCAN = SLR_EPT_SCAN;
+__host__ __device__ constexpr bool rec6(int ept, bool scan = false) { return SLR_REC6 && (scan || ept * SPLAT_THREADS == SEG_ONE); }
+__host__ __device__ constexpr size_t lds_head_bytes(int ept, bool scan = false) {
+    return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (rec6(ept, scan) ? 6 : 8) + 15) & ~(size_t)15;
 }
 // (the rare whole-tile instantiation carries a segment loop and would spill under the 80-register cap)
-constexpr int tile_min_waves(int ept, bool whole) { return (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1; }
+#ifndef SLR_CSPLIT_MAX
+#define SLR_CSPLIT_MAX 4          // channel groups per tile on small grids (1 = off)
+#endif
+#ifndef SLR_CSPLIT_SLOTS
+#define SLR_CSPLIT_SLOTS 512      // workgroup slots of the chip the groups may fill
+#endif
+#ifndef SLR_WAVES_SCAN
+#define SLR_WAVES_SCAN 4       // SCAN instantiation (it carries the pass loop): <= 128 VGPRs, two workgroups per CU
+#endif
+constexpr int tile_min_waves(int ept, bool whole, bool scan) {
+    return scan ? SLR_WAVES_SCAN : (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1;
+}
+#ifndef SLR_SCAN_CB
+#define SLR_SCAN_CB 5          // candidate source tiles per group of the scan (two groups' flow loads are in flight)
+#endif
 
-template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE>
-__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void splat_tile_kernel(SplatBatch batch) {
+// ---- segment sharing inside the SCAN kernel ------------------------------------------------------------------------
+// A tile with more than SEG entries (the ridges of an Euler-integrated field hold up to 7x the mean) used to be walked
+// pass by pass by its one workgroup while the rest of the chip went idle (768x1280, t = 59: 318 us against 246 with bins
+// and a plan).  Without a count pass nobody knows the heavy tiles in advance, so the split is made when they are found:
+// the tile's workgroup reserves ns partial-tile slots, PUSHES segments 1..ns-1 as 8-byte work words onto a queue in the
+// workspace and takes segment 0 itself.
+// Taking work is guarded by a semaphore (ctl[3] = words pushed and not yet claimed): a claim is one returning atomic
+// decrement; only a granted claim draws a queue index (fetch-add on the head), so the head can never overshoot the
+// tail and there is no compare-and-swap anywhere.  (Measured before it looked like this: a CAS-popped queue collapsed
+// under contention, 40 us per pop at t = 59; a list of open tiles with per-tile tickets that every finishing workgroup
+// looked at cost 16 us per workgroup end on average -- every step is a dependent memory-side operation behind the
+// streaming traffic, and ~50 workgroups end inside the age of one snapshot.)  Who claims:
+//   * a workgroup that has just finished a segment (the publisher after segment 0 included): always, on fresh state -- so
+//     every pushed word is taken by somebody even if nobody else turns up;
+//   * one workgroup in SLR_SHARE_HELPERS after its own tile, and only if the control words it fetched two chunks before
+//     the end of its work (arrived by then: no waiting) show words on offer.  The other workgroups never look.
+// Each segment's raw sums go to its partial slot with WRITE-THROUGH stores (sc1: straight to memory, no L2 write-back
+// fence -- the XCDs' L2s are not coherent), every storing wave drains vmcnt, then one agent-scope atomic counts the arrival;
+// the workgroup that arrives last makes ONE agent-scope acquire, reads all ns slots back, sums them in segment order,
+// normalises and stores the tile.  No plan, no combine launch, and the only wait on another workgroup is for a queue word
+// whose writer has already reserved it (it writes it a few instructions later).
+// Control words (zeroed by scan_box_kernel of the same call): ctl[0] queue head, ctl[1] queue tail, ctl[2] partial slots
+// used, ctl[3] semaphore (signed: claims may race ahead of a push and are given back).
+#ifndef SLR_SHARE_HELPERS
+#define SLR_SHARE_HELPERS 16   // 768x1280, C = 65, whole call: 4 / 8 / 16 -> Euler t=30 220 / 219 / 212 us, t=59 309 / 292 / 280 us
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+
+#ifndef SLR_SHARE_STORE
+#define SLR_SHARE_STORE 1      // partial slots: 0 = sc0 sc1 stores, 1 = sc1 stores, 2 = plain stores + an agent release fence per wave
+#endif
+__device__ __forceinline__ void store_wt16(float *p, f4v v) {          // 16-byte write-through store (untracked by the compiler's
+#if SLR_SHARE_STORE == 0
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");   // vmcnt bookkeeping: drained by hand)
+#elif SLR_SHARE_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<f4v *>(p) = v;
+#endif
+}
+__device__ __forceinline__ f4v load_wt16(const float *p) {             // two 8-byte loads that bypass L1 (agent scope)
+    const unsigned long long x = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long y = __hip_atomic_load((gu64 *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f4v r;
+    r.x = __uint_as_float((uint32_t)x); r.y = __uint_as_float((uint32_t)(x >> 32));
+    r.z = __uint_as_float((uint32_t)y); r.w = __uint_as_float((uint32_t)(y >> 32));
+    return r;
+}
+__device__ __forceinline__ void store_wt4(float *p, float v) {
+    __hip_atomic_store((gu32 *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_wt4(const float *p) {
+    return __uint_as_float(__hip_atomic_load((gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// work word: [63:38] tile + 1 (never 0), [37:30] segment, [29:22] segments of the tile, [21:4] first partial slot, [3:0] channel group
+__device__ __forceinline__ unsigned long long pack_work(uint32_t tile, uint32_t seg, uint32_t ns, uint32_t po, uint32_t grp) {
+    return ((unsigned long long)(tile + 1u) << 38) | ((unsigned long long)seg << 30) | ((unsigned long long)ns << 22) |
+           ((unsigned long long)po << 4) | grp;
+}
+constexpr uint32_t SHARE_MAX_SEG = 255u, SHARE_MAX_SLOT = 1u << 18, SHARE_MAX_TILE = (1u << 26) - 2u;
+
+template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE, bool SCAN = false>
+__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)) void splat_tile_kernel(SplatBatch batch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t bstart, bf, bx;                               // frame of this block, block index inside the frame's own grid
     if (batch.interleave) {
@@ -682,7 +819,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     uint32_t *cnt = smem;                     // [T]   records per output pixel
     uint32_t *wsum = smem + T;                // [T/64] wave sums of the scan
     uint16_t *off = reinterpret_cast<uint16_t *>(smem + T + 16);            // [T] exclusive prefix (< 2^16)
-    constexpr bool R6 = rec6(EPT_MAX);
+    constexpr bool R6 = rec6(EPT_MAX, SCAN);
     float *rec_w = reinterpret_cast<float *>(smem + T + 16 + T / 2);        // R6: [rec_cap] weights ...
     uint16_t *rec_e = reinterpret_cast<uint16_t *>(rec_w + rec_cap(EPT_MAX));   // ... and [rec_cap] entry indices (< SEG <= 2^16)
     uint2 *rec = reinterpret_cast<uint2 *>(smem + T + 16 + T / 2);          // !R6: [rec_cap] (entry index, weight bits)
@@ -691,7 +828,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     };
     auto REC_E = [&](uint32_t i) -> uint32_t { if constexpr (R6) return rec_e[i]; else return rec[i].x; };
     auto REC_W = [&](uint32_t i) -> float { if constexpr (R6) return rec_w[i]; else return __uint_as_float(rec[i].y); };
-    float4 *val4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem) + lds_head_bytes(EPT_MAX) + SLR_LDS_PAD);     // [SEG][CHUNK/4] staged source values
+    float4 *val4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem) + lds_head_bytes(EPT_MAX, SCAN) + SLR_LDS_PAD);     // [SEG][CHUNK/4] staged source values
 
     // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
     // Groups of XCD_GROUP consecutive work items (= horizontally neighbouring tiles) are placed on
@@ -699,7 +836,11 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     // the tile to its left: one 128-byte line per row for 4 useful bytes) is then served by that
     // XCD's L2 instead of HBM, while heavy image regions still spread over all XCDs.
     uint32_t item;
-    if (!WHOLE) {
+    if (SCAN) {                                        // no plan: block -> tile (same XCD grouping), one workgroup per tile
+        const uint32_t slot = bx >> 3;
+        item = ((slot / XCD_GROUP) * 8u + (bx & 7u)) * XCD_GROUP + slot % XCD_GROUP;
+        if (item >= a.nt) return;
+    } else if (!WHOLE) {
         const uint32_t total = a.totals[0];
         const uint32_t slot = bx >> 3;
         item = ((slot / XCD_GROUP) * 8u + (bx & 7u)) * XCD_GROUP + slot % XCD_GROUP;
@@ -708,8 +849,14 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         if (bx >= a.totals[4]) return;
         item = a.whole_items[bx];
     }
-  for (uint32_t wi = bx;;) {                           // one pass unless WHOLE
-    const ItemDesc it = a.items[item];
+  // SCAN: the current piece of work -- the block's own tile first, then segments of shared tiles (w_piece)
+  uint32_t w_grp = blockIdx.y, w_seg = 0, w_po = 0;
+  bool w_piece = false, w_counted = false;            // w_counted: the wave counts of this tile are known (its publisher)
+  uint32_t w_total = 0, w_wave_base = 0;
+  for (uint32_t wi = bx;;) {                           // one pass unless WHOLE (its items) or SCAN (popped segments)
+    ItemDesc it;
+    if (SCAN) { it = ItemDesc{}; it.tile = item; it.nseg = 1; }
+    else it = a.items[item];
     const uint32_t t = it.tile;
     // Normally one workgroup = one segment.  A tile whose segments did not fit into the partial-slot
     // budget (pathological flows: everything converging into a few tiles) is walked segment by
@@ -717,24 +864,213 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     // global memory (its own earlier store), and normalises after the last segment.
     // That is a separate instantiation (WHOLE) launched after the main one; the main kernel skips
     // those items, so its code carries no loop.
-    constexpr bool whole = WHOLE;
-    if ((it.nseg == 0) != WHOLE) return;
+    constexpr bool whole = WHOLE || SCAN;          // SCAN: a tile with more than SEG entries is walked pass by pass as well
+    if (!SCAN && (it.nseg == 0) != WHOLE) return;
     // Channel groups (gridDim.y > 1: small grids, see launch_batch): this workgroup builds the tile's records like
     // any other and gathers the planes [cb, cend) only.  Groups start on a multiple of 2 * CHUNK planes.
     const int cper = (((a.C + (int)gridDim.y - 1) / (int)gridDim.y + 2 * CHUNK - 1) / (2 * CHUNK)) * (2 * CHUNK);
-    const int cb = (int)blockIdx.y * cper, cend = min(a.C, cb + cper);
+    const int cb = (int)w_grp * cper, cend = min(a.C, cb + cper);
     if (cb >= a.C) return;
-    const uint32_t nloop = WHOLE ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;
+    uint32_t nloop = WHOLE ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;
     float nrm_total = 0.0f;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
     const int HW = a.H * a.W;
     const int tid = threadIdx.x;
 
+    // ---------------- SCAN front end: the tile's entry list is built here, in LDS, from the flow itself
+    // Candidates: source tiles whose destination box (scan_box_kernel) touches this tile -> a bit mask in LDS (order-free
+    // atomicOr), walked in index order by every wave; wave w scans row w of each candidate (coalesced), CB candidates'
+    // loads in flight together.  A hit (some corner of the pixel's footprint inside this tile) becomes an entry
+    // (source pixel, flow) in LDS.  Mode 0 hands out entry slots with one LDS atomic per wave and candidate; if the tile
+    // turns out to hold more than SEG entries, it is walked in passes of SEG entries whose membership must be the same
+    // in every pass: mode 1 counts the hits per wave, mode 2 emits the entries with ordinals (wave, candidate, lane)
+    // inside [lo, hi).
+    uint32_t *cmask = reinterpret_cast<uint32_t *>(off);          // [64] candidate bits of a block of 2048 source tiles, [64] entry
+                                                                  // counter, [65 + w] hits of wave w   (off[] is free until phase 1b)
+    uint32_t *ent_pix = reinterpret_cast<uint32_t *>(val4);       // [SEG] entries of the current pass ...
+    float *ent_fx = reinterpret_cast<float *>(val4) + SEG, *ent_fy = ent_fx + SEG;   // ... (val4 is free until the first chunk is staged)
+    uint32_t wave_base = 0, scan_total = 0;
+    uint32_t *clist = reinterpret_cast<uint32_t *>(smem + T + 16 + T / 2);   // [2048] candidate source tiles of the block, in index
+                                                                             // order (the record area is free until phase 1c)
+    auto scan = [&](auto mode_tag, uint32_t lo, uint32_t hi) -> uint32_t {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int CB = SLR_SCAN_CB;
+        const int lane = tid & 63, wid = tid >> 6;
+        const SrcBox *boxes = a.box + (size_t)n * a.tiles;
+        const float *fl = a.flow[0] + (size_t)n * 2 * HW;
+        const float inv_tx = 1.0f / (float)a.tiles_x;
+        uint32_t wcount = 0;                                      // hits of this wave so far (modes 1, 2)
+        for (int base = 0; base < a.tiles; base += 2048) {
+            // the box loads do not depend on LDS: issue them first
+            SrcBox bx4[2048 / T];
+#pragma unroll
+            for (int k = 0; k < 2048 / T; ++k) {
+                const int st = base + tid + k * T;
+                bx4[k] = boxes[st < a.tiles ? st : 0];
+            }
+            if (tid < 64) cmask[tid] = 0;
+            if (MODE == 0 && tid == 64 && base == 0) cmask[64] = 0;
+            __syncthreads();
+            if (MODE == 0) SLR_STAMP(33);
+#pragma unroll
+            for (int k = 0; k < 2048 / T; ++k) {
+                const int st = base + tid + k * T;
+                const SrcBox b = bx4[k];
+                if (st < a.tiles && b.x1 >= tx0 - 1 && b.x0 <= tx0 + TILE_W - 1 && b.y1 >= ty0 - 1 && b.y0 <= ty0 + TILE_H - 1)
+                    atomicOr(&cmask[(st - base) >> 5], 1u << (st & 31));
+            }
+            __syncthreads();
+            if (MODE == 0) SLR_STAMP(34);
+            // Every wave expands the bit mask into the ordered candidate list itself (lane l owns word l; a wave scan places its
+            // bits): the eight waves write identical values to the same LDS words, and each reads back only after its own writes.
+            const uint32_t word = cmask[lane];
+            const uint32_t pc = (uint32_t)__popc(word);
+            uint32_t inc = pc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d);
+                if (lane >= d) inc += o;
+            }
+            const int nc = (int)__shfl(inc, 63);
+#ifdef SLR_SCAN_STATS
+            if (tid == 0 && a.ctl) { atomicAdd(&a.ctl[8 + MODE], 1u); atomicAdd(&a.ctl[12 + MODE], (uint32_t)nc); }
+#endif
+            {
+                uint32_t w = word, at = inc - pc;
+                while (w) {
+                    const int bit = __ffs((int)w) - 1;
+                    w &= w - 1;
+                    clist[at++] = (uint32_t)(base + lane * 32 + bit);
+                }
+            }
+            // CB candidates per group: one row of each (wave w = row w), all flow loads of a group in flight together, and the
+            // next group's loads issued before this group's hits are processed
+            struct Group { float fx[CB], fy[CB]; int pix[CB]; int sx[CB], sy[CB]; };
+            auto issue = [&](Group &g, int k0) {
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    const int k = k0 + i;
+                    const int st = (int)clist[k < nc ? k : 0] - 0;               // (uniform address: one broadcast read)
+                    const int sty = (int)(((float)(st) + 0.5f) * inv_tx);      // st / tiles_x, exact for st < 2^22
+                    const int stx = st - sty * a.tiles_x;
+                    g.sy[i] = sty * TILE_H + wid;
+                    g.sx[i] = stx * TILE_W + lane;
+                    const bool in = (k < nc) & (g.sy[i] < a.H) & (g.sx[i] < a.W);
+                    g.pix[i] = in ? g.sy[i] * a.W + g.sx[i] : -1;
+                    const int q = in ? g.pix[i] : 0;
+                    g.fx[i] = fl[q];
+                    g.fy[i] = fl[HW + q];
+                }
+            };
+            auto process = [&](const Group &g) {
+                unsigned long long hm[CB];
+                uint32_t pre[CB], tot = 0;
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    const Corners c = make_corners(g.fx[i], g.fy[i], g.sx[i], g.sy[i]);
+                    const int lx = c.x0 - tx0, ly = c.y0 - ty0;
+                    const bool xa = (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W), xb = (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
+                    const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H), yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
+                    hm[i] = __ballot((g.pix[i] >= 0) & c.ok & (xa | xb) & (ya | yb));
+                    pre[i] = tot;
+                    tot += (uint32_t)__popcll(hm[i]);
+                }
+                if (tot == 0) return;                             // wave-uniform
+                uint32_t b0;
+                if (MODE == 0) {                                  // ONE slot reservation per wave and group
+                    b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(&cmask[64], tot);
+                    b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+                } else {
+                    b0 = wave_base + wcount;
+                    wcount += tot;
+                }
+                if (MODE != 1) {
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) {
+                        const uint32_t slot = b0 + pre[i] + (uint32_t)__popcll(hm[i] & ((1ull << lane) - 1ull));
+                        if (((hm[i] >> lane) & 1ull) && slot >= lo && slot < hi) {
+                            ent_pix[slot - lo] = (uint32_t)g.pix[i];
+                            ent_fx[slot - lo] = g.fx[i];
+                            ent_fy[slot - lo] = g.fy[i];
+                        }
+                    }
+                }
+            };
+            Group ga, gb;
+            if (nc > 0) issue(ga, 0);
+            for (int k0 = 0; k0 < nc; k0 += 2 * CB) {
+                if (k0 + CB < nc) issue(gb, k0 + CB);
+                process(ga);
+                if (k0 + CB < nc) {
+                    if (k0 + 2 * CB < nc) issue(ga, k0 + 2 * CB);
+                    process(gb);
+                }
+            }
+            if (MODE == 0) SLR_STAMP(35);
+            __syncthreads();
+        }
+        return MODE == 0 ? cmask[64] : wcount;
+    };
+    if (!w_piece) { SLR_STAMP(41); SLR_STAMP_RT(48); }
+    unsigned long long qsnap2 = 0;                                // ctl[2..3] as seen two chunks before the end of this work
+    // (a grid that fits the chip in one round ends all at once with nothing else to do: everybody helps)
+    const bool helper = ((bx >> 3) % (uint32_t)SLR_SHARE_HELPERS) == 0u || gridDim.x * gridDim.y <= (uint32_t)SLR_CSPLIT_SLOTS;
+    bool part = false;                                            // this piece of work is ONE segment of a shared tile
+    bool ctx = false;                                             // this workgroup holds a shared tile it may draw more tickets of
+    uint32_t ns_tile = 1;                                         // segments of the tile (part)
+    if (SCAN) {
+        if (!w_piece) { scan_total = scan(std::integral_constant<int, 0>{}, 0u, (uint32_t)SEG); w_counted = false; }
+        if (!w_piece) SLR_STAMP(42);
+        if (w_piece || scan_total > (uint32_t)SEG) {              // heavy tile: segments with reproducible membership
+            if (!w_counted) {
+                const uint32_t wc = scan(std::integral_constant<int, 1>{}, 0u, 0u);
+                if ((tid & 63) == 0) cmask[65 + (tid >> 6)] = wc;
+                __syncthreads();
+                uint32_t all = 0, wb = 0;
+#pragma unroll
+                for (int w = 0; w < T / 64; ++w) { const uint32_t c = cmask[65 + w]; all += c; wb += w < (tid >> 6) ? c : 0u; }
+                w_total = all; w_wave_base = wb; w_counted = true;
+                __syncthreads();
+            }
+            scan_total = w_total;                                 // (equals the optimistic count)
+            wave_base = w_wave_base;
+            ns_tile = (scan_total + SEG - 1) / SEG;
+            part = ctx = w_piece;
+            nloop = part ? 1u : ns_tile;                          // not shared: this workgroup walks all passes itself
+            if (!w_piece && a.ctl && ns_tile <= SHARE_MAX_SEG && t <= SHARE_MAX_TILE) {
+                // reserve ns slots; if they exist, push segments 1..ns-1 and keep segment 0
+                if (tid == 0) {
+                    const uint32_t po = atomicAdd(&a.ctl[2], ns_tile);
+                    uint32_t qp = 0xffffffffu;
+                    if (po + ns_tile <= a.part_slots && po + ns_tile <= SHARE_MAX_SLOT) qp = atomicAdd(&a.ctl[1], ns_tile - 1u);
+                    wsum[0] = po; wsum[1] = qp;
+                }
+                __syncthreads();
+                const uint32_t po = wsum[0], qp = wsum[1];
+                __syncthreads();
+                if (qp != 0xffffffffu) {                          // (sum of ns - 1 over successful reservations < part_slots = queue size)
+                    for (uint32_t i = tid; i + 1 < ns_tile; i += T)
+                        __hip_atomic_store((gu64 *)(a.q_items + qp + i), pack_work(t, i + 1u, ns_tile, po, w_grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the words are in memory before the semaphore says so
+                    __syncthreads();
+                    if (tid == 0) atomicAdd(&a.ctl[3], ns_tile - 1u);
+                    part = ctx = true; nloop = 1; w_seg = 0; w_po = po;
+                }
+#ifdef SLR_SCAN_STATS
+                if (tid == 0) { atomicAdd(&a.ctl[16], 1u); atomicAdd(&a.ctl[17], ns_tile); atomicMax(&a.ctl[18], ns_tile); if (!ctx) atomicAdd(&a.ctl[19], 1u); }
+#endif
+            }
+        }
+    }
+
   for (uint32_t si = 0; si < nloop; ++si) {
-    const uint32_t s = whole ? si : it.seg;
+    const uint32_t s = (SCAN && part) ? w_seg : whole ? si : it.seg;
     const bool first = si == 0, last = si + 1 == nloop;
-    SLR_STAMP(0);
+    if (!w_piece && first) SLR_STAMP(0);
+    if (!w_piece && first && SCAN && (nloop > 1 || part)) SLR_STAMP(36);
+    if (SCAN && (nloop > 1 || part)) scan(std::integral_constant<int, 2>{}, s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG);
     cnt[tid] = 0;
     __syncthreads();
 
@@ -766,30 +1102,41 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     {
         // entry j of this work-item = element lo + tid + j*T of [bin(flow0) ; bin(flow1)]
         const uint32_t c0 = it.cnt0, c1 = it.cnt1;
-        const uint32_t *l0 = a.list[0] + it.off0;
-        const uint32_t *l1 = a.ndir > 1 ? a.list[1] + it.off1 : l0;
+        const uint32_t *l0 = SCAN ? nullptr : a.list[0] + it.off0;
+        const uint32_t *l1 = SCAN ? nullptr : a.ndir > 1 ? a.list[1] + it.off1 : l0;
         const float *mp = has_mul ? a.mul + (size_t)n * HW : nullptr;
         bool (&val)[EPT_MAX] = e_val;
         int dir[EPT_MAX];
         // independent index loads first, then the dependent flow / weight loads
+        float fx[EPT_MAX], fy[EPT_MAX], mm[EPT_MAX];
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j) {
-            const uint32_t k = lo + tid + j * T;
-            val[j] = (k < hi) & (k < c0 + c1);
-            dir[j] = (k >= c0) ? 1 : 0;
-            e_pix[j] = val[j] ? (dir[j] ? l1[k - c0] : l0[k]) : 0u;
+            if (SCAN) {                                            // entries of this pass: in LDS, with their flow
+                const uint32_t k = tid + j * T;
+                val[j] = lo + k < scan_total && k < (uint32_t)SEG;
+                dir[j] = 0;
+                e_pix[j] = val[j] ? ent_pix[k] : 0u;
+                fx[j] = val[j] ? ent_fx[k] : 0.0f;
+                fy[j] = val[j] ? ent_fy[k] : 0.0f;
+            } else {
+                const uint32_t k = lo + tid + j * T;
+                val[j] = (k < hi) & (k < c0 + c1);
+                dir[j] = (k >= c0) ? 1 : 0;
+                e_pix[j] = val[j] ? (dir[j] ? l1[k - c0] : l0[k]) : 0u;
+            }
         }
         SLR_STAMP(28);
         // the plane loads of the first two chunks only need the source indices: issue them now,
         // they complete under the footprint math, the LDS atomics and the scan
         prefetch(preA, cb);
         prefetch(preB, cb + CHUNK);
-        float fx[EPT_MAX], fy[EPT_MAX], mm[EPT_MAX];
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j) {
-            const float *fl = a.flow[dir[j]] + (size_t)n * 2 * HW;
-            fx[j] = val[j] ? fl[e_pix[j]] : 0.0f;
-            fy[j] = val[j] ? fl[HW + e_pix[j]] : 0.0f;
+            if (!SCAN) {
+                const float *fl = a.flow[dir[j]] + (size_t)n * 2 * HW;
+                fx[j] = val[j] ? fl[e_pix[j]] : 0.0f;
+                fy[j] = val[j] ? fl[HW + e_pix[j]] : 0.0f;
+            }
             mm[j] = (val[j] && has_mul) ? mp[e_pix[j]] : 0.0f;
         }
 #pragma unroll
@@ -875,8 +1222,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         __syncthreads();
         atomicMax(&dbg_max, r1 - r0);
         __syncthreads();
-        if (a.trace && tid == 0) { a.trace[(size_t)blockIdx.x * 40 + 33] = dbg_max; a.trace[(size_t)blockIdx.x * 40 + 34] = wave_recs;
-                                   a.trace[(size_t)blockIdx.x * 40 + 35] = a.count[0][t]; a.trace[(size_t)blockIdx.x * 40 + 36] = s; }
+        if (a.trace && tid == 0) {
+            long long *tr = a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SLR_TRACE_SLOTS;
+            tr[43] = dbg_max; tr[44] = wave_recs; tr[45] = SCAN ? scan_total : it.cnt0 + it.cnt1; tr[46] = s;
+        }
     }
 #endif
     const uint32_t own = max((uint32_t)LMAX, 2u * ((wave_recs + 63u) >> 6));
@@ -889,6 +1238,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)(it.partoff + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
+    // SCAN, shared tile: slot (w_po + segment), laid out [chunk of 4 planes][work-item][4] so that a chunk is ONE 16-byte
+    // write-through store per work-item; the normaliser plane follows the last chunk
+    float *const pslot = (SCAN && part) ? a.partial + (size_t)(w_po + s) * a.part_stride : nullptr;
+    const size_t pnorm = (size_t)((a.C + 3) / 4) * 4 * TILE_PIX;
     // register-resident head of this pixel's record list (see the gather loop)
     constexpr uint32_t NULL_E = SEG;                   // staged-entry index of the all-zero slot
 #ifndef SLR_KREG_ONE
@@ -897,7 +1250,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
 #ifndef SLR_KREG_TWO
 #define SLR_KREG_TWO 6
 #endif
-    constexpr int KREG = EPT_MAX == EPT_ONE ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
+    constexpr int KREG = (EPT_MAX == EPT_ONE || SCAN) ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
     float cw[KREG];
     uint32_t ce[KREG];
 #pragma unroll
@@ -925,7 +1278,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
         }
         nrm_total += nrm;
         nrm = nrm_total;                                  // all segments seen so far (whole-tile items)
-        if (single) {
+        if (SCAN && part) {
+            store_wt4(pslot + pnorm + tid, nrm);
+        } else if (single) {
             if (a.norm_out && inside && last && cb == 0) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
         } else if (cb == 0) {
             a.partial[(size_t)(it.partoff + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid] = nrm;
@@ -950,7 +1305,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
 #pragma unroll
             for (int h = 0; h < CHUNK / 4; ++h)
                 val4[vslot<CHUNK>(tid + j * T, h)] = make_float4(pre[j][4 * h], pre[j][4 * h + 1], pre[j][4 * h + 2], pre[j][4 * h + 3]);
-        SLR_STAMP(4 + 3 * (c0 / CHUNK));
+        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(4 + 3 * ((c0 - cb) / CHUNK));
         __syncthreads();
 #if SLR_DBG & 4
         bool dbg_bad = false;                          // staged value != what global memory holds?
@@ -967,7 +1322,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
                 }
         }
 #endif
-        SLR_STAMP(5 + 3 * (c0 / CHUNK));
+        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(5 + 3 * ((c0 - cb) / CHUNK));
         prefetch(pre, c0 + 2 * CHUNK);                 // two chunks ahead (three: no gain fused, -20 % one flow: registers)
         float acc[CHUNK];
 #pragma unroll
@@ -1047,6 +1402,12 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
                 if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], part[u]) : acc[u] + part[u];
             }
         }
+        if (SCAN && part) {                            // raw sums of this segment -> its partial slot, write-through
+            static_assert(!SCAN || CHUNK == 4, "partial-slot layout of the SCAN kernel");
+            f4v pv;
+            pv.x = acc[0]; pv.y = acc[1]; pv.z = acc[2]; pv.w = acc[3];
+            store_wt16(pslot + ((size_t)(c0 >> 2) * T + tid) * 4, pv);
+        } else
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
             float r = acc[u];
@@ -1058,14 +1419,110 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE)) void
 #endif
             *dst = r;
         }
-        SLR_STAMP(6 + 3 * (c0 / CHUNK));
+        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(6 + 3 * ((c0 - cb) / CHUNK)); if (c0 + CHUNK >= cend) SLR_STAMP(40);
         __syncthreads();                               // val[] is overwritten by the next chunk
     };
     for (int c0 = cb; c0 < cend; c0 += 2 * CHUNK) {
+        // queue state for the pop after this piece of work: ONE load, issued when the last two chunks begin, consumed after them
+        if (SCAN && a.ctl && tid == 0 && last && !ctx && helper && c0 + 2 * CHUNK >= cend)
+            qsnap2 = __hip_atomic_load((gu64 *)a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         chunk(preA, c0);
         if (c0 + CHUNK < cend) chunk(preB, c0 + CHUNK);
     }
   }
+    if (SCAN) {
+        if (!w_piece) { SLR_STAMP(37); SLR_STAMP_RT(49); }
+        if (part) {
+            // every storing wave drains its write-through stores, then ONE arrival; the last segment to arrive combines
+#if SLR_SHARE_STORE == 2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#ifdef SLR_SHARE_SKIP_COMBINE
+            if (tid == 0) wsum[0] = 0;
+            if (false)
+#endif
+            if (tid == 0) {
+                wsum[0] = atomicAdd(&a.arrive[w_po], 1u);
+                // the partial slots were stored write-through and drained before their arrivals: ONE agent-scope acquire (drops this
+                // CU's stale lines) and the combine below may use plain, pipelined loads
+                if (wsum[0] + 1u == ns_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const bool last_seg = wsum[0] + 1u == ns_tile;
+            __syncthreads();
+            if (last_seg) {
+                const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
+                const int oy = ty0 + ly, ox = tx0 + lx;
+                const bool inside = (oy < a.H) & (ox < a.W);
+                const float *pb = a.partial + (size_t)w_po * a.part_stride;
+                const size_t pnorm = (size_t)((a.C + 3) / 4) * 4 * TILE_PIX;
+                float nrm = 0.0f;
+                if (NORM) {
+                    for (uint32_t q = 0; q < ns_tile; ++q) nrm += pb[(size_t)q * a.part_stride + pnorm + tid];
+                    if (a.norm_out && inside && cb == 0) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
+                }
+                float *o = a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox;
+                for (int c0 = cb; c0 < cend; c0 += 4) {
+                    const size_t at = ((size_t)(c0 >> 2) * T + tid) * 4;
+                    f4v acc = *reinterpret_cast<const f4v *>(pb + at);
+                    for (uint32_t q = 1; q < ns_tile; ++q) {                 // fixed order: reproducible
+                        const f4v v = *reinterpret_cast<const f4v *>(pb + (size_t)q * a.part_stride + at);
+                        if (MAXOP) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+                        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+                    }
+                    const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (inside && c0 + u < cend) o[(size_t)(c0 + u) * HW] = NORM ? finish(r[u], nrm, a.norm_mode, a.eps) : r[u];
+                }
+            }
+        }
+        if (!a.ctl) break;
+        // ---- next piece of work: claim a pushed segment (see the block comment above the kernel)
+        if (tid == 0) {
+            unsigned long long got = 0;
+            const bool seek = ctx || (helper && (int)(uint32_t)(qsnap2 >> 32) > 0);
+            if (seek) {
+#ifdef SLR_SCAN_STATS
+                atomicAdd(&a.ctl[22], 1u);
+#endif
+                const int old = (int)atomicSub(&a.ctl[3], 1u);
+                if (old <= 0) atomicAdd(&a.ctl[3], 1u);            // nothing on offer: give the claim back
+                else {
+                    const uint32_t idx = atomicAdd(&a.ctl[0], 1u);
+                    for (uint32_t spin = 0; spin < (1u << 24); ++spin) {             // reserved by its writer, written next
+                        got = __hip_atomic_load((gu64 *)(a.q_items + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (got) break;
+#ifdef SLR_SCAN_STATS
+                        atomicAdd(&a.ctl[20], 1u);
+#endif
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+            wsum[0] = (uint32_t)got; wsum[1] = (uint32_t)(got >> 32);
+        }
+        __syncthreads();
+        const unsigned long long wv = ((unsigned long long)wsum[1] << 32) | wsum[0];
+        __syncthreads();
+        SLR_STAMP(38); SLR_STAMP_RT(50);
+        if (wv == 0) break;
+#ifdef SLR_TRACE
+        if (a.trace && tid == 0) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SLR_TRACE_SLOTS + 39] += 1;
+#endif
+        w_piece = true;
+        {
+            const uint32_t nt2 = (uint32_t)(wv >> 38) - 1u, ng2 = (uint32_t)wv & 0xfu;
+            if (nt2 != item || ng2 != w_grp) w_counted = false;   // another tile: its wave counts are not known here
+            item = nt2;
+            w_grp = ng2;
+            w_seg = (uint32_t)(wv >> 30) & 0xffu;
+            w_po = (uint32_t)(wv >> 4) & 0x3ffffu;
+        }
+        continue;
+    }
     if (!WHOLE) break;
     wi += gridDim.x;
     if (wi >= a.totals[4]) break;
@@ -1151,6 +1608,9 @@ struct Ws {
     uint32_t *count, *cursor, *listoff, *list, *nseg, *partoff, *totals, *multi, *whole_items;
     ItemDesc *items;
     float *partial, *trash;
+    SrcBox *box;
+    uint32_t *ctl, *arrive;
+    unsigned long long *queue;
 };
 
 static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, const char *who) {
@@ -1172,6 +1632,10 @@ static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, co
     w.totals = (uint32_t *)(w.base + w.L.off_totals);
     w.partial = (float *)(w.base + w.L.off_partial);
     w.trash = (float *)(w.base + w.L.off_trash);
+    w.box = (SrcBox *)(w.base + w.L.off_box);
+    w.ctl = (uint32_t *)(w.base + w.L.off_ctl);
+    w.queue = (unsigned long long *)(w.base + w.L.off_queue);
+    w.arrive = (uint32_t *)(w.base + w.L.off_arrive);
     return 0;
 }
 
@@ -1205,7 +1669,7 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
     return 0;
 }
 
-template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE>
+template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE, bool SCAN = false>
 static int launch_tile_variant(const SplatBatch &b, uint32_t grid, uint32_t groups, size_t lds, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
     // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
@@ -1213,23 +1677,25 @@ static int launch_tile_variant(const SplatBatch &b, uint32_t grid, uint32_t grou
     int dev = 0;
     SLR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>,
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE, SCAN>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE>), dim3(grid, groups), dim3(SPLAT_THREADS), lds, st, b);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE, SCAN>), dim3(grid, groups), dim3(SPLAT_THREADS), lds, st, b);
     return 0;
 }
 
 // What the host knows about the plan of one frame (a clip plan's totals read back once per clip); < 0 = unknown ->
 // the grids cover the upper bounds and surplus workgroups exit at once.
 struct PlanHint { int n_items, n_multi, n_whole; };
-#ifndef SLR_CSPLIT_MAX
-#define SLR_CSPLIT_MAX 4          // channel groups per tile on small grids (1 = off)
-#endif
-#ifndef SLR_CSPLIT_SLOTS
-#define SLR_CSPLIT_SLOTS 512      // workgroup slots of the chip the groups may fill
-#endif
+
+static uint32_t channel_groups(uint32_t nt, int C, int chunk) {
+    if (SLR_CSPLIT_MAX <= 1) return 1u;
+    const uint32_t fit = SLR_CSPLIT_SLOTS / (nt ? nt : 1u), byc = (uint32_t)C / (2u * chunk);
+    uint32_t groups = fit < (uint32_t)SLR_CSPLIT_MAX ? fit : (uint32_t)SLR_CSPLIT_MAX;
+    groups = groups < byc ? groups : byc;
+    return groups < 1u ? 1u : groups;
+}
 
 // Tile kernel, whole-tile kernel and combine for nb frames whose plans are already in b.f[]: the main tile kernel
 // and combine as ONE launch each over all frames.
@@ -1261,13 +1727,7 @@ static int launch_batch(SplatBatch &b, const PlanHint *hint, uint32_t items_cap,
     // Small grids (fewer tiles than the chip has workgroup slots: 256 CUs x 2): a tile is one workgroup whose chunk
     // pipeline nothing overlaps with, so the planes are dealt to 2-4 workgroups per tile (gridDim.y; each builds the
     // tile's records itself, phase 1 is the cheap part).  256x480, C = 64 (config C2): 32 -> ... us.
-    uint32_t groups = 1;
-    if (b.nb == 1 && SLR_CSPLIT_MAX > 1) {
-        const uint32_t fit = SLR_CSPLIT_SLOTS / (nt ? nt : 1u), byc = (uint32_t)b.f[0].C / (2u * CHUNK);
-        groups = fit < (uint32_t)SLR_CSPLIT_MAX ? fit : (uint32_t)SLR_CSPLIT_MAX;
-        groups = groups < byc ? groups : byc;
-        groups = groups < 1u ? 1u : groups;
-    }
+    const uint32_t groups = b.nb == 1 ? channel_groups(nt, b.f[0].C, CHUNK) : 1u;
     if (grid)
         if (int e = launch_tile_variant<NORM, MAXOP, EPT, CHUNK, false>(b, grid, groups, lds, st)) return e;
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));         // the dominant kernel only
@@ -1312,6 +1772,50 @@ static int run_plan(SplatArgs &a, bool two_flows, uint32_t items_cap, uint32_t n
     b.nb = 1;
     const PlanHint h = {n_items, n_multi, n_whole};
     return run_batch<NORM, MAXOP>(b, &h, two_flows, items_cap, nt, part_slots, st);
+}
+
+#ifndef SLR_SCAN_SHARE
+#define SLR_SCAN_SHARE 1          // heavy tiles of the scan front end share their segments through the work queue (0: one workgroup walks them)
+#endif
+#ifndef SLR_SCAN_MAX_TILES
+#define SLR_SCAN_MAX_TILES 512    // one-flow calls on grids of at most this many tiles take the scan front end (two launches)
+#endif
+static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_splat_set_scan_max_tiles
+static bool use_scan(int prebinned, uint32_t nt) { return !prebinned && nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed); }
+
+// The scan front end of a one-flow call: box kernel + tile kernel, nothing else (no bins, no plan, no combine).
+template <bool NORM, bool MAXOP>
+static int do_splat_scan(SplatArgs a, Ws &w0, hipStream_t st) {
+    a.tiles_x = w0.L.tiles_x;
+    a.tiles = w0.L.tiles;
+    a.trash = w0.trash;
+    a.box = w0.box;
+    a.nt = w0.L.nt;
+    a.partial = w0.partial;
+    a.part_stride = w0.L.part_stride;
+    a.part_slots = w0.L.part_slots;
+    a.ctl = SLR_SCAN_SHARE ? w0.ctl : nullptr;
+    a.q_items = w0.queue;
+    a.arrive = w0.arrive;
+    a.ndir = 1;
+    a.seg = EPT_SCAN * SPLAT_THREADS;
+#ifdef SLR_TRACE
+    a.trace = g_trace;
+#endif
+    hipLaunchKernelGGL(scan_box_kernel, dim3(w0.L.nt), dim3(TILE_PIX), 0, st, a.flow[0], w0.box, a.H, a.W, w0.L.tiles_x, w0.L.tiles,
+                       w0.ctl, w0.queue, w0.arrive, w0.L.part_slots);
+    SplatBatch b = {};
+    b.f[0] = a;
+    b.nb = 1;
+    const uint32_t grid = ((w0.L.nt + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+    b.end[0] = grid;
+    const size_t lds = lds_head_bytes(EPT_SCAN, true) + (size_t)CHUNK_ONE * (EPT_SCAN * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
+    if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, false, true>(b, grid, channel_groups(w0.L.nt, a.C, CHUNK_ONE), lds, st)) return e;
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+    g_ev_start = g_ev_stop = nullptr;
+    SLR_CHECK_LAUNCH();
+    return 0;
 }
 
 // plan + splat + combine.  w0 holds the plan and the partial tiles; w1 (optional) the second bin.
@@ -1394,6 +1898,14 @@ SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {
     slr::g_ev_stop = ev_stop;
 }
 
+#ifdef SLR_SCAN_STATS
+SLR_EXPORT size_t slr_debug_ctl_offset(int N, int C, int H, int W) { return ws_layout(N, C, H, W).off_ctl; }
+#endif
+
+SLR_EXPORT int slr_splat_set_scan_max_tiles(int max_tiles) {
+    return slr::g_scan_max_tiles.exchange(max_tiles < 0 ? 0 : max_tiles);
+}
+
 SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {
     if (N <= 0 || C < 0 || H <= 0 || W <= 0) return 0;
     return ws_layout(N, C, H, W).total;
@@ -1426,10 +1938,12 @@ SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (!prebinned) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
+    const bool scan = use_scan(prebinned, w.L.nt);
+    if (!prebinned && !scan) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
+    if (scan) return do_splat_scan<false, false>(a, w, st);
     return do_splat<false, false>(a, w, nullptr, st);
 }
 
@@ -1445,12 +1959,14 @@ SLR_EXPORT int slr_softsplat_mode_forward(const float *in, const float *metric, 
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (!prebinned) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
+    const bool scan = use_scan(prebinned, w.L.nt);
+    if (!prebinned && !scan) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.mul = metric; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.mulmode = mode == SLR_MODE_AVERAGE ? MUL_ONE : mode == SLR_MODE_LINEAR ? MUL_PLANE : MUL_EXP;
     a.norm_mode = SLR_NORM_ZERO_TO_ONE;
+    if (scan) return do_splat_scan<true, false>(a, w, st);
     return do_splat<true, false>(a, w, nullptr, st);
 }
 
@@ -1506,10 +2022,12 @@ SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *o
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (!prebinned) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
+    const bool scan = use_scan(prebinned, w.L.nt);
+    if (!prebinned && !scan) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out; a.init = init;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
+    if (scan) return do_splat_scan<false, true>(a, w, st);
     return do_splat<false, true>(a, w, nullptr, st);
 }
 

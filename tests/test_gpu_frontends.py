@@ -1,0 +1,184 @@
+"""The two front ends of the one-flow operator (include/slr_splat.h: slr_splat_set_scan_max_tiles) against the oracle:
+`bins` (bin -> plan -> tile kernel -> combine) and `scan` (source-tile destination boxes, the tile kernel builds its
+entry list itself).  Every case runs with the front end FORCED, so both are covered at every size -- including
+BASELINE.json's config C2 as it is stated (FunctionSoftsplat(..., 'softmax'), 64 channels, 256x480, incoherent U(-8,8)
+and smooth flow; models/softsplat.py:665-690)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2 ** 31 - 1
+
+
+@pytest.fixture(scope="module")
+def S():
+    import slr_sfs_amd
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    slr_sfs_amd._lib.lib()
+    return slr_sfs_amd
+
+
+@pytest.fixture(params=["bins", "scan"])
+def frontend(request, S):
+    L = S._lib.lib()
+    prev = L.slr_splat_set_scan_max_tiles(0 if request.param == "bins" else INT_MAX)
+    yield request.param
+    L.slr_splat_set_scan_max_tiles(prev)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def smooth_motion(H, W, seed=0, amp=1.5):
+    rng = np.random.default_rng(seed)
+    p1, p2 = rng.uniform(0, 2 * np.pi, 2)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    u = amp * np.sin(2 * np.pi * (2 * x / W + y / H) + p1)
+    v = amp * np.cos(2 * np.pi * (x / W - 1.5 * y / H) + p2)
+    m = (x >= 0.35 * W).astype(np.float32)
+    return np.stack([u * m, v * m])[None].astype(np.float32)
+
+
+def test_default_threshold(S):
+    L = S._lib.lib()
+    prev = L.slr_splat_set_scan_max_tiles(7)
+    assert L.slr_splat_set_scan_max_tiles(prev) == 7
+    assert prev == 512
+
+
+@pytest.mark.parametrize("flowkind", ["incoherent", "smooth_t30", "smooth_t59"])
+def test_config_c2_literal(S, oracle, frontend, flowkind):
+    """BASELINE.json configs[1]: random 64-channel 256x480 feature + flow, FunctionSoftsplat softmax."""
+    H, W, C = 256, 480, 64
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    met = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    if flowkind == "incoherent":
+        flow = rng.uniform(-8, 8, (1, 2, H, W)).astype(np.float32)
+    else:
+        flow = oracle.euler_integration(smooth_motion(H, W), int(flowkind[-2:]))[0]
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), dev(met), "softmax"))
+    ref = oracle.function_softsplat(x, flow, met, "softmax")
+    err = float(np.abs(out - ref).max())
+    assert err < 1e-4, err                                  # north_star's bound; measured ~1e-6
+    assert np.array_equal((out == 0).all(axis=1), (ref == 0).all(axis=1))        # same holes
+
+
+@pytest.mark.parametrize("shape", [(1, 65, 256, 480), (2, 7, 45, 131), (1, 16, 100, 64), (3, 1, 17, 70), (1, 5, 300, 700)])
+def test_sum_vs_oracle_piled_up_euler_flow(S, oracle, frontend, shape):
+    """Strong Euler-integrated flow: tiles with several times SEG entries (bins: segments + combine; scan: passes)."""
+    N, C, H, W = shape
+    rng = np.random.default_rng(C)
+    flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=3.0), 40 + n)[0] for n in range(N)])
+    x = rng.standard_normal(shape).astype(np.float32)
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    ref = oracle.softsplat_forward(x, flow)
+    bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
+    assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+
+
+@pytest.mark.parametrize("kind", ["row", "column", "shrink", "point"])
+def test_collapsing_flows(S, oracle, frontend, kind):
+    H, W = 200, 328
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    z = np.zeros_like(x)
+    flow = {"row": np.stack([z, (H / 2 - y) * 0.999 - 0.2]),
+            "column": np.stack([(W / 2 - x) * 0.999 + 0.3, z]),
+            "shrink": np.stack([(W / 2 - x) * 0.75, (H / 2 - y) * 0.75]),
+            "point": np.stack([(W / 2 - x) * 0.97 + 0.3, (H / 2 - y) * 0.97 - 0.2])}[kind][None].astype(np.float32)
+    rng = np.random.default_rng(7)
+    v = rng.standard_normal((1, 10, H, W)).astype(np.float32)
+    met = (rng.standard_normal((1, 1, H, W)) * 0.5).astype(np.float32)
+    ref = oracle.softsplat_forward(v, flow)
+    out = host(S.FunctionSoftsplat(dev(v), dev(flow), None, "summation"))
+    bound = 4e-6 * oracle.softsplat_forward(np.abs(v), flow) + 1e-6
+    assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+    refn = oracle.function_softsplat(v, flow, met, "softmax")
+    outn = host(S.FunctionSoftsplat(dev(v), dev(flow), dev(met), "softmax"))
+    np.testing.assert_allclose(outn, refn, rtol=1e-3, atol=1e-4)
+    mx = host(S.ModuleMaximumsplat()(dev(v), dev(flow)))
+    assert np.array_equal(mx, oracle.maxsplat_forward(v, flow))                  # a maximum has no summation order
+
+
+def test_nonfinite_and_far_flows(S, oracle, frontend):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 4, 40, 72)).astype(np.float32)
+    flow = rng.uniform(-2, 2, (2, 2, 40, 72)).astype(np.float32)
+    flow[0, 0, 3, 5] = np.nan
+    flow[0, 1, 7, 9] = np.inf
+    flow[1, 0, 8, 1] = 3e9
+    flow[1, :, 10:20, 30:40] = 1e6               # a whole block that leaves the image
+    flow[0, :, 0:8, 0:64] = -1e4                 # a whole source tile that leaves the image: an empty box
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    np.testing.assert_allclose(out, oracle.softsplat_forward(x, flow), rtol=1e-5, atol=1e-5)
+    x[0, 1, 20, 63] = np.inf                     # lands across a tile edge: must pollute only its own corners
+    flow[0, :, 20, 63] = (0.5, 0.5)
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    ref = oracle.softsplat_forward(x, flow)
+    assert np.array_equal(np.isfinite(out), np.isfinite(ref))
+
+
+def test_everything_everywhere(S, oracle, frontend):
+    """A flow that sends every source block all over the image: every box covers everything (scan: every source
+    tile is a candidate of every output tile)."""
+    rng = np.random.default_rng(11)
+    N, C, H, W = 1, 3, 96, 330
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    flow = np.stack([rng.uniform(-W, W, (H, W)), rng.uniform(-H, H, (H, W))])[None].astype(np.float32)
+    met = (rng.standard_normal((N, 1, H, W)) * 0.5).astype(np.float32)
+    for mode in ("summation", "average", "linear", "softmax"):
+        m = np.abs(met) + 0.1 if mode == "linear" else met
+        out = host(S.FunctionSoftsplat(dev(x), dev(flow), dev(m), mode))
+        ref = oracle.function_softsplat(x, flow, m, mode)
+        assert np.allclose(out, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max()))), mode
+
+
+def test_randomised_sweep(S, oracle, frontend):
+    rng = np.random.default_rng(20260929)
+    modes = ["summation", "average", "linear", "softmax"]
+    for case in range(36):
+        N, C = int(rng.integers(1, 4)), int(rng.integers(1, 21))
+        H, W = int(rng.integers(1, 90)), int(rng.integers(1, 210))
+        y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        kind = case % 6
+        if kind == 0:
+            fl = rng.uniform(-3, 3, (N, 2, H, W))
+        elif kind == 1:
+            fl = rng.uniform(-60, 60, (N, 2, H, W))
+        elif kind == 2:
+            fl = np.stack([(W / 2 - x) * rng.uniform(0.5, 1.0), (H / 2 - y) * rng.uniform(0.5, 1.0)])[None].repeat(N, 0)
+        elif kind == 3:
+            fl = np.stack([np.sin(x / 7 + y / 11) * 6, np.cos(x / 9 - y / 5) * 6])[None].repeat(N, 0)
+        elif kind == 4:
+            fl = rng.integers(-5, 6, (N, 2, H, W)).astype(np.float32)
+        else:
+            fl = rng.uniform(-2, 2, (N, 2, H, W))
+            fl[rng.random(fl.shape) < 0.02] = np.nan
+        fl = fl.astype(np.float32)
+        v = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        met = (rng.standard_normal((N, 1, H, W)) * 0.7).astype(np.float32)
+        mode = modes[case % 4]
+        m = np.abs(met) + 0.1 if mode == "linear" else met
+        ref = oracle.function_softsplat(v, fl, m, mode)
+        out = host(S.FunctionSoftsplat(dev(v), dev(fl), dev(m), mode))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.allclose(out, ref, rtol=2e-4, atol=2e-5 * scale), (case, N, C, H, W, kind, mode,
+                                                                       float(np.abs(out - ref).max()))
+
+
+def test_full_size_planes_vs_oracle(S, oracle, frontend):
+    """768x1280 (1920 tiles: four rounds of the box test per workgroup in the scan front end), Euler t = 59."""
+    H, W, C = 768, 1280, 3
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    flow = oracle.euler_integration(smooth_motion(H, W), 59)[0]
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    ref = oracle.softsplat_forward(x, flow)
+    bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
+    assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
