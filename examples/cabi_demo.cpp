@@ -77,8 +77,9 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc(&ws, ws_bytes));
 
     SLR_OK(slr_euler_integrate(motion, H, W, nsteps, 1.0f, disp, vis, st));                        // a1
-    SLR_OK(slr_softsplat_forward(in, disp, out_sum, 1, C, H, W, ws, ws_bytes, 0, st));              // a3 (bins disp)
-    SLR_OK(slr_softsplat_mode_forward(in, metric, disp, out_soft, 1, C, H, W, SLR_MODE_SOFTMAX,     // a4, same bins
+    SLR_OK(slr_softsplat_forward(in, disp, out_sum, 1, C, H, W, ws, ws_bytes, 0, st));              // a3 (self-contained call)
+    SLR_OK(slr_splat_bin(disp, 1, C, H, W, ws, ws_bytes, st));                                      // bins of disp, made once ...
+    SLR_OK(slr_softsplat_mode_forward(in, metric, disp, out_soft, 1, C, H, W, SLR_MODE_SOFTMAX,     // a4 ... and reused
                                       ws, ws_bytes, 1, st));
     // argument errors come back as codes + message, nothing is launched
     if (slr_softsplat_forward(in, disp, out_sum, 1, C, H, W, ws, 16, 0, st) == 0) {

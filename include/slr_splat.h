@@ -113,7 +113,9 @@ int slr_splat_set_scan_max_tiles(int max_tiles);
 /* _FunctionSoftsplat.forward: summation splat.
  * Replaces kernel_Softsplat_updateOutput + its launcher, softsplat.py:157-202, 390-424.
  *   in [N,C,H,W], flow [N,2,H,W] -> out [N,C,H,W] (every element written; no pre-zeroing)
- * Bins `flow` into `ws` first (slr_splat_bin) unless prebinned != 0. */
+ * prebinned == 0: a self-contained call (front end chosen by slr_splat_set_scan_max_tiles; `ws` holds NO reusable bins
+ * afterwards).  prebinned != 0: `ws` was filled by slr_splat_bin / slr_splat_bin_pair with this flow (bins shared by
+ * several tensors splatted with the same flow). */
 int slr_softsplat_forward(const float *in, const float *flow, float *out,
                           int N, int C, int H, int W,
                           void *ws, size_t ws_bytes, int prebinned, void *stream);

@@ -850,9 +850,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         item = a.whole_items[bx];
     }
   // SCAN: the current piece of work -- the block's own tile first, then segments of shared tiles (w_piece)
+  const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t w_grp = blockIdx.y, w_seg = 0, w_po = 0;
-  bool w_piece = false, w_counted = false;            // w_counted: the wave counts of this tile are known (its publisher)
-  uint32_t w_total = 0, w_wave_base = 0;
+  bool w_piece = false;
   for (uint32_t wi = bx;;) {                           // one pass unless WHOLE (its items) or SCAN (popped segments)
     ItemDesc it;
     if (SCAN) { it = ItemDesc{}; it.tile = item; it.nseg = 1; }
@@ -876,7 +876,12 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
     const int HW = a.H * a.W;
-    const int tid = threadIdx.x;
+    // SCAN: the body is a loop (claimed segments); everything derived from the work-item index would be hoisted out of it and
+    // kept in registers across the whole body (+16 VGPRs: over the 128 of two workgroups per CU) -- so the index is rebuilt in
+    // every round from the wave's number (a scalar) and the lane count, and made to look loop-variant
+    uint32_t ones_ = ~0u;
+    if (SCAN) asm volatile("" : "+s"(ones_));                    // (a scalar the optimiser cannot see through)
+    const int tid = SCAN ? wave_in_group * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones_, __builtin_amdgcn_mbcnt_lo(ones_, 0u)) : (int)threadIdx.x;
 
     // ---------------- SCAN front end: the tile's entry list is built here, in LDS, from the flow itself
     // Candidates: source tiles whose destination box (scan_box_kernel) touches this tile -> a bit mask in LDS (order-free
@@ -946,19 +951,20 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
             }
             // CB candidates per group: one row of each (wave w = row w), all flow loads of a group in flight together, and the
             // next group's loads issued before this group's hits are processed
-            struct Group { float fx[CB], fy[CB]; int pix[CB]; int sx[CB], sy[CB]; };
+            // (a group keeps the flow values per lane and the candidates' tile coordinates as wave-uniform scalars: the pixel
+            // coordinates are recomputed where they are needed -- the scan is where this kernel's register pressure peaks)
+            struct Group { float fx[CB], fy[CB]; int stx[CB], sty[CB]; };
             auto issue = [&](Group &g, int k0) {
 #pragma unroll
                 for (int i = 0; i < CB; ++i) {
                     const int k = k0 + i;
-                    const int st = (int)clist[k < nc ? k : 0] - 0;               // (uniform address: one broadcast read)
+                    const int st = __builtin_amdgcn_readfirstlane((int)clist[k < nc ? k : 0]);   // (uniform address: one broadcast read)
                     const int sty = (int)(((float)(st) + 0.5f) * inv_tx);      // st / tiles_x, exact for st < 2^22
-                    const int stx = st - sty * a.tiles_x;
-                    g.sy[i] = sty * TILE_H + wid;
-                    g.sx[i] = stx * TILE_W + lane;
-                    const bool in = (k < nc) & (g.sy[i] < a.H) & (g.sx[i] < a.W);
-                    g.pix[i] = in ? g.sy[i] * a.W + g.sx[i] : -1;
-                    const int q = in ? g.pix[i] : 0;
+                    g.sty[i] = k < nc ? sty : -1;
+                    g.stx[i] = st - sty * a.tiles_x;
+                    const int sy = sty * TILE_H + wid, sx = g.stx[i] * TILE_W + lane;
+                    const bool in = (k < nc) & (sy < a.H) & (sx < a.W);
+                    const int q = in ? sy * a.W + sx : 0;
                     g.fx[i] = fl[q];
                     g.fy[i] = fl[HW + q];
                 }
@@ -968,11 +974,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
                 uint32_t pre[CB], tot = 0;
 #pragma unroll
                 for (int i = 0; i < CB; ++i) {
-                    const Corners c = make_corners(g.fx[i], g.fy[i], g.sx[i], g.sy[i]);
+                    const int sy = g.sty[i] * TILE_H + wid, sx = g.stx[i] * TILE_W + lane;
+                    const bool in = (g.sty[i] >= 0) & (sy < a.H) & (sx < a.W);
+                    const Corners c = make_corners(g.fx[i], g.fy[i], sx, sy);
                     const int lx = c.x0 - tx0, ly = c.y0 - ty0;
                     const bool xa = (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W), xb = (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
                     const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H), yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
-                    hm[i] = __ballot((g.pix[i] >= 0) & c.ok & (xa | xb) & (ya | yb));
+                    hm[i] = __ballot(in & c.ok & (xa | xb) & (ya | yb));
                     pre[i] = tot;
                     tot += (uint32_t)__popcll(hm[i]);
                 }
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
                     for (int i = 0; i < CB; ++i) {
                         const uint32_t slot = b0 + pre[i] + (uint32_t)__popcll(hm[i] & ((1ull << lane) - 1ull));
                         if (((hm[i] >> lane) & 1ull) && slot >= lo && slot < hi) {
-                            ent_pix[slot - lo] = (uint32_t)g.pix[i];
+                            ent_pix[slot - lo] = (uint32_t)((g.sty[i] * TILE_H + wid) * a.W + g.stx[i] * TILE_W + lane);
                             ent_fx[slot - lo] = g.fx[i];
                             ent_fy[slot - lo] = g.fy[i];
                         }
@@ -1014,28 +1022,27 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         return MODE == 0 ? cmask[64] : wcount;
     };
     if (!w_piece) { SLR_STAMP(41); SLR_STAMP_RT(48); }
-    unsigned long long qsnap2 = 0;                                // ctl[2..3] as seen two chunks before the end of this work
+    int qavail = 0;                                               // the semaphore as seen two chunks before the end of this work
     // (a grid that fits the chip in one round ends all at once with nothing else to do: everybody helps)
     const bool helper = ((bx >> 3) % (uint32_t)SLR_SHARE_HELPERS) == 0u || gridDim.x * gridDim.y <= (uint32_t)SLR_CSPLIT_SLOTS;
     bool part = false;                                            // this piece of work is ONE segment of a shared tile
     bool ctx = false;                                             // this workgroup holds a shared tile it may draw more tickets of
     uint32_t ns_tile = 1;                                         // segments of the tile (part)
     if (SCAN) {
-        if (!w_piece) { scan_total = scan(std::integral_constant<int, 0>{}, 0u, (uint32_t)SEG); w_counted = false; }
+        if (!w_piece) scan_total = scan(std::integral_constant<int, 0>{}, 0u, (uint32_t)SEG);
         if (!w_piece) SLR_STAMP(42);
         if (w_piece || scan_total > (uint32_t)SEG) {              // heavy tile: segments with reproducible membership
-            if (!w_counted) {
+            {
                 const uint32_t wc = scan(std::integral_constant<int, 1>{}, 0u, 0u);
                 if ((tid & 63) == 0) cmask[65 + (tid >> 6)] = wc;
                 __syncthreads();
                 uint32_t all = 0, wb = 0;
 #pragma unroll
                 for (int w = 0; w < T / 64; ++w) { const uint32_t c = cmask[65 + w]; all += c; wb += w < (tid >> 6) ? c : 0u; }
-                w_total = all; w_wave_base = wb; w_counted = true;
+                scan_total = all;                                 // (equals the optimistic count; a claimed segment has no other)
+                wave_base = wb;
                 __syncthreads();
             }
-            scan_total = w_total;                                 // (equals the optimistic count)
-            wave_base = w_wave_base;
             ns_tile = (scan_total + SEG - 1) / SEG;
             part = ctx = w_piece;
             nloop = part ? 1u : ns_tile;                          // not shared: this workgroup walks all passes itself
@@ -1048,7 +1055,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
                     wsum[0] = po; wsum[1] = qp;
                 }
                 __syncthreads();
-                const uint32_t po = wsum[0], qp = wsum[1];
+                const uint32_t po = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsum[0]), qp = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsum[1]);
                 __syncthreads();
                 if (qp != 0xffffffffu) {                          // (sum of ns - 1 over successful reservations < part_slots = queue size)
                     for (uint32_t i = tid; i + 1 < ns_tile; i += T)
@@ -1250,7 +1257,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
 #ifndef SLR_KREG_TWO
 #define SLR_KREG_TWO 6
 #endif
-    constexpr int KREG = (EPT_MAX == EPT_ONE || SCAN) ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
+#ifndef SLR_KREG_SCAN
+#define SLR_KREG_SCAN 4
+#endif
+    constexpr int KREG = SCAN ? SLR_KREG_SCAN : EPT_MAX == EPT_ONE ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
     float cw[KREG];
     uint32_t ce[KREG];
 #pragma unroll
@@ -1425,7 +1435,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     for (int c0 = cb; c0 < cend; c0 += 2 * CHUNK) {
         // queue state for the pop after this piece of work: ONE load, issued when the last two chunks begin, consumed after them
         if (SCAN && a.ctl && tid == 0 && last && !ctx && helper && c0 + 2 * CHUNK >= cend)
-            qsnap2 = __hip_atomic_load((gu64 *)a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qavail = (int)__hip_atomic_load((gu32 *)a.ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         chunk(preA, c0);
         if (c0 + CHUNK < cend) chunk(preB, c0 + CHUNK);
     }
@@ -1450,7 +1460,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
                 if (wsum[0] + 1u == ns_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            const bool last_seg = wsum[0] + 1u == ns_tile;
+            const bool last_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsum[0]) + 1u == ns_tile;
             __syncthreads();
             if (last_seg) {
                 const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
@@ -1483,7 +1493,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         // ---- next piece of work: claim a pushed segment (see the block comment above the kernel)
         if (tid == 0) {
             unsigned long long got = 0;
-            const bool seek = ctx || (helper && (int)(uint32_t)(qsnap2 >> 32) > 0);
+            const bool seek = ctx || (helper && qavail > 0);
             if (seek) {
 #ifdef SLR_SCAN_STATS
                 atomicAdd(&a.ctl[22], 1u);
@@ -1505,7 +1515,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
             wsum[0] = (uint32_t)got; wsum[1] = (uint32_t)(got >> 32);
         }
         __syncthreads();
-        const unsigned long long wv = ((unsigned long long)wsum[1] << 32) | wsum[0];
+        // (wave-uniform by construction: keep the claimed work in scalar registers, like the block's own tile)
+        const unsigned long long wv = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wsum[1]) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)wsum[0]);
         __syncthreads();
         SLR_STAMP(38); SLR_STAMP_RT(50);
         if (wv == 0) break;
@@ -1514,10 +1526,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
 #endif
         w_piece = true;
         {
-            const uint32_t nt2 = (uint32_t)(wv >> 38) - 1u, ng2 = (uint32_t)wv & 0xfu;
-            if (nt2 != item || ng2 != w_grp) w_counted = false;   // another tile: its wave counts are not known here
-            item = nt2;
-            w_grp = ng2;
+            item = (uint32_t)(wv >> 38) - 1u;
+            w_grp = (uint32_t)wv & 0xfu;
             w_seg = (uint32_t)(wv >> 30) & 0xffu;
             w_po = (uint32_t)(wv >> 4) & 0x3ffffu;
         }
