@@ -9,7 +9,10 @@ Workload: config C3 of BASELINE.json -- the full baseline pipeline
           reference architecture, fp32.  (--workload c4: the 2-layer SLR v1 pipeline.)
 A step  : ONE 60-frame clip, everything included (both all-frames Euler passes, binning + planning of
           all 120 displacement maps, encoder, 60 x (fused splat + decoder)), frames sharded round-robin
-          over the ranks and assembled with RCCL all-gathers -> "scaling": "strong" (total work fixed).
+          over the ranks and assembled with ONE RCCL all-gather of the finished clip (the form north_star
+          names: --assembly final --encoder redundant, the default) -> "scaling": "strong" (total work fixed).
+          N > 1 also reports `value_rounds_banded`: the same clip with one hidden all-gather per round of frames
+          and the encoder split into row bands (--assembly rounds --encoder banded), measured after the timed steps.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -30,7 +33,6 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   roofline_dropin / roofline_conv / c4 / fps_fp32_convs : context measured after the timed region (N = 1 only).
 """
 import argparse
-import contextlib
 import json
 import os
 import sys
@@ -45,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 H, W, NFRAMES = 768, 1280, 60
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TRAFFIC_FILE = "r2_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh) of the fused kernel; carries the build it was taken on
 
 
 def smooth_motion(h, w, seed=0, amp=1.5):
@@ -123,16 +126,19 @@ def splat_roofline(kev, sev, c_splat, kernel):
     frames = [(e0.elapsed_time(e1) * 1e3, nf) for k, e0, e1, nf in sev if k == "frame"]
     prep = [e0.elapsed_time(e1) * 1e3 for k, e0, e1, nf in sev if k == "prep"]
     stage_us = (sum(us for us, _ in frames) + sum(prep)) / max(1, sum(nf for _, nf in frames))
+    # the fused operator's own minimum traffic: 64 feature planes + Z + 2 x 2 displacement planes in, 64 planes out
+    min_bytes = (c_splat - 1 + 1 + 4 + c_splat - 1) * H * W * 4
     traffic, src = None, None
-    tf = os.path.join(ROOT, "profiles", "r2_splat_traffic.json")
+    tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if c_splat == 65 and os.path.exists(tf):
         traffic = round(json.load(open(tf))["traffic_bytes_per_launch"] * fpl)
-        src = ("static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/r2_splat_traffic.json (per frame of work) x "
+        src = (f"static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/{TRAFFIC_FILE} (per frame of work) x "
                "frames_per_launch, not measured in this run")
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "alg_bytes_per_launch": round(alg * fpl), "frames_per_launch": round(fpl, 2), "launch_avg_us": round(l_avg, 1),
-            "alg_bytes_per_frame": alg, "avg_us": round(k_avg, 1), "min_us": round(per_frame[0], 1),
+            "alg_bytes_per_frame": alg, "min_bytes_per_frame": min_bytes,
+            "frac_min_bytes": round(min_bytes / (k_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_us": round(k_avg, 1), "min_us": round(per_frame[0], 1),
             "max_us": round(per_frame[-1], 1), "launches": len(launches),
             "note": "avg/min/max_us = launch duration / frames in the launch; achieved = alg_bytes_per_launch / launch_avg_us",
             "stage_us": round(stage_us, 1), "stage_frac": round(alg / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -149,10 +155,11 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the context measurements after the timed region")
-    ap.add_argument("--assembly", default="rounds", choices=["rounds", "final"],
-                    help="N>1: all-gather per round of frames under the next round (default) | one all-gather of the clip")
-    ap.add_argument("--encoder", default="banded", choices=["banded", "redundant"],
-                    help="N>1: per-clip encoder in row bands + one all-gather (default) | every rank encodes the image")
+    ap.add_argument("--assembly", default="final", choices=["rounds", "final"],
+                    help="N>1: ONE all-gather of the finished clip (default, the north_star form) | all-gather per round of frames "
+                         "under the next round")
+    ap.add_argument("--encoder", default="redundant", choices=["banded", "redundant"],
+                    help="N>1: every rank encodes the image (default) | per-clip encoder in row bands + one all-gather")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -191,6 +198,13 @@ def main():
     roofline = splat_roofline(kev, sev, c_splat, "slr::splat_tile_kernel<true,false,3,4>")
 
     extra, cpu, parity = {}, None, None
+    if world > 1 and (a.assembly, a.encoder) == ("final", "redundant"):
+        # context beside the contract form: per-round hidden all-gathers + banded encoder (every rank takes part)
+        step2 = make_step(model, image, motion, rank, world, "rounds", "banded")
+        dt2, clip2, _, _ = timed_clips(step2, max(1, min(a.steps, 3)), 1, world, dev)
+        extra["value_rounds_banded"] = {"value": round(NFRAMES * max(1, min(a.steps, 3)) / dt2, 3), "unit": "frames/s",
+                                        "form": "all-gather per round of frames under the next round + encoder in row bands"}
+        del clip2
     if rank == 0 and world == 1:
         parity = parity_check(model, image, motion, a.workload, dev)
     if rank == 0 and world == 1 and not a.no_extras:
@@ -219,7 +233,11 @@ def main():
             "value": round(NFRAMES * a.steps / dt, 3), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (splat path: fp32 throughout; encoder/decoder convolutions: fp32 in/out and accumulation, operands as "
+                     "2 x f16 splits = 22 significant bits, 3 MFMAs per product -- NOT plain fp32 multiplies; the all-fp32 figure "
+                     "is fps_fp32_convs)",
+            "data": "synthetic",
             "config": {"workload": ("C3 baseline pipeline encoder->Euler->softmax-splat->pconv2 decoder"
                                     if a.workload == "c3" else
                                     "C4 SLR-v1 2-layer pipeline (fluid + background + alpha)") +
@@ -361,9 +379,11 @@ def context_measurements(workload, image, motion, dev):
     torch.manual_seed(0)
     m2 = (pipeline.SLRv1Animator() if other == "c4" else pipeline.BaselineAnimator()).to(dev).eval()
     step = make_step(m2, image, motion, 0, 1, "rounds", "banded")
-    dt, _, kev, sev = timed_clips(step, 2, 1, 1, dev)
+    osteps = 5
+    dt, _, kev, sev = timed_clips(step, osteps, 1, 1, dev)
     c2 = 67 if other == "c4" else 65
-    out[other] = {"value": round(NFRAMES * 2 / dt, 3), "unit": "frames/s", "steps": 2, "warmup": 1,
+    out[other] = {"value": round(NFRAMES * osteps / dt, 3), "unit": "frames/s", "steps": osteps, "warmup": 1,
+                  "parity_err": parity_check(m2, image, motion, other, dev),
                   "workload": ("C4 SLR-v1 2-layer pipeline (fluid + background + alpha), " if other == "c4" else
                                "C3 baseline pipeline, ") + "768x1280, N=60",
                   "roofline": splat_roofline(kev, sev, c2, "slr::splat_tile_kernel<true,false,3,4> (" +
@@ -372,72 +392,118 @@ def context_measurements(workload, image, motion, dev):
     # ---- the all-fp32 context: the same C3 pipeline with its convolutions through PyTorch-ROCm (MIOpen fp32)
     if workload == "c3":
         torch.manual_seed(0)
-        m3 = pipeline.BaselineAnimator().to(dev).eval()
-        with torch_convolutions():
-            m3.synthesize(image, motion, NFRAMES, frames=range(0, 6), batch=1)        # MIOpen picks its kernels
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
-            torch.cuda.synchronize()
-            out["fps_fp32_convs"] = {"value": round(20 / (time.perf_counter() - t1), 2), "unit": "frames/s",
-                                     "what": "same C3 clip (20 of its 60 frames) with every convolution of the "
-                                             "encoder / decoder as torch.nn.functional.conv2d (MIOpen fp32) and the "
-                                             "elementwise stages as torch ops; the splat stage unchanged"}
+        m3 = pipeline.BaselineAnimator(convs="fp32").to(dev).eval()      # the supported full-range route (nets.torch_convolutions)
+        m3.synthesize(image, motion, NFRAMES, frames=range(0, 6), batch=1)        # MIOpen picks its kernels
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
+        torch.cuda.synchronize()
+        out["fps_fp32_convs"] = {"value": round(20 / (time.perf_counter() - t1), 2), "unit": "frames/s",
+                                 "what": "same C3 clip (20 of its 60 frames) with BaselineAnimator(convs='fp32'): every convolution "
+                                         "of the encoder / decoder as torch.nn.functional.conv2d (MIOpen fp32) and the "
+                                         "elementwise stages as torch ops; the splat stage unchanged"}
         del m3
     return out
 
 
-@contextlib.contextmanager
-def torch_convolutions():
-    """Measurement only: route the networks' stages through the torch composition that DEFINES them (nets.py) on
-    the device, i.e. MIOpen fp32 convolutions -- the configuration north_star describes for the encoder/decoder."""
-    from slr_sfs_amd import nets
-    saved = nets._fused_ok, nets._b8
-    nets._fused_ok = lambda *ts: False
-    nets._b8 = lambda x, channels: False
-    try:
-        yield
-    finally:
-        nets._fused_ok, nets._b8 = saved
+def _graph_call_us(fn, reps=20, iters=10):
+    """GPU time of everything one call launches, without the host's launch pace: `reps` calls captured into ONE HIP
+    graph, the replay timed with an event pair, divided by reps (median of `iters` replays)."""
+    fn()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        fn()                                              # workspaces of this stream exist before the capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    torch.cuda.synchronize()
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 @torch.no_grad()
 def dropin_roofline(dev, motion):
     """The operator the reference scripts reach unchanged -- ModuleSoftsplat('summation') / _FunctionSoftsplat
     (softsplat.py:157-202, 390-424): one flow, C = 65 planes, 768x1280, on Euler-integrated flows; algorithmic bytes
-    B_sum = (2C+2)*H*W*4 = 519.0 MB per call.  `tile` = the tile kernel alone, `call` = everything the call launches
-    (binning of the flow, plan, tile kernel, combine).  Plus config C2: 64 channels, 256x480, softmax mode."""
+    B_sum = (2C+2)*H*W*4 = 519.0 MB per call.  `tile` = the tile kernel alone (events recorded by the library around that
+    launch), `call` = GPU time of EVERYTHING the call launches (front end + tile kernel + combine), measured by replaying a
+    HIP graph of 20 calls; `call_eager_us` = the same call issued from Python with an event pair per call (host launch pace
+    included).  Plus config C2 of BASELINE.json as stated (64 channels, 256x480, softmax mode, incoherent and smooth
+    flow) and two more small grids; `front_end` names what ran (include/slr_splat.h: slr_splat_set_scan_max_tiles)."""
     import slr_sfs_amd as S
     from slr_sfs_amd import synthesis
+    L = S._lib.lib()
     C = 65
     x = torch.randn(1, C, H, W, device=dev)
     alg = (2 * C + 2) * H * W * 4
-    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,4>", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "alg_bytes_per_call": alg, "flows": {}}
+    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,4> (bins) / <...,true> (scan)", "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "alg_bytes_per_call": alg, "flows": {},
+           "call": "GPU time of all launches of one call (HIP graph of 20 calls replayed); call_eager_us: Python call, event pair per call"}
+
+    def measure(f, alg_bytes, tile=True):
+        r = {}
+        if tile:
+            synthesis.kernel_timing = []
+            for _ in range(12):
+                synthesis._arm_timer(x)
+                f()
+            torch.cuda.synchronize()
+            kus = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1, _ in synthesis.kernel_timing[3:])
+            synthesis.kernel_timing = None
+            k_avg = sum(kus) / len(kus)
+            r.update({"tile_us": round(k_avg, 1), "tile_gbs": round(alg_bytes / k_avg / 1e3, 1),
+                      "tile_frac": round(alg_bytes / k_avg / 1e3 / HBM_PEAK_GBS, 4)})
+        eager, _ = _time_calls(f, 20)
+        call = _graph_call_us(f)
+        r.update({"call_us": round(call, 1), "call_frac": round(alg_bytes / call / 1e3 / HBM_PEAK_GBS, 4),
+                  "call_eager_us": round(eager, 1), "call_eager_frac": round(alg_bytes / eager / 1e3 / HBM_PEAK_GBS, 4)})
+        return r
+
     worst = None
-    for name, steps in (("euler_t30", 30), ("euler_t59", 59)):
-        flow, _ = S.euler_integration(motion, steps)
-        synthesis.kernel_timing = []
-        call_avg, call_min = _time_calls(lambda: (synthesis._arm_timer(x), S.FunctionSoftsplat(x, flow, None, "summation")), 20)
-        kev, synthesis.kernel_timing = synthesis.kernel_timing, None
-        torch.cuda.synchronize()
-        kus = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1, _ in kev[3:])
-        k_avg = sum(kus) / len(kus)
-        r = {"tile_us": round(k_avg, 1), "tile_gbs": round(alg / k_avg / 1e3, 1), "tile_frac": round(alg / k_avg / 1e3 / HBM_PEAK_GBS, 4),
-             "call_us": round(call_avg, 1), "call_frac": round(alg / call_avg / 1e3 / HBM_PEAK_GBS, 4)}
+    flows = [("euler_t30", S.euler_integration(motion, 30)[0]), ("euler_t59", S.euler_integration(motion, 59)[0]),
+             ("identity", torch.zeros(1, 2, H, W, device=dev)), ("incoherent", torch.rand(1, 2, H, W, device=dev) * 16 - 8)]
+    for name, flow in flows:
+        r = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
+        r["front_end"] = "bins"                            # 1920 tiles > the scan threshold (512): bin -> plan -> tile -> combine
+        prev = L.slr_splat_set_scan_max_tiles(2 ** 31 - 1)
+        r["scan_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
+        L.slr_splat_set_scan_max_tiles(prev)
         res["flows"][name] = r
-        if worst is None or r["tile_frac"] < worst["tile_frac"]:
+        if name.startswith("euler") and (worst is None or r["tile_frac"] < worst["tile_frac"]):
             worst = r
     res["achieved"], res["frac"], res["avg_us"] = worst["tile_gbs"], worst["tile_frac"], worst["tile_us"]
-    # config C2 of BASELINE.json: random 64-channel 256x480 features + incoherent flow, softmax mode, one call
-    h2, w2 = 256, 480
-    f2 = torch.randn(1, 64, h2, w2, device=dev)
-    met = torch.randn(1, 1, h2, w2, device=dev)
-    fl2 = (torch.rand(1, 2, h2, w2, device=dev) * 16 - 8)
-    alg2 = (2 * 64 + 3) * h2 * w2 * 4
-    c_avg, c_min = _time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 50, warm=5)
-    res["c2"] = {"workload": "C2: FunctionSoftsplat softmax, 64 ch, 256x480, incoherent U(-8,8) flow", "call_us": round(c_avg, 1),
-                 "call_min_us": round(c_min, 1), "alg_bytes": alg2, "call_frac": round(alg2 / c_avg / 1e3 / HBM_PEAK_GBS, 4)}
+    # config C2 of BASELINE.json: random 64-channel 256x480 features + flow, softmax mode, one call
+    small = {}
+    for tag, (c2, h2, w2) in (("c2", (64, 256, 480)), ("128x240", (64, 128, 240)), ("384x640", (65, 384, 640))):
+        f2 = torch.randn(1, c2, h2, w2, device=dev)
+        met = torch.randn(1, 1, h2, w2, device=dev)
+        alg2 = (2 * c2 + 3) * h2 * w2 * 4
+        cases = {"incoherent": torch.rand(1, 2, h2, w2, device=dev) * 16 - 8}
+        if tag == "c2":
+            cases["smooth_t30"] = S.euler_integration(torch.from_numpy(smooth_motion(h2, w2)).to(dev), 30)[0]
+        for fname, fl2 in cases.items():
+            r = measure(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), alg2, tile=False)
+            r.update({"workload": f"FunctionSoftsplat softmax, {c2} ch, {h2}x{w2}, {fname} flow", "alg_bytes": alg2,
+                      "front_end": "scan (box kernel + tile kernel: 2 launches)"})
+            prev = L.slr_splat_set_scan_max_tiles(0)
+            r["bins_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
+            L.slr_splat_set_scan_max_tiles(prev)
+            small[tag if fname == "incoherent" else f"{tag}_{fname}"] = r
+    res["c2"] = small.pop("c2")
+    res["c2"]["workload"] = "C2: " + res["c2"]["workload"] + " U(-8,8)"
+    res["small_grids"] = small
     return res
 
 

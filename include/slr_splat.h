@@ -236,12 +236,19 @@ int slr_pconv_epilogue(const float *raw0, const float *bias, const float *mask_b
                        const float *residual, const float *next_scale, const float *next_shift,
                        float *out, float *um_out, float winsize, int N, int C, int H, int W, void *stream);
 
-/* The split-f16 convolution kernels below represent an activation x as two f16 halves of x * 2^6: exact-domain for
- * |x| < 1023 (post-BN activations are O(1 .. 10^2)).  A larger activation is CLAMPED there (no inf / NaN), which makes
- * the frame wrong rather than inexact -- the reference's fp32 convolution has no such limit -- so every wave that had to
- * clamp adds to a per-device counter.  *count = the counter of the CURRENT device (synchronises with the device: call
- * it once per clip, not per layer); reset != 0 zeroes it.  The Python networks raise on a non-zero count. */
-int slr_conv_saturation_count(unsigned long long *count, int reset);
+/* The split-f16 convolution kernels below represent an activation x as two f16 halves of x * xscale (`xscale` of the
+ * forward calls: a power of two in (0, 64]; 64 = the default): exact-domain for |x| < 65472 / xscale -- 1023 at 64
+ * (post-BN activations are O(1 .. 10^2)), 65472 at 1 (the low halves of values below 2^-3 are then f16 subnormals:
+ * absolute error <= 2^-25 per value).  A larger activation is CLAMPED there (no inf / NaN), which makes the frame wrong
+ * rather than inexact -- the reference's fp32 convolution has no such limit -- so every wave that had to clamp adds to
+ * a counter.  The counter is ONE PER DEVICE (shared by all streams and host threads using that device).
+ *   slr_conv_saturation_count: *count = the counter of the current device after everything enqueued on `stream` so far
+ *       (synchronises that stream with the host); reset != 0 zeroes it.
+ *   slr_conv_saturation_record: asynchronous -- the current value is copied into *host_slot (PINNED host memory) in
+ *       stream order; read it after synchronising.  Differences of consecutive records tell which piece of work clamped.
+ * The Python networks react to a non-zero count (smaller xscale, then fp32 convolutions, or an exception: nets.py). */
+int slr_conv_saturation_count(unsigned long long *count, int reset, void *stream);
+int slr_conv_saturation_record(unsigned *host_slot, void *stream);
 
 /* ------------------------------------------------------------------ decoder convolution on the matrix cores (8 f3) */
 
@@ -270,7 +277,7 @@ int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit,
  * normalization.py:219-231), identity otherwise.  bias [Cout] or NULL; residual [N,Cout,H,W] or NULL
  * (the x_a + x_b of ResNet_Block, blocks.py:87). */
 int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual, float *out,
-                        int N, int Cin, int Cout, int H, int W, float wscale,
+                        int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
                         const float *pre_scale, const float *pre_shift, int layout, void *stream);
 
 /* One partial convolution of ResNet_Block_Pconv2 in a single kernel
@@ -287,7 +294,7 @@ int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, 
  *          or relu(.*next_scale - next_shift)*um;  um = clamp(um_raw, 0, 1) -> um_out.
  * Same operations in the same order as slr_bn_relu_mask -> convolution -> slr_pconv_epilogue. */
 int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
-                         const void *wsplit, float wscale, const float *bias, const float *residual,
+                         const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
                          const float *next_scale, const float *next_shift, float *out, float *um_out,
                          int N, int Cin, int Cout, int H, int W, int layout, void *stream);
 
@@ -298,7 +305,7 @@ size_t slr_conv1x1_weight_bytes(int Cout, int Cin);
 int slr_conv1x1_split_weights(const float *w /* [Cout,Cin,1,1] */, void *wsplit, int Cout, int Cin,
                               float wscale, void *stream);
 int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias /* [Cout] or NULL */, float *out,
-                        int N, int Cin, int Cout, int H, int W, float wscale, int layout, void *stream);
+                        int N, int Cin, int Cout, int H, int W, float wscale, float xscale, int layout, void *stream);
 
 /* ------------------------------------------------------------------ decoder resampling stages (8 f3) */
 

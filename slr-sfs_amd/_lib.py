@@ -19,7 +19,7 @@ SYMBOLS = (
     "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
     "slr_splat_scratch_bytes_batch", "slr_synth_group_clip_batch",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
-    "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count",
+    "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
@@ -90,12 +90,13 @@ def lib():
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],
             "slr_pconv_epilogue": [fp, fp, fp, f, fp, fp, fp, fp, fp, f, i, i, i, i, vp],
-            "slr_conv_saturation_count": [ctypes.POINTER(ctypes.c_ulonglong), i],
+            "slr_conv_saturation_count": [ctypes.POINTER(ctypes.c_ulonglong), i, vp],
+            "slr_conv_saturation_record": [vp, vp],
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv1x1_split_weights": [fp, vp, i, i, f, vp],
-            "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, i, vp],
-            "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, fp, fp, i, vp],
-            "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp],
+            "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, f, i, vp],
+            "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, f, fp, fp, i, vp],
+            "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp],
             "slr_avgpool3x3s2": [fp, fp, i, i, i, i, i, vp],
             "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, i, vp],
             "slr_conv1x1_small": [fp, fp, fp, fp, i, i, i, i, i, i, vp],
@@ -143,27 +144,40 @@ def require_device(*tensors):
 # part of the key; the cache is bounded -- a service that animates many resolutions or creates and destroys streams
 # would otherwise pin ~300 MB of HBM per (stream, shape) for ever.  Evicted tensors go back to torch's stream-ordered
 # caching allocator (safe: they were only ever used on the stream they were allocated on).
+# HIP graphs: a workspace that was handed out while its stream was CAPTURING has its address baked into the captured
+# graph, whose replays nobody can see from here -- such workspaces are pinned: never evicted (clear_workspaces(
+# include_captured=True) drops them once the graphs that use them are gone), and nothing is evicted during a capture.
 import collections
 
-WS_CACHE_MAX = int(os.environ.get("SLR_SFS_AMD_WS_CACHE", "8"))
+WS_CACHE_MAX = max(1, int(os.environ.get("SLR_SFS_AMD_WS_CACHE", "8")))
 _ws_cache = collections.OrderedDict()
+_ws_captured = {}
 
 
 def workspace(t, role, N, C, H, W, nbytes=None):
     """A torch-allocated (stream-ordered) workspace for splatting [N,<=C,H,W] on t's device."""
-    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream, role, N, C, H, W, nbytes)
+    stream = torch.cuda.current_stream(t.device)
+    key = (t.device.index, stream.cuda_stream, role, N, C, H, W, nbytes)
+    ws = _ws_captured.get(key)
+    if ws is not None:
+        return ws
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = _ws_cache.get(key)
     if ws is None:
         if nbytes is None:
             nbytes = int(lib().slr_splat_workspace_bytes(N, C, H, W))
-        while len(_ws_cache) >= max(1, WS_CACHE_MAX):
+        while not capturing and len(_ws_cache) >= WS_CACHE_MAX:
             _ws_cache.popitem(last=False)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
         _ws_cache[key] = ws
     else:
         _ws_cache.move_to_end(key)
+    if capturing:                                       # its address is now part of a graph: keep it for good
+        _ws_captured[key] = _ws_cache.pop(key)
     return ws
 
 
-def clear_workspaces():
+def clear_workspaces(include_captured=False):
     _ws_cache.clear()
+    if include_captured:
+        _ws_captured.clear()

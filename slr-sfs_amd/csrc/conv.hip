@@ -52,7 +52,9 @@ constexpr int CV_THREADS = 256;
                          // 8 staging without its loads, 32 no global writes
                          // (measured ceilings at 128->128, 768x1280: all three off 512 TFLOP/s; s_setprio around the MFMAs: -4 %)
 #endif
-constexpr float CV_XSCALE = 64.0f;                 // activations are scaled by 2^6 before the split
+constexpr float CV_XSCALE = 64.0f;                 // default pre-scale of the activations before the split (2^6); per call:
+                                                   // ConvArgs.xscale, a power of two in (0, 64] -- the split is exact-domain for
+                                                   // |activation| < 65472 / xscale (1023 at 2^6, 65472 at 1), see stage_value
 constexpr int CV_MAXCIN = 1024;                    // prologue scale/shift table in LDS
 
 enum { PRE_NONE = 0, PRE_BN = 1, PRE_BN_MASK = 2, PRE_BN_NONZERO = 3 };
@@ -62,7 +64,8 @@ struct ConvArgs {
     const h8 *w;           // split weights in fragment order (see above), scaled by wscale
     float *out;            // [N,Cout,H,W]
     int N, Cin, Cout, H, W, tiles_x, nchunk;
-    float unscale;         // 1 / (CV_XSCALE * wscale)
+    float unscale;         // 1 / (xscale * wscale)
+    float xscale;          // pre-scale of the activations (power of two)
     // prologue: relu(x*pre_scale[c] - pre_shift[c]) * mask
     int pre;
     const float *pre_scale, *pre_shift;                // [Cin]
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     if (PRE) {
         float *pssw = reinterpret_cast<float *>(&pss4[0][0]);
         for (int i = tid; i < nchunk * 16; i += CV_THREADS) {       // padded channels: scale = shift = 0 -> 0
-            pssw[i] = i < a.Cin ? a.pre_scale[i] * CV_XSCALE : 0.0f;
-            pssw[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] * CV_XSCALE : 0.0f;
+            pssw[i] = i < a.Cin ? a.pre_scale[i] * a.xscale : 0.0f;
+            pssw[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] * a.xscale : 0.0f;
         }
     }
 
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     }
     // per-item multiplier: the [N,1,H,W] mask value (1 without a mask), 0 for the zero padding outside
     // the image; without a prologue it also carries the 2^6 pre-scale of the split
-    const float unit = PRE ? 1.0f : CV_XSCALE;
+    const float unit = PRE ? 1.0f : a.xscale;
     const float mvA = (a.mask && okA) ? a.mask[(size_t)n * HW + offA] : 0.0f;
     const float mvB = (a.mask && okB) ? a.mask[(size_t)n * HW + offB] : 0.0f;
     if (a.mask) {                                      // mask plane of the halo block, for the 3x3 box sum of the epilogue
@@ -520,8 +523,8 @@ constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (s
 template <int NCT, bool INB8>
 __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restrict__ in, const h8 *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out,
-                                                            int Cin, int Cout, int HW, int nchunk, float unscale, int out_b8,
-                                                            unsigned *__restrict__ sat_count) {
+                                                            int Cin, int Cout, int HW, int nchunk, float unscale, float xscale,
+                                                            int out_b8, unsigned *__restrict__ sat_count) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.z;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
     for (int tile = 0, g = 0; tile < C1_TILES; ++tile) {
         const int p = p0 + tile * 32;
         const bool ok = p < HW;
-        const float okf = ok ? CV_XSCALE : 0.0f;
+        const float okf = ok ? xscale : 0.0f;
 #pragma unroll
         for (int t = 0; t < NCT; ++t)
 #pragma unroll
@@ -592,8 +595,8 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             h8 bh, bl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                sat |= fabsf(x0[j] * okf) > 65472.0f;
                 const float v = __builtin_amdgcn_fmed3f(x0[j] * okf, -65472.0f, 65472.0f);
+                sat |= fabsf(v) >= 65472.0f;                   // (the same test as the 3x3 kernel: after the clamp)
                 const _Float16 h = (_Float16)v;
                 bh[j] = h;
                 bl[j] = (_Float16)(v - (float)h);
@@ -669,8 +672,9 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float *__
     }
 }
 
-// Saturation counter of the split-f16 kernels, one per device (lazily allocated, zeroed): the kernels add to it when an
-// activation exceeds the f16 range of the split (|x| * 2^6 > 65472, i.e. |x| >= 1023) and had to be clamped.
+// Saturation counter of the split-f16 kernels, ONE PER DEVICE (lazily allocated, zeroed; shared by every stream and host
+// thread that runs convolutions on that device): the kernels add to it when an activation reaches the f16 range of the
+// split (|x| * xscale >= 65472, i.e. |x| >= 1023 at the default 2^6) and had to be clamped.
 static std::atomic<unsigned *> g_sat[64];
 static std::mutex g_sat_lock;
 static int sat_counter(unsigned **p) {
@@ -698,16 +702,29 @@ static int sat_counter(unsigned **p) {
 
 using namespace slr;
 
-SLR_EXPORT int slr_conv_saturation_count(unsigned long long *count, int reset) {
+SLR_EXPORT int slr_conv_saturation_count(unsigned long long *count, int reset, void *stream) {
     SLR_CHECK_ARG(count, "null pointer");
     unsigned *p = nullptr;
     if (int e = sat_counter(&p)) return e;
     unsigned v = 0;
     if (p) {
-        SLR_CHECK_HIP(hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost));      // synchronises with the device
-        if (reset && v) SLR_CHECK_HIP(hipMemset(p, 0, sizeof(v)));
+        // ordered on the CALLER's stream (the legacy null stream does not wait for hipStreamNonBlocking streams, which is
+        // what torch's side streams are): the convolutions enqueued on `stream` before this call are counted
+        hipStream_t st = (hipStream_t)stream;
+        SLR_CHECK_HIP(hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, st));
+        SLR_CHECK_HIP(hipStreamSynchronize(st));
+        if (reset && v) { SLR_CHECK_HIP(hipMemsetAsync(p, 0, sizeof(v), st)); SLR_CHECK_HIP(hipStreamSynchronize(st)); }
     }
     *count = v;
+    return 0;
+}
+
+SLR_EXPORT int slr_conv_saturation_record(unsigned *host_slot, void *stream) {
+    SLR_CHECK_ARG(host_slot, "null pointer");
+    unsigned *p = nullptr;
+    if (int e = sat_counter(&p)) return e;
+    if (!p) { *host_slot = 0; return 0; }
+    SLR_CHECK_HIP(hipMemcpyAsync(host_slot, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return 0;
 }
 
@@ -753,15 +770,22 @@ SLR_EXPORT int slr_conv1x1_split_weights(const float *w, void *wsplit, int Cout,
     return 0;
 }
 
+static int check_xscale(float xscale) {
+    int ex = 0;
+    SLR_CHECK_ARG(xscale > 0.0f && xscale <= CV_XSCALE && frexpf(xscale, &ex) == 0.5f, "xscale: a power of two in (0, 64]");
+    return 0;
+}
+
 SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias, float *out, int N, int Cin,
-                                   int Cout, int H, int W, float wscale, int layout, void *stream) {
+                                   int Cout, int H, int W, float wscale, float xscale, int layout, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
+    if (int e = check_xscale(xscale)) return e;
     if (int e = conv_check_layout(layout & ~SLR_CONV_RES_B8, in, out, Cin, Cout, nullptr, false)) return e;
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8), "layout flags");
     SLR_CHECK_ARG(N > 0 && N < 65536 && Cin > 0 && Cout > 0 && Cout < (1 << 20) && H > 0 && W > 0 &&
                   (long long)Cin * H * W < (1LL << 40) && (long long)H * W < (1LL << 31) - 128, "sizes");
     const int HW = H * W, nchunk = conv_cin_pad(Cin) / 16, nct = conv1x1_nct(Cout);
-    const float unscale = 1.0f / (CV_XSCALE * wscale);
+    const float unscale = 1.0f / (xscale * wscale);
     const dim3 grid((HW + 128 * C1_TILES - 1) / (128 * C1_TILES), conv1x1_cout_pad(Cout) / (nct * 32), N);
     hipStream_t st = (hipStream_t)stream;
     const int ob8 = (layout & SLR_CONV_OUT_B8) ? 1 : 0;
@@ -769,8 +793,8 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
     if (int e = sat_counter(&satp)) return e;
 #define C1_LAUNCH(T)                                                                                                       \
     do {                                                                                                                   \
-        if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8, satp); \
-        else hipLaunchKernelGGL((conv1x1_split_kernel<T, false>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, ob8, satp); \
+        if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
+        else hipLaunchKernelGGL((conv1x1_split_kernel<T, false>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
     } while (0)
     if (nct == 4) C1_LAUNCH(4); else if (nct == 2) C1_LAUNCH(2); else C1_LAUNCH(1);
 #undef C1_LAUNCH
@@ -778,10 +802,12 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
     return 0;
 }
 
-static int conv_launch(ConvArgs &a, float wscale, bool in_b8, hipStream_t st) {
+static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, hipStream_t st) {
+    if (int e = check_xscale(xscale)) return e;
     a.tiles_x = (a.W + CV_W - 1) / CV_W;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
-    a.unscale = 1.0f / (CV_XSCALE * wscale);
+    a.xscale = xscale;
+    a.unscale = 1.0f / (xscale * wscale);
     if (int e = sat_counter(&a.sat)) return e;
     const int tiles = a.tiles_x * ((a.H + CV_H - 1) / CV_H);
     int ct = conv_cout_tile(a.Cout);
@@ -830,7 +856,7 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
 }
 
 SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual,
-                                   float *out, int N, int Cin, int Cout, int H, int W, float wscale,
+                                   float *out, int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
                                    const float *pre_scale, const float *pre_shift, int layout, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
     if (int e = conv_check_layout(layout, in, out, Cin, Cout, residual, false)) return e;
@@ -845,11 +871,11 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.residual = residual;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
-    return conv_launch(a, wscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
+    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
 }
 
 SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
-                                    const void *wsplit, float wscale, const float *bias, const float *residual,
+                                    const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
                                     const float *next_scale, const float *next_shift, float *out, float *um_out,
                                     int N, int Cin, int Cout, int H, int W, int layout, void *stream) {
     SLR_CHECK_ARG(x && wsplit && bias && out, "null pointer");
@@ -871,5 +897,5 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
-    return conv_launch(a, wscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
+    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
 }

@@ -30,6 +30,8 @@ from . import _lib
 
 
 _CPU_REFERENCE = False
+_TORCH_CONVS = False                     # inside torch_convolutions(): every stage through its torch definition (fp32)
+ACT_SCALE = 64.0                         # pre-scale of the activations in the split-f16 kernels (include/slr_splat.h: xscale)
 IN_B8, OUT_B8, RES_B8 = 1, 2, 4          # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8
 
 
@@ -38,7 +40,47 @@ def _b8(x, channels):
     in memory, carried in a tensor of the logical shape [N,C,H,W]): all its producers and consumers are our kernels,
     which then move 16 bytes per lane and instruction instead of 4.  The networks' inputs and outputs (3-, 65-, 2-channel
     ends, the splat's feature planes) stay NCHW; no torch op ever touches a blocked tensor."""
-    return x.is_cuda and channels % 8 == 0
+    return x.is_cuda and channels % 8 == 0 and not _TORCH_CONVS
+
+
+class torch_convolutions:
+    """Context manager: the FULL-RANGE fp32 route of these networks on a device.  Inside it every stage runs the torch
+    composition that defines it (nets.py: F.conv2d -> MIOpen fp32 on ROCm, elementwise stages as torch ops) -- the
+    arithmetic the reference's decoder uses (models/layers/partialconv2d.py:61-74, models/networks/architectures.py:345-375),
+    with no limit on the magnitude of the activations.  About 4.6x slower than the split-f16 kernels at 768x1280
+    (bench.py: fps_fp32_convs).  The animators enter it on request (convs="fp32") or by themselves when the split-f16
+    kernels report a clamped activation (convs="auto", pipeline.py)."""
+
+    def __enter__(self):
+        global _TORCH_CONVS
+        self._prev, _TORCH_CONVS = _TORCH_CONVS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _TORCH_CONVS
+        _TORCH_CONVS = self._prev
+        return False
+
+
+class activation_scale:
+    """Context manager: pre-scale of the activations in the split-f16 kernels (a power of two in (0, 64]; default 64).
+    The exact domain of the split is |activation| < 65472 / scale: 1023 at 64, 65472 at 1 (csrc/conv.hip)."""
+
+    def __init__(self, scale):
+        m, e = math.frexp(float(scale))
+        if not (0.0 < scale <= 64.0 and m == 0.5):
+            raise ValueError("activation_scale: a power of two in (0, 64]")
+        self.scale = float(scale)
+
+    def __enter__(self):
+        global ACT_SCALE
+        self._prev, ACT_SCALE = ACT_SCALE, self.scale
+        return self
+
+    def __exit__(self, *exc):
+        global ACT_SCALE
+        ACT_SCALE = self._prev
+        return False
 
 
 class cpu_reference:
@@ -65,6 +107,8 @@ def _fused_ok(*ts):
     unless the caller is inside ``cpu_reference()`` (validation of these definitions against the
     reference classes): then they take the torch composition, which IS the definition the kernels are
     tested against (tests/test_gpu_parity.py)."""
+    if _TORCH_CONVS and all(t.is_cuda for t in ts):
+        return False                                       # the supported fp32 route (torch_convolutions)
     if not any(t.is_cuda for t in ts):
         if not _CPU_REFERENCE:
             raise NotImplementedError("slr_sfs_amd.nets run on ROCm device tensors only (no CPU path); the torch "
@@ -193,7 +237,7 @@ class Conv(nn.Module):
             sc, sh = pre_bn if pre_bn is not None else (None, None)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out),
-                                                          N, cin, cout, H, W, wscale, _lib.ptr(sc), _lib.ptr(sh),
+                                                          N, cin, cout, H, W, wscale, ACT_SCALE, _lib.ptr(sc), _lib.ptr(sh),
                                                           layout, _lib.stream_of(x)), "slr_conv3x3_forward")
             return out
         assert layout == 0 or x.is_cuda        # the channel-blocked intermediate exists on the device path only
@@ -219,7 +263,7 @@ class Conv(nn.Module):
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv1x1_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
-                                                          N, cin, cout, H, W, wscale, layout, _lib.stream_of(x)),
+                                                          N, cin, cout, H, W, wscale, ACT_SCALE, layout, _lib.stream_of(x)),
                            "slr_conv1x1_forward")
             return out
         return F.conv2d(x, self.weight, bias, padding=self.pad)
@@ -254,7 +298,7 @@ class PartialConv(Conv):
             nsc, nsh = next_bn if next_bn is not None else (None, None)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_pconv3x3_forward(
-                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale,
+                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale, ACT_SCALE,
                     _lib.ptr(self.bias), _lib.ptr(residual), _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um),
                     N, cin, cout, H, W, layout, _lib.stream_of(x)), "slr_pconv3x3_forward")
             return out, um
@@ -439,20 +483,90 @@ class BGDecoder(nn.Module):
         return x
 
 
-def check_saturation(device, what="convolution", reset=True):
-    """Raise if a split-f16 kernel on ``device`` had to clamp an activation since the last check (|x| >= 1023: outside the
-    exact domain of the split, csrc/conv.hip).  The result of such a launch is wrong, not merely inexact, and the
-    reference's fp32 convolution has no such limit -- so it is an error, never silent.  Synchronises with the device:
-    the pipelines call it once per clip."""
+def saturation_count(device, reset=True):
+    """Waves of the split-f16 kernels on ``device`` that had to clamp an activation since the last reset (|x| beyond the
+    exact domain of the split, csrc/conv.hip).  The counter is one per device; the read is ordered on torch's current
+    stream of that device and synchronises it with the host."""
     import ctypes
     n = ctypes.c_ulonglong(0)
     with torch.cuda.device(device):
-        _lib.check(_lib.lib().slr_conv_saturation_count(ctypes.byref(n), 1 if reset else 0), "slr_conv_saturation_count")
-    if n.value:
-        raise RuntimeError(f"slr_sfs_amd: {n.value} wave(s) of the {what} kernels met activations >= 1023 in magnitude, "
-                           f"outside the exact range of the split-f16 matrix-core convolution; the frames of this clip "
-                           f"are not valid (check the checkpoint's BN statistics / the input range)")
+        _lib.check(_lib.lib().slr_conv_saturation_count(ctypes.byref(n), 1 if reset else 0,
+                                                        ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                   "slr_conv_saturation_count")
+    return int(n.value)
+
+
+def check_saturation(device, what="convolution", reset=True):
+    """Raise if a split-f16 kernel on ``device`` had to clamp an activation since the last check.  The result of such a
+    launch is wrong, not merely inexact, and the reference's fp32 convolution has no such limit -- so it is an error,
+    never silent.  (The animators do better than raising: pipeline.py, convs="auto".)"""
+    n = saturation_count(device, reset)
+    if n:
+        raise RuntimeError(f"slr_sfs_amd: {n} wave(s) of the {what} kernels met activations >= {65472.0 / ACT_SCALE:.0f} in "
+                           f"magnitude, outside the exact range of the split-f16 matrix-core convolution; the result is not "
+                           f"valid (use a smaller nets.activation_scale, nets.torch_convolutions(), or the animators' "
+                           f"convs='auto')")
     return 0
+
+
+class SaturationLog:
+    """Asynchronous per-piece saturation records of one clip: ``mark()`` after a piece of work (a decoder batch) copies
+    the device counter into pinned host memory in stream order -- no host synchronisation; ``bad()`` (after the stream
+    has been synchronised) lists the pieces during which the counter moved."""
+
+    def __init__(self, device, capacity):
+        self.device = device
+        self.slots = torch.zeros(capacity + 1, dtype=torch.int32).pin_memory()
+        self.n = 0
+        self._record()                                   # the value the clip starts from
+
+    def _record(self):
+        import ctypes
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().slr_conv_saturation_record(ctypes.c_void_p(self.slots.data_ptr() + 4 * self.n),
+                                                             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                       "slr_conv_saturation_record")
+        self.n += 1
+
+    def mark(self):
+        self._record()
+
+    def bad(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        v = self.slots[:self.n].tolist()
+        return [i for i in range(self.n - 1) if v[i + 1] != v[i]]
+
+
+def guarded(fn, device, policy, what, owner=None):
+    """Run ``fn()`` (networks on split-f16 kernels) under the saturation policy of the animators:
+    "split": as is, raise if an activation was clamped; "fp32": inside torch_convolutions();
+    "auto": split-f16 at the default activation scale; clamped -> again at scale 1 (exact up to 65472); clamped again ->
+    inside torch_convolutions().  ``owner`` (an animator) remembers the rung that worked, so later clips start there.
+    Synchronises with the device once per call (per rung tried)."""
+    if policy == "fp32":
+        with torch_convolutions():
+            return fn()
+    if policy == "split":
+        out = fn()
+        check_saturation(device, what)
+        return out
+    assert policy == "auto", policy
+    rung = getattr(owner, "_conv_rung", 0) if owner is not None else 0
+    saturation_count(device)                                   # start from a clean counter
+    for r, scale in enumerate((64.0, 1.0)):
+        if r < rung:
+            continue
+        with activation_scale(scale):
+            out = fn()
+        if saturation_count(device) == 0:
+            return out
+        import warnings
+        warnings.warn(f"slr_sfs_amd: activations of the {what} exceed the exact range of the split-f16 convolutions at "
+                      f"activation scale {scale:g}; rendering again " + ("at scale 1" if r == 0 else "with fp32 convolutions"))
+        if owner is not None:
+            owner._conv_rung = r + 1
+    with torch_convolutions():
+        return fn()
 
 
 # --------------------------------------------------------------------------- checkpoints

@@ -113,30 +113,33 @@ def encoder_halo(encoder):
     return 2 * len(encoder.blocks)
 
 
-def encode_band(encoder, image, rank, world, halo=None):
-    """This rank's band of the encoder outputs -> ([1,C,y1-y0,W] all outputs concatenated along C, [C_i])."""
+def encode_band(encoder, image, rank, world, halo=None, guard=None):
+    """This rank's band of the encoder outputs -> ([1,C,y1-y0,W] all outputs concatenated along C, [C_i]).
+    guard: optional callable(thunk) -> thunk's result, wrapped around the network call (nets.guarded: what a rank does
+    about its own band's activations stays local -- every rank still enters the same all-gather)."""
     H = image.shape[2]
     halo = encoder_halo(encoder) if halo is None else halo
     y0, y1 = band_rows(H, rank, world)
     assert y1 > y0, f"rank {rank} of {world} has no rows of a {H}-row image"
     a0, a1 = max(0, y0 - halo), min(H, y1 + halo)
-    outs = encoder(image[:, :, a0:a1].contiguous())
+    band_in = image[:, :, a0:a1].contiguous()
+    outs = encoder(band_in) if guard is None else guard(lambda: encoder(band_in))
     outs = outs if isinstance(outs, tuple) else (outs,)
     band = torch.cat([o[:, :, y0 - a0:y1 - a0] for o in outs], 1)
     return band, [o.shape[1] for o in outs]
 
 
-def encode_banded(encoder, image, rank, world, group=None, halo=None):
+def encode_banded(encoder, image, rank, world, group=None, halo=None, guard=None):
     """encoder(image) computed in row bands across the ranks + one all-gather; same return type as encoder(image)."""
     if world == 1:
-        return encoder(image)
+        return encoder(image) if guard is None else guard(lambda: encoder(image))
     H, W = image.shape[2:]
     rows = -(-H // world)
     if (world - 1) * rows >= H:          # checked on EVERY rank before any work: a rank without rows must not leave the
         raise ValueError(               # others waiting in the collective
             f"encode_banded: {H} rows cannot be split into {world} non-empty bands of {rows} rows; use fewer ranks "
             f"(or the redundant encoder)")
-    band, split = encode_band(encoder, image, rank, world, halo)
+    band, split = encode_band(encoder, image, rank, world, halo, guard)
     C = band.shape[1]
     send = band.new_zeros(1, C, rows, W)
     send[0, :, :band.shape[2]] = band[0]

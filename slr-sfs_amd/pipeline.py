@@ -68,7 +68,7 @@ def _features_ahead(clip, frames, overlap=False):
 
 
 import os as _os
-DECODE_BATCH = int(_os.environ.get("SLR_SFS_AMD_DECODE_BATCH", "4"))      # frames decoded per launch of the decoder networks (measured at 768x1280: 6.04 / 5.95 / 5.87 ms per
+DECODE_BATCH = max(1, int(_os.environ.get("SLR_SFS_AMD_DECODE_BATCH", "4")))      # frames decoded per launch of the decoder networks (measured at 768x1280: 6.04 / 5.95 / 5.87 ms per
                       # frame at 1 / 2 / 4 -- fewer kernel tails; the splat writes straight into the batch buffer)
 
 
@@ -97,10 +97,120 @@ def _check_grid(image):
         raise ValueError(f"working resolution {H}x{W}: height and width must be multiples of 8")
 
 
-def _encode(encoder, image, shard):
+def _encode(encoder, image, shard, policy="split", owner=None, what="encoder"):
+    """The per-clip networks under the convolution policy (nets.guarded).  With a shard, every rank guards ITS band before
+    the all-gather: whatever a rank decides, all ranks enter the same collective."""
+    guard = (lambda fn: nets.guarded(fn, image.device, policy, what, owner)) if image.is_cuda else (lambda fn: fn())
     if shard is None:
-        return encoder(image)
-    return parallel.encode_banded(encoder, image, shard[0], shard[1], shard[2] if len(shard) > 2 else None)
+        return guard(lambda: encoder(image))
+    return parallel.encode_banded(encoder, image, shard[0], shard[1], shard[2] if len(shard) > 2 else None, guard=guard)
+
+
+CONV_POLICIES = ("auto", "split", "fp32")
+_RUNG_SCALE = (64.0, 1.0)
+
+
+def _rung_context(rung):
+    """Arithmetic of the decoder convolutions by rung of the ladder: 0 split-f16 at activation scale 2^6 (exact for
+    |x| < 1023), 1 split-f16 at scale 1 (|x| < 65472), 2 fp32 through torch (no limit)."""
+    return nets.torch_convolutions() if rung >= 2 else nets.activation_scale(_RUNG_SCALE[rung])
+
+
+def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_by_one=False):
+    """The frame loop of both animators.  decode(gen, afl) -> the batch's outputs; store(pos, outputs) puts them at
+    positions ``pos`` (indices into ``frames``).  ``policy`` (CONV_POLICIES):
+      "fp32"  every convolution through torch (MIOpen fp32), the reference's arithmetic;
+      "split" split-f16 matrix-core kernels; an activation outside their exact range raises after the clip;
+      "auto"  split-f16 kernels; every decoder batch leaves an asynchronous record of the device's saturation counter
+              (no host synchronisation inside the loop); after the last batch the records are read and the batches in
+              which an activation was clamped are rendered again one rung up (activation scale 1, then fp32) -- the
+              clip that comes back never contains a clamped frame.  The animator remembers the rung (``_conv_rung``).
+    With ``on_frame`` (frames leave the rank while the clip is still being rendered) a batch is checked before its
+    frames are handed on: one host synchronisation per batch."""
+    decode_batch, store = decode
+    frames = list(frames)
+    dev = clip.fs.device
+
+    def groups(sub):
+        if one_by_one:
+            return ((i, g, a) for i, (g, a) in enumerate((x if isinstance(x, tuple) else (x, None))
+                                                          for x in _features_ahead(clip, sub, overlap)))
+        return _feature_batches(clip, sub, batch)
+
+    def emit(pos):
+        if on_frame is not None:
+            for p_ in pos:
+                on_frame(p_)
+
+    if policy == "fp32" or not dev.type == "cuda":
+        with (nets.torch_convolutions() if policy == "fp32" else _null()):
+            for i0, gen, afl in groups(frames):
+                pos = list(range(i0, i0 + gen.shape[0]))
+                store(pos, decode_batch(gen, afl))
+                emit(pos)
+        return
+    if policy == "split":
+        for i0, gen, afl in groups(frames):
+            pos = list(range(i0, i0 + gen.shape[0]))
+            store(pos, decode_batch(gen, afl))
+            emit(pos)
+        nets.check_saturation(dev, "decoder")
+        return
+    assert policy == "auto", policy
+    rung = getattr(owner, "_conv_rung", 0)
+    if on_frame is not None:                              # frames leave as they are finished: check each batch first
+        nets.saturation_count(dev)
+        for i0, gen, afl in groups(frames):
+            pos = list(range(i0, i0 + gen.shape[0]))
+            while True:
+                with _rung_context(rung):
+                    outs = decode_batch(gen, afl)
+                if rung >= 2 or nets.saturation_count(dev) == 0:
+                    break
+                rung += 1
+                owner._conv_rung = rung
+                _warn_rung(rung)
+            store(pos, outs)
+            emit(pos)
+        return
+    todo = list(range(len(frames)))                       # positions still to render
+    while todo:
+        sub = [frames[p_] for p_ in todo]
+        if rung >= 2:
+            with _rung_context(rung):
+                for i0, gen, afl in groups(sub):
+                    store([todo[i0 + k] for k in range(gen.shape[0])], decode_batch(gen, afl))
+            return
+        log = nets.SaturationLog(dev, len(sub))
+        spans = []
+        with _rung_context(rung):
+            for i0, gen, afl in groups(sub):
+                pos = [todo[i0 + k] for k in range(gen.shape[0])]
+                store(pos, decode_batch(gen, afl))
+                log.mark()
+                spans.append(pos)
+        bad = log.bad()
+        if not bad:
+            return
+        todo = [p_ for b in bad for p_ in spans[b]]
+        rung += 1
+        owner._conv_rung = rung
+        _warn_rung(rung)
+
+
+def _warn_rung(rung):
+    import warnings
+    warnings.warn("slr_sfs_amd: decoder activations exceed the exact range of the split-f16 convolutions; rendering the "
+                  "affected frames again " + ("at activation scale 1 (exact up to 65472)" if rung == 1 else
+                                              "with fp32 convolutions (torch / MIOpen)"))
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def prepare_motion(flow, H, W, speed=1.0, align=None, N=None):
@@ -147,10 +257,14 @@ def splat_options(opts, two_layer):
 
 
 class BaselineAnimator(torch.nn.Module):
-    def __init__(self, encoder=None, decoder=None, clamp_z=None, softmax_v1=False, softmax_v2=False, opts=None):
+    def __init__(self, encoder=None, decoder=None, clamp_z=None, softmax_v1=False, softmax_v2=False, opts=None, convs="auto"):
         """clamp_z / softmax_v1 / softmax_v2: see ClipSynthesizer; ``opts`` (the checkpoint's pickled Namespace)
-        sets them the way the reference's forward_flow reads them (splat_options)."""
+        sets them the way the reference's forward_flow reads them (splat_options).  convs: arithmetic of the encoder /
+        decoder convolutions, one of CONV_POLICIES (see _render): "auto" = split-f16 matrix-core kernels with an automatic
+        step up (activation scale 1, then fp32 through torch) where an activation leaves their exact range."""
         super().__init__()
+        assert convs in CONV_POLICIES
+        self.convs, self._conv_rung = convs, 0
         self.encoder = encoder if encoder is not None else nets.EncoderWithZ()
         self.projector = decoder if decoder is not None else nets.DecoderPconv2(64, 3)
         self.splat_kw = dict(clamp_z=clamp_z, softmax_v1=softmax_v1, softmax_v2=softmax_v2)
@@ -158,12 +272,12 @@ class BaselineAnimator(torch.nn.Module):
             self.splat_kw = splat_options(opts, two_layer=False)
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N, shard=None, frames=None):
+    def begin_clip(self, image, motion, N, shard=None, frames=None, convs=None):
         """Frame-invariant part.  image [1,3,H,W] in [-1,1]; motion [1,2,H,W] px/frame.
         shard = (rank, world[, group]): the encoder runs in row bands across the ranks (parallel.encode_banded).
         frames: the frames that will be rendered (default all): bins / work plans are prepared for those."""
         plan = MotionPlan(motion, N, frames)                        # motion-only work first (its totals reach the host
-        fs, Z = _encode(self.encoder, image, shard)                 # under the encoder); start_fs, Z_f (:779-786)
+        fs, Z = _encode(self.encoder, image, shard, convs or self.convs, self)   # under the encoder); start_fs, Z_f (:779-786)
         return ClipSynthesizer(fs, Z, motion, N, plan=plan, **self.splat_kw)
 
     @torch.no_grad()
@@ -183,27 +297,26 @@ class BaselineAnimator(torch.nn.Module):
         return {"PredImg": torch.tanh(self.projector(gen)), "Z_f": Z}
 
     @torch.no_grad()
-    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None, batch=None):
+    def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None, batch=None, convs=None):
         """All (or the given) frames of one clip -> [len(frames),3,H,W] on the device.  batch (default DECODE_BATCH):
-        frames per decoder launch; overlap=True (see _features_ahead) decodes frame by frame."""
+        frames per decoder launch; overlap=True (see _features_ahead) decodes frame by frame; convs: overrides the
+        animator's convolution policy for this clip (CONV_POLICIES)."""
         _check_grid(image)
-        frames = range(N) if frames is None else frames
-        clip = self.begin_clip(image, motion, N, shard, frames)
+        frames = list(range(N) if frames is None else frames)
+        policy = self.convs if convs is None else convs
+        assert policy in CONV_POLICIES
+        clip = self.begin_clip(image, motion, N, shard, frames, convs=policy)
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         batch = DECODE_BATCH if batch is None else max(1, int(batch))
-        if overlap or batch == 1:
-            for i, gen_fs in enumerate(_features_ahead(clip, frames, overlap)):
-                out[i] = torch.tanh(self.projector(gen_fs))[0]
-                if on_frame is not None:
-                    on_frame(out[i])                                # e.g. parallel.ClipAssembler.push
-        else:
-            for i0, gen, _ in _feature_batches(clip, frames, batch):
-                torch.tanh(self.projector(gen), out=out[i0:i0 + gen.shape[0]])     # (no temporary + copy)
-                if on_frame is not None:
-                    for i in range(i0, i0 + gen.shape[0]):
-                        on_frame(out[i])
-        if image.is_cuda:
-            nets.check_saturation(image.device, "encoder / decoder")   # once per clip: no silent clamping (csrc/conv.hip)
+
+        def store(pos, frames_out):
+            if pos and pos[-1] - pos[0] + 1 == len(pos):
+                out[pos[0]:pos[0] + len(pos)] = frames_out
+            else:
+                out[torch.as_tensor(pos, device=out.device)] = frames_out
+
+        _render(self, clip, frames, batch, overlap, (lambda gen, afl: torch.tanh(self.projector(gen)), store), policy,
+                None if on_frame is None else (lambda p_: on_frame(out[p_])), one_by_one=overlap or batch == 1)
         return out
 
 
@@ -229,12 +342,14 @@ class SLRv1Animator(torch.nn.Module):
 
     def __init__(self, encoder=None, decoder=None, net_bg=None, alpha_encoder=None, alpha_decoder=None,
                  use_alpha0=True, softmax_v1=False, softmax_v2=False, use_alpha_softmax=False, clamp_alpha=0.0,
-                 use_fluid_alpha_only=False, use_bg_alpha_only=False, opts=None):
+                 use_fluid_alpha_only=False, use_bg_alpha_only=False, opts=None, convs="auto"):
         """Compositing options of ..._2layers_alpha_seperate.py:1060-1085 (all off in the shipped scripts):
         use_alpha_softmax, clamp_alpha (> 0: lower bound of the composited fluid alpha -- not the clamp of the time
         weight, which this model always applies, :952), use_fluid_alpha_only, use_bg_alpha_only.  ``opts`` (the
         checkpoint's pickled Namespace) sets all of them, use_alpha0 and the splat-weight variant."""
         super().__init__()
+        assert convs in CONV_POLICIES
+        self.convs, self._conv_rung = convs, 0                       # (see BaselineAnimator / _render)
         self.encoder = encoder if encoder is not None else nets.EncoderWithZ()
         self.projector = decoder if decoder is not None else nets.DecoderPconv2(64, 3)
         self.net_bg = net_bg if net_bg is not None else nets.BGDecoder()
@@ -263,12 +378,13 @@ class SLRv1Animator(torch.nn.Module):
         return clip
 
     @torch.no_grad()
-    def begin_clip(self, image, motion, N, shard=None, alpha_region=None, frames=None):
+    def begin_clip(self, image, motion, N, shard=None, alpha_region=None, frames=None, convs=None):
         """alpha_region [1,1,H,W]: optional edit mask (:867-906, 1079-1080): 1 = composite, 0 = fluid layer only."""
+        policy = convs or self.convs
         plan = MotionPlan(motion, N, frames)
-        fs, Z = _encode(self.encoder, image, shard)
-        bg = torch.tanh(self.net_bg(image))                         # test_v1_4eval_rawsize.py:209, :925-927
-        a = _encode(self.net_alpha_encoder, image, shard)           # :938 (frame-invariant -> hoisted)
+        fs, Z = _encode(self.encoder, image, shard, policy, self)
+        bg = torch.tanh(_encode(self.net_bg, image, None, policy, self, "background network"))   # test_v1_4eval_rawsize.py:209, :925-927
+        a = _encode(self.net_alpha_encoder, image, shard, policy, self, "alpha encoder")         # :938 (frame-invariant -> hoisted)
         return self._clip(fs, Z, motion, N, a, bg, alpha_region, plan=plan)
 
     @torch.no_grad()
@@ -333,35 +449,47 @@ class SLRv1Animator(torch.nn.Module):
 
     @torch.no_grad()
     def synthesize(self, image, motion, N, frames=None, overlap=False, on_frame=None, shard=None, keys=None,
-                   alpha_region=None, batch=None):
+                   alpha_region=None, batch=None, convs=None):
         """keys=None: PredImg frames [n,3,H,W] (as BaselineAnimator.synthesize).  keys=("PredImg", "FluidImg",
         "CompositeFluidAlpha", "BGImg", ...): a dict of those outputs of forward_flow, stacked over the frames
         ("BGImg" and "AlphaRegionMask" are frame-invariant: one [1,.,H,W] tensor) -- what
-        test_v1_4eval_rawsize.py:240-284 writes to disk."""
+        test_v1_4eval_rawsize.py:240-284 writes to disk.  An empty ``frames`` (a rank without frames of a short clip)
+        returns empty [0,.,H,W] tensors for every key, so that the callers' collectives are entered by every rank."""
         _check_grid(image)
-        frames = range(N) if frames is None else frames
-        clip = self.begin_clip(image, motion, N, shard, alpha_region, frames)
+        frames = list(range(N) if frames is None else frames)
+        policy = self.convs if convs is None else convs
+        assert policy in CONV_POLICIES
         want = ("PredImg",) if keys is None else tuple(keys)
         once = ("BGImg", "AlphaRegionMask")
-        outs = {}
+        channels = {"PredImg": 3, "FluidImg": 3, "CompositeFluidAlpha": 1, "EditedCompositeFluidAlpha": 1}
+        # every key is checked BEFORE any device work (and before any collective a sharded caller will enter)
+        for k in want:
+            if k not in channels and k not in once:
+                raise KeyError(f"SLRv1Animator.synthesize: unknown output {k!r}")
+            if k in ("EditedCompositeFluidAlpha", "AlphaRegionMask") and alpha_region is None:
+                raise KeyError(f"SLRv1Animator.synthesize: {k!r} needs an alpha_region")
+        if on_frame is not None and "PredImg" not in want:
+            raise KeyError("SLRv1Animator.synthesize: on_frame receives PredImg frames: request that key")
+        clip = self.begin_clip(image, motion, N, shard, alpha_region, frames, convs=policy)
+        H, W = image.shape[2:]
+        outs = {k: image.new_empty(len(frames), channels[k], H, W) for k in want if k not in once}
+        if "BGImg" in want:
+            outs["BGImg"] = clip.bg
+        if "AlphaRegionMask" in want:
+            outs["AlphaRegionMask"] = clip.alpha_region
         batch = DECODE_BATCH if batch is None else max(1, int(batch))
-        if overlap or batch == 1 or not clip.use_alpha0:
-            groups = ((i, g, a) for i, (g, a) in enumerate(_features_ahead(clip, frames, overlap)))
-        else:
-            groups = _feature_batches(clip, frames, batch)
-        for i0, gen_fs, alpha_fluid in groups:
-            d = self._decode(clip, gen_fs, alpha_fluid)              # every stage works on a batch of frames
-            b = gen_fs.shape[0]
+
+        def store(pos, d):
+            idx = None if (pos and pos[-1] - pos[0] + 1 == len(pos)) else torch.as_tensor(pos, device=image.device)
             for k in want:
                 if k in once:
-                    outs[k] = d[k]
                     continue
-                if k not in outs:
-                    outs[k] = d[k].new_empty(len(frames), *d[k].shape[1:])
-                outs[k][i0:i0 + b] = d[k]
-            if on_frame is not None:
-                for i in range(i0, i0 + b):
-                    on_frame(outs["PredImg"][i])
-        if image.is_cuda:
-            nets.check_saturation(image.device, "encoder / decoder")
+                if idx is None:
+                    outs[k][pos[0]:pos[0] + len(pos)] = d[k]
+                else:
+                    outs[k][idx] = d[k]
+
+        _render(self, clip, frames, batch, overlap, (lambda gen, afl: self._decode(clip, gen, afl), store), policy,
+                None if on_frame is None else (lambda p_: on_frame(outs["PredImg"][p_])),
+                one_by_one=overlap or batch == 1 or not clip.use_alpha0)
         return outs["PredImg"] if keys is None else outs

@@ -45,8 +45,8 @@ def animate_scene(model, image_path, flow_path, out_dir, name, H, W, N, speed, a
     if half_size:
         raw_w, raw_h = raw_w // 2, raw_h // 2
     image, motion = image.to(dev), motion.to(dev)
-    mine = parallel.shard_frames(N, rank, world)
-    shard = (rank, world, group) if world > 1 else None
+    mine = parallel.shard_frames(N, rank, world)      # (N < world: some ranks render nothing -- they still enter every
+    shard = (rank, world, group) if world > 1 else None   # collective below, with empty [0,.,H,W] contributions)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     if v1:

@@ -132,8 +132,11 @@ class MotionPlan:
             # all-frames Euler passes: forward t = 0..N-1 steps of +motion, backward 1..N steps of -motion
             self.disp_f, _ = euler_integration_all(motion, self.N - 1, +1.0, want_visible=False)
             self.disp_p, _ = euler_integration_all(motion, self.N, -1.0, want_visible=False)
-            for c0 in range(0, len(self.frames), PLAN_CHUNK):
-                self._build(self.frames[c0:c0 + PLAN_CHUNK])
+            # frames per plan: list offsets are 32-bit (8 * frames * H * W < 2^32, include/slr_splat.h), so large grids
+            # get shorter chunks instead of no plan at all
+            chunk = max(1, min(PLAN_CHUNK, (2 ** 32 - 1) // (8 * self.H * self.W)))
+            for c0 in range(0, len(self.frames), chunk):
+                self._build(self.frames[c0:c0 + chunk])
 
     def _build(self, ts):
         n, dev = len(ts), self.disp_f.device
@@ -203,7 +206,7 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
     return (out, norm) if return_norm else out
 
 
-MAX_BATCH = int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "8"))     # frames per launch of slr_synth_group_clip_batch (csrc: MAXB = 8)
+MAX_BATCH = min(8, max(1, int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "8"))))   # frames per launch of slr_synth_group_clip_batch (csrc: MAXB = 8)
 
 
 def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_weights=True, eps=1e-8, timed=False):

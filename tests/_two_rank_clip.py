@@ -1,7 +1,9 @@
-"""Child process of tests/test_gpu_parity.py::test_two_ranks_one_clip: rank RANK of WORLD_SIZE renders its share of one
-clip on cuda:0 (both ranks share the one GPU of the test box; the transport is gloo on device tensors) exactly as
-bench.py does on N GPUs -- encoder in row bands, frames round-robin, round-wise asynchronous assembly -- and compares
-the assembled clip with the single-process clip."""
+"""Child process of tests/test_gpu_parity.py::test_two_ranks_one_clip / test_two_ranks_on_rccl: rank RANK of WORLD_SIZE
+renders its share of one clip exactly as bench.py / runner.py do on N GPUs -- frames round-robin, both assembly forms (ONE
+all-gather of the finished clip = the north_star form; round-wise asynchronous all-gathers), encoder redundant or in row
+bands -- and compares the assembled clip with the single-process clip.
+SLR_TEST_BACKEND=gloo (default): every rank on cuda:0 (the test box has one GPU; gloo moves the device tensors);
+SLR_TEST_BACKEND=nccl: rank r on cuda:r, collectives over RCCL (needs >= WORLD_SIZE GPUs)."""
 import os
 import sys
 
@@ -13,24 +15,43 @@ import slr_sfs_amd as S  # noqa: E402
 from slr_sfs_amd import parallel  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dist.init_process_group("gloo", rank=rank, world_size=world)
-H, W, N = 48, 72, 7
+backend = os.environ.get("SLR_TEST_BACKEND", "gloo")
+if backend == "nccl":
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+else:
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+H, W = 48, 72
 for name, cls in (("baseline", S.pipeline.BaselineAnimator), ("slr-v1", S.pipeline.SLRv1Animator)):
-    torch.manual_seed(4)                                       # same weights, image and motion on every rank
-    an = cls().cuda().eval()
-    img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
-    m = torch.randn(1, 2, H, W, device="cuda") * 1.5
-    ref = an.synthesize(img, m, N)
-    mine = parallel.shard_frames(N, rank, world)
-    asm = parallel.ClipAssembler(N, rank, world)
-    an.synthesize(img, m, N, frames=mine, on_frame=asm.push, shard=(rank, world))
-    clip = asm.finish(like=img[0])
-    torch.cuda.synchronize()
-    err = (clip - ref).abs().max().item()
-    assert clip.shape == ref.shape and err < 1e-4, (name, rank, err)
-    one = parallel.gather_clip(an.synthesize(img, m, N, frames=mine), N, rank, world)      # the one-collective form
-    assert (one - ref).abs().max().item() < 1e-4, (name, rank)
+    for N in (7, 1):                                           # N = 1 < world: rank 1 renders nothing and must still enter
+        torch.manual_seed(4)                                   # every collective; same weights, image, motion on every rank
+        an = cls().cuda().eval()
+        img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+        m = torch.randn(1, 2, H, W, device="cuda") * 1.5
+        ref = an.synthesize(img, m, N)
+        mine = parallel.shard_frames(N, rank, world)
+        # round-wise asynchronous assembly + encoder in row bands
+        asm = parallel.ClipAssembler(N, rank, world)
+        an.synthesize(img, m, N, frames=mine, on_frame=asm.push, shard=(rank, world))
+        clip = asm.finish(like=img[0])
+        torch.cuda.synchronize()
+        err = (clip - ref).abs().max().item()
+        assert clip.shape == ref.shape and err < 1e-4, (name, N, rank, err)
+        # the north_star form: redundant encoder, ONE all-gather of the finished clip (uneven shards: N = 7 over 2 ranks)
+        one = parallel.gather_clip(an.synthesize(img, m, N, frames=mine), N, rank, world)
+        assert one.shape == ref.shape and (one - ref).abs().max().item() < 1e-4, (name, N, rank)
+        if name == "slr-v1":                                   # the runner's dict of outputs, every key gathered by every rank
+            outs = an.synthesize(img, m, N, frames=mine, shard=(rank, world), keys=cls.KEYS)
+            full = an.synthesize(img, m, N, keys=cls.KEYS)
+            for k in cls.KEYS:
+                got = outs[k] if k == "BGImg" else parallel.gather_clip(outs[k].contiguous(), N, rank, world)
+                assert got.shape == full[k].shape and (got - full[k]).abs().max().item() < 1e-4, (k, N, rank)
+        # the banded encoder by itself on device buffers
+        fs = parallel.encode_banded(an.encoder, img, rank, world)
+        fs0 = an.encoder(img)
+        for got, want in zip(fs if isinstance(fs, tuple) else (fs,), fs0 if isinstance(fs0, tuple) else (fs0,)):
+            assert torch.equal(got, want), (name, rank)
 dist.barrier()
 dist.destroy_process_group()
 print(f"RANK{rank} OK")

@@ -912,11 +912,7 @@ def test_banded_encoder_is_exact(S):
         assert (a - b).abs().max().item() < 1e-4
 
 
-def test_two_ranks_one_clip(S):
-    """The multi-GPU job of bench.py end to end with two processes (tests/_two_rank_clip.py): frames round-robin over
-    the ranks, encoder in row bands + all-gather, round-wise asynchronous clip assembly -- every rank ends with the clip
-    a single process renders.  The test box has one GPU, so both ranks use cuda:0 and the collectives travel over gloo;
-    on N GPUs the same code runs over RCCL (test_clip_assembler_on_rccl covers that backend)."""
+def _run_two_ranks(backend):
     import socket
     import subprocess
     import sys
@@ -927,14 +923,31 @@ def test_two_ranks_one_clip(S):
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_two_rank_clip.py")
     procs = []
     for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2",
+                   SLR_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for r, p in enumerate(procs):
-        out, err = p.communicate(timeout=600)
+        out, err = p.communicate(timeout=900)
         assert p.returncode == 0 and f"RANK{r} OK" in out, (r, out[-500:], err[-3000:])
 
 
-@pytest.mark.parametrize("form", [(), ("--assembly", "final", "--encoder", "redundant")])
+def test_two_ranks_one_clip(S):
+    """The multi-GPU job of bench.py / runner.py end to end with two processes (tests/_two_rank_clip.py): frames
+    round-robin over the ranks; ONE all-gather of the finished clip (north_star form) and round-wise asynchronous assembly;
+    encoder redundant and in row bands; a clip SHORTER than the world (a rank without frames still enters every
+    collective); the 2-layer model's dict of outputs -- every rank ends with what a single process renders.  The test box
+    has one GPU, so both ranks use cuda:0 and the collectives travel over gloo; test_two_ranks_on_rccl is the same on RCCL."""
+    _run_two_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (enables itself on a multi-GPU node)")
+def test_two_ranks_on_rccl(S):
+    """tests/_two_rank_clip.py with backend nccl (= RCCL over xGMI), rank r on cuda:r: gather_clip, ClipAssembler and
+    encode_banded on real device buffers of two GPUs, uneven shards (N = 7) and an empty one (N = 1)."""
+    _run_two_ranks("nccl")
+
+
+@pytest.mark.parametrize("form", [(), ("--assembly", "rounds", "--encoder", "banded")])
 def test_bench_two_ranks_on_one_gpu(form):
     """bench.py's own multi-rank path, launched the way the driver launches it (torch.distributed.run, 2 ranks):
     warm-up, barrier-bracketed timed steps, MAX over ranks, rank 0's extra measurements while the other rank waits,
@@ -962,16 +975,18 @@ def test_bench_two_ranks_on_one_gpu(form):
     assert d["value"] > 0 and abs(d["value"] - 60 / (d["ms_per_step"] * 1e-3)) < 0.05 * d["value"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"] is None                       # rank 0 at N=1 only
-    # the line says which multi-GPU form ran and what it moved: default = per-round all-gathers + banded encoder,
-    # the north_star form = redundant encoder + ONE all-gather of the finished clip
+    # the line says which multi-GPU form ran and what it moved: default = the north_star form (redundant encoder + ONE
+    # all-gather of the finished clip), with the other form's figure beside it; explicit = per-round all-gathers + banded encoder
     cfg = d["config"]
     frame = 3 * 768 * 1280 * 4
-    if form:
+    if not form:
         assert cfg["assembly"] == "final" and cfg["encoder"] == "redundant"
         assert cfg["collective_bytes_received_per_rank_per_clip"] == 30 * frame
+        assert d["value_rounds_banded"]["value"] > 0
     else:
         assert cfg["assembly"] == "rounds" and cfg["encoder"] == "banded"
         assert cfg["collective_bytes_received_per_rank_per_clip"] == 30 * frame + 65 * 768 * 1280 * 4 // 2
+        assert "value_rounds_banded" not in d
 
 
 def test_clip_assembler_on_rccl(S, tmp_path):
@@ -1523,6 +1538,107 @@ def test_conv3x3_saturates_instead_of_nan(S):
         ref = torch.nn.functional.conv2d(ok.double(), c2.weight.double(), padding=1)
         assert nets.check_saturation(dev0) == 0
         assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+class _ScaledEncoder(torch.nn.Module):
+    """An encoder whose features are `gain` times the wrapped one's: activations far outside the exact range of the
+    split-f16 convolutions at their default scale (|x| < 1023), as an untrained / badly normalised checkpoint produces."""
+
+    def __init__(self, enc, gain):
+        super().__init__()
+        self.enc, self.gain = enc, gain
+        self.blocks = enc.blocks
+
+    def forward(self, x):
+        fs, Z = self.enc(x)
+        return fs * self.gain, Z
+
+
+@pytest.mark.parametrize("gain,rung", [(1.5e3, 1), (3.0e6, 2)])
+def test_large_activations_are_rendered_not_refused(S, gain, rung):
+    """The reference's decoder is plain fp32 with no magnitude limit (models/layers/partialconv2d.py:61-74,
+    models/networks/architectures.py:345-375).  With the default policy (convs="auto") a clip whose decoder activations
+    leave the exact range of the split-f16 kernels is rendered again one rung up -- activation scale 1 (exact to 65472),
+    then fp32 convolutions through torch -- instead of raising: frames within 1e-4 of the fp64 definition of the same
+    networks, the raw decoder output within 1e-4 of its range.  convs="split" still refuses such a clip loudly."""
+    import copy
+    import warnings
+    from slr_sfs_amd import nets, pipeline
+    torch.manual_seed(11)
+    H, W, N = 64, 96, 5
+    base = pipeline.BaselineAnimator()
+    an = pipeline.BaselineAnimator(encoder=_ScaledEncoder(base.encoder, gain), decoder=base.projector).cuda().eval()
+    img = torch.rand(1, 3, H, W, device="cuda") * 2 - 1
+    m = torch.randn(1, 2, H, W, device="cuda")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        frames = an.synthesize(img, m, N)                              # no exception
+    assert an._conv_rung == rung and any("exact range" in str(x.message) for x in w)
+    assert bool(torch.isfinite(frames).all())
+    # the fp64 definition of the same decoder on the same decoder inputs.  With decoder outputs of magnitude ~gain in
+    # front of the tanh, "within 1e-4" is a statement about the RAW output (relative to its range: 1e-5 here); on the
+    # frames themselves fp32 arithmetic of any kind is only good to eps * |raw| where raw crosses zero, so the frames are
+    # held to the error the all-fp32 route (convs="fp32": torch / MIOpen) makes against the same fp64 reference.
+    clip = an.begin_clip(img, m, N)
+    dec64 = copy.deepcopy(an.projector).double()
+    f32 = an.synthesize(img, m, N, convs="fp32")
+    worst_raw, err_auto, err_f32 = 0.0, 0.0, 0.0
+    for t in range(N):
+        gen = clip.features(t)
+        assert float(gen.abs().max()) > 1023.0                         # really outside the default exact range
+        with nets.torch_convolutions(), torch.no_grad():
+            raw64 = dec64(gen.double())
+        raw = nets.guarded(lambda: an.projector(gen), gen.device, "auto", "decoder", an)
+        worst_raw = max(worst_raw, float((raw.double() - raw64).abs().max() / raw64.abs().max()))
+        err_auto = max(err_auto, float((frames[t:t + 1].double() - torch.tanh(raw64)).abs().max()))
+        err_f32 = max(err_f32, float((f32[t:t + 1].double() - torch.tanh(raw64)).abs().max()))
+    assert worst_raw < 1e-5, worst_raw
+    assert err_auto <= max(1e-4, 4.0 * err_f32), (err_auto, err_f32)
+    # a second clip starts on the rung that worked: no further warning, same frames
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        again = an.synthesize(img, m, N)
+    assert not w2 and float((again - frames).abs().max()) <= max(1e-4, 8.0 * err_f32)    # (the encoder now runs on that rung too)
+    # frames leaving the rank one by one (multi-GPU rounds form) are checked before they go
+    an._conv_rung = 0
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        an.synthesize(img, m, N, on_frame=lambda f: seen.append(f.clone()))
+    assert len(seen) == N and all(float((a - b).abs().max()) <= max(1e-4, 8.0 * err_f32) for a, b in zip(seen, frames))
+    # the explicit policies
+    with pytest.raises(RuntimeError, match="exact range"):
+        an.synthesize(img, m, N, convs="split")
+    assert float((f32 - frames).abs().max()) <= max(1e-4, 8.0 * err_f32)
+
+
+def test_saturation_counter_follows_the_callers_stream(S):
+    """slr_conv_saturation_count is ordered on the stream it is given (torch's side streams are non-blocking streams:
+    the legacy null stream does not wait for them), and slr_conv_saturation_record leaves asynchronous per-piece records."""
+    from slr_sfs_amd import nets
+    dev0 = torch.device("cuda", torch.cuda.current_device())
+    nets.saturation_count(dev0)
+    conv = nets.Conv(16, 32, 3, bias=False).cuda()
+    big = torch.full((1, 16, 64, 128), 5.0e4, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(20):
+            conv(big)
+        assert nets.saturation_count(dev0) > 0                         # read on `side`, right behind its convolutions
+        log = nets.SaturationLog(dev0, 3)
+        conv(torch.ones(1, 16, 8, 32, device="cuda")); log.mark()
+        conv(big); log.mark()
+        conv(torch.ones(1, 16, 8, 32, device="cuda")); log.mark()
+        assert log.bad() == [1]
+        assert nets.saturation_count(dev0) > 0                         # (records do not reset the counter; this read does)
+        with nets.activation_scale(1.0):                               # 5e4 is inside the exact range at scale 1
+            y = conv(big)
+            assert nets.saturation_count(dev0) == 0
+        ref = torch.nn.functional.conv2d(big.double(), conv.weight.double(), padding=1)
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    torch.cuda.current_stream().wait_stream(side)
+    nets.saturation_count(dev0)
 
 
 @pytest.mark.parametrize("cin,cout,h,w,bias", [(64, 128, 16, 40, False), (128, 256, 9, 33, True), (3, 32, 7, 19, True),
