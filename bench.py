@@ -329,6 +329,22 @@ def parity_check(model, image, motion, workload, dev, t=30):
         fr = an.synthesize(torch.from_numpy(img).to(dev), torch.from_numpy(mo).to(dev), n, frames=ts).cpu().numpy()
         ref = g["v1_PredImg"] if v1 else g["baseline_PredImg"]
         out["frames_vs_reference_models_max_abs"] = float(np.abs(fr - ref).max())
+    # (4) the same at 256 x 256 (the multi-tile / channel-blocked convolution variants of the timed clip), against digests of
+    # the reference models' frames (tests/golden/large_nets_e2e.npz, tools/make_golden_large.py)
+    lpath = os.path.join(ROOT, "tests", "golden", "large_nets_e2e.npz")
+    if os.path.exists(epath) and os.path.exists(lpath):
+        gl = np.load(lpath)
+        S_, n2 = int(gl["S"]), int(gl["N"])
+        img2, mo2, _ = NF.e2e_inputs(S_, n2)
+        kind = "v1" if workload != "c3" else "baseline"
+        ts2 = [n2 // 2] if kind == "v1" else [int(t) for t in gl["ts"]]
+        fr2 = an.synthesize(torch.from_numpy(img2).to(dev), torch.from_numpy(mo2).to(dev), n2, frames=ts2).cpu().numpy()
+        worst = 0.0
+        for k2, t2 in enumerate(ts2):
+            tag = f"{kind}_PredImg_t{t2}"
+            pos = NF.digest_positions(tag, fr2[k2:k2 + 1].size, int(gl["npos"]))
+            worst = max(worst, float(np.abs(fr2[k2:k2 + 1].ravel()[pos] - gl[f"{tag}_val"]).max()))
+        out["frames_256_vs_reference_models_digest_max_abs"] = worst
     out["ok"] = bool(max(v for k, v in out.items() if k.endswith("max_abs")) < out["tolerance"])
     return out
 

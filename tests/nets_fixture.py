@@ -73,6 +73,25 @@ def net_input(net):
     return torch.from_numpy(x)
 
 
+def net_input_large(net, S=256):
+    """Inputs of the 256 x 256 digests (tests/golden/large_nets_e2e.npz): like net_input, with a hole, a zero column and a
+    zero row band (the partial convolutions' masks matter on several tiles of the convolution kernels)."""
+    cin = NETS[net][1][1]
+    r = _rng(net, "input_large", S)
+    if cin == 3:
+        return torch.from_numpy(r.uniform(-1, 1, (1, 3, S, S)).astype(np.float32))
+    x = r.standard_normal((1, cin, S, S)).astype(np.float32)
+    x[:, :, 40:90, 100:190] = 0.0
+    x[:, 3, 0, 0] = 0.0
+    x[:, :, :, S - 1] = 0.0
+    x[:, :, 200:203, :] = 0.0
+    return torch.from_numpy(x)
+
+
+def digest_positions(tag, size, n=4096):
+    return _rng("digest", tag, size).integers(0, size, n)
+
+
 def e2e_inputs(W=64, N=8):
     """Inputs of the end-to-end fixture (tests/golden/pipeline_e2e.npz): an image in [-1, 1] and a motion field
     (px / frame at the working resolution, zero outside the 'fluid' region like the data set's masks), seeded."""

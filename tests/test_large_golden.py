@@ -1,0 +1,75 @@
+"""The networks and the FRAMES at 256 x 256 against digests of the reference's own classes / models
+(tests/golden/large_nets_e2e.npz, tools/make_golden_large.py): the grid on which the convolution kernels run their
+multi-tile, channel-blocked 128-channel variants (conv3x3_split_kernel<1,4,*,true>: two thirds of a timed clip) -- the
+small fixtures (16x24 / 32x48 nets, 64x64 frames) never reach those.  Per tensor: 4096 seeded positions, per-plane sums
+and the max-abs of the reference's output.
+CPU (not gpu): the package's torch definition of the decoder (pins the definition the kernels are tested against);
+GPU (-m gpu): the HIP kernels / the animators, within 5e-5 of the range (nets) and 1e-4 max-abs (frames: north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import nets_fixture as NF
+from test_e2e_golden import _baseline, _net, _v1
+
+
+def _check(g, tag, x, tol_rel=None, tol_abs=None):
+    x = np.ascontiguousarray(x.detach().cpu().numpy() if torch.is_tensor(x) else x, dtype=np.float32)
+    assert list(x.shape) == [int(v) for v in g[f"{tag}_shape"]], tag
+    pos = NF.digest_positions(tag, x.size, int(g["npos"]))
+    scale = float(g[f"{tag}_absmax"])
+    tol = tol_abs if tol_abs is not None else tol_rel * scale
+    err = float(np.abs(x.ravel()[pos] - g[f"{tag}_val"]).max())
+    assert err <= tol, (tag, err, tol)
+    sums = x.reshape(-1, x.shape[-2] * x.shape[-1]).astype(np.float64).sum(1)
+    hw = x.shape[-2] * x.shape[-1]
+    assert float(np.abs(sums - g[f"{tag}_plane_sums"]).max()) <= tol * hw * 0.05, tag      # (mean error per pixel << tol)
+    return err
+
+
+def _mine(name):
+    from slr_sfs_amd import nets
+    return {"encoder": nets.EncoderWithZ, "projector": lambda: nets.DecoderPconv2(64, 3),
+            "net_alpha_decoder": lambda: nets.DecoderPconv2(65, 1)}[name]()
+
+
+def test_torch_definition_of_the_decoder_at_256(golden_dir):
+    from slr_sfs_amd import nets
+    g = np.load(f"{golden_dir}/large_nets_e2e.npz")
+    net = _net(golden_dir, "projector", _mine("projector"))
+    with nets.cpu_reference(), torch.no_grad():
+        out = net(NF.net_input_large("projector", int(g["S"])))
+    _check(g, "projector_out0", out, tol_rel=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["encoder", "projector", "net_alpha_decoder"])
+def test_hip_networks_at_256_vs_reference_digests(golden_dir, name):
+    import slr_sfs_amd
+    slr_sfs_amd._lib.lib()
+    g = np.load(f"{golden_dir}/large_nets_e2e.npz")
+    net = _net(golden_dir, name, _mine(name)).cuda()
+    with torch.no_grad():
+        out = net(NF.net_input_large(name, int(g["S"])).cuda())
+    out = out if isinstance(out, tuple) else (out,)
+    assert len(out) == int(g[f"{name}_nout"])
+    for i, o in enumerate(out):
+        _check(g, f"{name}_out{i}", o, tol_rel=5e-5)
+
+
+@pytest.mark.gpu
+def test_frames_at_256_vs_reference_models(golden_dir):
+    """Frames of both animators at 256 x 256 (HIP kernels throughout) within 1e-4 max-abs of the frames the reference's own
+    models produce from the same seeded weights, image and motion."""
+    g = np.load(f"{golden_dir}/large_nets_e2e.npz")
+    S, N = int(g["S"]), int(g["N"])
+    img, motion, _ = NF.e2e_inputs(S, N)
+    img, motion = torch.from_numpy(img).cuda(), torch.from_numpy(motion).cuda()
+    ts = [int(t) for t in g["ts"]]
+    frames = _baseline(golden_dir).cuda().synthesize(img, motion, N, frames=ts)
+    for k, t in enumerate(ts):
+        _check(g, f"baseline_PredImg_t{t}", frames[k:k + 1], tol_abs=1e-4)
+    t = N // 2
+    outs = _v1(golden_dir).cuda().synthesize(img, motion, N, frames=[t], keys=("PredImg", "FluidImg", "CompositeFluidAlpha"))
+    for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
+        _check(g, f"v1_{k}_t{t}", outs[k], tol_abs=1e-4)
