@@ -47,7 +47,19 @@ sys.path.insert(0, ROOT)
 
 H, W, NFRAMES = 768, 1280, 60
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = "r2_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh) of the fused kernel; carries the build it was taken on
+TRAFFIC_FILE = "r3_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh + tools/pmc_traffic.py) of the fused kernel; carries the
+                                           # hash of the kernel sources it was taken on (a figure from another build is labelled stale)
+
+
+def csrc_hash():
+    """sha256 (first 16 hex digits) over the kernel sources of the library, in name order."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "slr-sfs_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def smooth_motion(h, w, seed=0, amp=1.5):
@@ -131,9 +143,12 @@ def splat_roofline(kev, sev, c_splat, kernel):
     traffic, src = None, None
     tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if c_splat == 65 and os.path.exists(tf):
-        traffic = round(json.load(open(tf))["traffic_bytes_per_launch"] * fpl)
+        tj = json.load(open(tf))
+        traffic = round(tj["traffic_bytes_per_launch"] * fpl)
+        same = tj.get("source_sha16") == csrc_hash()
         src = (f"static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/{TRAFFIC_FILE} (per frame of work) x "
-               "frames_per_launch, not measured in this run")
+               "frames_per_launch, not measured in this run; " +
+               ("taken on these kernel sources" if same else "STALE: taken on other kernel sources (re-run tools/pmc_traffic.sh)"))
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "alg_bytes_per_launch": round(alg * fpl), "frames_per_launch": round(fpl, 2), "launch_avg_us": round(l_avg, 1),

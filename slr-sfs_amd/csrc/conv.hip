@@ -12,7 +12,7 @@
 // 2^-22 relative).  Both operands are pre-scaled by powers of two so the lo halves stay normal
 // f16 numbers; the inverse scale is applied (exactly) to the accumulators at the end.
 // Measured error vs an fp64 convolution: 2-5e-6 on outputs of magnitude 4, the class of MIOpen's
-// fp32 Winograd kernels (1-6e-6), at 3x their speed (tools/convbench.py).
+// fp32 Winograd kernels (1-6e-6), at 3x their speed (tools/dev/convbench.py).
 //
 // Data flow of one workgroup (256 work-items = 4 waves, output block = 8 rows x 32 columns x
 // (128 | 64 | 32) output channels of one sample):
@@ -48,7 +48,7 @@ constexpr int CV_HW = CV_W + 2, CV_HH = CV_H + 2;  // input halo block
 constexpr int CV_NPX = CV_HW * CV_HH;              // 340 halo pixels
 constexpr int CV_THREADS = 256;
 #ifndef CV_EXP
-#define CV_EXP 0          // development experiments (tools/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging,
+#define CV_EXP 0          // development experiments (tools/dev/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging,
                          // 8 staging without its loads, 32 no global writes
                          // (measured ceilings at 128->128, 768x1280: all three off 512 TFLOP/s; s_setprio around the MFMAs: -4 %)
 #endif
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 // converts its 32 pixels x 16 channels in registers and multiplies them with all NCT 32-channel
 // weight tiles (A fragments from global memory / L2).  Input loads run two chunks ahead.
 #ifndef C1_EXP
-#define C1_EXP 0          // development experiments (tools/conv1x1bench.py), 64->128 at 768x1280, 249 us as shipped:
+#define C1_EXP 0          // development experiments (tools/dev/conv1x1bench.py), 64->128 at 768x1280, 249 us as shipped:
                          // 1 no stores 128 us, 2 no input loads 162 us, 4 no prefetch registers 251 us -- the read and
                          // the write phase of a wave barely overlap; 128-byte segments per plane cap both
 #endif

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/slr_splat.h"
+#include "slr_tuning.hpp"
 
 #define SLR_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -26,19 +27,10 @@ void set_error(const char *fmt, ...);
 // One workgroup owns a TILE_H x TILE_W block of OUTPUT pixels of one sample ("tile"); its bin
 // lists the source pixels whose bilinear footprint touches the tile.  Long bins are cut into segments of SEG entries so that no workgroup gets more than
 // ~2x the average work; a tile with several segments is finished by the combine kernel.
-#ifndef SLR_TILE_H
-#define SLR_TILE_H 8
-#endif
 constexpr int TILE_W   = 64;      // one wavefront of consecutive x
 constexpr int TILE_H   = SLR_TILE_H;
 constexpr int TILE_PIX = TILE_W * TILE_H;
-#ifndef SLR_EPT_ONE
-#define SLR_EPT_ONE 2
-#endif
 constexpr int SEG_ONE  = SLR_EPT_ONE * TILE_PIX;   // segment length, one flow per tile
-#ifndef SLR_EPT_TWO
-#define SLR_EPT_TWO 3
-#endif
 constexpr int SEG_TWO  = SLR_EPT_TWO * TILE_PIX;   // segment length, forward+backward flows per tile
 
 // Workspace layout (all offsets 256-byte aligned).  `hdr` is zeroed at the start of binning.

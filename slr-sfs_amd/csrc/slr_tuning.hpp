@@ -1,0 +1,96 @@
+// slr_tuning.hpp -- every compile-time knob of libslrsplat in one place, with the value that ships and the measurement
+// behind it (MI355X, gfx950; details in DESIGN.md).  Variant builds override them on the command line:
+//     make -C slr-sfs_amd/csrc OUT=../lib/var_x.so DEFS="-DSLR_XCD_GROUP=8"
+// and are compared with SLR_SFS_AMD_LIB=<variant> (tools/dropin_bench.py, tools/frontend_bench.py, tools/dev/variants.sh).
+#pragma once
+
+// ---- geometry (slr_common.hpp)
+#ifndef SLR_TILE_H
+#define SLR_TILE_H 8            // output tile = 8 rows x 64 columns = 512 work-items.  4: incoherent +28 %; 16: +6..15 %; 1 / 2: 1.5-3x slower
+#endif
+#ifndef SLR_EPT_ONE
+#define SLR_EPT_ONE 2           // bin entries per work-item, one flow: segment = 1024 entries (46 KiB of LDS with SLR_REC6 + SLR_CHUNK_ONE 4)
+#endif
+#ifndef SLR_EPT_TWO
+#define SLR_EPT_TWO 3           // two flows (fused frame): segment = 1536 entries (66 KiB, two workgroups per CU).  2: almost every tile becomes
+#endif                          // multi-segment, a frame goes from 340 to 610 us
+#ifndef SLR_EPT_SCAN
+#define SLR_EPT_SCAN 2          // SCAN instantiation.  3 (fewer shared tiles): 768x1280 Euler t=30 206 -> 188 us, but identity 145 -> 152, config C2 39 -> 44
+#endif
+
+// ---- tile kernel
+#ifndef SLR_CHUNK_ONE
+#define SLR_CHUNK_ONE 4         // planes staged per pass, one flow.  8 (round 1): 152 / 196 / 244 / 228 us vs 144 / 178 / 223 / 208 (identity / t=30 / t=59 / incoherent)
+#endif
+#ifndef SLR_REC6
+#define SLR_REC6 1              // one-flow / scan variants: records as (u16 entry, f32 weight), 6 instead of 8 bytes.  The two-flow variant keeps
+#endif                          // 8-byte records (one ds_read_b64 per record: 201 vs 206 us per frame)
+#ifndef SLR_WAVES_ONE
+#define SLR_WAVES_ONE 5         // __launch_bounds__ waves per SIMD, one-flow: <= 96 VGPRs.  4 / 5 / 6 measure the same (118.7 / 119.2 / 118.2 us identity);
+#endif                          // 6 leaves the normalising variant two registers short
+#ifndef SLR_WAVES_SCAN
+#define SLR_WAVES_SCAN 4        // SCAN instantiation (work loop + pass loop): <= 128 VGPRs = two workgroups per CU, no scratch.  5 / 6: spills (+10..70 %)
+#endif
+#ifndef SLR_KREG_ONE
+#define SLR_KREG_ONE 4          // records of an output pixel kept in registers across the chunks (one flow; 8 / 10: < 1 % gain)
+#endif
+#ifndef SLR_KREG_TWO
+#define SLR_KREG_TWO 6          // ... two flows
+#endif
+#ifndef SLR_KREG_SCAN
+#define SLR_KREG_SCAN 4         // ... SCAN instantiation (3 saves four registers, not needed)
+#endif
+#ifndef SLR_LMAX
+#define SLR_LMAX 16             // records a work-item walks alone before the wave helps (8 / 16 / 32: within 1 %)
+#endif
+#ifndef SLR_HEAVY_SLACK
+#define SLR_HEAVY_SLACK 24      // a list this much longer than the wave's share is walked by the whole wave (8: t=59 +55 %; 64: +10 %)
+#endif
+#ifndef SLR_XCD_GROUP
+#define SLR_XCD_GROUP 4         // neighbouring tiles kept on one XCD (column halo from its L2: -12 % HBM fetch).  1 / 2 / 4 / 8: 183.9 / 182.9 / 185.5 / 182.3 us per frame
+#endif
+#ifndef SLR_MAXB
+#define SLR_MAXB 8              // frames per launch of the fused kernel (kernel arguments: 8 x 256 bytes).  1 / 4 / 8: 239 / 208 / 195 us per frame of work
+#endif
+#ifndef SLR_BATCH_INTERLEAVE
+#define SLR_BATCH_INTERLEAVE 1  // block groups of the frames of a launch dealt round-robin: same tile of consecutive frames shares an L2 (fetch 770 -> 482 MB per frame)
+#endif
+
+// ---- plan (bins front end)
+#ifndef SLR_PLAN_SY
+#define SLR_PLAN_SY 1           // tile rows per super-tile of the work-item order.  2 (+ XCD group 8): -7 % fetch, +1 % time
+#endif
+#ifndef SLR_PLAN_HEAVY
+#define SLR_PLAN_HEAVY 6        // single launches: tiles with more than 6/4 of the mean entry count go first (t=30 149.6 -> 142.4 us; 5/4 .. 8/4 within 2 %)
+#endif
+
+// ---- small grids / scan front end
+#ifndef SLR_CSPLIT_MAX
+#define SLR_CSPLIT_MAX 4        // channel groups per tile on grids smaller than the chip (256x480: 2 groups 37.5 -> 33.5 us; 128x240: 4 groups 34 -> 21 us)
+#endif
+#ifndef SLR_CSPLIT_SLOTS
+#define SLR_CSPLIT_SLOTS 512    // workgroup slots of the chip the groups may fill (256 CUs x 2).  1024 / 8 groups: config C2 39 -> 54 us
+#endif
+#ifndef SLR_SCAN_MAX_TILES
+#define SLR_SCAN_MAX_TILES 512  // default of slr_splat_set_scan_max_tiles: one-flow calls on grids of at most this many tiles take the scan front end
+#endif                          // (config C2: 55.9 -> 38.1 us per call; at 1920 tiles: identity 182 -> 148, incoherent 232 -> 211, Euler t=30 209 -> 212, t=59 252 -> 280)
+#ifndef SLR_SCAN_CB
+#define SLR_SCAN_CB 5           // candidate source tiles per group of the scan (two groups' flow loads in flight).  3 / 4 / 5 / 8: C2 36.7 / 38.6 / 38.6 / 40.8 us
+#endif
+#ifndef SLR_SCAN_SHARE
+#define SLR_SCAN_SHARE 1        // heavy tiles share their segments through the work queue.  0 (one workgroup walks them): 768x1280 t=30 236 / t=59 336 us vs 212 / 280
+#endif
+#ifndef SLR_SHARE_HELPERS
+#define SLR_SHARE_HELPERS 16    // one workgroup in this many looks for shared segments after its own tile.  4 / 8 / 16: t=30 220 / 219 / 212 us, t=59 309 / 292 / 280
+#endif
+#ifndef SLR_SHARE_STORE
+#define SLR_SHARE_STORE 1       // partial slots: 0 = sc0 sc1 stores, 1 = sc1 stores, 2 = plain stores + an agent release fence per wave (all within 3 %)
+#endif
+
+// ---- development aids
+#ifndef SLR_DBG
+#define SLR_DBG 0               // 1 drain vmcnt before staging, 4 verify staged values against global memory
+#endif
+#ifndef SLR_LDS_PAD
+#define SLR_LDS_PAD 0           // bytes of unused LDS in front of the staged values
+#endif

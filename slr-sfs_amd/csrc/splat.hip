@@ -392,15 +392,6 @@ struct ItemDesc {
                                  // segment); first partial slot (multi-segment tiles)
 };
 
-#ifndef SLR_HEAVY_SLACK
-#define SLR_HEAVY_SLACK 24     // a list this much longer than the wave's share is walked by the whole wave (64: +10 % time)
-#endif
-#ifndef SLR_PLAN_SY
-#define SLR_PLAN_SY 1
-#endif
-#ifndef SLR_PLAN_HEAVY
-#define SLR_PLAN_HEAVY 6       // single launches: tiles with more than 6/4 of the mean entry count are scheduled first
-#endif
 constexpr uint32_t PLAN_SX = 4, PLAN_SY = SLR_PLAN_SY;   // super-tile of the work-item order (plan_kernel).  Measured with
 // PLAN_SY = 2 / XCD_GROUP = 8: -7 % HBM fetch (764 -> 708 MB per frame) but no time gain (+1 %): the kernel is not
 // traffic-bound at this point, so the simpler row-major order stays the default.
@@ -593,12 +584,6 @@ struct SplatArgs {
 // before the next frame's first round may start; measured with two streams, letting consecutive frames overlap takes
 // the splat of a frame from 243 to 190-200 us.  The arguments of up to MAXB frames travel as kernel arguments; a
 // workgroup finds its frame from its block index (ranges end[] for the tile kernel, cend[] for combine), wave-uniform.
-#ifndef SLR_MAXB
-#define SLR_MAXB 8
-#endif
-#ifndef SLR_BATCH_INTERLEAVE
-#define SLR_BATCH_INTERLEAVE 1
-#endif
 constexpr int MAXB = SLR_MAXB;
 struct SplatBatch {
     SplatArgs f[MAXB];
@@ -640,20 +625,8 @@ __device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps)
 #endif
 
 constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
-#ifndef SLR_XCD_GROUP
-#define SLR_XCD_GROUP 4
-#endif
 constexpr int XCD_GROUP = SLR_XCD_GROUP;                    // neighbouring tiles kept on one XCD (L2 halo reuse)
 constexpr int RB = 4;                          // records per batch in the gather loop
-#ifndef SLR_DBG
-#define SLR_DBG 0                              // development: 1 drain vmcnt before staging, 4 verify staged values (tools/ovl_debug6.py)
-#endif
-#ifndef SLR_LDS_PAD
-#define SLR_LDS_PAD 0                          // development: bytes of unused LDS in front of the staged values
-#endif
-#ifndef SLR_LMAX
-#define SLR_LMAX 16
-#endif
 constexpr int LMAX = SLR_LMAX;                       // records a work-item walks alone (longer lists: wave-cooperative)
 constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 // Per-variant shape: EPT bin entries per work-item (segment = EPT*TILE_PIX entries), CHUNK planes
@@ -665,17 +638,7 @@ constexpr int COMBINE_CHUNK = 8;               // planes per combine workgroup
 //   6-byte records, CHUNK 4             : 144 / 178 / 223 / 208
 // (6-byte records alone: no change; CHUNK 4 alone: 148 / 188 / 236 / 218.  The register cap does not matter: 4 / 5 / 6
 // waves per SIMD = 2 / 2 / 3 workgroups per CU measure the same within 1 %.)
-#ifndef SLR_CHUNK_ONE
-#define SLR_CHUNK_ONE 4
-#endif
-#ifndef SLR_REC6
-#define SLR_REC6 1             // ONE-FLOW variant: records as (u16 entry, f32 weight) in two LDS arrays, 6 instead of 8 bytes.
-#endif                         // The two-flow variant keeps 8-byte records (one ds_read_b64 per record instead of two reads:
                                // its lists are longer; measured 201 vs 206 us per frame)
-#ifndef SLR_WAVES_ONE
-#define SLR_WAVES_ONE 5        // __launch_bounds__ waves per SIMD of the one-flow instantiation: <= 96 VGPRs (6 = 80 VGPRs
-                               // measures the same -- the table below -- but leaves the NORM variant 2 registers short: spills)
-#endif
 constexpr int EPT_ONE = SEG_ONE / SPLAT_THREADS, CHUNK_ONE = SLR_CHUNK_ONE;     // (CHUNK 4 measures the same: the chunk count /
                                                                     // barrier count is not what bounds the kernel)
 constexpr int EPT_TWO = SEG_TWO / SPLAT_THREADS, CHUNK_TWO = 4;
@@ -711,30 +674,15 @@ __device__ __forceinline__ uint32_t vslot(uint32_t e, int h) {
 //
 // Workgroup = (tile, segment); TILE_PIX threads; LDS = counts + offsets + 4*seg records + 8*seg values.
 // bytes of LDS in front of the staged values: counts, wave sums, offsets, records (16-byte aligned)
-#ifndef SLR_EPT_SCAN
-#define SLR_EPT_SCAN 2         // entries per work-item of the SCAN instantiation (segment = EPT * 512 entries)
-#endif
 constexpr int EPT_SCAN = SLR_EPT_SCAN;
 __host__ __device__ constexpr bool rec6(int ept, bool scan = false) { return SLR_REC6 && (scan || ept * SPLAT_THREADS == SEG_ONE); }
 __host__ __device__ constexpr size_t lds_head_bytes(int ept, bool scan = false) {
     return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (rec6(ept, scan) ? 6 : 8) + 15) & ~(size_t)15;
 }
 // (the rare whole-tile instantiation carries a segment loop and would spill under the 80-register cap)
-#ifndef SLR_CSPLIT_MAX
-#define SLR_CSPLIT_MAX 4          // channel groups per tile on small grids (1 = off)
-#endif
-#ifndef SLR_CSPLIT_SLOTS
-#define SLR_CSPLIT_SLOTS 512      // workgroup slots of the chip the groups may fill
-#endif
-#ifndef SLR_WAVES_SCAN
-#define SLR_WAVES_SCAN 4       // SCAN instantiation (it carries the pass loop): <= 128 VGPRs, two workgroups per CU
-#endif
 constexpr int tile_min_waves(int ept, bool whole, bool scan) {
     return scan ? SLR_WAVES_SCAN : (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1;
 }
-#ifndef SLR_SCAN_CB
-#define SLR_SCAN_CB 5          // candidate source tiles per group of the scan (two groups' flow loads are in flight)
-#endif
 
 // ---- segment sharing inside the SCAN kernel ------------------------------------------------------------------------
 // A tile with more than SEG entries (the ridges of an Euler-integrated field hold up to 7x the mean) used to be walked
@@ -759,16 +707,10 @@ constexpr int tile_min_waves(int ept, bool whole, bool scan) {
 // whose writer has already reserved it (it writes it a few instructions later).
 // Control words (zeroed by scan_box_kernel of the same call): ctl[0] queue head, ctl[1] queue tail, ctl[2] partial slots
 // used, ctl[3] semaphore (signed: claims may race ahead of a push and are given back).
-#ifndef SLR_SHARE_HELPERS
-#define SLR_SHARE_HELPERS 16   // 768x1280, C = 65, whole call: 4 / 8 / 16 -> Euler t=30 220 / 219 / 212 us, t=59 309 / 292 / 280 us
-#endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 
-#ifndef SLR_SHARE_STORE
-#define SLR_SHARE_STORE 1      // partial slots: 0 = sc0 sc1 stores, 1 = sc1 stores, 2 = plain stores + an agent release fence per wave
-#endif
 __device__ __forceinline__ void store_wt16(float *p, f4v v) {          // 16-byte write-through store (untracked by the compiler's
 #if SLR_SHARE_STORE == 0
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");   // vmcnt bookkeeping: drained by hand)
@@ -1251,15 +1193,6 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     const size_t pnorm = (size_t)((a.C + 3) / 4) * 4 * TILE_PIX;
     // register-resident head of this pixel's record list (see the gather loop)
     constexpr uint32_t NULL_E = SEG;                   // staged-entry index of the all-zero slot
-#ifndef SLR_KREG_ONE
-#define SLR_KREG_ONE 4
-#endif
-#ifndef SLR_KREG_TWO
-#define SLR_KREG_TWO 6
-#endif
-#ifndef SLR_KREG_SCAN
-#define SLR_KREG_SCAN 4
-#endif
     constexpr int KREG = SCAN ? SLR_KREG_SCAN : EPT_MAX == EPT_ONE ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
     float cw[KREG];
     uint32_t ce[KREG];
@@ -1669,7 +1602,7 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
     }
     // the per-tile counts of both flows are zeroed by one launch of our own (not hipMemsetAsync: one launch
     // instead of two runtime fill kernels, and a captured hipMemsetAsync node on a workspace from torch's graph-private
-    // pool made HIP-graph replays of the binning fault -- tools/graph_try.py, test_frame_is_graph_capturable)
+    // pool made HIP-graph replays of the binning fault -- tools/dev/graph_try.py, test_frame_is_graph_capturable)
     hipLaunchKernelGGL(zero_counts_kernel, dim3((w0.L.nt + 255) / 256, nf), dim3(256), 0, st, b, w0.L.nt);
     dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), N, nf);
     hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, b, H, W, w0.L.tiles_x, w0.L.tiles);
@@ -1784,12 +1717,6 @@ static int run_plan(SplatArgs &a, bool two_flows, uint32_t items_cap, uint32_t n
     return run_batch<NORM, MAXOP>(b, &h, two_flows, items_cap, nt, part_slots, st);
 }
 
-#ifndef SLR_SCAN_SHARE
-#define SLR_SCAN_SHARE 1          // heavy tiles of the scan front end share their segments through the work queue (0: one workgroup walks them)
-#endif
-#ifndef SLR_SCAN_MAX_TILES
-#define SLR_SCAN_MAX_TILES 512    // one-flow calls on grids of at most this many tiles take the scan front end (two launches)
-#endif
 static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_splat_set_scan_max_tiles
 static bool use_scan(int prebinned, uint32_t nt) { return !prebinned && nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed); }
 

@@ -1,7 +1,9 @@
 """Cost of the round-wise clip assembly on RCCL (one GPU: world_size 1, collective path forced): frames/s of the C3
 clip with and without it.  The multi-GPU runs are the driver's; this bounds the per-collective overhead."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import os, sys, time, torch, torch.distributed as dist
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import slr_sfs_amd as S
 from slr_sfs_amd import parallel
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29555", RANK="0", WORLD_SIZE="1")

@@ -1,6 +1,8 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, '/root/repo')
+pass
 import bench
 from slr_sfs_amd import pipeline
 H, W = 768, 1280

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """3x3 convolution of the decoder: split-f16 MFMA kernel (csrc/conv.hip) vs MIOpen fp32, per decoder
 shape at the 768x1280 working resolution (development aid): error vs an fp64 convolution + time."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import math
 import os
 import sys
@@ -9,7 +11,7 @@ import time
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import slr_sfs_amd as S  # noqa: F401
 from slr_sfs_amd import _lib
 

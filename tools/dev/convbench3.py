@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Channel-blocked variants of the matrix-core convolution at the decoder's heaviest shape (development aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slr_sfs_amd import nets
 I, O, R = nets.IN_B8, nets.OUT_B8, nets.RES_B8
 

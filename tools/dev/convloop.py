@@ -1,6 +1,8 @@
 """The 128->128 3x3 matrix-core convolution at 768x1280 back to back for argv[1] seconds; prints the TFLOP/s of every second."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slr_sfs_amd import nets
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 10
 torch.manual_seed(0)

@@ -1,5 +1,7 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import copy, sys, torch
-sys.path.insert(0, '/root/repo')
+pass
 from slr_sfs_amd import nets
 torch.manual_seed(3)
 dec = nets.DecoderPconv2(64, 3).eval()

@@ -3,9 +3,11 @@
 The same 60 frames (fused two-direction splat, 64 features, 768x1280) issued one frame per launch (a) on one stream,
 (b) alternately on 2 / 3 / 4 streams, (c) 8 frames per launch (slr_synth_group_clip_batch).  Round 2, one MI355X:
 (a) 243 us per frame, (b) 190-200, (c) 195-205 (block ranges end to end) / 178-186 (block groups interleaved)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import slr_sfs_amd as S
 from bench import smooth_motion, H, W, NFRAMES
 dev = torch.device("cuda:0")

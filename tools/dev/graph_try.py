@@ -1,8 +1,10 @@
 """hipGraph capture (torch.cuda.CUDAGraph) of one frame of the pipeline vs eager launches: the frame is GPU-bound even at
 256x480, so replay buys nothing (1.48 vs 1.47 ms; 6.61 vs 6.58 ms at 768x1280) -- but it shows that a frame is capturable:
 every launch on the caller's stream, no allocation or synchronisation inside."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import sys, time, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+pass
 import slr_sfs_amd as S
 from test_gpu_parity import smooth_motion, dev
 for (H, W) in ((256, 480), (768, 1280)):

@@ -1,4 +1,6 @@
 """One-line summary of tools/kbench.py's JSON lines (stdin): mean microseconds per case."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import json, sys
 r = {}
 for l in sys.stdin:

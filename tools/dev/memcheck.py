@@ -1,6 +1,8 @@
 """Device memory over repeated clips (allocated / reserved after each): no growth, with and without the two-stream option."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import sys, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+pass
 import slr_sfs_amd as S
 from test_gpu_parity import smooth_motion, dev
 H, W, N = 768, 1280, 60

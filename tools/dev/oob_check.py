@@ -1,5 +1,7 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import sys, ctypes, torch
-sys.path.insert(0, '/root/repo')
+pass
 import slr_sfs_amd as S
 from slr_sfs_amd import nets, _lib
 L = _lib.lib()

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Clock and power of the GPU while the 128->128 3x3 convolution runs back to back (evidence for the
-# "clock(power)-limited" statement of DESIGN.md 3.4): rocm-smi sampled once a second next to tools/convloop.py.
+# "clock(power)-limited" statement of DESIGN.md 3.4): rocm-smi sampled once a second next to tools/dev/convloop.py.
 out=$1
 mkdir -p $out
-python tools/convloop.py 14 > $out/convloop.log 2>&1 &
+python tools/dev/convloop.py 14 > $out/convloop.log 2>&1 &
 pid=$!
 sleep 3                                   # import + warm-up
 for i in 1 2 3 4 5 6 7 8; do

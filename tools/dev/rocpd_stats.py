@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Per-kernel duration summary from a rocprofv3 rocpd (.db) kernel trace -> text (stdout).
 rocprofv3 --kernel-trace writes SQLite in this image; this prints what --stats would."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import glob
 import sqlite3
 import sys
