@@ -176,6 +176,22 @@ int slr_synth_group_clip_batch(const float *values, const float *wlogit, const f
                                float *const *out, float *const *norm_out, int C, int H, int W, float eps,
                                const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
                                void *scratch, size_t scratch_bytes, const int *hints, void *stream);
+
+/* slr_synth_group_clip_batch with a SECOND WEIGHT GROUP splatted by the same launch: ONE more value plane with its own
+ * weight plane -- the alpha plane of the 2-layer model, which the reference splats with CompositeFluidAlpha_I0 as weights
+ * next to the 64 feature planes weighted by Z (..._2layers_alpha_seperate.py:963-1045).  The two groups share the flow, so
+ * they share the per-tile records: the records keep the pure bilinear weights, the first group's weight multiplies its values
+ * when they are staged, and one extra chunk (the first group's weight | values2 * w2 | w2 per source pixel) yields both
+ * normalisers and the second group's sum -- instead of a second launch that rebuilds every tile's records for one plane
+ * (41 us per 768x1280 frame).
+ *   values2 [H,W], wlogit2 [H,W]: w2 = exp(wlogit2) if exp_weights2 else wlogit2;  out2[k] [H,W] per frame:
+ *   out2 = (splat(values2*w2*a, disp_f) + splat(values2*w2*(1-a), disp_p)) / max(same for w2, eps). */
+int slr_synth_two_groups_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                                    const float *values2, const float *wlogit2, int exp_weights2,
+                                    const float *const *disp_f, const float *const *disp_p, const float *alpha,
+                                    float *const *out, float *const *out2, int C, int H, int W, float eps,
+                                    const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                    void *scratch, size_t scratch_bytes, const int *hints, void *stream);
 /* slr_synth_group for frame `frame` of a built clip plan (disp_f / disp_p: that frame's two maps). */
 int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                          const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,

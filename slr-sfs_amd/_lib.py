@@ -17,7 +17,7 @@ SYMBOLS = (
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
     "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
-    "slr_splat_scratch_bytes_batch", "slr_synth_group_clip_batch",
+    "slr_splat_scratch_bytes_batch", "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
@@ -85,6 +85,7 @@ def lib():
             "slr_clip_plan_build": [fp, vp, fp, vp, i, i, i, vp, sz, vp],
             "slr_synth_group_clip": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, sz, i, i, vp, sz, i, i, i, vp],
             "slr_synth_group_clip_batch": [fp, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, sz, vp, vp],
+            "slr_synth_two_groups_clip_batch": [fp, fp, fp, i, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, sz, vp, vp],
             "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],

@@ -577,6 +577,12 @@ struct SplatArgs {
     uint32_t *ctl;          // SCAN front end, segment sharing (see ScanCtl): head / tail / slots used; nullptr = off
     unsigned long long *q_items;   // [part_slots] queue of (tile, segment) work, one 8-byte word each, 0 = not written yet
     uint32_t *arrive;       // [part_slots] arrival counter of a shared tile, indexed by its first partial slot
+    // SECOND WEIGHT GROUP of the fused two-flow kernel (the 2-layer model's alpha plane: ONE value plane with its own
+    // weight plane, ..._2layers_alpha_seperate.py:963-1045), splatted by the same launch with the same records:
+    const float *in2;       // [N,1,H,W] or nullptr
+    const float *mul2;      // [N,1,H,W] its weight logits: w2 = exp(mul2) (mulmode2 == MUL_EXP) or mul2 (MUL_PLANE)
+    float *out2;            // [N,1,H,W] = sum(w * w2 * in2) / max(sum(w * w2), eps)
+    int mulmode2, pad2_;
 };
 
 // Several frames of a clip in ONE launch: kernels on a stream run one after the other, so with one launch per frame
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     const int cb = (int)w_grp * cper, cend = min(a.C, cb + cper);
     if (cb >= a.C) return;
     uint32_t nloop = WHOLE ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;
-    float nrm_total = 0.0f;
+    float nrm_total = 0.0f, g2_sum = 0.0f, g2_nrm = 0.0f;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
     const int HW = a.H * a.W;
@@ -1024,16 +1030,21 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     __syncthreads();
 
     // ---------------- phase 1a: footprints of this work-item's bin entries, slot reservation
+    constexpr bool G2OK = NORM && !MAXOP && !SCAN && CHUNK == 4 && EPT_MAX == EPT_TWO;
+    const bool g2 = G2OK && a.in2 != nullptr;
     const float shift = (a.mulmode == MUL_EXP_SHIFT) ? a.mulmax[0] : 0.0f;
     const bool has_mul = a.mulmode != MUL_ONE;
     const uint32_t lo = s * (uint32_t)a.seg, hi = lo + (uint32_t)a.seg;   // range of the concatenated bin
     uint32_t e_pix[EPT_MAX];
+    float e_m[EPT_MAX];              // g2: the first group's weight of the entry (applied when its values are staged)
     bool e_val[EPT_MAX];
     uint32_t e_ts[EPT_MAX][4];      // (output pixel << 16) | slot, 0xffffffff = corner not in tile
     float e_w[EPT_MAX][4];
 #pragma unroll
     for (int j = 0; j < EPT_MAX; ++j) {
         e_pix[j] = 0;
+        e_m[j] = 1.0f;
+        if (g2) val4[vslot<CHUNK>(tid + j * T, 0)] = make_float4(0.f, 0.f, 0.f, 0.f);     // (entries past the bin: no records point here)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { e_ts[j][k] = 0xffffffffu; e_w[j][k] = 0.0f; }
     }
@@ -1097,6 +1108,17 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
             float m = a.scale[dir[j]];
             if (a.mulmode == MUL_PLANE) m = mm[j] * m;
             else if (a.mulmode >= MUL_EXP) m = expf(mm[j] - shift) * m;
+            if (g2) {
+                // two weight groups share the records: the records keep the PURE bilinear weights, the first group's weight
+                // m multiplies its values when they are staged, and the entry's slot of the special chunk (gathered
+                // before the value planes) carries  m | in2 * m2 | m2  -> the two normalisers and the second group's sum
+                float m2 = a.scale[dir[j]];
+                const float l2 = a.mul2[(size_t)n * HW + pix];
+                m2 = a.mulmode2 == MUL_PLANE ? l2 * m2 : expf(l2) * m2;
+                val4[vslot<CHUNK>(tid + j * T, 0)] = make_float4(m, a.in2[(size_t)n * HW + pix] * m2, m2, 0.0f);
+                e_m[j] = m;
+                m = 1.0f;
+            }
             const int lx = c.x0 - tx0, ly = c.y0 - ty0;
             const bool xa = c.ok & (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W);
             const bool xb = c.ok & (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
@@ -1208,7 +1230,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         if (tid == 0) val4[vslot<CHUNK>(NULL_E, h)] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float nrm = 0.0f;
-    if (NORM) {
+    if (NORM && !g2) {
         for (uint32_t r = r0; r < rl; ++r) nrm += REC_W(r);
         for (unsigned long long hv = heavy; hv; hv &= hv - 1) {        // long lists: the wave walks them together
             const int src = __ffsll((long long)hv) - 1;
@@ -1239,35 +1261,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     float *const trash = a.trash + tid;
     if (!inside && single) op = trash;
     const size_t ostr = (!inside && single) ? (size_t)0 : ostride;
-    auto chunk = [&](float (&pre)[EPT_MAX][CHUNK], int c0) {
-#if SLR_DBG & 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-        for (int j = 0; j < EPT_MAX; ++j)
-#pragma unroll
-            for (int h = 0; h < CHUNK / 4; ++h)
-                val4[vslot<CHUNK>(tid + j * T, h)] = make_float4(pre[j][4 * h], pre[j][4 * h + 1], pre[j][4 * h + 2], pre[j][4 * h + 3]);
-        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(4 + 3 * ((c0 - cb) / CHUNK));
-        __syncthreads();
-#if SLR_DBG & 4
-        bool dbg_bad = false;                          // staged value != what global memory holds?
-        {
-            float fresh[EPT_MAX][CHUNK];
-            prefetch(fresh, c0);
-#pragma unroll
-            for (int j = 0; j < EPT_MAX; ++j)
-#pragma unroll
-                for (int u = 0; u < CHUNK; ++u) {
-                    const float4 q = val4[vslot<CHUNK>(tid + j * T, u / 4)];
-                    const float sv = (u & 3) == 0 ? q.x : (u & 3) == 1 ? q.y : (u & 3) == 2 ? q.z : q.w;
-                    dbg_bad |= __float_as_uint(sv) != __float_as_uint(fresh[j][u]);
-                }
-        }
-#endif
-        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(5 + 3 * ((c0 - cb) / CHUNK));
-        prefetch(pre, c0 + 2 * CHUNK);                 // two chunks ahead (three: no gain fused, -20 % one flow: registers)
-        float acc[CHUNK];
+    auto gather = [&](float (&acc)[CHUNK]) {
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) acc[u] = MAXOP ? a.init : 0.0f;
         // The first KREG records of the pixel live in registers (loaded once, reused by every chunk);
@@ -1345,6 +1339,61 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
                 if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], part[u]) : acc[u] + part[u];
             }
         }
+    };
+    // ---- second weight group (g2): the special chunk staged in phase 1a, gathered with the same records BEFORE the value planes
+    // acc2[0] = sum w*m (normaliser of the first group), acc2[1] = sum w*m2*in2, acc2[2] = sum w*m2
+    if (g2) {
+        __syncthreads();                               // the special values of all entries + the NULL slot are in LDS
+        float acc2[CHUNK];
+        gather(acc2);
+        nrm_total += acc2[0];
+        g2_sum += acc2[1];
+        g2_nrm += acc2[2];
+        nrm = nrm_total;                               // (all segments seen so far: whole-tile items)
+        if (single) {
+            if (last && cb == 0 && inside) {
+                if (a.norm_out) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
+                a.out2[(size_t)n * HW + (size_t)oy * a.W + ox] = finish(g2_sum, g2_nrm, a.norm_mode, a.eps);
+            }
+        } else if (cb == 0) {
+            float *pp = a.partial + (size_t)(it.partoff + s) * a.part_stride + (size_t)a.C * TILE_PIX + tid;
+            pp[0] = acc2[0];
+            pp[TILE_PIX] = acc2[1];
+            pp[2 * TILE_PIX] = acc2[2];
+        }
+        __syncthreads();                               // val4 is overwritten by the first value chunk
+    }
+    auto chunk = [&](float (&pre)[EPT_MAX][CHUNK], int c0) {
+#if SLR_DBG & 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+        for (int j = 0; j < EPT_MAX; ++j)
+#pragma unroll
+            for (int h = 0; h < CHUNK / 4; ++h)
+                val4[vslot<CHUNK>(tid + j * T, h)] = G2OK ? make_float4(pre[j][4 * h] * e_m[j], pre[j][4 * h + 1] * e_m[j], pre[j][4 * h + 2] * e_m[j], pre[j][4 * h + 3] * e_m[j])
+                                                          : make_float4(pre[j][4 * h], pre[j][4 * h + 1], pre[j][4 * h + 2], pre[j][4 * h + 3]);
+        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(4 + 3 * ((c0 - cb) / CHUNK));
+        __syncthreads();
+#if SLR_DBG & 4
+        bool dbg_bad = false;                          // staged value != what global memory holds?
+        {
+            float fresh[EPT_MAX][CHUNK];
+            prefetch(fresh, c0);
+#pragma unroll
+            for (int j = 0; j < EPT_MAX; ++j)
+#pragma unroll
+                for (int u = 0; u < CHUNK; ++u) {
+                    const float4 q = val4[vslot<CHUNK>(tid + j * T, u / 4)];
+                    const float sv = (u & 3) == 0 ? q.x : (u & 3) == 1 ? q.y : (u & 3) == 2 ? q.z : q.w;
+                    dbg_bad |= __float_as_uint(sv) != __float_as_uint(fresh[j][u]);
+                }
+        }
+#endif
+        if ((c0 - cb) / CHUNK < 9) SLR_STAMP(5 + 3 * ((c0 - cb) / CHUNK));
+        prefetch(pre, c0 + 2 * CHUNK);                 // two chunks ahead (three: no gain fused, -20 % one flow: registers)
+        float acc[CHUNK];
+        gather(acc);
         if (SCAN && part) {                            // raw sums of this segment -> its partial slot, write-through
             static_assert(!SCAN || CHUNK == 4, "partial-slot layout of the SCAN kernel");
             f4v pv;
@@ -1498,6 +1547,14 @@ __global__ __launch_bounds__(SPLAT_THREADS) void combine_kernel(SplatBatch batch
         for (uint32_t s = 0; s < ns; ++s) nrm += src[(size_t)s * a.part_stride + (size_t)a.C * TILE_PIX];
         if (a.norm_out && blockIdx.y == 0)
             a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
+        if (a.in2 && blockIdx.y == 0) {                            // second weight group: raw sum and normaliser planes C+1, C+2
+            float s2 = 0.0f, n2 = 0.0f;
+            for (uint32_t s = 0; s < ns; ++s) {
+                s2 += src[(size_t)s * a.part_stride + (size_t)(a.C + 1) * TILE_PIX];
+                n2 += src[(size_t)s * a.part_stride + (size_t)(a.C + 2) * TILE_PIX];
+            }
+            a.out2[(size_t)n * HW + (size_t)oy * a.W + ox] = finish(s2, n2, a.norm_mode, a.eps);
+        }
     }
     float *op = a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox;
     for (int c = c0; c < min(c0 + COMBINE_CHUNK, a.C); ++c) {
@@ -1978,7 +2035,7 @@ SLR_EXPORT size_t slr_clip_plan_bytes(int nframes, int H, int W) {
 SLR_EXPORT size_t slr_splat_scratch_bytes(int C, int H, int W) {
     if (C <= 0 || H <= 0 || W <= 0) return 0;
     const ClipLayout L = clip_layout(1, H, W);
-    const size_t stride = (size_t)(C + 1) * TILE_PIX * 4;
+    const size_t stride = (size_t)(C + 3) * TILE_PIX * 4;
     return al256(stride) + al256((size_t)L.part_slots * stride);
 }
 
@@ -2031,7 +2088,7 @@ SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const 
 static void clip_frame_args(SplatArgs &a, const ClipLayout &L, const void *plan, int frame, void *scratch, int slot, int C) {
     const char *b = (const char *)plan;
     const size_t i = (size_t)frame;
-    const size_t stride = (size_t)(C + 1) * TILE_PIX;
+    const size_t stride = (size_t)(C + 3) * TILE_PIX;        // value planes, normaliser, second group's sum and normaliser
     const size_t slot_bytes = al256((size_t)L.part_slots * stride * 4);
     a.tiles_x = L.tiles_x; a.tiles = L.tiles;
     a.count[0] = (const uint32_t *)(b + L.off_count) + i * L.nt;
@@ -2049,7 +2106,7 @@ static void clip_frame_args(SplatArgs &a, const ClipLayout &L, const void *plan,
 }
 
 static size_t clip_scratch_need(const ClipLayout &L, int C, int nb) {
-    const size_t stride = (size_t)(C + 1) * TILE_PIX;
+    const size_t stride = (size_t)(C + 3) * TILE_PIX;
     return al256(stride * 4) + (size_t)nb * al256((size_t)L.part_slots * stride * 4);
 }
 
@@ -2058,12 +2115,14 @@ SLR_EXPORT size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb) {
     return clip_scratch_need(clip_layout(1, H, W), C, nb);
 }
 
-SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
-                                          const float *const *disp_f, const float *const *disp_p, const float *alpha,
-                                          float *const *out, float *const *norm_out, int C, int H, int W, float eps,
-                                          const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                                          void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+static int synth_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                            const float *values2, const float *wlogit2, int exp_weights2, float *const *out2,
+                            const float *const *disp_f, const float *const *disp_p, const float *alpha,
+                            float *const *out, float *const *norm_out, int C, int H, int W, float eps,
+                            const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                            void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
     SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && alpha && out && plan && scratch && frame, "null pointer");
+    SLR_CHECK_ARG((!values2 && !wlogit2 && !out2) || (values2 && wlogit2 && out2), "the second group needs values, weights and outputs");
     SLR_CHECK_ARG(nb >= 1 && nb <= MAXB, "1 <= nb <= 8 frames per launch");
     if (int e = check_dims(1, C, H, W, __func__)) return e;
     if (int e = clip_check(nframes, H, W, __func__)) return e;
@@ -2089,12 +2148,37 @@ SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlog
         a.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
         a.norm_mode = SLR_NORM_CLAMP_EPS;
         a.eps = eps;
+        if (values2) {
+            SLR_CHECK_ARG(out2[k], "null pointer");
+            a.in2 = values2; a.mul2 = wlogit2; a.out2 = out2[k];
+            a.mulmode2 = exp_weights2 ? MUL_EXP : MUL_PLANE;
+        }
         clip_frame_args(a, L, plan, frame[k], scratch, k, C);
         h[k].n_items = hints ? hints[3 * k] : -1;
         h[k].n_multi = hints ? hints[3 * k + 1] : -1;
         h[k].n_whole = hints ? hints[3 * k + 2] : -1;
     }
     return run_batch<true, false>(b, h, true, L.items_cap, L.nt, L.part_slots, (hipStream_t)stream);
+}
+
+SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                                          const float *const *disp_f, const float *const *disp_p, const float *alpha,
+                                          float *const *out, float *const *norm_out, int C, int H, int W, float eps,
+                                          const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                          void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+    return synth_clip_batch(values, wlogit, wmax, exp_weights, nullptr, nullptr, 0, nullptr, disp_f, disp_p, alpha, out, norm_out,
+                            C, H, W, eps, plan, plan_bytes, nframes, frame, nb, scratch, scratch_bytes, hints, stream);
+}
+
+SLR_EXPORT int slr_synth_two_groups_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
+                                               const float *values2, const float *wlogit2, int exp_weights2,
+                                               const float *const *disp_f, const float *const *disp_p, const float *alpha,
+                                               float *const *out, float *const *out2, int C, int H, int W, float eps,
+                                               const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                               void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+    SLR_CHECK_ARG(values2 && wlogit2 && out2, "null pointer");
+    return synth_clip_batch(values, wlogit, wmax, exp_weights, values2, wlogit2, exp_weights2, out2, disp_f, disp_p, alpha, out,
+                            nullptr, C, H, W, eps, plan, plan_bytes, nframes, frame, nb, scratch, scratch_bytes, hints, stream);
 }
 
 SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,

@@ -209,9 +209,12 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
 MAX_BATCH = min(8, max(1, int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "8"))))   # frames per launch of slr_synth_group_clip_batch (csrc: MAXB = 8)
 
 
-def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_weights=True, eps=1e-8, timed=False):
+def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_weights=True, eps=1e-8, timed=False,
+                           group2=None):
     """synth_group_clip for up to MAX_BATCH frames `ts` of ONE chunk of a MotionPlan in one launch of the tile kernel:
-    outs[k] ([1,C,H,W], e.g. the samples of a decoder batch) receives frame ts[k]."""
+    outs[k] ([1,C,H,W], e.g. the samples of a decoder batch) receives frame ts[k].
+    group2 = (values2 [1,1,H,W], wlogit2 [1,1,H,W], outs2): a second weight group (exp weights) splatted by the same launch
+    with the same records -- the 2-layer model's alpha plane (slr_synth_two_groups_clip_batch)."""
     require_device(values, wlogit, wmax, *outs)
     assert values.shape[0] == 1 and wlogit.shape[1] == 1 and 1 <= len(ts) <= MAX_BATCH and len(outs) == len(ts)
     _, C, H, W = values.shape
@@ -233,9 +236,20 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
     with torch.cuda.device(values.device):
         if timed and kernel_timing is not None:
             _arm_timer(values, nb)
-        check(L.slr_synth_group_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, df, dp, al, op,
-                                           None, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb, ptr(scratch),
-                                           scratch.numel(), hints, stream_of(values)), "slr_synth_group_clip_batch")
+        if group2 is None:
+            check(L.slr_synth_group_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, df, dp, al, op,
+                                               None, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb, ptr(scratch),
+                                               scratch.numel(), hints, stream_of(values)), "slr_synth_group_clip_batch")
+        else:
+            v2, w2, outs2 = group2
+            require_device(v2, w2, *outs2)
+            assert v2.shape == (1, 1, H, W) and w2.shape == (1, 1, H, W) and len(outs2) == nb
+            assert all(o.shape == (1, 1, H, W) and o.is_contiguous() for o in outs2)
+            op2 = PP(*[o.data_ptr() for o in outs2])
+            check(L.slr_synth_two_groups_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, ptr(v2), ptr(w2), 1,
+                                                    df, dp, al, op, op2, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb,
+                                                    ptr(scratch), scratch.numel(), hints, stream_of(values)),
+                  "slr_synth_two_groups_clip_batch")
     return outs
 
 
@@ -324,11 +338,10 @@ class ClipSynthesizer:
             grp = ts[k0:k1]
             al = [self.alpha(t) for t in grp]
             with _stage("frame", self.fs.device, frames=len(grp)):
+                # (2-layer model: the alpha plane, weighted by alpha0, rides in the same launch as a second weight group)
                 synth_group_clip_batch(self.fs, self.Z, self.plan, grp, al, [out[k:k + 1] for k in range(k0, k1)],
-                                       wmax=self.zmax, timed=True)
-                if self.v1:
-                    synth_group_clip_batch(self.af, self.A0, self.plan, grp, al,
-                                           [out_alpha[k:k + 1] for k in range(k0, k1)], wmax=None, exp_weights=True)
+                                       wmax=self.zmax, timed=True,
+                                       group2=(self.af, self.A0, [out_alpha[k:k + 1] for k in range(k0, k1)]) if self.v1 else None)
             k0 = k1
 
     def _features(self, t, return_norm, out=None, out_alpha=None):
@@ -339,6 +352,11 @@ class ClipSynthesizer:
             Zt = self.Z - _FunctionMaximumWarpNormsplat(self.Z, self.disp_f[t:t + 1].contiguous())
             if self.clamp_z is not None:
                 Zt = torch.clamp(Zt, min=self.clamp_z[0], max=self.clamp_z[1])
+        if self.v1 and self.use_alpha0 and not return_norm:      # both weight groups in one launch
+            gen = out if out is not None else torch.empty_like(self.fs)
+            afl = out_alpha if out_alpha is not None else self.fs.new_empty(1, 1, *self.fs.shape[2:])
+            synth_group_clip_batch(self.fs, Zt, self.plan, [t], [a], [gen], wmax=self.zmax, timed=True, group2=(self.af, self.A0, [afl]))
+            return gen, afl
         res = synth_group_clip(self.fs, Zt, self.plan, t, a, wmax=self.zmax, return_norm=return_norm, timed=True, out=out)
         gen, norm = res if return_norm else (res, None)
         if not self.v1:
