@@ -21,6 +21,9 @@ namespace slr {
 #ifndef SLR_GRAD_U
 #define SLR_GRAD_U 4
 #endif
+#ifndef SLR_GRAD_TILED
+#define SLR_GRAD_TILED 1       // 1: grad_tile_kernel (gathers through LDS where the block's destination box fits), 0: grad_kernel
+#endif
 
 template <bool GIN, bool GFLOW>
 __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in, const float *__restrict__ flow,
@@ -87,6 +90,160 @@ __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in,
     }
 }
 
+// ---- the same gradients with the gathers served from LDS ---------------------------------------------------------------
+// On Euler-integrated flows the four corner gathers of grad_kernel land on 1-6 cache lines per wave and instruction and
+// run at 1.7-2.2 TB/s (identity flow: 4.6).  A flow that is smooth over a tile keeps the destinations of an 8x64 block of
+// source pixels inside a small bounding box: the workgroup (one work-item per source pixel of the block) reduces that box,
+// stages the box of gradOutput for U channels with coalesced row loads (wave w takes rows w, w+8, ...), and every
+// work-item gathers its four corners from LDS -- same values, same terms, same order: bit-identical to grad_kernel.
+// A block whose box does not fit (incoherent or strongly stretching flow), or whose rows stay straight (the direct gathers
+// are then already coalesced), takes the direct gathers instead (decided per block).
+// Measured (768x1280, C = 65, tools/bwdbench.py; grad_kernel -> this kernel): Euler t=30 gradInput 254 -> 186 us, gradFlow
+// 242 -> 173, both gradients 279 -> 222 (0.35 -> 0.44 of 8 TB/s on 3C planes); t=59 both 346 -> 297; identity flow
+// gradInput 119 -> 129, both 165 -> 195 (the direct path carries this kernel's registers: 96 VGPRs).
+constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
+#ifndef SLR_GRAD_BOX
+#define SLR_GRAD_BOX 2048                              // floats of LDS per channel (e.g. 20 rows x 100 columns); x U channels x 4 bytes = 32 KiB
+#endif
+#ifndef SLR_GRAD_TU
+#define SLR_GRAD_TU 4                                  // channels per pass of the tiled kernel (4 / 8 / 16 at box 2048 / 1536 / 1024: Euler t=30,
+#endif                                                 // both gradients, 223 / 245 / 301 us; grad_kernel: 279)
+#ifndef SLR_GRAD_BENT
+#define SLR_GRAD_BENT 2                                // stage through LDS only where a wave's destinations spread over more rows than this
+#endif
+#ifndef SLR_GRAD_WAVES
+#define SLR_GRAD_WAVES 4                               // __launch_bounds__ waves per SIMD of the tiled kernel
+#endif
+constexpr int GT_BOX = SLR_GRAD_BOX;
+
+template <bool GIN, bool GFLOW>
+__global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(const float *__restrict__ in, const float *__restrict__ flow,
+                                                               const float *__restrict__ gout, float *__restrict__ gin,
+                                                               float *__restrict__ gflow, int C, int H, int W, int tiles_x) {
+    constexpr int U = SLR_GRAD_TU;
+    __shared__ float box[U][GT_BOX];
+    __shared__ int red[TILE_H][4];
+    const int HW = H * W;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int y = (blockIdx.x / tiles_x) * TILE_H + wid, x = (blockIdx.x % tiles_x) * TILE_W + lane;
+    const bool live_px = (y < H) & (x < W);
+    const int i = live_px ? y * W + x : 0;
+    const float *f = flow + (size_t)n * 2 * HW;
+    const float fxv = f[i], fyv = f[HW + i];
+    const Corners c = make_corners(fxv, fyv, x, y);
+    const bool k0 = live_px & c.ok & in_image(c.x0, c.y0, H, W), k1 = live_px & c.ok & in_image(c.x0 + 1, c.y0, H, W);
+    const bool k2 = live_px & c.ok & in_image(c.x0, c.y0 + 1, H, W), k3 = live_px & c.ok & in_image(c.x0 + 1, c.y0 + 1, H, W);
+    const float X = (float)x + fxv, Y = (float)y + fyv;
+    const float ax = (float)(c.x0 + 1) - X, bx = X - (float)c.x0;
+    const float ay = (float)(c.y0 + 1) - Y, by = Y - (float)c.y0;
+    const float dx[4] = {(-1.0f) * ay, (+1.0f) * ay, (-1.0f) * by, (+1.0f) * by};
+    const float dy[4] = {ax * (-1.0f), bx * (-1.0f), ax * (+1.0f), bx * (+1.0f)};
+    // bounding box of the in-image corners of the block
+    const bool any = k0 | k1 | k2 | k3;
+    int bx0 = any ? max(c.x0, 0) : 0x7fffffff, bx1 = any ? min(c.x0 + 1, W - 1) : -1;
+    int by0 = any ? max(c.y0, 0) : 0x7fffffff, by1 = any ? min(c.y0 + 1, H - 1) : -1;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
+        by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
+    }
+    if (lane == 0) { red[wid][0] = bx0; red[wid][1] = bx1; red[wid][2] = by0; red[wid][3] = by1; }
+    __syncthreads();
+    // rows of gradOutput ONE wave's 64 destinations spread over: 2 for a flow that keeps rows straight (the direct gathers
+    // are then as coalesced as they get: identity flow 4.7 TB/s), more where the flow bends them
+    int bent = 0;
+#pragma unroll
+    for (int w = 0; w < TILE_H; ++w) {
+        bent = max(bent, red[w][3] - red[w][2] + 1);
+        bx0 = min(bx0, red[w][0]); bx1 = max(bx1, red[w][1]); by0 = min(by0, red[w][2]); by1 = max(by1, red[w][3]);
+    }
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;              // (<= 0: nothing of this block lands in the image)
+    const bool staged = bw > 0 && bh > 0 && (long long)bw * bh <= GT_BOX && bent > SLR_GRAD_BENT;   // workgroup-uniform
+    const int o = c.y0 * W + c.x0;
+    // global offsets (direct gathers) / LDS offsets (staged); an out-of-image corner reads a valid address and its
+    // PRODUCT is replaced by +0.0 (see grad_kernel)
+    const int g0 = k0 ? o : i, g1 = k1 ? o + 1 : i, g2 = k2 ? o + W : i, g3 = k3 ? o + W + 1 : i;
+    const int lo = (c.y0 - by0) * bw + (c.x0 - bx0);
+    const int l0 = k0 ? lo : 0, l1 = k1 ? lo + 1 : 0, l2 = k2 ? lo + bw : 0, l3 = k3 ? lo + bw + 1 : 0;
+    const float *ip = in + (size_t)n * C * HW;
+    const float *gp = gout + (size_t)n * C * HW;
+    float *op = gin + (size_t)n * C * HW;
+    float gx = 0.0f, gy = 0.0f;
+    // staged path: the box is walked as ONE linear index range (dense wave loads across row ends); the values of the NEXT
+    // pass are loaded into registers while this pass is gathered from LDS, and written to LDS after the barrier
+    constexpr int NS = (GT_BOX + GT_THREADS - 1) / GT_THREADS;
+    const int nbox = bw * bh;
+    int soff[NS];                                                  // global offset of this work-item's k-th box element
+    const float inv_bw = 1.0f / (float)(bw > 0 ? bw : 1);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int idx = tid + k * GT_THREADS;
+        const int r = (int)(((float)idx + 0.5f) * inv_bw);         // idx / bw, exact for idx < 2^22
+        soff[k] = (staged && idx < nbox) ? (by0 + r) * W + bx0 + (idx - r * bw) : 0;
+    }
+    float sv[NS][U];
+    auto issue = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float *pl = gp + (size_t)min(ch + u, C - 1) * HW;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sv[k][u] = pl[soff[k]];
+        }
+    };
+    if (staged) issue(0);
+    for (int ch = 0; ch < C; ch += U) {
+        float a0[U], a1[U], a2[U], a3[U], v[U];
+        if (staged) {
+            __syncthreads();                                       // the previous pass has been gathered
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int idx = tid + k * GT_THREADS;
+                if (idx < nbox)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) box[u][idx] = sv[k][u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (GFLOW) v[u] = ip[(size_t)min(ch + u, C - 1) * HW + i];
+            __syncthreads();
+            if (ch + U < C) issue(ch + U);                         // in flight under this pass's gathers, sums and stores
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a0[u] = box[u][l0]; a1[u] = box[u][l1]; a2[u] = box[u][l2]; a3[u] = box[u][l3]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t po = (size_t)min(ch + u, C - 1) * HW;
+                a0[u] = gp[po + g0]; a1[u] = gp[po + g1]; a2[u] = gp[po + g2]; a3[u] = gp[po + g3];
+                if (GFLOW) v[u] = ip[po + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = (ch + u < C) & live_px;
+            if (GIN) {
+                float g = 0.0f;
+                g += k0 ? a0[u] * c.w[0] : 0.0f;
+                g += k1 ? a1[u] * c.w[1] : 0.0f;
+                g += k2 ? a2[u] * c.w[2] : 0.0f;
+                g += k3 ? a3[u] * c.w[3] : 0.0f;
+                if (live) op[(size_t)(ch + u) * HW + i] = g;
+            }
+            if (GFLOW && live) {
+                const float t0 = v[u] * a0[u], t1 = v[u] * a1[u], t2 = v[u] * a2[u], t3 = v[u] * a3[u];
+                gx += k0 ? t0 * dx[0] : 0.0f; gy += k0 ? t0 * dy[0] : 0.0f;
+                gx += k1 ? t1 * dx[1] : 0.0f; gy += k1 ? t1 * dy[1] : 0.0f;
+                gx += k2 ? t2 * dx[2] : 0.0f; gy += k2 ? t2 * dy[2] : 0.0f;
+                gx += k3 ? t3 * dx[3] : 0.0f; gy += k3 ? t3 * dy[3] : 0.0f;
+            }
+        }
+    }
+    if (GFLOW && live_px) {
+        gflow[(size_t)n * 2 * HW + i] = gx;
+        gflow[(size_t)n * 2 * HW + HW + i] = gy;
+    }
+}
+
 // out[src] = max(seed[src], max over in-bounds corners of maxwarp[corner])
 // (kernel_Inversesplat_updateOutput, softsplat.py:84-155; seed = input.clone(), :606)
 __global__ __launch_bounds__(256) void inverse_max_kernel(const float *__restrict__ seed,
@@ -125,11 +282,19 @@ SLR_EXPORT int slr_softsplat_backward(const float *in, const float *flow, const 
     SLR_CHECK_ARG(flow && grad_out, "null pointer");
     SLR_CHECK_ARG(!grad_flow || in, "input required for grad_flow");
     SLR_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && (long long)N * H * W < (1LL << 29), "sizes");
-    dim3 grid((H * W + 255) / 256, N);
     hipStream_t st = (hipStream_t)stream;
+#if SLR_GRAD_TILED
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    dim3 grid(tiles_x * tiles_y, N);
+    if (grad_in && grad_flow) hipLaunchKernelGGL((grad_tile_kernel<true, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
+    else if (grad_in) hipLaunchKernelGGL((grad_tile_kernel<true, false>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
+    else if (grad_flow) hipLaunchKernelGGL((grad_tile_kernel<false, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
+#else
+    dim3 grid((H * W + 255) / 256, N);
     if (grad_in && grad_flow) hipLaunchKernelGGL((grad_kernel<true, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
     else if (grad_in) hipLaunchKernelGGL((grad_kernel<true, false>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
     else if (grad_flow) hipLaunchKernelGGL((grad_kernel<false, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
+#endif
     SLR_CHECK_LAUNCH();
     return 0;
 }
