@@ -583,6 +583,9 @@ struct SplatArgs {
     const float *mul2;      // [N,1,H,W] its weight logits: w2 = exp(mul2) (mulmode2 == MUL_EXP) or mul2 (MUL_PLANE)
     float *out2;            // [N,1,H,W] = sum(w * w2 * in2) / max(sum(w * w2), eps)
     int mulmode2, pad2_;
+#ifdef SLR_SCAN_ORDER_HOOK
+    const uint32_t *order;
+#endif
 };
 
 // Several frames of a clip in ONE launch: kernels on a stream run one after the other, so with one launch per frame
@@ -788,6 +791,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         const uint32_t slot = bx >> 3;
         item = ((slot / XCD_GROUP) * 8u + (bx & 7u)) * XCD_GROUP + slot % XCD_GROUP;
         if (item >= a.nt) return;
+#ifdef SLR_SCAN_ORDER_HOOK
+        if (a.order) item = a.order[bx < a.nt ? bx : 0];          // experiment: tiles in a given order (heaviest first)
+#endif
     } else if (!WHOLE) {
         const uint32_t total = a.totals[0];
         const uint32_t slot = bx >> 3;
@@ -1774,6 +1780,9 @@ static int run_plan(SplatArgs &a, bool two_flows, uint32_t items_cap, uint32_t n
     return run_batch<NORM, MAXOP>(b, &h, two_flows, items_cap, nt, part_slots, st);
 }
 
+#ifdef SLR_SCAN_ORDER_HOOK
+static const uint32_t *g_scan_order = nullptr;
+#endif
 static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_splat_set_scan_max_tiles
 static bool use_scan(int prebinned, uint32_t nt) { return !prebinned && nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed); }
 
@@ -1795,6 +1804,9 @@ static int do_splat_scan(SplatArgs a, Ws &w0, hipStream_t st) {
     a.seg = EPT_SCAN * SPLAT_THREADS;
 #ifdef SLR_TRACE
     a.trace = g_trace;
+#endif
+#ifdef SLR_SCAN_ORDER_HOOK
+    a.order = g_scan_order;
 #endif
     hipLaunchKernelGGL(scan_box_kernel, dim3(w0.L.nt), dim3(TILE_PIX), 0, st, a.flow[0], w0.box, a.H, a.W, w0.L.tiles_x, w0.L.tiles,
                        w0.ctl, w0.queue, w0.arrive, w0.L.part_slots);
@@ -1894,6 +1906,10 @@ SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {
 
 #ifdef SLR_SCAN_STATS
 SLR_EXPORT size_t slr_debug_ctl_offset(int N, int C, int H, int W) { return ws_layout(N, C, H, W).off_ctl; }
+#endif
+
+#ifdef SLR_SCAN_ORDER_HOOK
+SLR_EXPORT void slr_debug_scan_order(const uint32_t *order) { slr::g_scan_order = order; }
 #endif
 
 SLR_EXPORT int slr_splat_set_scan_max_tiles(int max_tiles) {
