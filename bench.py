@@ -52,13 +52,12 @@ TRAFFIC_FILE = "r3_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh + 
 
 
 def csrc_hash():
-    """sha256 (first 16 hex digits) over the kernel sources of the library, in name order."""
-    import glob
+    """sha256 (first 16 hex digits) over the sources of the splat kernels (the files the fused tile kernel is built from)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "slr-sfs_amd", "csrc", "*.h*"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in ("slr_common.hpp", "slr_tuning.hpp", "splat.hip"):
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "slr-sfs_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 
