@@ -182,3 +182,16 @@ def test_full_size_planes_vs_oracle(S, oracle, frontend):
     ref = oracle.softsplat_forward(x, flow)
     bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
     assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+
+
+def test_more_than_2048_source_tiles_per_sample(S, oracle, frontend):
+    """560 x 2048 = 70 x 32 = 2240 tiles per sample: the scan front end tests the source tiles' boxes in rounds of 2048
+    (two rounds here, the second one ragged), two samples."""
+    H, W, C = 560, 2048, 2
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=2.0), 12 + n)[0] for n in range(2)])
+    out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+    ref = oracle.softsplat_forward(x, flow)
+    bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
+    assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())

@@ -1328,6 +1328,45 @@ def test_fused_synthesis_with_sink_motion_vs_oracle(S, oracle):
         np.testing.assert_allclose(host(aa), afl, rtol=2e-4, atol=5e-5)
 
 
+def test_two_weight_groups_whole_tile_items_and_underflowing_weights(S, oracle):
+    """The 2-layer model's alpha plane rides in the feature launch as a second weight group (shared records, pure
+    bilinear weights).  (1) every source pixel onto one corner: whole-tile items (tiles over the partial-slot budget are
+    walked segment by segment by one workgroup) next to ordinary frames of the batch; (2) Z spread over 400: e^(Z - Zmax)
+    underflows to 0 for most pixels -- their features vanish as in the reference, their alpha (weights e^alpha0 = O(1)) must
+    not."""
+    H, W, N = 320, 640, 3
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    m = np.stack([W / 2 - x - 0.5, H / 2 - y - 0.5])[None].astype(np.float32)
+    rng = np.random.default_rng(28)
+    fs = rng.standard_normal((1, 6, H, W)).astype(np.float32)
+    Z = (rng.standard_normal((1, 1, H, W)) * 0.3).astype(np.float32)
+    a = rng.standard_normal((1, 2, H, W)).astype(np.float32)
+    abg = (1 / (1 + np.exp(-a[:, 0:1]))).astype(np.float32)
+    cv = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=dev(abg))
+    ts = [1, 0, 2]
+    assert cv.plan.lookup(1)[3][2] > 0                                 # frame 1 has whole-tile items
+    out, outa = torch.empty(3, 6, H, W, device="cuda"), torch.empty(3, 1, H, W, device="cuda")
+    cv.features_batch(ts, out, outa)
+    for k, t in enumerate(ts):
+        g, afl, _ = oracle.synth_v1(fs, Z, a[:, 1:2], abg, m, t, N)
+        np.testing.assert_allclose(host(out[k:k + 1]), g, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(g).max())), err_msg=str(t))
+        np.testing.assert_allclose(host(outa[k:k + 1]), afl, rtol=1e-3, atol=1e-4, err_msg=str(t))
+    # (2)
+    H, W, N = 96, 200, 8
+    fs = rng.standard_normal((1, 9, H, W)).astype(np.float32)
+    Z = (rng.uniform(-400, 0, (1, 1, H, W))).astype(np.float32)
+    a = rng.standard_normal((1, 2, H, W)).astype(np.float32)
+    abg = (1 / (1 + np.exp(-a[:, 0:1]))).astype(np.float32)
+    m = smooth_motion(H, W, 3, amp=2.0)
+    cv = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=dev(abg))
+    for t in (1, 5):
+        g, afl, _ = oracle.synth_v1(fs, Z, a[:, 1:2], abg, m, t, N)
+        gg, aa = cv.features(t)
+        assert float(np.abs(afl).max()) > 0.5 and (g == 0).mean() > 0.2          # features mostly gone, alpha plane alive
+        np.testing.assert_allclose(host(aa), afl, rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(host(gg), g, rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("tag", ["c2", "c3"])
 def test_full_size_reference_digests(S, golden_dir, tag):
     """HIP path vs digests of the REFERENCE's own outputs at the C2 / C3 grids (no oracle involved):
