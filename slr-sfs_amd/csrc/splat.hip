@@ -729,19 +729,8 @@ __device__ __forceinline__ void store_wt16(float *p, f4v v) {          // 16-byt
     *reinterpret_cast<f4v *>(p) = v;
 #endif
 }
-__device__ __forceinline__ f4v load_wt16(const float *p) {             // two 8-byte loads that bypass L1 (agent scope)
-    const unsigned long long x = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long y = __hip_atomic_load((gu64 *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f4v r;
-    r.x = __uint_as_float((uint32_t)x); r.y = __uint_as_float((uint32_t)(x >> 32));
-    r.z = __uint_as_float((uint32_t)y); r.w = __uint_as_float((uint32_t)(y >> 32));
-    return r;
-}
 __device__ __forceinline__ void store_wt4(float *p, float v) {
     __hip_atomic_store((gu32 *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float load_wt4(const float *p) {
-    return __uint_as_float(__hip_atomic_load((gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 // work word: [63:38] tile + 1 (never 0), [37:30] segment, [29:22] segments of the tile, [21:4] first partial slot, [3:0] channel group
 __device__ __forceinline__ unsigned long long pack_work(uint32_t tile, uint32_t seg, uint32_t ns, uint32_t po, uint32_t grp) {
@@ -1437,10 +1426,6 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-#ifdef SLR_SHARE_SKIP_COMBINE
-            if (tid == 0) wsum[0] = 0;
-            if (false)
-#endif
             if (tid == 0) {
                 wsum[0] = atomicAdd(&a.arrive[w_po], 1u);
                 // the partial slots were stored write-through and drained before their arrivals: ONE agent-scope acquire (drops this
