@@ -7,13 +7,14 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/slr_splat.h declares
 SYMBOLS = (
     "slr_abi_version", "slr_last_error", "slr_splat_time_next",
     "slr_euler_integrate", "slr_euler_integrate_all", "slr_euler_backward",
     "slr_splat_workspace_bytes", "slr_splat_bin", "slr_splat_bin_pair", "slr_splat_set_scan_max_tiles",
+    "slr_splat_set_front_end",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
     "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
@@ -58,6 +59,8 @@ def lib():
         L.slr_splat_time_next.argtypes = [vp, vp]
         L.slr_splat_set_scan_max_tiles.restype = i
         L.slr_splat_set_scan_max_tiles.argtypes = [i]
+        L.slr_splat_set_front_end.restype = i
+        L.slr_splat_set_front_end.argtypes = [i]
         L.slr_splat_workspace_bytes.restype = sz
         L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
         L.slr_clip_plan_bytes.restype = sz

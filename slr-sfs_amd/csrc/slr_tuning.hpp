@@ -87,6 +87,26 @@
 #define SLR_SHARE_STORE 1       // partial slots: 0 = sc0 sc1 stores, 1 = sc1 stores, 2 = plain stores + an agent release fence per wave (all within 3 %)
 #endif
 
+// ---- rows front end (row segments binned per tile, plan in the same launch)
+#ifndef SLR_ROW_CAP
+#define SLR_ROW_CAP 256         // row segments (64 source pixels of one image row) a tile's list holds; a tile touched by more is
+#endif                          // scanned from the whole flow instead (pathological flows only; identity ~30, Euler t=59 < 200)
+#ifndef SLR_ROW_CB
+#define SLR_ROW_CB 3            // row segments per wave whose flow loads are in flight together
+#endif
+#ifndef SLR_WAVES_ROWS
+#define SLR_WAVES_ROWS 5        // waves per SIMD the rows tile kernel is compiled for (it needs 88-92 VGPRs without a cap)
+#endif
+#ifndef SLR_ROWS_COMBINE
+#define SLR_ROWS_COMBINE 0      // 1: multi-piece tiles of the rows front end go through plain partial tiles + the combine kernel (as with bins)
+#endif
+#ifndef SLR_ROW_SORT
+#define SLR_ROW_SORT 1          // the tile kernel puts its row-segment list into image order before scanning (the appends arrive in any order)
+#endif
+#ifndef SLR_FRONT_END
+#define SLR_FRONT_END -1        // default of slr_splat_set_front_end: -1 = by grid size, 0 bins, 1 scan (boxes), 2 rows
+#endif
+
 // ---- development aids
 #ifndef SLR_DBG
 #define SLR_DBG 0               // 1 drain vmcnt before staging, 4 verify staged values against global memory

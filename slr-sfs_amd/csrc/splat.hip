@@ -550,6 +550,242 @@ __global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restr
     }
 }
 
+// =========================================================================== rows front end
+// The bins cost a stand-alone call 55-80 us around its tile kernel at 768x1280 (zero, count, offsets, fill, plan, combine:
+// seven launches, two passes over the flow with one atomic per pixel footprint); the scan front end above has no plan, so
+// it meets a heavy tile only when its workgroup happens to start.  Third form: bin ROW SEGMENTS instead of pixels.  A row
+// segment = 64 consecutive source pixels of one image row (one wave's coalesced load).  rowbin_kernel reads the flow once;
+// every wave finds the few tiles its segment's footprints touch (ballots, no LDS) and appends (segment, hits) to each of
+// them with ONE returning 64-bit atomic -- ~40 k atomics at 768x1280 instead of ~4 M -- which also sums the tile's exact
+// entry count.  The workgroup that finishes last turns the counts into the work plan (heavy tiles first, no piece above
+// SEG entries: what the scan front end lacks) -- no separate count / offsets / fill / plan launches.  The tile kernel
+// (ROWS instantiation) loads its tile's list (<= SLR_ROW_CAP segments), scans exactly those rows of the flow and places
+// the hits at slots known from the list's counts: no LDS atomics, no count pass, a segment of a heavy tile scans only its
+// own rows.  Multi-segment tiles are summed by their last-arriving workgroup (the partial-slot code of the scan front end).
+// A tile touched by more than SLR_ROW_CAP segments (pathological flows) is scanned from ALL rows of its sample instead.
+constexpr int ROW_CAP = SLR_ROW_CAP;
+struct RowRec { uint32_t sy, sx_cnt; };     // row segment: image row, (x / 64) << 8 | its hits in the tile (<= 64)
+
+// Work plan from the per-tile (entries, row segments) words; run by ONE workgroup of TILE_PIX work-items (the last one of
+// rowbin_kernel) in ONE pass over the tiles.  A round covers 4 * TILE_PIX tiles: every work-item loads the words of 4
+// CONSECUTIVE tiles together (one memory round trip per round), sums them locally, and two workgroup scans per round -- partial
+// slots, then (heavy | other) items packed in one 64-bit word -- place them (a scan is a chain of cross-lane steps and
+// barriers, ~0.5 us: one per tile and quantity made the plan 9.5 us of a 32 us kernel at 1920 tiles).
+// Tiles in row-major order; on grids of more than one round of workgroups the heavy tiles (more than SLR_PLAN_HEAVY / 4 of an
+// undisturbed tile's ~585 entries) go first: their items fill items[] from the front, everybody else's from the back
+// (items[cap - 1 - k]), and the tile kernel reads item i < totals[5] from the front.  Segments of `seg` entries; a tile whose
+// segments do not fit the partial-slot budget is left to one workgroup (nseg 0).
+template <typename V>
+__device__ __forceinline__ V exscan_tile_pix(V v, V *excl, V *wsum /*[TILE_PIX / 64]*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    V inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const V o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    V woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < TILE_PIX / 64; ++w) {
+        const V q = wsum[w];
+        if (w < wid) woff += q;
+        total += q;
+    }
+    __syncthreads();
+    *excl = woff + inc - v;
+    return total;
+}
+
+__device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__ rowcnt, uint32_t nt, uint32_t seg, uint32_t part_slots,
+                                          uint32_t heavy, uint32_t items_cap, ItemDesc *__restrict__ items,
+                                          uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals, uint32_t *__restrict__ arrive,
+                                          uint32_t *__restrict__ multi, uint32_t *__restrict__ nseg_out, uint32_t *__restrict__ partoff_out) {
+    __shared__ unsigned long long wsum[TILE_PIX / 64];
+    // The words were written by other workgroups' agent-scope atomics (performed at the memory side, before their arrival
+    // atomics); this XCD's L2 may still hold the zeros of rows_zero_kernel.  They are read with agent-scope (sc1) loads, all four
+    // of a round in flight together (as __hip_atomic_load the compiler waits after each; an agent-scope acquire fence + plain
+    // loads costs an L2 invalidate: ~8 us here).
+    constexpr uint32_t PER = 4;
+    static_assert(PER == 4, "the load block below is written out for 4 words");
+#ifdef SLR_PLAN_STAMPS
+#define PSTAMP(k) do { if (threadIdx.x == 0) ((unsigned long long *)totals)[8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+    PSTAMP(0);
+    const uint32_t heavy_thr = heavy ? (heavy * 585u) / 4u : 0xffffffffu;
+    uint32_t run_heavy = 0, run_light = 0, run_parts = 0;
+    __shared__ uint32_t n_whole, n_multi;
+    if (threadIdx.x == 0) { n_whole = 0; n_multi = 0; }
+    for (uint32_t b = 0; b < nt; b += PER * TILE_PIX) {
+        const uint32_t t0 = b + PER * threadIdx.x;
+        unsigned long long w[PER];
+        uint32_t ns[PER], po[PER];
+        uint32_t parts = 0;
+        {
+            const unsigned long long *p0 = rowcnt + (t0 + 0 < nt ? t0 + 0 : 0u), *p1 = rowcnt + (t0 + 1 < nt ? t0 + 1 : 0u);
+            const unsigned long long *p2 = rowcnt + (t0 + 2 < nt ? t0 + 2 : 0u), *p3 = rowcnt + (t0 + 3 < nt ? t0 + 3 : 0u);
+            asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\t"
+                         "global_load_dwordx2 %2, %6, off sc1\n\tglobal_load_dwordx2 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) if (t0 + k >= nt) w[k] = 0ull;
+        }
+        PSTAMP(1);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t cnt = (uint32_t)(w[k] >> 32);
+            ns[k] = t0 + k < nt ? (cnt > seg ? (cnt + seg - 1) / seg : 1u) : 0u;
+            po[k] = parts;
+            parts += ns[k] > 1 ? ns[k] : 0u;
+        }
+        unsigned long long pex;
+        const uint32_t ptot = (uint32_t)exscan_tile_pix<unsigned long long>(parts, &pex, wsum);
+        PSTAMP(2);
+        unsigned long long mine = 0;                                          // (heavy items << 32) | other items of my 4 tiles
+        bool whole[PER], hv[PER];
+        uint32_t io[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            po[k] += run_parts + (uint32_t)pex;
+            whole[k] = ns[k] > 1 && po[k] + ns[k] > part_slots;               // partial-slot budget exhausted
+            if (whole[k]) ns[k] = 1;
+            hv[k] = ns[k] && (uint32_t)(w[k] >> 32) > heavy_thr;
+            io[k] = hv[k] ? (uint32_t)(mine >> 32) : (uint32_t)mine;
+            mine += hv[k] ? (unsigned long long)ns[k] << 32 : (unsigned long long)ns[k];
+        }
+        unsigned long long iex;
+        const unsigned long long itot = exscan_tile_pix<unsigned long long>(mine, &iex, wsum);
+        PSTAMP(3);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            if (!ns[k]) continue;
+            ItemDesc d;
+            d.tile = t0 + k; d.cnt0 = (uint32_t)(w[k] >> 32); d.cnt1 = (uint32_t)w[k]; d.off0 = 0; d.off1 = 0;
+            d.nseg = whole[k] ? 0u : ns[k]; d.partoff = po[k];
+            const uint32_t at = hv[k] ? run_heavy + (uint32_t)(iex >> 32) + io[k] : run_light + (uint32_t)iex + io[k];
+            for (uint32_t q = 0; q < ns[k]; ++q) {
+                d.seg = q;
+                items[hv[k] ? at + q : items_cap - 1u - (at + q)] = d;
+            }
+            if (whole[k]) whole_items[atomicAdd(&n_whole, 1u)] = hv[k] ? at : items_cap - 1u - at;    // (position in items[]; rare)
+            if (ns[k] > 1) {
+                for (uint32_t g = 0; g < 4; ++g) arrive[(size_t)g * part_slots + po[k]] = 0u;
+#if SLR_ROWS_COMBINE
+                multi[atomicAdd(&n_multi, 1u)] = t0 + k; nseg_out[t0 + k] = ns[k]; partoff_out[t0 + k] = po[k];
+#endif
+            }
+        }
+        run_heavy += (uint32_t)(itot >> 32);
+        run_light += (uint32_t)itot;
+        run_parts += ptot;
+        PSTAMP(4);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { totals[0] = run_heavy + run_light; totals[1] = run_parts; totals[3] = n_multi; totals[4] = n_whole; totals[5] = run_heavy; }
+}
+
+__global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restrict__ flow, unsigned long long *__restrict__ rowcnt,
+                                                          RowRec *__restrict__ rowlist, int H, int W, int tiles_x, int tiles,
+                                                          uint32_t nt, uint32_t *__restrict__ ctl, uint32_t *__restrict__ arrive1,
+                                                          uint32_t seg, uint32_t part_slots, uint32_t heavy, uint32_t items_cap, ItemDesc *__restrict__ items,
+                                                          uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals,
+                                                          uint32_t *__restrict__ arrive, uint32_t *__restrict__ multi,
+                                                          uint32_t *__restrict__ nseg_out, uint32_t *__restrict__ partoff_out) {
+    const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef SLR_PLAN_STAMPS
+    const unsigned long long k_entry = wall_clock64();
+    if (t == 0 && tid == 0) ((unsigned long long *)totals)[15] = k_entry;
+#endif
+    const int stx = tl % tiles_x, y = (tl / tiles_x) * TILE_H + wid, x = stx * TILE_W + lane;
+    int t0 = -1, t1 = -1, t2 = -1, t3 = -1;               // the <= 4 tiles this pixel's footprint touches
+    if (y < H && x < W) {
+        const float *f = flow + (size_t)n * 2 * H * W + (size_t)y * W + x;
+        const Corners c = make_corners(f[0], f[(size_t)H * W], x, y);
+        const TileSet q = footprint_tiles(c, H, W);
+        if (q.vxa & q.vya) t0 = q.tya * tiles_x + q.txa;
+        if (q.vxb & q.vya) t1 = q.tya * tiles_x + q.txb;
+        if (q.vxa & q.vyb) t2 = q.tyb * tiles_x + q.txa;
+        if (q.vxb & q.vyb) t3 = q.tyb * tiles_x + q.txb;
+    }
+    // distinct tiles of the wave's 64 footprints, one per round: the first lane with something left names a tile, a ballot
+    // counts the lanes that touch it; round k's (tile, hits) is parked in lane k and all appends go out as ONE atomic instruction
+    if (y < H) {                                            // (wave-uniform)
+        unsigned long long *cnt_n = rowcnt + (size_t)n * tiles;
+        RowRec *list_n = rowlist + (size_t)n * tiles * ROW_CAP;
+        int my_tile = -1;
+        uint32_t my_cnt = 0;
+        int k = 0;
+        auto flush = [&]() {
+#if defined(SLR_RB_CUT) && SLR_RB_CUT == 1
+            if (my_tile == -12345)          // (measurement: no appends)
+#else
+            if (my_tile >= 0)
+#endif
+            {
+                const unsigned long long old = atomicAdd(cnt_n + my_tile, 1ull | ((unsigned long long)my_cnt << 32));
+                const uint32_t slot = (uint32_t)old;
+                if (slot < (uint32_t)ROW_CAP) list_n[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)y, ((uint32_t)stx << 8) | my_cnt};
+            }
+            my_tile = -1;
+            k = 0;
+        };
+        for (;;) {
+            const int cand = t0 >= 0 ? t0 : t1 >= 0 ? t1 : t2 >= 0 ? t2 : t3;
+            const unsigned long long pend = __ballot(cand >= 0);
+            if (!pend) break;
+            const int leader = __ffsll((long long)pend) - 1;
+            const int T = __builtin_amdgcn_readlane(cand, leader);
+            const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
+            const uint32_t c = (uint32_t)__popcll(__ballot(h));
+            if (t0 == T) t0 = -1;
+            if (t1 == T) t1 = -1;
+            if (t2 == T) t2 = -1;
+            if (t3 == T) t3 = -1;
+            if (lane == k) { my_tile = T; my_cnt = c; }
+            if (++k == 64) flush();
+        }
+        flush();
+    }
+    // ---- the last workgroup to get here plans the call (every append above has returned: its value was used)
+    // (two levels: thousands of returning atomics on ONE word are served one after the other -- 35 us at 1920 workgroups)
+    __shared__ uint32_t last;
+#if defined(SLR_RB_CUT) && SLR_RB_CUT <= 2
+    return;                                     // (measurement: no arrival, no plan)
+#endif
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t grp = blockIdx.x >> 6, ngrp = (gridDim.x + 63u) >> 6;
+        const uint32_t members = min(64u, gridDim.x - (grp << 6));
+        uint32_t l = 0;
+        if (atomicAdd(&arrive1[(size_t)grp * 32u], 1u) == members - 1u) l = atomicAdd(&ctl[0], 1u) == ngrp - 1u ? 1u : 0u;
+        last = l;
+    }
+    __syncthreads();
+    if (!last) return;
+#if defined(SLR_RB_CUT) && SLR_RB_CUT <= 3
+    return;                                     // (measurement: no plan)
+#endif
+#ifdef SLR_PLAN_STAMPS
+    if (tid == 0) { ((unsigned long long *)totals)[14] = k_entry; ((unsigned long long *)totals)[13] = (unsigned long long)wall_clock64(); }
+#endif
+    rows_plan(rowcnt, nt, seg, part_slots, heavy, items_cap, items, whole_items, totals, arrive, multi, nseg_out, partoff_out);
+}
+
+// (rowcnt words and the arrival counter of rowbin_kernel, zeroed at the start of every call: the workspace is the caller's memory)
+__global__ __launch_bounds__(256) void rows_zero_kernel(unsigned long long *__restrict__ rowcnt, uint32_t nt, uint32_t *__restrict__ ctl,
+                                                        uint32_t *__restrict__ arrive1) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nt) rowcnt[i] = 0ull;
+    if (i < (nt + 63u) / 64u) arrive1[(size_t)i * 32u] = 0u;    // first-level arrival counters of rowbin_kernel: one per 64
+                                                                 // workgroups, each on its own 128-byte line (atomics on one line are served
+                                                                 // one after the other: 1920 arrivals on one line cost 14 us)
+    if (i < 16u) ctl[i] = 0u;
+}
+
 // =========================================================================== splat
 
 enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
@@ -577,6 +813,8 @@ struct SplatArgs {
     uint32_t *ctl;          // SCAN front end, segment sharing (see ScanCtl): head / tail / slots used; nullptr = off
     unsigned long long *q_items;   // [part_slots] queue of (tile, segment) work, one 8-byte word each, 0 = not written yet
     uint32_t *arrive;       // [part_slots] arrival counter of a shared tile, indexed by its first partial slot
+    uint32_t items_cap, pad3_;   // ROWS front end: size of items[] (rows_plan fills it from both ends)
+    const RowRec *rowlist;  // ROWS front end: [N * tiles][ROW_CAP] row segments of every tile (rowbin_kernel)
     // SECOND WEIGHT GROUP of the fused two-flow kernel (the 2-layer model's alpha plane: ONE value plane with its own
     // weight plane, ..._2layers_alpha_seperate.py:963-1045), splatted by the same launch with the same records:
     const float *in2;       // [N,1,H,W] or nullptr
@@ -631,6 +869,11 @@ __device__ __forceinline__ float norm_value(float nrm, int norm_mode, float eps)
 #else
 #define SLR_STAMP(slot) do { } while (0)
 #define SLR_STAMP_RT(slot) do { } while (0)
+#endif
+#ifdef SLR_CUT                                   // measurement builds: the SCAN kernel ends at phase boundary SLR_CUT (time-to-phase)
+#define SLR_CUT_AT(k) do { if (SLR_CUT == (k)) return; } while (0)
+#else
+#define SLR_CUT_AT(k) do { } while (0)
 #endif
 
 constexpr int SPLAT_THREADS = TILE_PIX;        // one work-item per output pixel of the tile
@@ -689,8 +932,8 @@ __host__ __device__ constexpr size_t lds_head_bytes(int ept, bool scan = false) 
     return ((size_t)(SPLAT_THREADS + 16 + SPLAT_THREADS / 2) * 4 + (size_t)rec_cap(ept) * (rec6(ept, scan) ? 6 : 8) + 15) & ~(size_t)15;
 }
 // (the rare whole-tile instantiation carries a segment loop and would spill under the 80-register cap)
-constexpr int tile_min_waves(int ept, bool whole, bool scan) {
-    return scan ? SLR_WAVES_SCAN : (ept == EPT_ONE && SLR_WAVES_ONE > 0 && !whole) ? SLR_WAVES_ONE : 1;
+constexpr int tile_min_waves(int ept, bool whole, int fe) {
+    return whole ? 1 : fe == 2 ? SLR_WAVES_ROWS : fe == 1 ? SLR_WAVES_SCAN : (ept == EPT_ONE && SLR_WAVES_ONE > 0) ? SLR_WAVES_ONE : 1;
 }
 
 // ---- segment sharing inside the SCAN kernel ------------------------------------------------------------------------
@@ -721,13 +964,35 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 
 __device__ __forceinline__ void store_wt16(float *p, f4v v) {          // 16-byte write-through store (untracked by the compiler's
-#if SLR_SHARE_STORE == 0
+#if SLR_SHARE_STORE == 3
+    // two 8-byte agent-scope stores the COMPILER issues (global_store_dwordx2 ... sc1) and therefore counts: an inline-asm store is
+    // invisible to its vmcnt bookkeeping, so every wait for a prefetched plane also waited for the younger write-through store
+    // to be acknowledged by memory -- one write latency per chunk, 17 per piece
+    typedef unsigned long long u64a __attribute__((may_alias));
+    const u64a lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    const u64a hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+    __hip_atomic_store((gu64 *)p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu64 *)p + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif SLR_SHARE_STORE == 0
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");   // vmcnt bookkeeping: drained by hand)
 #elif SLR_SHARE_STORE == 1
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<f4v *>(p) = v;
 #endif
+}
+// agent-scope (sc1) loads of what other workgroups stored write-through: they do not trust this XCD's L2.  Issued in batches and
+// waited for by hand (as __hip_atomic_load the compiler waits after every single one; an agent-scope acquire fence + plain loads
+// invalidates the XCD's whole L2 under everybody else's feet: +26 us per call at 128 multi-piece tiles).
+__device__ __forceinline__ f4v load_sc1_16(const float *p) {
+    f4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float load_sc1_4(const float *p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
 }
 __device__ __forceinline__ void store_wt4(float *p, float v) {
     __hip_atomic_store((gu32 *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -739,8 +1004,11 @@ __device__ __forceinline__ unsigned long long pack_work(uint32_t tile, uint32_t 
 }
 constexpr uint32_t SHARE_MAX_SEG = 255u, SHARE_MAX_SLOT = 1u << 18, SHARE_MAX_TILE = (1u << 26) - 2u;
 
-template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE, bool SCAN = false>
-__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)) void splat_tile_kernel(SplatBatch batch) {
+// FE: front end of the launch -- 0 bins (entry lists + plan), 1 scan (boxes, no plan), 2 rows (row-segment lists + plan)
+template <bool NORM, bool MAXOP, int EPT_MAX, int CHUNK, bool WHOLE, int FE = 0>
+__global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) void splat_tile_kernel(SplatBatch batch) {
+    constexpr bool SCAN = FE != 0;          // the tile's entries are built in LDS from the flow itself (no bin lists)
+    constexpr bool ROWS = FE == 2;          // ... from the tile's row-segment list, work items from a plan
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t bstart, bf, bx;                               // frame of this block, block index inside the frame's own grid
     if (batch.interleave) {
@@ -776,7 +1044,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     // the tile to its left: one 128-byte line per row for 4 useful bytes) is then served by that
     // XCD's L2 instead of HBM, while heavy image regions still spread over all XCDs.
     uint32_t item;
-    if (SCAN) {                                        // no plan: block -> tile (same XCD grouping), one workgroup per tile
+    if (SCAN && !ROWS) {                               // no plan: block -> tile (same XCD grouping), one workgroup per tile
         const uint32_t slot = bx >> 3;
         item = ((slot / XCD_GROUP) * 8u + (bx & 7u)) * XCD_GROUP + slot % XCD_GROUP;
         if (item >= a.nt) return;
@@ -798,7 +1066,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
   bool w_piece = false;
   for (uint32_t wi = bx;;) {                           // one pass unless WHOLE (its items) or SCAN (popped segments)
     ItemDesc it;
-    if (SCAN) { it = ItemDesc{}; it.tile = item; it.nseg = 1; }
+    if (SCAN && !ROWS) { it = ItemDesc{}; it.tile = item; it.nseg = 1; }
+    else if (ROWS && !WHOLE) { const uint32_t nh = a.totals[5]; it = a.items[item < nh ? item : a.items_cap - 1u - (item - nh)]; }   // heavy from the front, the rest from the back
     else it = a.items[item];
     const uint32_t t = it.tile;
     // Normally one workgroup = one segment.  A tile whose segments did not fit into the partial-slot
@@ -807,14 +1076,14 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     // global memory (its own earlier store), and normalises after the last segment.
     // That is a separate instantiation (WHOLE) launched after the main one; the main kernel skips
     // those items, so its code carries no loop.
-    constexpr bool whole = WHOLE || SCAN;          // SCAN: a tile with more than SEG entries is walked pass by pass as well
-    if (!SCAN && (it.nseg == 0) != WHOLE) return;
+    constexpr bool whole = WHOLE || (SCAN && !ROWS);   // scan front end: a tile with more than SEG entries is walked pass by pass as well
+    if ((!SCAN || ROWS) && (it.nseg == 0) != WHOLE) return;
     // Channel groups (gridDim.y > 1: small grids, see launch_batch): this workgroup builds the tile's records like
     // any other and gathers the planes [cb, cend) only.  Groups start on a multiple of 2 * CHUNK planes.
     const int cper = (((a.C + (int)gridDim.y - 1) / (int)gridDim.y + 2 * CHUNK - 1) / (2 * CHUNK)) * (2 * CHUNK);
     const int cb = (int)w_grp * cper, cend = min(a.C, cb + cper);
     if (cb >= a.C) return;
-    uint32_t nloop = WHOLE ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;
+    uint32_t nloop = WHOLE ? (it.cnt0 + (ROWS ? 0u : it.cnt1) + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;   // (rows: cnt1 = its row segments)
     float nrm_total = 0.0f, g2_sum = 0.0f, g2_nrm = 0.0f;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
@@ -823,8 +1092,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     // kept in registers across the whole body (+16 VGPRs: over the 128 of two workgroups per CU) -- so the index is rebuilt in
     // every round from the wave's number (a scalar) and the lane count, and made to look loop-variant
     uint32_t ones_ = ~0u;
-    if (SCAN) asm volatile("" : "+s"(ones_));                    // (a scalar the optimiser cannot see through)
-    const int tid = SCAN ? wave_in_group * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones_, __builtin_amdgcn_mbcnt_lo(ones_, 0u)) : (int)threadIdx.x;
+    if (SCAN && !ROWS) asm volatile("" : "+s"(ones_));           // (a scalar the optimiser cannot see through)
+    const int tid = (SCAN && !ROWS) ? wave_in_group * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones_, __builtin_amdgcn_mbcnt_lo(ones_, 0u)) : (int)threadIdx.x;
 
     // ---------------- SCAN front end: the tile's entry list is built here, in LDS, from the flow itself
     // Candidates: source tiles whose destination box (scan_box_kernel) touches this tile -> a bit mask in LDS (order-free
@@ -964,6 +1233,135 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         }
         return MODE == 0 ? cmask[64] : wcount;
     };
+    // ROWS: entries [lo, hi) of the tile from its row-segment list.  The list's hit counts give every segment its first slot
+    // (exclusive scan): no atomics, no count pass, and a piece of a heavy tile reads only the rows that hold its entries.
+    // A tile whose list overflowed (more than ROW_CAP segments: everything converging on it) walks ALL row segments of its
+    // sample instead, counting first (wave w takes segments w, w + 8, ...: ordinal = hits of the waves before + own so far).
+    auto rowscan = [&](uint32_t lo, uint32_t hi) {
+        constexpr int CB = SLR_ROW_CB;
+        const int lane = tid & 63, wid = tid >> 6;
+        const float *fl = a.flow[0] + (size_t)n * 2 * HW;
+        uint32_t *rl_sy = clist, *rl_sx = clist + ROW_CAP, *rl_base = clist + 2 * ROW_CAP;      // [ROW_CAP], [ROW_CAP], [ROW_CAP + 1]
+        const bool ovf = it.cnt1 > (uint32_t)ROW_CAP;
+        const uint32_t nrows = ovf ? (uint32_t)a.H * (uint32_t)a.tiles_x : it.cnt1;
+        if (!ovf) {
+            RowRec r = {0u, 0u};
+            if ((uint32_t)tid < nrows) r = a.rowlist[(size_t)t * ROW_CAP + tid];
+            uint32_t c = r.sx_cnt & 0xffu;
+#if SLR_ROW_SORT
+            // the appends arrived in any order: put the list into image order (row, column) -- the order the bins have, which the
+            // staging loads and the record lists like best -- by ranking every key among the others (<= ROW_CAP broadcast reads)
+            const unsigned long long mykey = ((unsigned long long)r.sy << 24) | (r.sx_cnt >> 8);
+            if ((uint32_t)tid < nrows) { rl_sy[tid] = r.sy; rl_sx[tid] = r.sx_cnt >> 8; }
+            __syncthreads();
+            uint32_t rank = 0;
+            if ((uint32_t)tid < nrows)
+                for (uint32_t q = 0; q < nrows; ++q) {
+                    const unsigned long long k2 = ((unsigned long long)rl_sy[q] << 24) | rl_sx[q];
+                    rank += (k2 < mykey) ? 1u : 0u;                    // (keys are distinct: one append per (segment, tile))
+                }
+            __syncthreads();
+            if ((uint32_t)tid < nrows) { rl_sy[rank] = r.sy; rl_sx[rank] = r.sx_cnt >> 8; rl_base[rank] = c; }
+            __syncthreads();
+            c = (uint32_t)tid < nrows ? rl_base[tid] : 0u;             // counts in sorted order
+            __syncthreads();
+#else
+            if (tid < ROW_CAP) { rl_sy[tid] = r.sy; rl_sx[tid] = r.sx_cnt >> 8; }
+#endif
+            uint32_t inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) wsum[wid] = inc;
+            __syncthreads();
+            uint32_t woff = 0;
+#pragma unroll
+            for (int w = 0; w < T / 64; ++w) woff += (w < wid) ? wsum[w] : 0u;
+            if (tid <= ROW_CAP) rl_base[tid] = woff + inc - c;
+            __syncthreads();
+        }
+        const uint32_t my_n = nrows > (uint32_t)wid ? (nrows - (uint32_t)wid + (uint32_t)(T / 64) - 1u) / (uint32_t)(T / 64) : 0u;
+        uint32_t wave_base = 0;
+        struct Group { float fx[CB], fy[CB]; int sy[CB], stx[CB]; uint32_t b0[CB]; };
+        auto issue = [&](Group &g, uint32_t j0) {
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+                const uint32_t j = j0 + (uint32_t)i, ri = (uint32_t)wid + j * (uint32_t)(T / 64);
+                bool on = j < my_n;
+                int sy, stx;
+                uint32_t base = 0;
+                if (ovf) {
+                    sy = (int)(ri / (uint32_t)a.tiles_x);
+                    stx = (int)(ri - (uint32_t)sy * (uint32_t)a.tiles_x);
+                } else {
+                    const uint32_t q = on ? ri : 0u;
+                    sy = __builtin_amdgcn_readfirstlane((int)rl_sy[q]);
+                    stx = __builtin_amdgcn_readfirstlane((int)rl_sx[q]);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q]);
+                    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q + 1u]);
+                    on = on && end > lo && base < hi;                  // (pieces of a heavy tile: only the rows that hold their entries)
+                }
+                g.sy[i] = on ? sy : -1;
+                g.stx[i] = stx;
+                g.b0[i] = base;
+                const int sx = stx * TILE_W + lane;
+                const bool in = on & (sx < a.W);
+                const int q = in ? sy * a.W + sx : 0;
+                g.fx[i] = fl[q];
+                g.fy[i] = fl[HW + q];
+            }
+        };
+        uint32_t wcount = 0;
+        auto process = [&](const Group &g, auto emit_tag) {
+            constexpr bool EMIT = decltype(emit_tag)::value;
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+                const int sy = g.sy[i], sx = g.stx[i] * TILE_W + lane;
+                const bool in = (sy >= 0) & (sx < a.W);
+                const Corners c = make_corners(g.fx[i], g.fy[i], sx, sy);
+                const int lx = c.x0 - tx0, ly = c.y0 - ty0;
+                const bool xa = (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W), xb = (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
+                const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H), yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
+                const bool hit = in & c.ok & (xa | xb) & (ya | yb);
+                const unsigned long long hm = __ballot(hit);
+                const uint32_t b0 = ovf ? wave_base + wcount : g.b0[i];
+                wcount += (uint32_t)__popcll(hm);
+                if (EMIT) {
+                    const uint32_t slot = b0 + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                    if (hit && slot >= lo && slot < hi) {
+                        ent_pix[slot - lo] = (uint32_t)(sy * a.W + sx);
+                        ent_fx[slot - lo] = g.fx[i];
+                        ent_fy[slot - lo] = g.fy[i];
+                    }
+                }
+            }
+        };
+        auto walk = [&](auto emit_tag) {
+            wcount = 0;
+            Group ga, gb;
+            if (my_n > 0) issue(ga, 0u);
+            for (uint32_t j0 = 0; j0 < my_n; j0 += 2 * CB) {
+                if (j0 + CB < my_n) issue(gb, j0 + CB);
+                process(ga, emit_tag);
+                if (j0 + CB < my_n) {
+                    if (j0 + 2 * CB < my_n) issue(ga, j0 + 2 * CB);
+                    process(gb, emit_tag);
+                }
+            }
+        };
+        if (ovf) {
+            walk(std::false_type{});
+            if (lane == 0) cmask[65 + wid] = wcount;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < T / 64; ++w) wave_base += (w < wid) ? cmask[65 + w] : 0u;
+            __syncthreads();
+        }
+        walk(std::true_type{});
+        __syncthreads();
+    };
     if (!w_piece) { SLR_STAMP(41); SLR_STAMP_RT(48); }
     int qavail = 0;                                               // the semaphore as seen two chunks before the end of this work
     // (a grid that fits the chip in one round ends all at once with nothing else to do: everybody helps)
@@ -971,9 +1369,15 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     bool part = false;                                            // this piece of work is ONE segment of a shared tile
     bool ctx = false;                                             // this workgroup holds a shared tile it may draw more tickets of
     uint32_t ns_tile = 1;                                         // segments of the tile (part)
-    if (SCAN) {
+    if (ROWS) {
+        scan_total = it.cnt0;                                     // exact (rowbin_kernel)
+        part = !SLR_ROWS_COMBINE && it.nseg > 1;
+        ns_tile = part ? it.nseg : 1u;
+        w_seg = it.seg; w_po = it.partoff;
+    } else if (SCAN) {
         if (!w_piece) scan_total = scan(std::integral_constant<int, 0>{}, 0u, (uint32_t)SEG);
         if (!w_piece) SLR_STAMP(42);
+        SLR_CUT_AT(1);
         if (w_piece || scan_total > (uint32_t)SEG) {              // heavy tile: segments with reproducible membership
             {
                 const uint32_t wc = scan(std::integral_constant<int, 1>{}, 0u, 0u);
@@ -1020,7 +1424,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     const bool first = si == 0, last = si + 1 == nloop;
     if (!w_piece && first) SLR_STAMP(0);
     if (!w_piece && first && SCAN && (nloop > 1 || part)) SLR_STAMP(36);
-    if (SCAN && (nloop > 1 || part)) scan(std::integral_constant<int, 2>{}, s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG);
+    if (ROWS) { rowscan(s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG); SLR_CUT_AT(1); }
+    else if (SCAN && (nloop > 1 || part)) scan(std::integral_constant<int, 2>{}, s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG);
     cnt[tid] = 0;
     __syncthreads();
 
@@ -1085,6 +1490,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         // they complete under the footprint math, the LDS atomics and the scan
         prefetch(preA, cb);
         prefetch(preB, cb + CHUNK);
+#if SLR_DBG & 8
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (measurement: raw latency of the first plane loads)
+        SLR_STAMP(29);
+#endif
 #pragma unroll
         for (int j = 0; j < EPT_MAX; ++j) {
             if (!SCAN) {
@@ -1135,6 +1544,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     SLR_STAMP(1);
     __syncthreads();
     SLR_STAMP(2);
+    SLR_CUT_AT(2);
 
     // ---------------- phase 1b: exclusive scan of the counts (T values, one per work-item)
     {
@@ -1168,6 +1578,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     __syncthreads();
 
     SLR_STAMP(3);
+    SLR_CUT_AT(3);
     // ---------------- phase 2: stage a chunk of planes in LDS, gather per output pixel
     // A work-item walks at most LMAX records of its own list; what is left of a longer list (a
     // "sink" pixel where hundreds of sources converge) is walked by the whole wave, lane-strided,
@@ -1200,9 +1611,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
     const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
     const int oy = ty0 + ly, ox = tx0 + lx;
     const bool inside = (oy < a.H) & (ox < a.W);
-    const bool single = it.nseg <= 1;               // results go straight to the output tensor
+    const bool single = it.nseg <= 1 && !(SCAN && part);   // results go straight to the output tensor
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
-                       : a.partial + (size_t)(it.partoff + s) * a.part_stride + tid;
+                       : a.partial + (size_t)((SCAN ? w_po : it.partoff) + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
     // SCAN, shared tile: slot (w_po + segment), laid out [chunk of 4 planes][work-item][4] so that a chunk is ONE 16-byte
     // write-through store per work-item; the normaliser plane follows the last chunk
@@ -1389,32 +1800,43 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
         prefetch(pre, c0 + 2 * CHUNK);                 // two chunks ahead (three: no gain fused, -20 % one flow: registers)
         float acc[CHUNK];
         gather(acc);
-        if (SCAN && part) {                            // raw sums of this segment -> its partial slot, write-through
-            static_assert(!SCAN || CHUNK == 4, "partial-slot layout of the SCAN kernel");
-            f4v pv;
-            pv.x = acc[0]; pv.y = acc[1]; pv.z = acc[2]; pv.w = acc[3];
-            store_wt16(pslot + ((size_t)(c0 >> 2) * T + tid) * 4, pv);
-        } else
+        // (a piece of a shared tile stores its raw sums into its partial slot: same addresses-by-selection, same NUMBER of store
+        // instructions, only their scope differs -- an earlier form with one 16-byte inline-asm store was invisible to the
+        // compiler's vmcnt bookkeeping, so every wait for a prefetched plane also waited for the write-through store's
+        // acknowledgement, and a store path of its own made the counts differ where the paths merge)
+        float rr[CHUNK];
+        float *dd[CHUNK];
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
             float r = acc[u];
             float *dst = (c0 + u < cend) ? op + (size_t)(c0 + u) * ostr : trash;
+#ifdef SLR_CUT
+            if (SLR_CUT == 5) dst = trash;   // (no output traffic)
+#endif
             if (whole && !first) r = MAXOP ? fmaxf(r, *dst) : r + *dst;      // earlier segments of this tile
             if (NORM && single && last) r = finish(r, nrm, a.norm_mode, a.eps);
 #if SLR_DBG & 4
             if (dbg_bad) r = 12345.0f;
 #endif
-            *dst = r;
+            rr[u] = r; dd[u] = dst;
+        }
+        if (SCAN && part) {                            // agent-scope stores (sc1): read by another XCD inside this launch
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) store_wt4(dd[u], rr[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) *dd[u] = rr[u];
         }
         if ((c0 - cb) / CHUNK < 9) SLR_STAMP(6 + 3 * ((c0 - cb) / CHUNK)); if (c0 + CHUNK >= cend) SLR_STAMP(40);
         __syncthreads();                               // val[] is overwritten by the next chunk
     };
     for (int c0 = cb; c0 < cend; c0 += 2 * CHUNK) {
         // queue state for the pop after this piece of work: ONE load, issued when the last two chunks begin, consumed after them
-        if (SCAN && a.ctl && tid == 0 && last && !ctx && helper && c0 + 2 * CHUNK >= cend)
+        if (SCAN && !ROWS && a.ctl && tid == 0 && last && !ctx && helper && c0 + 2 * CHUNK >= cend)
             qavail = (int)__hip_atomic_load((gu32 *)a.ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         chunk(preA, c0);
         if (c0 + CHUNK < cend) chunk(preB, c0 + CHUNK);
+        SLR_CUT_AT(4);                                 // (after the first two chunks)
     }
   }
     if (SCAN) {
@@ -1427,10 +1849,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                wsum[0] = atomicAdd(&a.arrive[w_po], 1u);
+                wsum[0] = atomicAdd(&a.arrive[(ROWS ? (size_t)w_grp * a.part_slots : (size_t)0) + w_po], 1u);   // (rows: one counter per channel group)
                 // the partial slots were stored write-through and drained before their arrivals: ONE agent-scope acquire (drops this
                 // CU's stale lines) and the combine below may use plain, pipelined loads
-                if (wsum[0] + 1u == ns_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
             }
             __syncthreads();
             const bool last_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsum[0]) + 1u == ns_tile;
@@ -1442,27 +1864,45 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, SCAN)
                 const float *pb = a.partial + (size_t)w_po * a.part_stride;
                 const size_t pnorm = (size_t)((a.C + 3) / 4) * 4 * TILE_PIX;
                 float nrm = 0.0f;
+                float *o = a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox;
+                // agent-scope (sc1) loads, 8 in flight per wait (two pieces x four planes); pieces in fixed order: reproducible
                 if (NORM) {
-                    for (uint32_t q = 0; q < ns_tile; ++q) nrm += pb[(size_t)q * a.part_stride + pnorm + tid];
+                    for (uint32_t q = 0; q < ns_tile; q += 4) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = load_sc1_4(pb + (size_t)min(q + i, ns_tile - 1u) * a.part_stride + pnorm + tid);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) nrm += q + i < ns_tile ? v[i] : 0.0f;
+                    }
                     if (a.norm_out && inside && cb == 0) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
                 }
-                float *o = a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox;
-                for (int c0 = cb; c0 < cend; c0 += 4) {
-                    const size_t at = ((size_t)(c0 >> 2) * T + tid) * 4;
-                    f4v acc = *reinterpret_cast<const f4v *>(pb + at);
-                    for (uint32_t q = 1; q < ns_tile; ++q) {                 // fixed order: reproducible
-                        const f4v v = *reinterpret_cast<const f4v *>(pb + (size_t)q * a.part_stride + at);
-                        if (MAXOP) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
-                        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-                    }
-                    const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+                constexpr int CP = 8;                          // planes per round: 2 pieces x 8 planes = 16 loads in flight per wait (16 planes: spills)
+                for (int c0 = cb; c0 < cend; c0 += CP) {
+                    float acc[CP];
+                    for (uint32_t q = 0; q < ns_tile; q += 2) {
+                        float v[2][CP];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (inside && c0 + u < cend) o[(size_t)(c0 + u) * HW] = NORM ? finish(r[u], nrm, a.norm_mode, a.eps) : r[u];
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int k = 0; k < CP; ++k)
+                                v[i][k] = load_sc1_4(pb + (size_t)min(q + i, ns_tile - 1u) * a.part_stride + (size_t)min(c0 + k, cend - 1) * TILE_PIX + tid);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int k = 0; k < CP; ++k) {
+                                asm volatile("" : "+v"(v[i][k]));          // (read only after the wait above)
+                                if (q + i < ns_tile) acc[k] = q + i == 0 ? v[i][k] : MAXOP ? fmaxf(acc[k], v[i][k]) : acc[k] + v[i][k];
+                            }
+                    }
+#pragma unroll
+                    for (int k = 0; k < CP; ++k)
+                        if (inside && c0 + k < cend) o[(size_t)(c0 + k) * HW] = NORM ? finish(acc[k], nrm, a.norm_mode, a.eps) : acc[k];
                 }
             }
         }
-        if (!a.ctl) break;
+        if (ROWS || !a.ctl) break;                    // (rows: the plan cut the pieces, one per workgroup)
         // ---- next piece of work: claim a pushed segment (see the block comment above the kernel)
         if (tid == 0) {
             unsigned long long got = 0;
@@ -1601,7 +2041,8 @@ struct Ws {
     float *partial, *trash;
     SrcBox *box;
     uint32_t *ctl, *arrive;
-    unsigned long long *queue;
+    unsigned long long *queue, *rowcnt;
+    RowRec *rowlist;
 };
 
 static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, const char *who) {
@@ -1627,6 +2068,8 @@ static int ws_open(Ws &w, int N, int C, int H, int W, void *ws, size_t bytes, co
     w.ctl = (uint32_t *)(w.base + w.L.off_ctl);
     w.queue = (unsigned long long *)(w.base + w.L.off_queue);
     w.arrive = (uint32_t *)(w.base + w.L.off_arrive);
+    w.rowcnt = (unsigned long long *)(w.base + w.L.off_rowcnt);
+    w.rowlist = (RowRec *)(w.base + w.L.off_rowlist);
     return 0;
 }
 
@@ -1660,7 +2103,7 @@ static int do_bin(const float *flow0, Ws &w0, const float *flow1, Ws *w1, int N,
     return 0;
 }
 
-template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE, bool SCAN = false>
+template <bool NORM, bool MAXOP, int EPT, int CHUNK, bool WHOLE, int FE = 0>
 static int launch_tile_variant(const SplatBatch &b, uint32_t grid, uint32_t groups, size_t lds, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may drive
     // several GPUs, e.g. the DataParallel replicas of the reference's training scripts)
@@ -1668,11 +2111,11 @@ static int launch_tile_variant(const SplatBatch &b, uint32_t grid, uint32_t grou
     int dev = 0;
     SLR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE, SCAN>,
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE, FE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE, SCAN>), dim3(grid, groups), dim3(SPLAT_THREADS), lds, st, b);
+    hipLaunchKernelGGL((splat_tile_kernel<NORM, MAXOP, EPT, CHUNK, WHOLE, FE>), dim3(grid, groups), dim3(SPLAT_THREADS), lds, st, b);
     return 0;
 }
 
@@ -1769,7 +2212,15 @@ static int run_plan(SplatArgs &a, bool two_flows, uint32_t items_cap, uint32_t n
 static const uint32_t *g_scan_order = nullptr;
 #endif
 static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_splat_set_scan_max_tiles
-static bool use_scan(int prebinned, uint32_t nt) { return !prebinned && nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed); }
+static std::atomic<int> g_front_end{SLR_FRONT_END};                    // slr_splat_set_front_end
+// Front end of a one-flow call that brings no bins: 0 bins, 1 scan (boxes), 2 rows.  By default the grid decides: scan up to
+// slr_splat_set_scan_max_tiles tiles (single-round grids: no plan to wait for), rows above.
+static int front_end(int prebinned, uint32_t nt) {
+    if (prebinned) return 0;
+    const int fe = g_front_end.load(std::memory_order_relaxed);
+    if (fe >= 0 && fe <= 2) return fe;
+    return nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed) ? 1 : 2;
+}
 
 // The scan front end of a one-flow call: box kernel + tile kernel, nothing else (no bins, no plan, no combine).
 template <bool NORM, bool MAXOP>
@@ -1802,9 +2253,63 @@ static int do_splat_scan(SplatArgs a, Ws &w0, hipStream_t st) {
     b.end[0] = grid;
     const size_t lds = lds_head_bytes(EPT_SCAN, true) + (size_t)CHUNK_ONE * (EPT_SCAN * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
-    if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, false, true>(b, grid, channel_groups(w0.L.nt, a.C, CHUNK_ONE), lds, st)) return e;
+    if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, false, 1>(b, grid, channel_groups(w0.L.nt, a.C, CHUNK_ONE), lds, st)) return e;
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+// The rows front end of a one-flow call: zero + rowbin (with the plan) + tile kernel (multi-segment tiles summed in-kernel).
+template <bool NORM, bool MAXOP>
+static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
+    a.tiles_x = w0.L.tiles_x;
+    a.tiles = w0.L.tiles;
+    a.trash = w0.trash;
+    a.nt = w0.L.nt;
+    a.partial = w0.partial;
+    a.part_stride = w0.L.part_stride;
+    a.part_slots = w0.L.part_slots;
+    a.ctl = nullptr;
+    a.arrive = w0.arrive;
+    a.rowlist = w0.rowlist;
+    a.items_cap = w0.L.items_cap;
+    a.items = w0.items;
+    a.totals = w0.totals;
+    a.whole_items = w0.whole_items;
+    a.nseg = w0.nseg; a.partoff = w0.partoff; a.multi = w0.multi;
+    a.ndir = 1;
+    a.seg = EPT_SCAN * SPLAT_THREADS;
+#ifdef SLR_TRACE
+    a.trace = g_trace;
+#endif
+    const uint32_t nt = w0.L.nt;
+    hipLaunchKernelGGL(rows_zero_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w0.rowcnt, nt, w0.ctl, (uint32_t *)w0.box);   // (the box array of
+    // the scan front end doubles as rowbin_kernel's first-level arrival counters)
+    hipLaunchKernelGGL(rowbin_kernel, dim3(nt), dim3(TILE_PIX), 0, st, a.flow[0], w0.rowcnt, w0.rowlist, a.H, a.W, w0.L.tiles_x,
+                       w0.L.tiles, nt, w0.ctl, (uint32_t *)w0.box, (uint32_t)a.seg, w0.L.part_slots, nt > 512u ? (uint32_t)SLR_PLAN_HEAVY : 0u, w0.L.items_cap,
+                       w0.items, w0.whole_items, w0.totals, w0.arrive, w0.multi, w0.nseg, w0.partoff);
+    SplatBatch b = {};
+    b.f[0] = a;
+    b.nb = 1;
+    uint32_t cover = w0.L.items_cap;
+#ifdef SLR_ROWS_GRID_HOOK
+    if (const char *g = getenv("SLR_ROWS_GRID")) cover = (uint32_t)atoi(g);      // (experiment: how much do the surplus blocks cost?)
+#endif
+    const uint32_t grid = ((cover + 8 * XCD_GROUP - 1) / (8 * XCD_GROUP)) * 8 * XCD_GROUP;
+    b.end[0] = grid;
+    const size_t lds = lds_head_bytes(EPT_SCAN, true) + (size_t)CHUNK_ONE * (EPT_SCAN * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
+    if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, false, 2>(b, grid, channel_groups(nt, a.C, CHUNK_ONE), lds, st)) return e;
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+    g_ev_start = g_ev_stop = nullptr;
+    // tiles whose pieces did not fit the partial-slot budget (none for ordinary flows): pass by pass, one workgroup each
+    b.end[0] = nt < 256u ? nt : 256u;
+    if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, true, 2>(b, b.end[0], 1u, lds, st)) return e;
+#if SLR_ROWS_COMBINE
+    b.cend[0] = w0.L.part_slots / 2;
+    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(b.cend[0], (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK), dim3(SPLAT_THREADS), 0, st, b);
+#endif
     SLR_CHECK_LAUNCH();
     return 0;
 }
@@ -1893,12 +2398,21 @@ SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {
 SLR_EXPORT size_t slr_debug_ctl_offset(int N, int C, int H, int W) { return ws_layout(N, C, H, W).off_ctl; }
 #endif
 
+#ifdef SLR_PLAN_STAMPS
+SLR_EXPORT size_t slr_debug_totals_offset(int N, int C, int H, int W) { return ws_layout(N, C, H, W).off_totals; }
+SLR_EXPORT size_t slr_debug_rowcnt_offset(int N, int C, int H, int W) { return ws_layout(N, C, H, W).off_rowcnt; }
+#endif
+
 #ifdef SLR_SCAN_ORDER_HOOK
 SLR_EXPORT void slr_debug_scan_order(const uint32_t *order) { slr::g_scan_order = order; }
 #endif
 
 SLR_EXPORT int slr_splat_set_scan_max_tiles(int max_tiles) {
     return slr::g_scan_max_tiles.exchange(max_tiles < 0 ? 0 : max_tiles);
+}
+
+SLR_EXPORT int slr_splat_set_front_end(int front_end) {
+    return slr::g_front_end.exchange(front_end < 0 || front_end > 2 ? -1 : front_end);
 }
 
 SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {
@@ -1933,12 +2447,13 @@ SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const bool scan = use_scan(prebinned, w.L.nt);
-    if (!prebinned && !scan) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
+    const int fe = front_end(prebinned, w.L.nt);
+    if (!prebinned && fe == 0) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
-    if (scan) return do_splat_scan<false, false>(a, w, st);
+    if (fe == 1) return do_splat_scan<false, false>(a, w, st);
+    if (fe == 2) return do_splat_rows<false, false>(a, w, st);
     return do_splat<false, false>(a, w, nullptr, st);
 }
 
@@ -1954,14 +2469,15 @@ SLR_EXPORT int slr_softsplat_mode_forward(const float *in, const float *metric, 
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const bool scan = use_scan(prebinned, w.L.nt);
-    if (!prebinned && !scan) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
+    const int fe = front_end(prebinned, w.L.nt);
+    if (!prebinned && fe == 0) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.mul = metric; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.mulmode = mode == SLR_MODE_AVERAGE ? MUL_ONE : mode == SLR_MODE_LINEAR ? MUL_PLANE : MUL_EXP;
     a.norm_mode = SLR_NORM_ZERO_TO_ONE;
-    if (scan) return do_splat_scan<true, false>(a, w, st);
+    if (fe == 1) return do_splat_scan<true, false>(a, w, st);
+    if (fe == 2) return do_splat_rows<true, false>(a, w, st);
     return do_splat<true, false>(a, w, nullptr, st);
 }
 
@@ -2017,12 +2533,13 @@ SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *o
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const bool scan = use_scan(prebinned, w.L.nt);
-    if (!prebinned && !scan) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
+    const int fe = front_end(prebinned, w.L.nt);
+    if (!prebinned && fe == 0) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out; a.init = init;
     a.N = N; a.C = C; a.H = H; a.W = W; a.mulmode = MUL_ONE;
-    if (scan) return do_splat_scan<false, true>(a, w, st);
+    if (fe == 1) return do_splat_scan<false, true>(a, w, st);
+    if (fe == 2) return do_splat_rows<false, true>(a, w, st);
     return do_splat<false, true>(a, w, nullptr, st);
 }
 

@@ -1,6 +1,7 @@
-"""The two front ends of the one-flow operator (include/slr_splat.h: slr_splat_set_scan_max_tiles) against the oracle:
-`bins` (bin -> plan -> tile kernel -> combine) and `scan` (source-tile destination boxes, the tile kernel builds its
-entry list itself).  Every case runs with the front end FORCED, so both are covered at every size -- including
+"""The three front ends of the one-flow operator (include/slr_splat.h: slr_splat_set_front_end) against the oracle:
+`bins` (bin -> plan -> tile kernel -> combine), `scan` (source-tile destination boxes, the tile kernel builds its
+entry list itself) and `rows` (row segments binned per tile + the plan in one launch, the tile kernel scans the listed
+rows).  Every case runs with the front end FORCED, so all are covered at every size -- including
 BASELINE.json's config C2 as it is stated (FunctionSoftsplat(..., 'softmax'), 64 channels, 256x480, incoherent U(-8,8)
 and smooth flow; models/softsplat.py:665-690)."""
 import numpy as np
@@ -19,12 +20,15 @@ def S():
     return slr_sfs_amd
 
 
-@pytest.fixture(params=["bins", "scan"])
+FRONT_ENDS = {"bins": 0, "scan": 1, "rows": 2}
+
+
+@pytest.fixture(params=list(FRONT_ENDS))
 def frontend(request, S):
     L = S._lib.lib()
-    prev = L.slr_splat_set_scan_max_tiles(0 if request.param == "bins" else INT_MAX)
+    prev = L.slr_splat_set_front_end(FRONT_ENDS[request.param])
     yield request.param
-    L.slr_splat_set_scan_max_tiles(prev)
+    L.slr_splat_set_front_end(prev)
 
 
 def dev(a):

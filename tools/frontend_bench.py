@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Both front ends of the one-flow operator (bins | scan) on the small grids of config C2 and at 768x1280:
+"""The front ends of the one-flow operator (bins | scan | rows) on the small grids of config C2 and at 768x1280:
 tile kernel alone (events recorded by the library around that launch) and the whole call.
 `graph`: the call captured into a HIP graph of 20 calls and replayed -- GPU time per call without the host's launch pace."""
 import os, sys
@@ -11,7 +11,7 @@ from bench import smooth_motion
 from kbench import timeit
 dev = torch.device("cuda:0")
 L = S._lib.lib()
-which = sys.argv[1:] or ["small", "full"]
+which = (sys.argv[1:] or ["small", "full"]) if __name__ == "__main__" else []
 
 
 def graph_us(fn, reps=20, iters=10):
@@ -35,8 +35,8 @@ def graph_us(fn, reps=20, iters=10):
 
 def measure(tag, x, fl, met, mode, alg):
     row = []
-    for fe, thr in (("bins", 0), ("scan", 2 ** 31 - 1)):
-        prev = L.slr_splat_set_scan_max_tiles(thr)
+    for fe, code in (("bins", 0), ("scan", 1), ("rows", 2)):
+        prev = L.slr_splat_set_front_end(code)
         f = lambda: S.FunctionSoftsplat(x, fl, met, mode)
         synthesis.kernel_timing = []
         for _ in range(25):
@@ -52,7 +52,7 @@ def measure(tag, x, fl, met, mode, alg):
         except Exception as e:                                   # noqa
             gus = float("nan")
         row.append(f"{fe}: tile {k:6.1f} call {call:6.1f} graph {gus:6.1f} us ({alg / gus / 1e3 / 8000:.3f})")
-        L.slr_splat_set_scan_max_tiles(prev)
+        L.slr_splat_set_front_end(prev)
     print(f"{tag:22s} " + " | ".join(row), flush=True)
 
 
