@@ -39,6 +39,7 @@ struct WsLayout {
     uint32_t nt;                          // N * tiles
     uint32_t part_slots;                  // partial-tile slots available to the plan
     uint32_t items_cap;                   // upper bound of work items (tiles + part_slots)
+    uint32_t rows_items_cap;              // ... of the rows front end (pieces by output rows; items[] holds this many)
     size_t off_count;     // uint32[nt]   entries per tile                 (bin)
     size_t off_cursor;    // uint32[nt]   fill cursors                     (bin)
     size_t off_listoff;   // uint32[nt+1] exclusive prefix of count        (bin)
@@ -72,6 +73,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.nt = (uint32_t)N * L.tiles;
     L.part_slots = L.nt < 64 ? 64 : L.nt;       // one partial-tile slot per tile on average
     L.items_cap = L.nt + L.part_slots;
+    L.rows_items_cap = L.items_cap > 4u * L.nt ? L.items_cap : 4u * L.nt;      // rows front end: up to 8 pieces per tile
     size_t o = 0;
     L.off_count = o;   o += al256((size_t)L.nt * 4);
     L.off_cursor = o;  o += al256((size_t)L.nt * 4);
@@ -81,7 +83,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_partoff = o; o += al256((size_t)L.nt * 4);
     L.off_multi = o;   o += al256((size_t)L.nt * 4);
     L.off_whole = o;   o += al256((size_t)L.nt * 4);
-    L.off_items = o;   o += al256((size_t)L.items_cap * 32);
+    L.off_items = o;   o += al256((size_t)L.rows_items_cap * 32);
     L.off_totals = o;  o += 256;
     L.off_box = o;     o += al256((size_t)L.nt * 16);
     L.off_ctl = o;     o += 256;

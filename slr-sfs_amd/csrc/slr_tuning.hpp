@@ -97,9 +97,6 @@
 #ifndef SLR_WAVES_ROWS
 #define SLR_WAVES_ROWS 5        // waves per SIMD the rows tile kernel is compiled for (it needs 88-92 VGPRs without a cap)
 #endif
-#ifndef SLR_ROWS_COMBINE
-#define SLR_ROWS_COMBINE 0      // 1: multi-piece tiles of the rows front end go through plain partial tiles + the combine kernel (as with bins)
-#endif
 #ifndef SLR_ROW_SORT
 #define SLR_ROW_SORT 1          // the tile kernel puts its row-segment list into image order before scanning (the appends arrive in any order)
 #endif

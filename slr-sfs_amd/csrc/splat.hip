@@ -598,15 +598,12 @@ __device__ __forceinline__ V exscan_tile_pix(V v, V *excl, V *wsum /*[TILE_PIX /
     return total;
 }
 
-__device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__ rowcnt, uint32_t nt, uint32_t seg, uint32_t part_slots,
-                                          uint32_t heavy, uint32_t items_cap, ItemDesc *__restrict__ items,
-                                          uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals, uint32_t *__restrict__ arrive,
-                                          uint32_t *__restrict__ multi, uint32_t *__restrict__ nseg_out, uint32_t *__restrict__ partoff_out) {
+__device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__ rowcnt, uint32_t nt, uint32_t seg, uint32_t heavy,
+                                          uint32_t items_cap, ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
     __shared__ unsigned long long wsum[TILE_PIX / 64];
     // The words were written by other workgroups' agent-scope atomics (performed at the memory side, before their arrival
     // atomics); this XCD's L2 may still hold the zeros of rows_zero_kernel.  They are read with agent-scope (sc1) loads, all four
-    // of a round in flight together (as __hip_atomic_load the compiler waits after each; an agent-scope acquire fence + plain
-    // loads costs an L2 invalidate: ~8 us here).
+    // of a round in flight together (as __hip_atomic_load the compiler waits after each).
     constexpr uint32_t PER = 4;
     static_assert(PER == 4, "the load block below is written out for 4 words");
 #ifdef SLR_PLAN_STAMPS
@@ -616,14 +613,11 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
 #endif
     PSTAMP(0);
     const uint32_t heavy_thr = heavy ? (heavy * 585u) / 4u : 0xffffffffu;
-    uint32_t run_heavy = 0, run_light = 0, run_parts = 0;
-    __shared__ uint32_t n_whole, n_multi;
-    if (threadIdx.x == 0) { n_whole = 0; n_multi = 0; }
+    uint32_t run_heavy = 0, run_light = 0, run_extra = 0;
+    const uint32_t extra_cap = items_cap - nt;                                // items beyond one per tile that items[] can hold
     for (uint32_t b = 0; b < nt; b += PER * TILE_PIX) {
         const uint32_t t0 = b + PER * threadIdx.x;
         unsigned long long w[PER];
-        uint32_t ns[PER], po[PER];
-        uint32_t parts = 0;
         {
             const unsigned long long *p0 = rowcnt + (t0 + 0 < nt ? t0 + 0 : 0u), *p1 = rowcnt + (t0 + 1 < nt ? t0 + 1 : 0u);
             const unsigned long long *p2 = rowcnt + (t0 + 2 < nt ? t0 + 2 : 0u), *p3 = rowcnt + (t0 + 3 < nt ? t0 + 3 : 0u);
@@ -634,25 +628,28 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
             for (uint32_t k = 0; k < PER; ++k) if (t0 + k >= nt) w[k] = 0ull;
         }
         PSTAMP(1);
+        unsigned long long mine = 0;                                          // (heavy items << 32) | other items of my 4 tiles
+        uint32_t ns[PER], io[PER], xo[PER];
+        bool hv[PER];
+        unsigned long long extra = 0;
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t cnt = (uint32_t)(w[k] >> 32);
-            ns[k] = t0 + k < nt ? (cnt > seg ? (cnt + seg - 1) / seg : 1u) : 0u;
-            po[k] = parts;
-            parts += ns[k] > 1 ? ns[k] : 0u;
+            // pieces = output-row ranges of the tile (1, 2, 4 or 8).  A footprint covers two output rows, so a piece of 8 / ns rows
+            // holds ~cnt * (1 / ns + 1 / 8) entries; 15 % margin for uneven rows (Euler t = 59 at 768x1280: no piece above 877 of
+            // 1024 this way).  A piece that still exceeds `seg` is found by its own workgroup and handed to the pass-by-pass launch.
+            const unsigned long long c115 = (unsigned long long)cnt * 115u;
+            ns[k] = t0 + k >= nt ? 0u : cnt <= seg ? 1u : c115 * 5u <= 800ull * seg ? 2u : c115 * 3u <= 800ull * seg ? 4u : 8u;
+            xo[k] = (uint32_t)extra;
+            extra += ns[k] ? ns[k] - 1u : 0u;
         }
-        unsigned long long pex;
-        const uint32_t ptot = (uint32_t)exscan_tile_pix<unsigned long long>(parts, &pex, wsum);
-        PSTAMP(2);
-        unsigned long long mine = 0;                                          // (heavy items << 32) | other items of my 4 tiles
-        bool whole[PER], hv[PER];
-        uint32_t io[PER];
+        unsigned long long xex;
+        const uint32_t xtot = (uint32_t)exscan_tile_pix<unsigned long long>(extra, &xex, wsum);
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
-            po[k] += run_parts + (uint32_t)pex;
-            whole[k] = ns[k] > 1 && po[k] + ns[k] > part_slots;               // partial-slot budget exhausted
-            if (whole[k]) ns[k] = 1;
-            hv[k] = ns[k] && (uint32_t)(w[k] >> 32) > heavy_thr;
+            const uint32_t cnt = (uint32_t)(w[k] >> 32);
+            if (ns[k] > 1u && run_extra + (uint32_t)xex + xo[k] + ns[k] - 1u > extra_cap) ns[k] = 1u;     // items[] is full: one piece (pass by pass)
+            hv[k] = ns[k] && cnt > heavy_thr;
             io[k] = hv[k] ? (uint32_t)(mine >> 32) : (uint32_t)mine;
             mine += hv[k] ? (unsigned long long)ns[k] << 32 : (unsigned long long)ns[k];
         }
@@ -664,36 +661,27 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
             if (!ns[k]) continue;
             ItemDesc d;
             d.tile = t0 + k; d.cnt0 = (uint32_t)(w[k] >> 32); d.cnt1 = (uint32_t)w[k]; d.off0 = 0; d.off1 = 0;
-            d.nseg = whole[k] ? 0u : ns[k]; d.partoff = po[k];
+            d.nseg = ns[k]; d.partoff = 0;
             const uint32_t at = hv[k] ? run_heavy + (uint32_t)(iex >> 32) + io[k] : run_light + (uint32_t)iex + io[k];
             for (uint32_t q = 0; q < ns[k]; ++q) {
                 d.seg = q;
                 items[hv[k] ? at + q : items_cap - 1u - (at + q)] = d;
             }
-            if (whole[k]) whole_items[atomicAdd(&n_whole, 1u)] = hv[k] ? at : items_cap - 1u - at;    // (position in items[]; rare)
-            if (ns[k] > 1) {
-                for (uint32_t g = 0; g < 4; ++g) arrive[(size_t)g * part_slots + po[k]] = 0u;
-#if SLR_ROWS_COMBINE
-                multi[atomicAdd(&n_multi, 1u)] = t0 + k; nseg_out[t0 + k] = ns[k]; partoff_out[t0 + k] = po[k];
-#endif
-            }
         }
         run_heavy += (uint32_t)(itot >> 32);
         run_light += (uint32_t)itot;
-        run_parts += ptot;
+        run_extra += xtot;
         PSTAMP(4);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { totals[0] = run_heavy + run_light; totals[1] = run_parts; totals[3] = n_multi; totals[4] = n_whole; totals[5] = run_heavy; }
+    // totals[4]: pieces that turn out to need more than one pass (appended by their workgroups, read by the WHOLE launch)
+    if (threadIdx.x == 0) { totals[0] = run_heavy + run_light; totals[1] = 0; totals[3] = 0; totals[4] = 0; totals[5] = run_heavy; }
 }
 
 __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restrict__ flow, unsigned long long *__restrict__ rowcnt,
                                                           RowRec *__restrict__ rowlist, int H, int W, int tiles_x, int tiles,
                                                           uint32_t nt, uint32_t *__restrict__ ctl, uint32_t *__restrict__ arrive1,
-                                                          uint32_t seg, uint32_t part_slots, uint32_t heavy, uint32_t items_cap, ItemDesc *__restrict__ items,
-                                                          uint32_t *__restrict__ whole_items, uint32_t *__restrict__ totals,
-                                                          uint32_t *__restrict__ arrive, uint32_t *__restrict__ multi,
-                                                          uint32_t *__restrict__ nseg_out, uint32_t *__restrict__ partoff_out) {
+                                                          uint32_t seg, uint32_t heavy, uint32_t items_cap,
+                                                          ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
     const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #ifdef SLR_PLAN_STAMPS
@@ -772,7 +760,7 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
 #ifdef SLR_PLAN_STAMPS
     if (tid == 0) { ((unsigned long long *)totals)[14] = k_entry; ((unsigned long long *)totals)[13] = (unsigned long long)wall_clock64(); }
 #endif
-    rows_plan(rowcnt, nt, seg, part_slots, heavy, items_cap, items, whole_items, totals, arrive, multi, nseg_out, partoff_out);
+    rows_plan(rowcnt, nt, seg, heavy, items_cap, items, totals);
 }
 
 // (rowcnt words and the arrival counter of rowbin_kernel, zeroed at the start of every call: the workspace is the caller's memory)
@@ -1066,8 +1054,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
   bool w_piece = false;
   for (uint32_t wi = bx;;) {                           // one pass unless WHOLE (its items) or SCAN (popped segments)
     ItemDesc it;
+    uint32_t item_at = item;                       // ROWS: position of the item in items[]
     if (SCAN && !ROWS) { it = ItemDesc{}; it.tile = item; it.nseg = 1; }
-    else if (ROWS && !WHOLE) { const uint32_t nh = a.totals[5]; it = a.items[item < nh ? item : a.items_cap - 1u - (item - nh)]; }   // heavy from the front, the rest from the back
+    else if (ROWS && !WHOLE) { const uint32_t nh = a.totals[5]; item_at = item < nh ? item : a.items_cap - 1u - (item - nh); it = a.items[item_at]; }   // heavy from the front, the rest from the back
     else it = a.items[item];
     const uint32_t t = it.tile;
     // Normally one workgroup = one segment.  A tile whose segments did not fit into the partial-slot
@@ -1077,13 +1066,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     // That is a separate instantiation (WHOLE) launched after the main one; the main kernel skips
     // those items, so its code carries no loop.
     constexpr bool whole = WHOLE || (SCAN && !ROWS);   // scan front end: a tile with more than SEG entries is walked pass by pass as well
-    if ((!SCAN || ROWS) && (it.nseg == 0) != WHOLE) return;
+    if (!SCAN && (it.nseg == 0) != WHOLE) return;
     // Channel groups (gridDim.y > 1: small grids, see launch_batch): this workgroup builds the tile's records like
     // any other and gathers the planes [cb, cend) only.  Groups start on a multiple of 2 * CHUNK planes.
     const int cper = (((a.C + (int)gridDim.y - 1) / (int)gridDim.y + 2 * CHUNK - 1) / (2 * CHUNK)) * (2 * CHUNK);
     const int cb = (int)w_grp * cper, cend = min(a.C, cb + cper);
     if (cb >= a.C) return;
-    uint32_t nloop = WHOLE ? (it.cnt0 + (ROWS ? 0u : it.cnt1) + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;   // (rows: cnt1 = its row segments)
+    uint32_t nloop = (WHOLE && !ROWS) ? (it.cnt0 + it.cnt1 + (uint32_t)a.seg - 1) / (uint32_t)a.seg : 1u;   // (rows, WHOLE: set after its count pass)
     float nrm_total = 0.0f, g2_sum = 0.0f, g2_nrm = 0.0f;
     const int n = t / a.tiles, tl = t - n * a.tiles;
     const int ty0 = (tl / a.tiles_x) * TILE_H, tx0 = (tl % a.tiles_x) * TILE_W;
@@ -1233,37 +1222,43 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
         }
         return MODE == 0 ? cmask[64] : wcount;
     };
-    // ROWS: entries [lo, hi) of the tile from its row-segment list.  The list's hit counts give every segment its first slot
-    // (exclusive scan): no atomics, no count pass, and a piece of a heavy tile reads only the rows that hold its entries.
-    // A tile whose list overflowed (more than ROW_CAP segments: everything converging on it) walks ALL row segments of its
-    // sample instead, counting first (wave w takes segments w, w + 8, ...: ordinal = hits of the waves before + own so far).
-    auto rowscan = [&](uint32_t lo, uint32_t hi) {
-        constexpr int CB = SLR_ROW_CB;
+    // ROWS: the entries of this piece of work from the tile's row-segment list.  A piece = the output rows [ra, rb) of the
+    // tile (plan: 1, 2, 4 or 8 pieces per tile): it owns its output pixels, so nothing is summed across pieces -- no partial
+    // tiles, no combine.  Entry slots:
+    //   mode 0  (whole tile, <= SEG entries): the list's hit counts give every row segment its first slot (exclusive scan);
+    //   mode 1  (a row range, or a tile whose list overflowed and that walks ALL row segments of its sample): one LDS atomic per
+    //           wave and row segment; more than SEG hits -> the piece is handed to the pass-by-pass launch (WHOLE);
+    //   mode 2  (WHOLE): ordinals (wave w takes segments w, w + 8, ...: hits of the waves before + own so far) after a count
+    //           pass; pass si emits the ordinals [si * SEG, (si + 1) * SEG).
+    const int ra = ROWS ? (int)(it.seg * (uint32_t)TILE_H / max(it.nseg, 1u)) : 0;
+    const int rb = ROWS ? (int)((it.seg + 1u) * (uint32_t)TILE_H / max(it.nseg, 1u)) : TILE_H;
+    const bool rows_ovf = ROWS && it.cnt1 > (uint32_t)ROW_CAP;
+    uint32_t rows_n = 0;                                           // row segments to walk
+    auto rows_setup = [&]() {                                      // list -> LDS (image order) + first slots; needs the record area
         const int lane = tid & 63, wid = tid >> 6;
-        const float *fl = a.flow[0] + (size_t)n * 2 * HW;
         uint32_t *rl_sy = clist, *rl_sx = clist + ROW_CAP, *rl_base = clist + 2 * ROW_CAP;      // [ROW_CAP], [ROW_CAP], [ROW_CAP + 1]
-        const bool ovf = it.cnt1 > (uint32_t)ROW_CAP;
-        const uint32_t nrows = ovf ? (uint32_t)a.H * (uint32_t)a.tiles_x : it.cnt1;
-        if (!ovf) {
+        rows_n = rows_ovf ? (uint32_t)a.H * (uint32_t)a.tiles_x : it.cnt1;
+        if (tid == 0) cmask[64] = 0;
+        if (!rows_ovf) {
             RowRec r = {0u, 0u};
-            if ((uint32_t)tid < nrows) r = a.rowlist[(size_t)t * ROW_CAP + tid];
+            if ((uint32_t)tid < rows_n) r = a.rowlist[(size_t)t * ROW_CAP + tid];
             uint32_t c = r.sx_cnt & 0xffu;
 #if SLR_ROW_SORT
             // the appends arrived in any order: put the list into image order (row, column) -- the order the bins have, which the
             // staging loads and the record lists like best -- by ranking every key among the others (<= ROW_CAP broadcast reads)
             const unsigned long long mykey = ((unsigned long long)r.sy << 24) | (r.sx_cnt >> 8);
-            if ((uint32_t)tid < nrows) { rl_sy[tid] = r.sy; rl_sx[tid] = r.sx_cnt >> 8; }
+            if ((uint32_t)tid < rows_n) { rl_sy[tid] = r.sy; rl_sx[tid] = r.sx_cnt >> 8; }
             __syncthreads();
             uint32_t rank = 0;
-            if ((uint32_t)tid < nrows)
-                for (uint32_t q = 0; q < nrows; ++q) {
+            if ((uint32_t)tid < rows_n)
+                for (uint32_t q = 0; q < rows_n; ++q) {
                     const unsigned long long k2 = ((unsigned long long)rl_sy[q] << 24) | rl_sx[q];
                     rank += (k2 < mykey) ? 1u : 0u;                    // (keys are distinct: one append per (segment, tile))
                 }
             __syncthreads();
-            if ((uint32_t)tid < nrows) { rl_sy[rank] = r.sy; rl_sx[rank] = r.sx_cnt >> 8; rl_base[rank] = c; }
+            if ((uint32_t)tid < rows_n) { rl_sy[rank] = r.sy; rl_sx[rank] = r.sx_cnt >> 8; rl_base[rank] = c; }
             __syncthreads();
-            c = (uint32_t)tid < nrows ? rl_base[tid] : 0u;             // counts in sorted order
+            c = (uint32_t)tid < rows_n ? rl_base[tid] : 0u;            // counts in sorted order
             __syncthreads();
 #else
             if (tid < ROW_CAP) { rl_sy[tid] = r.sy; rl_sx[tid] = r.sx_cnt >> 8; }
@@ -1280,28 +1275,35 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
 #pragma unroll
             for (int w = 0; w < T / 64; ++w) woff += (w < wid) ? wsum[w] : 0u;
             if (tid <= ROW_CAP) rl_base[tid] = woff + inc - c;
-            __syncthreads();
         }
-        const uint32_t my_n = nrows > (uint32_t)wid ? (nrows - (uint32_t)wid + (uint32_t)(T / 64) - 1u) / (uint32_t)(T / 64) : 0u;
-        uint32_t wave_base = 0;
+        __syncthreads();
+    };
+    uint32_t rows_wave_base = 0;
+    // one walk over this wave's row segments; returns the wave's hits.  MODE as above; EMIT: write the entries with slots in [lo, hi)
+    auto rows_walk = [&](auto mode_tag, auto emit_tag, uint32_t lo, uint32_t hi) -> uint32_t {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool EMIT = decltype(emit_tag)::value;
+        constexpr int CB = SLR_ROW_CB;
+        const int lane = tid & 63, wid = tid >> 6;
+        const float *fl = a.flow[0] + (size_t)n * 2 * HW;
+        const uint32_t *rl_sy = clist, *rl_sx = clist + ROW_CAP, *rl_base = clist + 2 * ROW_CAP;
+        const uint32_t my_n = rows_n > (uint32_t)wid ? (rows_n - (uint32_t)wid + (uint32_t)(T / 64) - 1u) / (uint32_t)(T / 64) : 0u;
         struct Group { float fx[CB], fy[CB]; int sy[CB], stx[CB]; uint32_t b0[CB]; };
         auto issue = [&](Group &g, uint32_t j0) {
 #pragma unroll
             for (int i = 0; i < CB; ++i) {
                 const uint32_t j = j0 + (uint32_t)i, ri = (uint32_t)wid + j * (uint32_t)(T / 64);
-                bool on = j < my_n;
+                const bool on = j < my_n;
                 int sy, stx;
                 uint32_t base = 0;
-                if (ovf) {
+                if (rows_ovf) {
                     sy = (int)(ri / (uint32_t)a.tiles_x);
                     stx = (int)(ri - (uint32_t)sy * (uint32_t)a.tiles_x);
                 } else {
                     const uint32_t q = on ? ri : 0u;
                     sy = __builtin_amdgcn_readfirstlane((int)rl_sy[q]);
                     stx = __builtin_amdgcn_readfirstlane((int)rl_sx[q]);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q]);
-                    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q + 1u]);
-                    on = on && end > lo && base < hi;                  // (pieces of a heavy tile: only the rows that hold their entries)
+                    if (MODE == 0) base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q]);
                 }
                 g.sy[i] = on ? sy : -1;
                 g.stx[i] = stx;
@@ -1314,8 +1316,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
             }
         };
         uint32_t wcount = 0;
-        auto process = [&](const Group &g, auto emit_tag) {
-            constexpr bool EMIT = decltype(emit_tag)::value;
+        auto process = [&](const Group &g) {
 #pragma unroll
             for (int i = 0; i < CB; ++i) {
                 const int sy = g.sy[i], sx = g.stx[i] * TILE_W + lane;
@@ -1323,11 +1324,18 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                 const Corners c = make_corners(g.fx[i], g.fy[i], sx, sy);
                 const int lx = c.x0 - tx0, ly = c.y0 - ty0;
                 const bool xa = (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W), xb = (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
-                const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H), yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
+                const bool ya = (ly >= ra) & (ly < rb) & (c.y0 < a.H), yb = (ly + 1 >= ra) & (ly + 1 < rb) & (c.y0 + 1 < a.H);
                 const bool hit = in & c.ok & (xa | xb) & (ya | yb);
                 const unsigned long long hm = __ballot(hit);
-                const uint32_t b0 = ovf ? wave_base + wcount : g.b0[i];
-                wcount += (uint32_t)__popcll(hm);
+                const uint32_t pc = (uint32_t)__popcll(hm);
+                if (sy < 0) continue;                                  // (wave-uniform: no row segment here)
+                uint32_t b0;
+                if (MODE == 0) b0 = g.b0[i];
+                else if (MODE == 1) {
+                    b0 = 0;
+                    if (pc) { if (lane == 0) b0 = atomicAdd(&cmask[64], pc); b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); }
+                } else b0 = rows_wave_base + wcount;
+                wcount += pc;
                 if (EMIT) {
                     const uint32_t slot = b0 + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
                     if (hit && slot >= lo && slot < hi) {
@@ -1338,29 +1346,17 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                 }
             }
         };
-        auto walk = [&](auto emit_tag) {
-            wcount = 0;
-            Group ga, gb;
-            if (my_n > 0) issue(ga, 0u);
-            for (uint32_t j0 = 0; j0 < my_n; j0 += 2 * CB) {
-                if (j0 + CB < my_n) issue(gb, j0 + CB);
-                process(ga, emit_tag);
-                if (j0 + CB < my_n) {
-                    if (j0 + 2 * CB < my_n) issue(ga, j0 + 2 * CB);
-                    process(gb, emit_tag);
-                }
+        Group ga, gb;
+        if (my_n > 0) issue(ga, 0u);
+        for (uint32_t j0 = 0; j0 < my_n; j0 += 2 * CB) {
+            if (j0 + CB < my_n) issue(gb, j0 + CB);
+            process(ga);
+            if (j0 + CB < my_n) {
+                if (j0 + 2 * CB < my_n) issue(ga, j0 + 2 * CB);
+                process(gb);
             }
-        };
-        if (ovf) {
-            walk(std::false_type{});
-            if (lane == 0) cmask[65 + wid] = wcount;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < T / 64; ++w) wave_base += (w < wid) ? cmask[65 + w] : 0u;
-            __syncthreads();
         }
-        walk(std::true_type{});
-        __syncthreads();
+        return wcount;
     };
     if (!w_piece) { SLR_STAMP(41); SLR_STAMP_RT(48); }
     int qavail = 0;                                               // the semaphore as seen two chunks before the end of this work
@@ -1369,11 +1365,35 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     bool part = false;                                            // this piece of work is ONE segment of a shared tile
     bool ctx = false;                                             // this workgroup holds a shared tile it may draw more tickets of
     uint32_t ns_tile = 1;                                         // segments of the tile (part)
-    if (ROWS) {
-        scan_total = it.cnt0;                                     // exact (rowbin_kernel)
-        part = !SLR_ROWS_COMBINE && it.nseg > 1;
-        ns_tile = part ? it.nseg : 1u;
-        w_seg = it.seg; w_po = it.partoff;
+    if (ROWS && !WHOLE) {
+        rows_setup();
+        if (it.nseg <= 1u && !rows_ovf) {
+            rows_walk(std::integral_constant<int, 0>{}, std::true_type{}, 0u, (uint32_t)SEG);
+            scan_total = it.cnt0;                                 // exact (rowbin_kernel), <= SEG (the plan)
+            __syncthreads();
+        } else {
+            rows_walk(std::integral_constant<int, 1>{}, std::true_type{}, 0u, (uint32_t)SEG);
+            __syncthreads();
+            scan_total = cmask[64];
+            if (scan_total > (uint32_t)SEG) {                     // (uniform) more than one pass: the pass-by-pass launch takes it
+                // (one entry per piece: every channel group of the piece gets here, the pass-by-pass workgroup covers all planes)
+                if (tid == 0 && blockIdx.y == 0) const_cast<uint32_t *>(a.whole_items)[atomicAdd(const_cast<uint32_t *>(a.totals) + 4, 1u)] = item_at;
+                return;
+            }
+        }
+        SLR_CUT_AT(1);
+    } else if (ROWS) {                                            // WHOLE: count, then nloop passes over the ordinals
+        rows_setup();
+        const uint32_t wc = rows_walk(std::integral_constant<int, 2>{}, std::false_type{}, 0u, 0u);
+        if ((tid & 63) == 0) cmask[65 + (tid >> 6)] = wc;
+        __syncthreads();
+        uint32_t all = 0, wb = 0;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) { const uint32_t c = cmask[65 + w]; all += c; wb += w < (tid >> 6) ? c : 0u; }
+        scan_total = all;
+        rows_wave_base = wb;
+        nloop = max(1u, (all + (uint32_t)SEG - 1u) / (uint32_t)SEG);
+        __syncthreads();
     } else if (SCAN) {
         if (!w_piece) scan_total = scan(std::integral_constant<int, 0>{}, 0u, (uint32_t)SEG);
         if (!w_piece) SLR_STAMP(42);
@@ -1420,12 +1440,15 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     }
 
   for (uint32_t si = 0; si < nloop; ++si) {
-    const uint32_t s = (SCAN && part) ? w_seg : whole ? si : it.seg;
+    const uint32_t s = ROWS ? (WHOLE ? si : 0u) : (SCAN && part) ? w_seg : whole ? si : it.seg;
     const bool first = si == 0, last = si + 1 == nloop;
     if (!w_piece && first) SLR_STAMP(0);
     if (!w_piece && first && SCAN && (nloop > 1 || part)) SLR_STAMP(36);
-    if (ROWS) { rowscan(s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG); SLR_CUT_AT(1); }
-    else if (SCAN && (nloop > 1 || part)) scan(std::integral_constant<int, 2>{}, s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG);
+    if (ROWS && WHOLE) {
+        if (si > 0) rows_setup();                                 // (the list shares LDS with the previous pass's records)
+        rows_walk(std::integral_constant<int, 2>{}, std::true_type{}, s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG);
+        __syncthreads();
+    } else if (SCAN && !ROWS && (nloop > 1 || part)) scan(std::integral_constant<int, 2>{}, s * (uint32_t)SEG, (s + 1) * (uint32_t)SEG);
     cnt[tid] = 0;
     __syncthreads();
 
@@ -1526,8 +1549,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
             const int lx = c.x0 - tx0, ly = c.y0 - ty0;
             const bool xa = c.ok & (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W);
             const bool xb = c.ok & (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
-            const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H);
-            const bool yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
+            const bool ya = (ly >= ra) & (ly < rb) & (c.y0 < a.H);          // (rows front end: this piece's output rows only)
+            const bool yb = (ly + 1 >= ra) & (ly + 1 < rb) & (c.y0 + 1 < a.H);
             const int oc = ly * TILE_W + lx;
             const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
             const int tg[4] = {oc, oc + 1, oc + TILE_W, oc + TILE_W + 1};
@@ -1610,8 +1633,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     const unsigned long long heavy = __ballot(r1 > rl);
     const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
     const int oy = ty0 + ly, ox = tx0 + lx;
-    const bool inside = (oy < a.H) & (ox < a.W);
-    const bool single = it.nseg <= 1 && !(SCAN && part);   // results go straight to the output tensor
+    const bool inside = (oy < a.H) & (ox < a.W) & (ly >= ra) & (ly < rb);       // (rows front end: the piece's output rows)
+    const bool single = ROWS || (it.nseg <= 1 && !(SCAN && part));   // results go straight to the output tensor
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)((SCAN ? w_po : it.partoff) + s) * a.part_stride + tid;
     const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
@@ -1841,7 +1864,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
   }
     if (SCAN) {
         if (!w_piece) { SLR_STAMP(37); SLR_STAMP_RT(49); }
-        if (part) {
+        if (!ROWS && part) {                     // (rows front end: pieces own their output rows, nothing to sum)
             // every storing wave drains its write-through stores, then ONE arrival; the last segment to arrive combines
 #if SLR_SHARE_STORE == 2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1877,7 +1900,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                     }
                     if (a.norm_out && inside && cb == 0) a.norm_out[(size_t)n * HW + (size_t)oy * a.W + ox] = norm_value(nrm, a.norm_mode, a.eps);
                 }
-                constexpr int CP = 8;                          // planes per round: 2 pieces x 8 planes = 16 loads in flight per wait (16 planes: spills)
+                constexpr int CP = 4;                          // planes per round: 2 pieces x 4 planes = 8 loads in flight per wait (8: spills)
                 for (int c0 = cb; c0 < cend; c0 += CP) {
                     float acc[CP];
                     for (uint32_t q = 0; q < ns_tile; q += 2) {
@@ -2273,11 +2296,10 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     a.ctl = nullptr;
     a.arrive = w0.arrive;
     a.rowlist = w0.rowlist;
-    a.items_cap = w0.L.items_cap;
+    a.items_cap = w0.L.rows_items_cap;
     a.items = w0.items;
     a.totals = w0.totals;
     a.whole_items = w0.whole_items;
-    a.nseg = w0.nseg; a.partoff = w0.partoff; a.multi = w0.multi;
     a.ndir = 1;
     a.seg = EPT_SCAN * SPLAT_THREADS;
 #ifdef SLR_TRACE
@@ -2287,12 +2309,12 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     hipLaunchKernelGGL(rows_zero_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w0.rowcnt, nt, w0.ctl, (uint32_t *)w0.box);   // (the box array of
     // the scan front end doubles as rowbin_kernel's first-level arrival counters)
     hipLaunchKernelGGL(rowbin_kernel, dim3(nt), dim3(TILE_PIX), 0, st, a.flow[0], w0.rowcnt, w0.rowlist, a.H, a.W, w0.L.tiles_x,
-                       w0.L.tiles, nt, w0.ctl, (uint32_t *)w0.box, (uint32_t)a.seg, w0.L.part_slots, nt > 512u ? (uint32_t)SLR_PLAN_HEAVY : 0u, w0.L.items_cap,
-                       w0.items, w0.whole_items, w0.totals, w0.arrive, w0.multi, w0.nseg, w0.partoff);
+                       w0.L.tiles, nt, w0.ctl, (uint32_t *)w0.box, (uint32_t)a.seg, nt > 512u ? (uint32_t)SLR_PLAN_HEAVY : 0u,
+                       w0.L.rows_items_cap, w0.items, w0.totals);
     SplatBatch b = {};
     b.f[0] = a;
     b.nb = 1;
-    uint32_t cover = w0.L.items_cap;
+    uint32_t cover = w0.L.rows_items_cap;
 #ifdef SLR_ROWS_GRID_HOOK
     if (const char *g = getenv("SLR_ROWS_GRID")) cover = (uint32_t)atoi(g);      // (experiment: how much do the surplus blocks cost?)
 #endif
@@ -2303,13 +2325,9 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, false, 2>(b, grid, channel_groups(nt, a.C, CHUNK_ONE), lds, st)) return e;
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
-    // tiles whose pieces did not fit the partial-slot budget (none for ordinary flows): pass by pass, one workgroup each
+    // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass
     b.end[0] = nt < 256u ? nt : 256u;
     if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, true, 2>(b, b.end[0], 1u, lds, st)) return e;
-#if SLR_ROWS_COMBINE
-    b.cend[0] = w0.L.part_slots / 2;
-    hipLaunchKernelGGL((combine_kernel<NORM, MAXOP>), dim3(b.cend[0], (a.C + COMBINE_CHUNK - 1) / COMBINE_CHUNK), dim3(SPLAT_THREADS), 0, st, b);
-#endif
     SLR_CHECK_LAUNCH();
     return 0;
 }
