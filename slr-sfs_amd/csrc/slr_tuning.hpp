@@ -91,6 +91,9 @@
 #ifndef SLR_ROW_CAP
 #define SLR_ROW_CAP 256         // row segments (64 source pixels of one image row) a tile's list holds; a tile touched by more is
 #endif                          // scanned from the whole flow instead (pathological flows only; identity ~30, Euler t=59 < 200)
+#ifndef SLR_ROWBIN_R
+#define SLR_ROWBIN_R 2          // source tiles (vertically adjacent) per workgroup of rowbin_kernel = row segments per wave
+#endif
 #ifndef SLR_ROW_CB
 #define SLR_ROW_CB 3            // row segments per wave whose flow loads are in flight together
 #endif

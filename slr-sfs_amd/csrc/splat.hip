@@ -564,7 +564,7 @@ __global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restr
 // own rows.  Multi-segment tiles are summed by their last-arriving workgroup (the partial-slot code of the scan front end).
 // A tile touched by more than SLR_ROW_CAP segments (pathological flows) is scanned from ALL rows of its sample instead.
 constexpr int ROW_CAP = SLR_ROW_CAP;
-struct RowRec { uint32_t sy, sx_cnt; };     // row segment: image row, (x / 64) << 8 | its hits in the tile (<= 64)
+struct RowRec { uint32_t sy, sx_cnt; };     // row segment: image row | column octants of the tile it touches << 24, (x / 64) << 8 | its hits in the tile (<= 64)
 
 // Work plan from the per-tile (entries, row segments) words; run by ONE workgroup of TILE_PIX work-items (the last one of
 // rowbin_kernel) in ONE pass over the tiles.  A round covers 4 * TILE_PIX tiles: every work-item loads the words of 4
@@ -635,11 +635,12 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t cnt = (uint32_t)(w[k] >> 32);
-            // pieces = output-row ranges of the tile (1, 2, 4 or 8).  A footprint covers two output rows, so a piece of 8 / ns rows
-            // holds ~cnt * (1 / ns + 1 / 8) entries; 15 % margin for uneven rows (Euler t = 59 at 768x1280: no piece above 877 of
-            // 1024 this way).  A piece that still exceeds `seg` is found by its own workgroup and handed to the pass-by-pass launch.
+            // pieces = output-column ranges of the tile (64 / ns columns: 1, 2, 4 or 8 pieces).  A footprint covers two output
+            // columns, so a piece holds ~cnt * (1 / ns + 1 / 64) entries (row ranges would duplicate 1/8 per cut: 1.78x the staged
+            // entries at 8 pieces, columns 1.10x; measured on Euler t = 59, 768x1280: pieces of 4 -> at most 1.10 of the mean);
+            // 15 % margin.  A piece that still exceeds `seg` is found by its own workgroup and handed to the pass-by-pass launch.
             const unsigned long long c115 = (unsigned long long)cnt * 115u;
-            ns[k] = t0 + k >= nt ? 0u : cnt <= seg ? 1u : c115 * 5u <= 800ull * seg ? 2u : c115 * 3u <= 800ull * seg ? 4u : 8u;
+            ns[k] = t0 + k >= nt ? 0u : cnt <= seg ? 1u : c115 * 33u <= 6400ull * seg ? 2u : c115 * 17u <= 6400ull * seg ? 4u : 8u;
             xo[k] = (uint32_t)extra;
             extra += ns[k] ? ns[k] - 1u : 0u;
         }
@@ -677,50 +678,73 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
     if (threadIdx.x == 0) { totals[0] = run_heavy + run_light; totals[1] = 0; totals[3] = 0; totals[4] = 0; totals[5] = run_heavy; }
 }
 
+// grid: N * tiles_x * ceil(tiles_y / ROWBIN_R) workgroups; a workgroup covers ROWBIN_R vertically adjacent source tiles (wave w: rows
+// w, w + 8, ... of the block, all their flow loads in flight together, their appends in ONE atomic instruction): a wave's life is
+// one load round trip + one atomic round trip however many rows it carries, and 1920 one-tile workgroups took 2.5 rounds of that.
+constexpr int ROWBIN_R = SLR_ROWBIN_R;
 __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restrict__ flow, unsigned long long *__restrict__ rowcnt,
-                                                          RowRec *__restrict__ rowlist, int H, int W, int tiles_x, int tiles,
+                                                          RowRec *__restrict__ rowlist, int H, int W, int tiles_x, int tiles_y,
                                                           uint32_t nt, uint32_t *__restrict__ ctl, uint32_t *__restrict__ arrive1,
                                                           uint32_t seg, uint32_t heavy, uint32_t items_cap,
                                                           ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
-    const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
+    const int tiles = tiles_x * tiles_y, by_n = (tiles_y + ROWBIN_R - 1) / ROWBIN_R, per_n = tiles_x * by_n;
+    const int b = blockIdx.x, n = b / per_n, bl = b - n * per_n;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #ifdef SLR_PLAN_STAMPS
     const unsigned long long k_entry = wall_clock64();
-    if (t == 0 && tid == 0) ((unsigned long long *)totals)[15] = k_entry;
+    if (b == 0 && tid == 0) ((unsigned long long *)totals)[15] = k_entry;
 #endif
-    const int stx = tl % tiles_x, y = (tl / tiles_x) * TILE_H + wid, x = stx * TILE_W + lane;
-    int t0 = -1, t1 = -1, t2 = -1, t3 = -1;               // the <= 4 tiles this pixel's footprint touches
-    if (y < H && x < W) {
-        const float *f = flow + (size_t)n * 2 * H * W + (size_t)y * W + x;
-        const Corners c = make_corners(f[0], f[(size_t)H * W], x, y);
-        const TileSet q = footprint_tiles(c, H, W);
-        if (q.vxa & q.vya) t0 = q.tya * tiles_x + q.txa;
-        if (q.vxb & q.vya) t1 = q.tya * tiles_x + q.txb;
-        if (q.vxa & q.vyb) t2 = q.tyb * tiles_x + q.txa;
-        if (q.vxb & q.vyb) t3 = q.tyb * tiles_x + q.txb;
+    const int stx = bl % tiles_x, y_base = (bl / tiles_x) * ROWBIN_R * TILE_H + wid, x = stx * TILE_W + lane;
+    const float *fl = flow + (size_t)n * 2 * H * W;
+    float fx[ROWBIN_R], fy[ROWBIN_R];
+#pragma unroll
+    for (int r = 0; r < ROWBIN_R; ++r) {
+        const int y = y_base + r * TILE_H;
+        const size_t q = (y < H && x < W) ? (size_t)y * W + x : 0;
+        fx[r] = fl[q];
+        fy[r] = fl[(size_t)H * W + q];
     }
-    // distinct tiles of the wave's 64 footprints, one per round: the first lane with something left names a tile, a ballot
-    // counts the lanes that touch it; round k's (tile, hits) is parked in lane k and all appends go out as ONE atomic instruction
-    if (y < H) {                                            // (wave-uniform)
-        unsigned long long *cnt_n = rowcnt + (size_t)n * tiles;
-        RowRec *list_n = rowlist + (size_t)n * tiles * ROW_CAP;
-        int my_tile = -1;
-        uint32_t my_cnt = 0;
-        int k = 0;
-        auto flush = [&]() {
+    // distinct tiles of a row's 64 footprints, one per round: the first lane with something left names a tile, a ballot counts the
+    // lanes that touch it; round k's (tile, row, hits) is parked in lane k and all appends go out as ONE atomic instruction
+    unsigned long long *cnt_n = rowcnt + (size_t)n * tiles;
+    RowRec *list_n = rowlist + (size_t)n * tiles * ROW_CAP;
+    int my_tile = -1, my_y = 0;
+    uint32_t my_cnt = 0;
+    int k = 0;
+    auto flush = [&]() {
 #if defined(SLR_RB_CUT) && SLR_RB_CUT == 1
-            if (my_tile == -12345)          // (measurement: no appends)
+        if (my_tile == -12345)          // (measurement: no appends)
 #else
-            if (my_tile >= 0)
+        if (my_tile >= 0)
 #endif
-            {
-                const unsigned long long old = atomicAdd(cnt_n + my_tile, 1ull | ((unsigned long long)my_cnt << 32));
-                const uint32_t slot = (uint32_t)old;
-                if (slot < (uint32_t)ROW_CAP) list_n[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)y, ((uint32_t)stx << 8) | my_cnt};
-            }
-            my_tile = -1;
-            k = 0;
-        };
+        {
+            const unsigned long long old = atomicAdd(cnt_n + my_tile, 1ull | ((unsigned long long)my_cnt << 32));
+            const uint32_t slot = (uint32_t)old;
+            if (slot < (uint32_t)ROW_CAP) list_n[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)my_y, ((uint32_t)stx << 8) | my_cnt};
+        }
+        my_tile = -1;
+        k = 0;
+    };
+#pragma unroll
+    for (int r = 0; r < ROWBIN_R; ++r) {
+        const int y = y_base + r * TILE_H;
+        if (y >= H) break;                                   // (wave-uniform)
+        int t0 = -1, t1 = -1, t2 = -1, t3 = -1;             // the <= 4 tiles this pixel's footprint touches
+        uint32_t cm_a = 0, cm_b = 0;                        // column octants (bits) it touches in the left / right of them
+        if (x < W) {
+            const Corners c = make_corners(fx[r], fy[r], x, y);
+            const TileSet q = footprint_tiles(c, H, W);
+            if (q.vxa & q.vya) t0 = q.tya * tiles_x + q.txa;
+            if (q.vxb & q.vya) t1 = q.tya * tiles_x + q.txb;
+            if (q.vxa & q.vyb) t2 = q.tyb * tiles_x + q.txa;
+            if (q.vxb & q.vyb) t3 = q.tyb * tiles_x + q.txb;
+            // tile column a holds corner column x0 (if in the image) and x0 + 1 when it lies in the same tile column; tile column b
+            // (valid only when distinct) holds x0 + 1.  Octant = 8 output columns (the finest piece of a heavy tile).
+            const bool x0in = c.ok & (c.x0 >= 0) & (c.x0 < W), x1in = c.ok & (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
+            if (q.vxa) cm_a = (x0in ? 1u << ((c.x0 & (TILE_W - 1)) >> 3) : 0u) |
+                              ((x1in && (c.x0 + 1) / TILE_W == q.txa) ? 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3) : 0u);
+            if (q.vxb) cm_b = 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3);
+        }
         for (;;) {
             const int cand = t0 >= 0 ? t0 : t1 >= 0 ? t1 : t2 >= 0 ? t2 : t3;
             const unsigned long long pend = __ballot(cand >= 0);
@@ -729,15 +753,18 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
             const int T = __builtin_amdgcn_readlane(cand, leader);
             const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
             const uint32_t c = (uint32_t)__popcll(__ballot(h));
+            uint32_t rm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) rm |= __shfl_xor(rm, d);
             if (t0 == T) t0 = -1;
             if (t1 == T) t1 = -1;
             if (t2 == T) t2 = -1;
             if (t3 == T) t3 = -1;
-            if (lane == k) { my_tile = T; my_cnt = c; }
+            if (lane == k) { my_tile = T; my_cnt = c; my_y = y | (int)(rm << 24); }
             if (++k == 64) flush();
         }
-        flush();
     }
+    flush();
     // ---- the last workgroup to get here plans the call (every append above has returned: its value was used)
     // (two levels: thousands of returning atomics on ONE word are served one after the other -- 35 us at 1920 workgroups)
     __shared__ uint32_t last;
@@ -1230,8 +1257,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     //           wave and row segment; more than SEG hits -> the piece is handed to the pass-by-pass launch (WHOLE);
     //   mode 2  (WHOLE): ordinals (wave w takes segments w, w + 8, ...: hits of the waves before + own so far) after a count
     //           pass; pass si emits the ordinals [si * SEG, (si + 1) * SEG).
-    const int ra = ROWS ? (int)(it.seg * (uint32_t)TILE_H / max(it.nseg, 1u)) : 0;
-    const int rb = ROWS ? (int)((it.seg + 1u) * (uint32_t)TILE_H / max(it.nseg, 1u)) : TILE_H;
+    const int pw = ROWS ? TILE_W / (int)max(it.nseg, 1u) : TILE_W;            // piece width: 64, 32, 16 or 8 output columns
+    const int pw_log = ROWS ? 31 - __builtin_clz((unsigned)pw) : 6;
+    const int pca = ROWS ? (int)it.seg * pw : 0, pcb = pca + pw;           // its output columns [pca, pcb)
     const bool rows_ovf = ROWS && it.cnt1 > (uint32_t)ROW_CAP;
     uint32_t rows_n = 0;                                           // row segments to walk
     auto rows_setup = [&]() {                                      // list -> LDS (image order) + first slots; needs the record area
@@ -1246,13 +1274,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
 #if SLR_ROW_SORT
             // the appends arrived in any order: put the list into image order (row, column) -- the order the bins have, which the
             // staging loads and the record lists like best -- by ranking every key among the others (<= ROW_CAP broadcast reads)
-            const unsigned long long mykey = ((unsigned long long)r.sy << 24) | (r.sx_cnt >> 8);
+            const unsigned long long mykey = ((unsigned long long)(r.sy & 0xffffffu) << 24) | (r.sx_cnt >> 8);
             if ((uint32_t)tid < rows_n) { rl_sy[tid] = r.sy; rl_sx[tid] = r.sx_cnt >> 8; }
             __syncthreads();
             uint32_t rank = 0;
             if ((uint32_t)tid < rows_n)
                 for (uint32_t q = 0; q < rows_n; ++q) {
-                    const unsigned long long k2 = ((unsigned long long)rl_sy[q] << 24) | rl_sx[q];
+                    const unsigned long long k2 = ((unsigned long long)(rl_sy[q] & 0xffffffu) << 24) | rl_sx[q];
                     rank += (k2 < mykey) ? 1u : 0u;                    // (keys are distinct: one append per (segment, tile))
                 }
             __syncthreads();
@@ -1288,12 +1316,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
         const float *fl = a.flow[0] + (size_t)n * 2 * HW;
         const uint32_t *rl_sy = clist, *rl_sx = clist + ROW_CAP, *rl_base = clist + 2 * ROW_CAP;
         const uint32_t my_n = rows_n > (uint32_t)wid ? (rows_n - (uint32_t)wid + (uint32_t)(T / 64) - 1u) / (uint32_t)(T / 64) : 0u;
+        const uint32_t range_mask = ((1u << ((pcb + 7) >> 3)) - 1u) & ~((1u << (pca >> 3)) - 1u);      // the piece's column octants
         struct Group { float fx[CB], fy[CB]; int sy[CB], stx[CB]; uint32_t b0[CB]; };
         auto issue = [&](Group &g, uint32_t j0) {
 #pragma unroll
             for (int i = 0; i < CB; ++i) {
                 const uint32_t j = j0 + (uint32_t)i, ri = (uint32_t)wid + j * (uint32_t)(T / 64);
-                const bool on = j < my_n;
+                bool on = j < my_n;
                 int sy, stx;
                 uint32_t base = 0;
                 if (rows_ovf) {
@@ -1301,7 +1330,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                     stx = (int)(ri - (uint32_t)sy * (uint32_t)a.tiles_x);
                 } else {
                     const uint32_t q = on ? ri : 0u;
-                    sy = __builtin_amdgcn_readfirstlane((int)rl_sy[q]);
+                    const uint32_t syw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_sy[q]);
+                    sy = (int)(syw & 0xffffffu);
+                    on = on && ((syw >> 24) & range_mask) != 0u;       // (a piece only loads the segments that touch its output rows)
                     stx = __builtin_amdgcn_readfirstlane((int)rl_sx[q]);
                     if (MODE == 0) base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q]);
                 }
@@ -1323,8 +1354,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                 const bool in = (sy >= 0) & (sx < a.W);
                 const Corners c = make_corners(g.fx[i], g.fy[i], sx, sy);
                 const int lx = c.x0 - tx0, ly = c.y0 - ty0;
-                const bool xa = (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W), xb = (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
-                const bool ya = (ly >= ra) & (ly < rb) & (c.y0 < a.H), yb = (ly + 1 >= ra) & (ly + 1 < rb) & (c.y0 + 1 < a.H);
+                const bool xa = (lx >= pca) & (lx < pcb) & (c.x0 < a.W), xb = (lx + 1 >= pca) & (lx + 1 < pcb) & (c.x0 + 1 < a.W);
+                const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H), yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
                 const bool hit = in & c.ok & (xa | xb) & (ya | yb);
                 const unsigned long long hm = __ballot(hit);
                 const uint32_t pc = (uint32_t)__popcll(hm);
@@ -1547,13 +1578,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                 m = 1.0f;
             }
             const int lx = c.x0 - tx0, ly = c.y0 - ty0;
-            const bool xa = c.ok & (lx >= 0) & (lx < TILE_W) & (c.x0 < a.W);
-            const bool xb = c.ok & (lx + 1 >= 0) & (lx + 1 < TILE_W) & (c.x0 + 1 < a.W);
-            const bool ya = (ly >= ra) & (ly < rb) & (c.y0 < a.H);          // (rows front end: this piece's output rows only)
-            const bool yb = (ly + 1 >= ra) & (ly + 1 < rb) & (c.y0 + 1 < a.H);
-            const int oc = ly * TILE_W + lx;
+            const bool xa = c.ok & (lx >= pca) & (lx < pcb) & (c.x0 < a.W);          // (rows front end: this piece's output columns only)
+            const bool xb = c.ok & (lx + 1 >= pca) & (lx + 1 < pcb) & (c.x0 + 1 < a.W);
+            const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H);
+            const bool yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
+            const int oc = (int)((unsigned)ly << pw_log) + lx - pca;      // output pixel = work-item: the piece's pixels are packed (row-major, pw wide)
             const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
-            const int tg[4] = {oc, oc + 1, oc + TILE_W, oc + TILE_W + 1};
+            const int tg[4] = {oc, oc + 1, oc + pw, oc + pw + 1};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (kb[k]) {
@@ -1631,9 +1662,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     const uint32_t own = max((uint32_t)LMAX, 2u * ((wave_recs + 63u) >> 6));
     const uint32_t rl = (r1 - r0 >= own + (uint32_t)SLR_HEAVY_SLACK) ? r0 + own : r1;
     const unsigned long long heavy = __ballot(r1 > rl);
-    const int ly = tid / TILE_W, lx = tid - ly * TILE_W;
-    const int oy = ty0 + ly, ox = tx0 + lx;
-    const bool inside = (oy < a.H) & (ox < a.W) & (ly >= ra) & (ly < rb);       // (rows front end: the piece's output rows)
+    const int ly = tid >> pw_log, lx = pca + (tid & (pw - 1));                   // (rows front end: work-items past the piece's
+    const int oy = ty0 + ly, ox = tx0 + lx;                                     //  8 * pw pixels own nothing)
+    const bool inside = (oy < a.H) & (ox < a.W) & (ly < TILE_H);
     const bool single = ROWS || (it.nseg <= 1 && !(SCAN && part));   // results go straight to the output tensor
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)((SCAN ? w_po : it.partoff) + s) * a.part_stride + tid;
@@ -2238,11 +2269,12 @@ static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_sp
 static std::atomic<int> g_front_end{SLR_FRONT_END};                    // slr_splat_set_front_end
 // Front end of a one-flow call that brings no bins: 0 bins, 1 scan (boxes), 2 rows.  By default the grid decides: scan up to
 // slr_splat_set_scan_max_tiles tiles (single-round grids: no plan to wait for), rows above.
-static int front_end(int prebinned, uint32_t nt) {
+static int front_end(int prebinned, uint32_t nt, int H) {
     if (prebinned) return 0;
-    const int fe = g_front_end.load(std::memory_order_relaxed);
-    if (fe >= 0 && fe <= 2) return fe;
-    return nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed) ? 1 : 2;
+    int fe = g_front_end.load(std::memory_order_relaxed);
+    if (fe < 0 || fe > 2) fe = nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed) ? 1 : 2;
+    if (fe == 2 && H >= (1 << 24)) fe = 0;             // (a row-list entry keeps the image row in 24 bits)
+    return fe;
 }
 
 // The scan front end of a one-flow call: box kernel + tile kernel, nothing else (no bins, no plan, no combine).
@@ -2308,8 +2340,9 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     const uint32_t nt = w0.L.nt;
     hipLaunchKernelGGL(rows_zero_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w0.rowcnt, nt, w0.ctl, (uint32_t *)w0.box);   // (the box array of
     // the scan front end doubles as rowbin_kernel's first-level arrival counters)
-    hipLaunchKernelGGL(rowbin_kernel, dim3(nt), dim3(TILE_PIX), 0, st, a.flow[0], w0.rowcnt, w0.rowlist, a.H, a.W, w0.L.tiles_x,
-                       w0.L.tiles, nt, w0.ctl, (uint32_t *)w0.box, (uint32_t)a.seg, nt > 512u ? (uint32_t)SLR_PLAN_HEAVY : 0u,
+    const uint32_t rb_grid = (uint32_t)a.N * (uint32_t)w0.L.tiles_x * (uint32_t)((w0.L.tiles_y + ROWBIN_R - 1) / ROWBIN_R);
+    hipLaunchKernelGGL(rowbin_kernel, dim3(rb_grid), dim3(TILE_PIX), 0, st, a.flow[0], w0.rowcnt, w0.rowlist, a.H, a.W, w0.L.tiles_x,
+                       w0.L.tiles_y, nt, w0.ctl, (uint32_t *)w0.box, (uint32_t)a.seg, nt > 512u ? (uint32_t)SLR_PLAN_HEAVY : 0u,
                        w0.L.rows_items_cap, w0.items, w0.totals);
     SplatBatch b = {};
     b.f[0] = a;
@@ -2326,8 +2359,15 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
     // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass
+    // (their planes dealt to up to 8 workgroups each: these run after everybody else, on an empty chip, one pass after the other)
     b.end[0] = nt < 256u ? nt : 256u;
-    if (int e = launch_tile_variant<NORM, MAXOP, EPT_SCAN, CHUNK_ONE, true, 2>(b, b.end[0], 1u, lds, st)) return e;
+    const uint32_t wgroups = (uint32_t)a.C / (2u * CHUNK_ONE) < 1u ? 1u : (uint32_t)a.C / (2u * CHUNK_ONE) > 8u ? 8u : (uint32_t)a.C / (2u * CHUNK_ONE);
+    // (and with passes of 2048 entries -- 86 KiB of LDS, one workgroup per CU: most of these pieces are just over the 1024 of the
+    // main kernel and finish in one pass)
+    constexpr int EPT_DEFER = 2 * EPT_SCAN;
+    b.f[0].seg = EPT_DEFER * SPLAT_THREADS;
+    const size_t lds_defer = lds_head_bytes(EPT_DEFER, true) + (size_t)CHUNK_ONE * (EPT_DEFER * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
+    if (int e = launch_tile_variant<NORM, MAXOP, EPT_DEFER, CHUNK_ONE, true, 2>(b, b.end[0], wgroups, lds_defer, st)) return e;
     SLR_CHECK_LAUNCH();
     return 0;
 }
@@ -2465,7 +2505,7 @@ SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const int fe = front_end(prebinned, w.L.nt);
+    const int fe = front_end(prebinned, w.L.nt, H);
     if (!prebinned && fe == 0) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
@@ -2487,7 +2527,7 @@ SLR_EXPORT int slr_softsplat_mode_forward(const float *in, const float *metric, 
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const int fe = front_end(prebinned, w.L.nt);
+    const int fe = front_end(prebinned, w.L.nt, H);
     if (!prebinned && fe == 0) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.mul = metric; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out;
@@ -2551,7 +2591,7 @@ SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *o
     Ws w;
     if (int e = ws_open(w, N, C, H, W, ws, ws_bytes, __func__)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const int fe = front_end(prebinned, w.L.nt);
+    const int fe = front_end(prebinned, w.L.nt, H);
     if (!prebinned && fe == 0) if (int e = do_bin(flow, w, nullptr, nullptr, N, H, W, st)) return e;
     SplatArgs a = {};
     a.in = in; a.flow[0] = flow; a.scale[0] = 1.0f; a.out = out; a.init = init;
