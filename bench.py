@@ -474,14 +474,15 @@ def dropin_roofline(dev, motion):
     launch), `call` = GPU time of EVERYTHING the call launches (front end + tile kernel + combine), measured by replaying a
     HIP graph of 20 calls; `call_eager_us` = the same call issued from Python with an event pair per call (host launch pace
     included).  Plus config C2 of BASELINE.json as stated (64 channels, 256x480, softmax mode, incoherent and smooth
-    flow) and two more small grids; `front_end` names what ran (include/slr_splat.h: slr_splat_set_scan_max_tiles)."""
+    flow) and two more small grids.  `front_end` names what a call takes by default (include/slr_splat.h:
+    slr_splat_set_front_end: scan up to 512 tiles, rows above); the other front ends are timed beside it."""
     import slr_sfs_amd as S
     from slr_sfs_amd import synthesis
     L = S._lib.lib()
     C = 65
     x = torch.randn(1, C, H, W, device=dev)
     alg = (2 * C + 2) * H * W * 4
-    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,4> (bins) / <...,true> (scan)", "peak": HBM_PEAK_GBS,
+    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,4,false,FE>, FE = 2 rows (default at 1920 tiles) / 0 bins / 1 scan", "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "alg_bytes_per_call": alg, "flows": {},
            "call": "GPU time of all launches of one call (HIP graph of 20 calls replayed); call_eager_us: Python call, event pair per call"}
 
@@ -513,10 +514,11 @@ def dropin_roofline(dev, motion):
              ("identity", torch.zeros(1, 2, H, W, device=dev)), ("incoherent", torch.rand(1, 2, H, W, device=dev) * 16 - 8)]
     for name, flow in flows:
         r = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
-        r["front_end"] = "bins"                            # 1920 tiles > the scan threshold (512): bin -> plan -> tile -> combine
-        prev = L.slr_splat_set_scan_max_tiles(2 ** 31 - 1)
-        r["scan_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
-        L.slr_splat_set_scan_max_tiles(prev)
+        r["front_end"] = "rows"                            # 1920 tiles > the scan threshold (512): zero + rows/plan + tile kernel (+ deferred pieces)
+        for fe_name, fe in (("bins", 0), ("scan", 1)):
+            prev = L.slr_splat_set_front_end(fe)
+            r[fe_name + "_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
+            L.slr_splat_set_front_end(prev)
         res["flows"][name] = r
         if name.startswith("euler") and (worst is None or r["tile_frac"] < worst["tile_frac"]):
             worst = r
@@ -534,12 +536,13 @@ def dropin_roofline(dev, motion):
             r = measure(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), alg2, tile=False)
             r.update({"workload": f"FunctionSoftsplat softmax, {c2} ch, {h2}x{w2}, {fname} flow", "alg_bytes": alg2,
                       "front_end": "scan (box kernel + tile kernel: 2 launches)"})
-            prev = L.slr_splat_set_scan_max_tiles(0)
-            try:
-                r["bins_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
-            except Exception:
-                r["bins_front_end_call_us"] = round(_time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 20)[0], 1)
-            L.slr_splat_set_scan_max_tiles(prev)
+            for fe_name, fe in (("bins", 0), ("rows", 2)):
+                prev = L.slr_splat_set_front_end(fe)
+                try:
+                    r[fe_name + "_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
+                except Exception:
+                    r[fe_name + "_front_end_call_us"] = round(_time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 20)[0], 1)
+                L.slr_splat_set_front_end(prev)
             small[tag if fname == "incoherent" else f"{tag}_{fname}"] = r
     res["c2"] = small.pop("c2")
     res["c2"]["workload"] = "C2: " + res["c2"]["workload"] + " U(-8,8)"

@@ -54,7 +54,7 @@ struct WsLayout {
     size_t off_ctl;       // uint32[4]    scan front end, segment sharing: queue head, tail, partial slots used
     size_t off_queue;     // uint64[part_slots] work words (tile, segment, segments, first slot, channel group)
     size_t off_arrive;    // uint32[4 * part_slots] arrivals per shared tile (rows front end: per channel group)
-    size_t off_rowcnt;    // uint64[nt]   rows front end: (entries << 32) | row segments appended, zero between calls
+    size_t off_rowcnt;    // uint64[nt][2] rows front end: (entries << 32) | row segments appended; entries per column octant / 16, 8 bits each
     size_t off_rowlist;   // uint32[nt][SLR_ROW_CAP][2]  (row segment, its entries in the tile)
     size_t off_trash;     // float[planes][TILE_PIX]  sink for work-items outside the image
     size_t off_partial;   // float[part_slots][planes][TILE_PIX]           (main -> combine)
@@ -89,7 +89,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_ctl = o;     o += 256;
     L.off_queue = o;   o += al256((size_t)L.part_slots * 8);
     L.off_arrive = o;  o += al256((size_t)L.part_slots * 4 * 4);
-    L.off_rowcnt = o;  o += al256((size_t)L.nt * 8);
+    L.off_rowcnt = o;  o += al256((size_t)L.nt * 16);
     L.off_rowlist = o; o += al256((size_t)L.nt * SLR_ROW_CAP * 8);
     // C value planes (rounded up to whole chunks of 4: the scan front end stores a chunk per 16-byte word) + the normaliser plane
     L.part_stride = (size_t)((C + 3) / 4 * 4 + 1) * TILE_PIX;

@@ -46,6 +46,9 @@
 #ifndef SLR_HEAVY_SLACK
 #define SLR_HEAVY_SLACK 24      // a list this much longer than the wave's share is walked by the whole wave (8: t=59 +55 %; 64: +10 %)
 #endif
+#ifndef SLR_HEAVY_MAX
+#define SLR_HEAVY_MAX 4         // at most this many cooperative (whole-wave) list walks per wave and chunk; more long lists: every lane walks its own
+#endif
 #ifndef SLR_XCD_GROUP
 #define SLR_XCD_GROUP 4         // neighbouring tiles kept on one XCD (column halo from its L2: -12 % HBM fetch).  1 / 2 / 4 / 8: 183.9 / 182.9 / 185.5 / 182.3 us per frame
 #endif
@@ -98,7 +101,13 @@
 #define SLR_ROW_CB 3            // row segments per wave whose flow loads are in flight together
 #endif
 #ifndef SLR_WAVES_ROWS
-#define SLR_WAVES_ROWS 5        // waves per SIMD the rows tile kernel is compiled for (it needs 88-92 VGPRs without a cap)
+#define SLR_WAVES_ROWS 6        // waves per SIMD the rows tile kernel is compiled for: 80 VGPRs = three workgroups per CU (two: +5..10 %)
+#endif
+#ifndef SLR_KREG_ROWS
+#define SLR_KREG_ROWS 4         // register-resident records per output pixel in the rows tile kernel 
+#endif
+#ifndef SLR_ROWS_GROUP
+#define SLR_ROWS_GROUP 0        // narrow pieces: 0 one lane per output pixel; 1 groups of 8 / 4 lanes up to 16 columns; 2 also pairs up to 32 columns
 #endif
 #ifndef SLR_ROW_SORT
 #define SLR_ROW_SORT 1          // the tile kernel puts its row-segment list into image order before scanning (the appends arrive in any order)

@@ -617,30 +617,54 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
     const uint32_t extra_cap = items_cap - nt;                                // items beyond one per tile that items[] can hold
     for (uint32_t b = 0; b < nt; b += PER * TILE_PIX) {
         const uint32_t t0 = b + PER * threadIdx.x;
-        unsigned long long w[PER];
-        {
-            const unsigned long long *p0 = rowcnt + (t0 + 0 < nt ? t0 + 0 : 0u), *p1 = rowcnt + (t0 + 1 < nt ? t0 + 1 : 0u);
-            const unsigned long long *p2 = rowcnt + (t0 + 2 < nt ? t0 + 2 : 0u), *p3 = rowcnt + (t0 + 3 < nt ? t0 + 3 : 0u);
-            asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\t"
-                         "global_load_dwordx2 %2, %6, off sc1\n\tglobal_load_dwordx2 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+        unsigned long long w[PER], oh[PER];
 #pragma unroll
-            for (uint32_t k = 0; k < PER; ++k) if (t0 + k >= nt) w[k] = 0ull;
+        for (uint32_t k = 0; k < PER; ++k) {                  // 8 agent-scope loads in flight, one wait
+            const unsigned long long *pw_ = rowcnt + 2 * (size_t)(t0 + k < nt ? t0 + k : 0u);
+            asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:8 sc1"
+                         : "=&v"(w[k]), "=&v"(oh[k]) : "v"(pw_) : "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(oh[0]), "+v"(oh[1]), "+v"(oh[2]), "+v"(oh[3])
+                     :: "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) if (t0 + k >= nt) w[k] = 0ull;
         PSTAMP(1);
         unsigned long long mine = 0;                                          // (heavy items << 32) | other items of my 4 tiles
         uint32_t ns[PER], io[PER], xo[PER];
+        unsigned long long pcs[PER];                                          // pieces of the tile: (first octant | octants << 4), 8 bits each
         bool hv[PER];
         unsigned long long extra = 0;
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t cnt = (uint32_t)(w[k] >> 32);
-            // pieces = output-column ranges of the tile (64 / ns columns: 1, 2, 4 or 8 pieces).  A footprint covers two output
-            // columns, so a piece holds ~cnt * (1 / ns + 1 / 64) entries (row ranges would duplicate 1/8 per cut: 1.78x the staged
-            // entries at 8 pieces, columns 1.10x; measured on Euler t = 59, 768x1280: pieces of 4 -> at most 1.10 of the mean);
-            // 15 % margin.  A piece that still exceeds `seg` is found by its own workgroup and handed to the pass-by-pass launch.
-            const unsigned long long c115 = (unsigned long long)cnt * 115u;
-            ns[k] = t0 + k >= nt ? 0u : cnt <= seg ? 1u : c115 * 33u <= 6400ull * seg ? 2u : c115 * 17u <= 6400ull * seg ? 4u : 8u;
+            // Pieces of a heavy tile = ranges of its 8 column octants (8 output columns each), cut greedily so that no piece's octant
+            // counts add up to more than 7/8 of a segment (an entry on an octant boundary counts in both: the sum bounds the piece
+            // from above).  Columns, not rows: a footprint is two pixels wide and two high, so 8 pieces by rows stage 1.78x the
+            // tile's entries, by columns 1.10x.  An octant that holds more than a segment by itself makes a piece that its workgroup
+            // finds too long and hands to the pass-by-pass launch.
+            pcs[k] = 0x80ull;                                                 // one piece: octants [0, 8)
+            ns[k] = t0 + k >= nt ? 0u : 1u;
+            if (ns[k] && cnt > seg) {
+                const uint32_t limit = seg - seg / 8u;
+                // (the histogram is an estimate -- units of 16 entries, small appends left out -- scaled to the tile's count + 1/8
+                // for the entries that sit on an octant boundary and count twice)
+                uint32_t hsum = 0;
+#pragma unroll
+                for (uint32_t o = 0; o < 8; ++o) hsum += (uint32_t)(oh[k] >> (8 * o)) & 0xffu;
+                const uint32_t osum = cnt + cnt / 8u;
+                const unsigned long long scale16 = ((unsigned long long)osum << 16) / (hsum ? hsum : 1u);
+                const uint32_t even = osum / ((osum + limit - 1u) / limit);        // pieces of about equal weight, not one full + a rest
+                uint32_t start = 0, sum = 0, np = 0;
+                unsigned long long p = 0;
+#pragma unroll
+                for (uint32_t o = 0; o < 8; ++o) {
+                    const uint32_t co = (uint32_t)((((oh[k] >> (8 * o)) & 0xffull) * scale16) >> 16);
+                    if ((sum + co > limit || sum + co / 2u >= even) && o > start) { p |= (unsigned long long)(start | ((o - start) << 4)) << (8 * np); ++np; start = o; sum = 0; }
+                    sum += co;
+                }
+                p |= (unsigned long long)(start | ((8u - start) << 4)) << (8 * np); ++np;
+                pcs[k] = p; ns[k] = np;
+            }
             xo[k] = (uint32_t)extra;
             extra += ns[k] ? ns[k] - 1u : 0u;
         }
@@ -649,7 +673,7 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t cnt = (uint32_t)(w[k] >> 32);
-            if (ns[k] > 1u && run_extra + (uint32_t)xex + xo[k] + ns[k] - 1u > extra_cap) ns[k] = 1u;     // items[] is full: one piece (pass by pass)
+            if (ns[k] > 1u && run_extra + (uint32_t)xex + xo[k] + ns[k] - 1u > extra_cap) { ns[k] = 1u; pcs[k] = 0x80ull; }   // items[] is full: one piece (pass by pass)
             hv[k] = ns[k] && cnt > heavy_thr;
             io[k] = hv[k] ? (uint32_t)(mine >> 32) : (uint32_t)mine;
             mine += hv[k] ? (unsigned long long)ns[k] << 32 : (unsigned long long)ns[k];
@@ -661,11 +685,12 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
         for (uint32_t k = 0; k < PER; ++k) {
             if (!ns[k]) continue;
             ItemDesc d;
-            d.tile = t0 + k; d.cnt0 = (uint32_t)(w[k] >> 32); d.cnt1 = (uint32_t)w[k]; d.off0 = 0; d.off1 = 0;
-            d.nseg = ns[k]; d.partoff = 0;
+            d.tile = t0 + k; d.cnt0 = (uint32_t)(w[k] >> 32); d.cnt1 = (uint32_t)w[k]; d.off0 = 0; d.off1 = 0; d.partoff = 0;
             const uint32_t at = hv[k] ? run_heavy + (uint32_t)(iex >> 32) + io[k] : run_light + (uint32_t)iex + io[k];
             for (uint32_t q = 0; q < ns[k]; ++q) {
-                d.seg = q;
+                const uint32_t pc = (uint32_t)(pcs[k] >> (8 * q)) & 0xffu;
+                d.seg = pc & 0xfu;                                            // first column octant of the piece
+                d.nseg = pc >> 4;                                             // its octants (8 = the whole tile)
                 items[hv[k] ? at + q : items_cap - 1u - (at + q)] = d;
             }
         }
@@ -706,10 +731,11 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
     }
     // distinct tiles of a row's 64 footprints, one per round: the first lane with something left names a tile, a ballot counts the
     // lanes that touch it; round k's (tile, row, hits) is parked in lane k and all appends go out as ONE atomic instruction
-    unsigned long long *cnt_n = rowcnt + (size_t)n * tiles;
+    unsigned long long *cnt_n = rowcnt + 2 * (size_t)n * tiles;
     RowRec *list_n = rowlist + (size_t)n * tiles * ROW_CAP;
     int my_tile = -1, my_y = 0;
     uint32_t my_cnt = 0;
+    unsigned long long my_hist = 0;                      // hits per column octant of the tile in units of 16, 8 bits each
     int k = 0;
     auto flush = [&]() {
 #if defined(SLR_RB_CUT) && SLR_RB_CUT == 1
@@ -718,7 +744,8 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
         if (my_tile >= 0)
 #endif
         {
-            const unsigned long long old = atomicAdd(cnt_n + my_tile, 1ull | ((unsigned long long)my_cnt << 32));
+            const unsigned long long old = atomicAdd(cnt_n + 2 * (size_t)my_tile, 1ull | ((unsigned long long)my_cnt << 32));
+            if (my_hist) atomicAdd(cnt_n + 2 * (size_t)my_tile + 1, my_hist);       // (no return value: fire and forget)
             const uint32_t slot = (uint32_t)old;
             if (slot < (uint32_t)ROW_CAP) list_n[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)my_y, ((uint32_t)stx << 8) | my_cnt};
         }
@@ -753,14 +780,26 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
             const int T = __builtin_amdgcn_readlane(cand, leader);
             const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
             const uint32_t c = (uint32_t)__popcll(__ballot(h));
-            uint32_t rm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
+            const uint32_t lm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
+            // Column-octant histogram of the tile (what the plan cuts heavy tiles by): ONE more atomic per append, 8 bits per octant
+            // in units of 16 entries with a pseudo-random rounding offset (unbiased: a tile's sum over its ~50 appends is what
+            // matters; two 16-bit-per-octant words cost +7 us per call at 46 k appends).  Appends of fewer than 8 hits -- the
+            // one-column overlaps into the neighbouring tile, half of all appends -- stay out of it.
+            uint32_t rm = 0;
+            unsigned long long hist = 0;
+            const uint32_t rnd = ((uint32_t)y * 2654435761u + (uint32_t)T * 40503u) >> 16;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) rm |= __shfl_xor(rm, d);
+            for (int o = 0; o < 8; ++o) {
+                const uint32_t co = (uint32_t)__popcll(__ballot((lm >> o) & 1u));
+                rm |= co ? 1u << o : 0u;
+                hist |= (unsigned long long)((co + ((rnd >> o) & 15u)) >> 4) << (8 * o);
+            }
+            if (c < 8u) hist = 0;
             if (t0 == T) t0 = -1;
             if (t1 == T) t1 = -1;
             if (t2 == T) t2 = -1;
             if (t3 == T) t3 = -1;
-            if (lane == k) { my_tile = T; my_cnt = c; my_y = y | (int)(rm << 24); }
+            if (lane == k) { my_tile = T; my_cnt = c; my_y = y | (int)(rm << 24); my_hist = hist; }
             if (++k == 64) flush();
         }
     }
@@ -794,7 +833,7 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
 __global__ __launch_bounds__(256) void rows_zero_kernel(unsigned long long *__restrict__ rowcnt, uint32_t nt, uint32_t *__restrict__ ctl,
                                                         uint32_t *__restrict__ arrive1) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nt) rowcnt[i] = 0ull;
+    if (i < nt) { rowcnt[2 * (size_t)i] = 0ull; rowcnt[2 * (size_t)i + 1] = 0ull; }
     if (i < (nt + 63u) / 64u) arrive1[(size_t)i * 32u] = 0u;    // first-level arrival counters of rowbin_kernel: one per 64
                                                                  // workgroups, each on its own 128-byte line (atomics on one line are served
                                                                  // one after the other: 1920 arrivals on one line cost 14 us)
@@ -1257,9 +1296,14 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     //           wave and row segment; more than SEG hits -> the piece is handed to the pass-by-pass launch (WHOLE);
     //   mode 2  (WHOLE): ordinals (wave w takes segments w, w + 8, ...: hits of the waves before + own so far) after a count
     //           pass; pass si emits the ordinals [si * SEG, (si + 1) * SEG).
-    const int pw = ROWS ? TILE_W / (int)max(it.nseg, 1u) : TILE_W;            // piece width: 64, 32, 16 or 8 output columns
-    const int pw_log = ROWS ? 31 - __builtin_clz((unsigned)pw) : 6;
-    const int pca = ROWS ? (int)it.seg * pw : 0, pcb = pca + pw;           // its output columns [pca, pcb)
+    const int p_oct = ROWS ? (int)min(max(it.nseg, 1u), 8u) : 8;             // the piece: p_oct column octants from octant it.seg
+    const int pw = 8 * p_oct;                                                // its width in output columns (8 .. 64)
+    const int pca = ROWS ? 8 * (int)it.seg : 0, pcb = pca + pw;              // its output columns [pca, pcb)
+    // A narrow piece keeps the tile's shape -- wave w = output row w -- and gives every output pixel G = 8, 4 or 2 lanes (8, 16,
+    // <= 32 columns): a ridge piles ~750 entries onto 64 pixels, lists of 150 records that one lane per pixel walked for
+    // 170-250 us while the rest of its wave sat idle; G lanes walk a list strided and add up through log2(G) cross-lane steps.
+    const int g_log = !(ROWS && SLR_ROWS_GROUP) ? 0 : pw <= 8 ? 3 : pw <= 16 ? 2 : (pw <= 32 && SLR_ROWS_GROUP > 1) ? 1 : 0;
+    const int pid = ROWS ? (tid & ~63) | ((tid & 63) >> g_log) : tid;       // the output pixel (tile-local index) this work-item serves
     const bool rows_ovf = ROWS && it.cnt1 > (uint32_t)ROW_CAP;
     uint32_t rows_n = 0;                                           // row segments to walk
     auto rows_setup = [&]() {                                      // list -> LDS (image order) + first slots; needs the record area
@@ -1316,7 +1360,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
         const float *fl = a.flow[0] + (size_t)n * 2 * HW;
         const uint32_t *rl_sy = clist, *rl_sx = clist + ROW_CAP, *rl_base = clist + 2 * ROW_CAP;
         const uint32_t my_n = rows_n > (uint32_t)wid ? (rows_n - (uint32_t)wid + (uint32_t)(T / 64) - 1u) / (uint32_t)(T / 64) : 0u;
-        const uint32_t range_mask = ((1u << ((pcb + 7) >> 3)) - 1u) & ~((1u << (pca >> 3)) - 1u);      // the piece's column octants
+        const uint32_t range_mask = ((1u << p_oct) - 1u) << (pca >> 3);            // the piece's column octants
         struct Group { float fx[CB], fy[CB]; int sy[CB], stx[CB]; uint32_t b0[CB]; };
         auto issue = [&](Group &g, uint32_t j0) {
 #pragma unroll
@@ -1398,7 +1442,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     uint32_t ns_tile = 1;                                         // segments of the tile (part)
     if (ROWS && !WHOLE) {
         rows_setup();
-        if (it.nseg <= 1u && !rows_ovf) {
+        if (it.nseg >= 8u && it.cnt0 <= (uint32_t)SEG && !rows_ovf) {
             rows_walk(std::integral_constant<int, 0>{}, std::true_type{}, 0u, (uint32_t)SEG);
             scan_total = it.cnt0;                                 // exact (rowbin_kernel), <= SEG (the plan)
             __syncthreads();
@@ -1582,9 +1626,9 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
             const bool xb = c.ok & (lx + 1 >= pca) & (lx + 1 < pcb) & (c.x0 + 1 < a.W);
             const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < a.H);
             const bool yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < a.H);
-            const int oc = (int)((unsigned)ly << pw_log) + lx - pca;      // output pixel = work-item: the piece's pixels are packed (row-major, pw wide)
+            const int oc = ly * TILE_W + lx - pca;        // tile-local output pixel (a piece's columns start at lane 0 of the row's wave)
             const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
-            const int tg[4] = {oc, oc + 1, oc + pw, oc + pw + 1};
+            const int tg[4] = {oc, oc + 1, oc + TILE_W, oc + TILE_W + 1};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (kb[k]) {
@@ -1637,7 +1681,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     // A work-item walks at most LMAX records of its own list; what is left of a longer list (a
     // "sink" pixel where hundreds of sources converge) is walked by the whole wave, lane-strided,
     // and wave-reduced -- otherwise one lane serialises thousands of records in every chunk.
-    const uint32_t r0 = off[tid], r1 = r0 + cnt[tid];
+    // (rows front end, narrow pieces: lane g of a pixel's G lanes takes records g, g + G, ... of its list -- r0 is ITS first record;
+    // everywhere else G = 1)
+    const uint32_t r1 = off[pid] + cnt[pid];
+    const uint32_t r0 = off[pid] + (ROWS ? (uint32_t)tid & ((1u << g_log) - 1u) : 0u);
     const int lane = tid & 63;
     uint32_t wave_recs = r1 - r0;                          // records of this wave's 64 output pixels
 #pragma unroll
@@ -1660,28 +1707,33 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     }
 #endif
     const uint32_t own = max((uint32_t)LMAX, 2u * ((wave_recs + 63u) >> 6));
-    const uint32_t rl = (r1 - r0 >= own + (uint32_t)SLR_HEAVY_SLACK) ? r0 + own : r1;
-    const unsigned long long heavy = __ballot(r1 > rl);
-    const int ly = tid >> pw_log, lx = pca + (tid & (pw - 1));                   // (rows front end: work-items past the piece's
-    const int oy = ty0 + ly, ox = tx0 + lx;                                     //  8 * pw pixels own nothing)
-    const bool inside = (oy < a.H) & (ox < a.W) & (ly < TILE_H);
+    uint32_t rl = (r1 - r0 >= own + (uint32_t)SLR_HEAVY_SLACK) ? r0 + own : r1;
+    unsigned long long heavy = __ballot(r1 > rl);
+    // (the cooperative passes run one after the other, ~1.5 k cycles each per chunk, while lanes walking their own lists run side by
+    // side: with many long lists in one wave -- a piece of a ridge tile: 750 entries into 64 pixels, 15 lists over the limit --
+    // they cost 250 us per workgroup; more than SLR_HEAVY_MAX of them and every lane walks its own)
+    if (__popcll(heavy) > SLR_HEAVY_MAX || (ROWS && g_log)) { rl = r1; heavy = 0ull; }
+    const int ly = pid / TILE_W, lx = pca + pid - ly * TILE_W;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    const bool inside = (oy < a.H) & (ox < a.W) & (lx < pcb) & ((tid & ((1 << g_log) - 1)) == 0);   // (rows front end: the piece's
+                                                                                    // columns; the first lane of a pixel's group stores)
     const bool single = ROWS || (it.nseg <= 1 && !(SCAN && part));   // results go straight to the output tensor
     float *op = single ? a.out + (size_t)n * a.C * HW + (size_t)oy * a.W + ox
                        : a.partial + (size_t)((SCAN ? w_po : it.partoff) + s) * a.part_stride + tid;
-    const size_t ostride = single ? (size_t)HW : (size_t)TILE_PIX;
+    const uint32_t ostride = single ? (uint32_t)HW : (uint32_t)TILE_PIX;      // (elements; HW < 2^29)
     // SCAN, shared tile: slot (w_po + segment), laid out [chunk of 4 planes][work-item][4] so that a chunk is ONE 16-byte
     // write-through store per work-item; the normaliser plane follows the last chunk
     float *const pslot = (SCAN && part) ? a.partial + (size_t)(w_po + s) * a.part_stride : nullptr;
     const size_t pnorm = (size_t)((a.C + 3) / 4) * 4 * TILE_PIX;
     // register-resident head of this pixel's record list (see the gather loop)
     constexpr uint32_t NULL_E = SEG;                   // staged-entry index of the all-zero slot
-    constexpr int KREG = SCAN ? SLR_KREG_SCAN : EPT_MAX == EPT_ONE ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
+    constexpr int KREG = ROWS ? SLR_KREG_ROWS : SCAN ? SLR_KREG_SCAN : EPT_MAX == EPT_ONE ? SLR_KREG_ONE : SLR_KREG_TWO;   // 4 records for one flow, 6 for two (8 / 10: < 1 % gain)
     float cw[KREG];
     uint32_t ce[KREG];
 #pragma unroll
     for (int k = 0; k < KREG; ++k) {
-        const bool on = r0 + k < rl;
-        const uint32_t qi = on ? r0 + k : 0u;
+        const bool on = r0 + ((uint32_t)k << g_log) < rl;
+        const uint32_t qi = on ? r0 + ((uint32_t)k << g_log) : 0u;
         ce[k] = on ? REC_E(qi) : NULL_E;
         cw[k] = on ? REC_W(qi) : 0.0f;
     }
@@ -1691,6 +1743,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
 
     float nrm = 0.0f;
     if (NORM && !g2) {
+        if (ROWS && g_log) {                               // G lanes per pixel: strided, then added up
+            const uint32_t G = 1u << g_log;
+            for (uint32_t r = r0; r < r1; r += G) nrm += REC_W(r);
+            if (g_log >= 3) nrm += __shfl_xor(nrm, 4);
+            if (g_log >= 2) nrm += __shfl_xor(nrm, 2);
+            nrm += __shfl_xor(nrm, 1);
+        } else
         for (uint32_t r = r0; r < rl; ++r) nrm += REC_W(r);
         for (unsigned long long hv = heavy; hv; hv &= hv - 1) {        // long lists: the wave walks them together
             const int src = __ffsll((long long)hv) - 1;
@@ -1720,7 +1779,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
     // and emits s_waitcnt vmcnt(N) with N > 0 instead of draining everything.
     float *const trash = a.trash + tid;
     if (!inside && single) op = trash;
-    const size_t ostr = (!inside && single) ? (size_t)0 : ostride;
+    const uint32_t ostr = (!inside && single) ? 0u : ostride;
     auto gather = [&](float (&acc)[CHUNK]) {
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) acc[u] = MAXOP ? a.init : 0.0f;
@@ -1745,13 +1804,13 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                     else acc[u] = __builtin_fmaf(v[k][u], cw[k], acc[u]);
                 }
         }
-        for (uint32_t r = r0 + KREG; r < rl; r += RB) {
+        for (uint32_t r = r0 + ((uint32_t)KREG << g_log); r < rl; r += (uint32_t)RB << g_log) {
             float w[RB];
             uint32_t e[RB];
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
-                const bool on = r + k < rl;
-                const uint32_t qi = on ? r + k : r;
+                const bool on = r + ((uint32_t)k << g_log) < rl;
+                const uint32_t qi = on ? r + ((uint32_t)k << g_log) : r;
                 e[k] = on ? REC_E(qi) : NULL_E;
                 w[k] = on ? REC_W(qi) : 0.0f;
             }
@@ -1797,6 +1856,14 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                     part[u] = MAXOP ? fmaxf(part[u], o) : part[u] + o;
                 }
                 if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], part[u]) : acc[u] + part[u];
+            }
+        }
+        if (ROWS && g_log) {                               // the G lanes of a pixel add up (every one of them ends up with the sum)
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) {
+                if (g_log >= 3) { const float o = __shfl_xor(acc[u], 4); acc[u] = MAXOP ? fmaxf(acc[u], o) : acc[u] + o; }
+                if (g_log >= 2) { const float o = __shfl_xor(acc[u], 2); acc[u] = MAXOP ? fmaxf(acc[u], o) : acc[u] + o; }
+                { const float o = __shfl_xor(acc[u], 1); acc[u] = MAXOP ? fmaxf(acc[u], o) : acc[u] + o; }
             }
         }
     };
@@ -1863,7 +1930,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
             float r = acc[u];
-            float *dst = (c0 + u < cend) ? op + (size_t)(c0 + u) * ostr : trash;
+            float *dst = (c0 + u < cend) ? op + (size_t)(uint32_t)(c0 + u) * ostr : trash;
 #ifdef SLR_CUT
             if (SLR_CUT == 5) dst = trash;   // (no output traffic)
 #endif

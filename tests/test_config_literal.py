@@ -35,7 +35,7 @@ def test_oracle_vs_reference_operators(oracle, golden_dir, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("front_end", ["bins", "scan"])
+@pytest.mark.parametrize("front_end", ["bins", "scan", "rows"])
 @pytest.mark.parametrize("tag", TAGS)
 def test_hip_operators_vs_reference_operators(golden_dir, tag, front_end):
     import slr_sfs_amd as S
@@ -43,7 +43,7 @@ def test_hip_operators_vs_reference_operators(golden_dir, tag, front_end):
     g = np.load(f"{golden_dir}/config_literal.npz")
     x, metric, motion, steps, flow = config_inputs(tag)
     d = lambda a: torch.from_numpy(a).cuda()
-    prev = L.slr_splat_set_scan_max_tiles(0 if front_end == "bins" else 2 ** 31 - 1)
+    prev = L.slr_splat_set_front_end({"bins": 0, "scan": 1, "rows": 2}[front_end])
     try:
         fl = d(flow) if flow is not None else S.euler_integration(d(motion), steps)[0]
         if flow is None:
@@ -52,5 +52,5 @@ def test_hip_operators_vs_reference_operators(golden_dir, tag, front_end):
         mod = S.ModuleSoftsplat("softmax")(d(x), fl, d(metric))                          # the module form the models use
         assert torch.equal(out, mod) or float((out - mod).abs().max()) < 1e-5
     finally:
-        L.slr_splat_set_scan_max_tiles(prev)
+        L.slr_splat_set_front_end(prev)
     _check(g, tag, out.cpu().numpy(), 1e-4)                                              # north_star's bound; measured ~1e-6

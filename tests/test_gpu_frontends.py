@@ -54,6 +54,36 @@ def test_default_threshold(S):
     prev = L.slr_splat_set_scan_max_tiles(7)
     assert L.slr_splat_set_scan_max_tiles(prev) == 7
     assert prev == 512
+    prev = L.slr_splat_set_front_end(2)                      # explicit choice: returns the previous one (-1 = by grid size)
+    assert prev == -1 and L.slr_splat_set_front_end(17) == 2 and L.slr_splat_set_front_end(-1) == -1
+
+
+def test_rows_pieces_and_the_pass_by_pass_launch(S, oracle):
+    """The rows front end cuts a heavy tile into column ranges by an ESTIMATED histogram; a piece that still holds more than a
+    segment (1024 entries) is handed to a second launch that walks it in passes of 2048.  Three flows that force every
+    path: everything into one 8-column strip (one octant over 2048 entries: several passes), into one pixel, and a
+    moderate squeeze (pieces of 2 - 4 octants, nothing deferred); every mode."""
+    L = S._lib.lib()
+    H, W, C = 64, 256, 9
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    met = rng.standard_normal((2, 1, H, W)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    strip = np.stack([(100.3 + (xx % 7)) - xx, (20.6 + (yy % 8)) - yy])                  # 16384 sources -> 7 x 8 pixels
+    point = np.stack([130.5 - xx, 33.25 - yy])
+    squeeze = np.stack([(xx - 128) * -0.6, (yy - 32) * -0.3])
+    prev = L.slr_splat_set_front_end(2)
+    try:
+        for name, fl in (("strip", strip), ("point", point), ("squeeze", squeeze)):
+            flow = np.stack([fl, fl[:, ::-1, ::-1].copy()]).astype(np.float32)          # (sample 1: mirrored)
+            for mode, m in (("summation", None), ("softmax", met), ("average", None), ("linear", np.abs(met) + 0.1)):
+                out = host(S.FunctionSoftsplat(dev(x), dev(flow), None if m is None else dev(m), mode))
+                ref = oracle.function_softsplat(x, flow, m, mode)
+                scale = max(1.0, float(np.abs(ref).max()))
+                assert float(np.abs(out - ref).max()) < 2e-4 * scale, (name, mode, float(np.abs(out - ref).max()), scale)
+                assert np.array_equal((out == 0).all(axis=1), (ref == 0).all(axis=1)), (name, mode)
+    finally:
+        L.slr_splat_set_front_end(prev)
 
 
 @pytest.mark.parametrize("flowkind", ["incoherent", "smooth_t30", "smooth_t59"])

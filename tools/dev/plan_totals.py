@@ -29,8 +29,12 @@ for name, fl in (("id", torch.zeros(1, 2, H, W, device="cuda")), ("t30", S.euler
         torch.cuda.synchronize()
         t = ws[off:off + 32].cpu().numpy().view(np.uint32)
         if fe == 2:
-            rc = ws[roff:roff + nt * 8].cpu().numpy().view(np.uint64)
+            rc3 = ws[roff:roff + nt * 16].cpu().numpy().view(np.uint64).reshape(nt, 2)
+            rc = rc3[:, 0]
+            octs = 16 * np.stack([(rc3[:, 1] >> np.uint64(8 * o)) & np.uint64(0xff) for o in range(8)], 1).astype(np.int64)
             rows, ent = (rc & np.uint64(0xffffffff)).astype(np.int64), (rc >> np.uint64(32)).astype(np.int64)
+            hv = ent > 1024
+            print(f"     octant sums / entries (heavy tiles): {octs[hv].sum() / max(ent[hv].sum(), 1):.2f}; max octant {octs.max()}; heavy tiles {hv.sum()}")
             print(f"     rows per tile mean {rows.mean():.1f} p50 {np.median(rows):.0f} p99 {np.percentile(rows, 99):.0f} max {rows.max()} | entries mean {ent.mean():.0f} max {ent.max()} | scanned px / entries {64 * rows.sum() / ent.sum():.2f}"
                   f" | heavy tiles (>877): rows mean {rows[ent > 877].mean() if (ent > 877).any() else 0:.0f}, entries mean {ent[ent > 877].mean() if (ent > 877).any() else 0:.0f}")
         print(f"{name:4s} fe {fe}: items {t[0]} partial slots {t[1]} multi {t[3]} whole {t[4]} heavy-first items {t[5]}")
