@@ -475,7 +475,7 @@ def dropin_roofline(dev, motion):
     HIP graph of 20 calls; `call_eager_us` = the same call issued from Python with an event pair per call (host launch pace
     included).  Plus config C2 of BASELINE.json as stated (64 channels, 256x480, softmax mode, incoherent and smooth
     flow) and two more small grids.  `front_end` names what a call takes by default (include/slr_splat.h:
-    slr_splat_set_front_end: scan up to 512 tiles, rows above); the other front ends are timed beside it."""
+    slr_splat_set_front_end: scan up to 1024 tiles, rows above); the other front ends are timed beside it."""
     import slr_sfs_amd as S
     from slr_sfs_amd import synthesis
     L = S._lib.lib()
@@ -514,7 +514,7 @@ def dropin_roofline(dev, motion):
              ("identity", torch.zeros(1, 2, H, W, device=dev)), ("incoherent", torch.rand(1, 2, H, W, device=dev) * 16 - 8)]
     for name, flow in flows:
         r = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
-        r["front_end"] = "rows"                            # 1920 tiles > the scan threshold (512): zero + rows/plan + tile kernel (+ deferred pieces)
+        r["front_end"] = "rows"                            # 1920 tiles > the scan threshold (1024): zero + rows/plan + tile kernel (+ deferred pieces)
         for fe_name, fe in (("bins", 0), ("scan", 1)):
             prev = L.slr_splat_set_front_end(fe)
             r[fe_name + "_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)

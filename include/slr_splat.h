@@ -100,10 +100,10 @@ int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, i
 
 /* Front end of the one-flow calls below (slr_softsplat_forward, slr_softsplat_mode_forward, slr_maxsplat_forward,
  * slr_max_warp_norm with prebinned == 0).  Exact front ends:
- *   bins : slr_splat_bin + a work plan + the tile kernel + combine (8 launches) -- sized for large grids;
+ *   bins : slr_splat_bin + a work plan + the tile kernel + combine (8 launches) -- what prebinned calls and the clip plans use;
  *   scan : one kernel writes the destination box of every 8x64 block of source pixels, then every output tile's
  *          workgroup scans the flow of the blocks whose box touches it (2 launches, no bins, no plan, no combine).
- * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64)); default 512,
+ * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64)); default 1024,
  * 0 = never scan, INT_MAX = always scan (larger grids: see slr_splat_set_front_end).  Process-wide; returns the previous value.
  * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199.) */
 int slr_splat_set_scan_max_tiles(int max_tiles);
@@ -111,10 +111,12 @@ int slr_splat_set_scan_max_tiles(int max_tiles);
 /* Third front end, and the explicit choice:
  *   rows : one kernel appends every row segment (64 consecutive source pixels of an image row) to the few tiles its
  *          footprints touch -- one 64-bit atomic per (segment, tile), which also sums the tile's exact entry count -- and
- *          its last workgroup writes the work plan (heavy tiles first, pieces of <= 1024 entries); the tile kernel scans
- *          exactly the listed rows and sums multi-piece tiles itself (3 launches: zero, rows + plan, tile kernel).
+ *          its last workgroup writes the work plan: heavy tiles first, a tile of more than 1024 entries cut into ranges
+ *          of output COLUMNS (each piece owns its output pixels: no partial tiles, no combine); the tile kernel scans
+ *          exactly the listed rows.  4 launches: zero, rows + plan, tile kernel, and a (normally empty) pass-by-pass
+ *          launch for pieces that still hold more than 1024 entries.
  * front_end: 0 bins, 1 scan, 2 rows, anything else = automatic (the default): scan up to slr_splat_set_scan_max_tiles
- * tiles, rows above.  Process-wide; returns the previous value (-1 = automatic).  All three are exact. */
+ * tiles (single-digit rounds of workgroups: no plan to wait for), rows above (heavy tiles first, pieces in parallel).  Process-wide; returns the previous value (-1 = automatic).  All three are exact. */
 int slr_splat_set_front_end(int front_end);
 
 /* ------------------------------------------------------------------ splat: forward */

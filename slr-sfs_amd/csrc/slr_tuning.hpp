@@ -75,8 +75,9 @@
 #define SLR_CSPLIT_SLOTS 512    // workgroup slots of the chip the groups may fill (256 CUs x 2).  1024 / 8 groups: config C2 39 -> 54 us
 #endif
 #ifndef SLR_SCAN_MAX_TILES
-#define SLR_SCAN_MAX_TILES 512  // default of slr_splat_set_scan_max_tiles: one-flow calls on grids of at most this many tiles take the scan front end
-#endif                          // (config C2: 55.9 -> 38.1 us per call; at 1920 tiles: identity 182 -> 148, incoherent 232 -> 211, Euler t=30 209 -> 212, t=59 252 -> 280)
+#define SLR_SCAN_MAX_TILES 1024 // default of slr_splat_set_scan_max_tiles: one-flow calls on grids of at most this many tiles take the scan front end,
+#endif                          // larger ones the rows front end (config C2, 240 tiles: bins 56 / scan 39 / rows 56 us; 384x640, 960 tiles: incoherent
+                                // 80 / 61 / 77, Euler t=30 124 / 116 / 112; 768x1280, 1920 tiles: identity 175 / 142 / 146, t=30 202 / 207 / 165, t=59 245 / 278 / 216)
 #ifndef SLR_SCAN_CB
 #define SLR_SCAN_CB 5           // candidate source tiles per group of the scan (two groups' flow loads in flight).  3 / 4 / 5 / 8: C2 36.7 / 38.6 / 38.6 / 40.8 us
 #endif
@@ -107,7 +108,7 @@
 #define SLR_KREG_ROWS 4         // register-resident records per output pixel in the rows tile kernel 
 #endif
 #ifndef SLR_ROWS_GROUP
-#define SLR_ROWS_GROUP 0        // narrow pieces: 0 one lane per output pixel; 1 groups of 8 / 4 lanes up to 16 columns; 2 also pairs up to 32 columns
+#define SLR_ROWS_GROUP 2        // narrow pieces: 0 one lane per output pixel; 1 groups of 8 / 4 lanes up to 16 columns; 2 also pairs up to 32 columns
 #endif
 #ifndef SLR_ROW_SORT
 #define SLR_ROW_SORT 1          // the tile kernel puts its row-segment list into image order before scanning (the appends arrive in any order)

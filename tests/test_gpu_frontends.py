@@ -53,7 +53,7 @@ def test_default_threshold(S):
     L = S._lib.lib()
     prev = L.slr_splat_set_scan_max_tiles(7)
     assert L.slr_splat_set_scan_max_tiles(prev) == 7
-    assert prev == 512
+    assert prev == 1024
     prev = L.slr_splat_set_front_end(2)                      # explicit choice: returns the previous one (-1 = by grid size)
     assert prev == -1 and L.slr_splat_set_front_end(17) == 2 and L.slr_splat_set_front_end(-1) == -1
 
