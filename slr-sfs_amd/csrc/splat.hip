@@ -2427,7 +2427,7 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     g_ev_start = g_ev_stop = nullptr;
     // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass
     // (their planes dealt to up to 8 workgroups each: these run after everybody else, on an empty chip, one pass after the other)
-    b.end[0] = nt < 256u ? nt : 256u;
+    b.end[0] = nt < 64u ? nt : 64u;                     // (grid-strided over the list; normally it is empty)
     const uint32_t wgroups = (uint32_t)a.C / (2u * CHUNK_ONE) < 1u ? 1u : (uint32_t)a.C / (2u * CHUNK_ONE) > 8u ? 8u : (uint32_t)a.C / (2u * CHUNK_ONE);
     // (and with passes of 2048 entries -- 86 KiB of LDS, one workgroup per CU: most of these pieces are just over the 1024 of the
     // main kernel and finish in one pass)

@@ -10,6 +10,7 @@ import slr_sfs_amd as S
 from kbench import smooth_motion
 L = S._lib.lib()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+fe_under_test = int(sys.argv[2]) if len(sys.argv) > 2 else 1            # 1 scan, 2 rows
 torch.manual_seed(0)
 cases = []
 for (C, H, W, steps, amp) in ((65, 768, 1280, 59, 1.5), (64, 256, 480, 30, 1.5), (16, 128, 240, 30, 1.5), (7, 200, 328, 40, 3.0)):
@@ -21,10 +22,10 @@ for (C, H, W, steps, amp) in ((65, 768, 1280, 59, 1.5), (64, 256, 480, 30, 1.5),
 bad = 0
 t0 = time.time()
 for ci, (x, fl, met) in enumerate(cases):
-    L.slr_splat_set_scan_max_tiles(0)
+    L.slr_splat_set_front_end(0)
     ref_sum = S.FunctionSoftsplat(x, fl, None, "summation")
     ref_soft = S.FunctionSoftsplat(x, fl, met, "softmax")
-    L.slr_splat_set_scan_max_tiles(2 ** 31 - 1)
+    L.slr_splat_set_front_end(fe_under_test)
     scale = float(ref_sum.abs().max())
     for r in range(reps):
         a = S.FunctionSoftsplat(x, fl, None, "summation")
