@@ -107,6 +107,9 @@
 #ifndef SLR_KREG_ROWS
 #define SLR_KREG_ROWS 4         // register-resident records per output pixel in the rows tile kernel 
 #endif
+#ifndef SLR_ROWS_EVEN_FIRST
+#define SLR_ROWS_EVEN_FIRST 0   // plan: 1 = plain halves / quarters of a heavy tile where the histogram says they fit, the greedy cut otherwise (measured: t=30 166.0 vs 166.5, t=59 210 vs 215 us)
+#endif
 #ifndef SLR_ROWS_GROUP
 #define SLR_ROWS_GROUP 2        // narrow pieces: 0 one lane per output pixel; 1 groups of 8 / 4 lanes up to 16 columns; 2 also pairs up to 32 columns
 #endif

@@ -551,18 +551,20 @@ __global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restr
 }
 
 // =========================================================================== rows front end
-// The bins cost a stand-alone call 55-80 us around its tile kernel at 768x1280 (zero, count, offsets, fill, plan, combine:
-// seven launches, two passes over the flow with one atomic per pixel footprint); the scan front end above has no plan, so
-// it meets a heavy tile only when its workgroup happens to start.  Third form: bin ROW SEGMENTS instead of pixels.  A row
-// segment = 64 consecutive source pixels of one image row (one wave's coalesced load).  rowbin_kernel reads the flow once;
-// every wave finds the few tiles its segment's footprints touch (ballots, no LDS) and appends (segment, hits) to each of
-// them with ONE returning 64-bit atomic -- ~40 k atomics at 768x1280 instead of ~4 M -- which also sums the tile's exact
-// entry count.  The workgroup that finishes last turns the counts into the work plan (heavy tiles first, no piece above
-// SEG entries: what the scan front end lacks) -- no separate count / offsets / fill / plan launches.  The tile kernel
-// (ROWS instantiation) loads its tile's list (<= SLR_ROW_CAP segments), scans exactly those rows of the flow and places
-// the hits at slots known from the list's counts: no LDS atomics, no count pass, a segment of a heavy tile scans only its
-// own rows.  Multi-segment tiles are summed by their last-arriving workgroup (the partial-slot code of the scan front end).
-// A tile touched by more than SLR_ROW_CAP segments (pathological flows) is scanned from ALL rows of its sample instead.
+// The bins cost a stand-alone call 55-95 us around its tile kernel at 768x1280 (zero, count, offsets, fill, plan, whole, combine:
+// seven launches, two passes over the flow with one atomic per pixel footprint, 18-34 us of combine); the scan front end above
+// has no plan, so it meets a heavy tile only when its workgroup happens to start.  Third form: bin ROW SEGMENTS instead of pixels.
+// A row segment = 64 consecutive source pixels of one image row (one wave's coalesced load).  rowbin_kernel reads the flow once;
+// every wave finds the few tiles its segment's footprints touch (ballots, no LDS) and appends (segment, hits) to each of them
+// with ONE returning 64-bit atomic -- ~35-100 k atomics at 768x1280 instead of ~4 M -- which also sums the tile's exact entry
+// count; a second, non-returning atomic adds to the tile's column-octant histogram.  The workgroup that finishes last turns the
+// counts into the work plan: heavy tiles first, a tile of more than SEG entries cut into ranges of its OUTPUT COLUMNS -- a piece
+// stages every entry that touches its columns and writes its output pixels itself, so there are no partial tiles and nothing to
+// combine.  The tile kernel (FE = 2) loads its tile's list (<= SLR_ROW_CAP segments), scans exactly those rows of the flow and
+// places the hits at slots known from the list's counts (whole tiles) or handed out by one LDS atomic per row (pieces); it has
+// no pass loop and no work loop: 80 VGPRs, three workgroups per CU.  A piece that still holds more than SEG entries is handed
+// to a second, normally empty launch (WHOLE) that walks it pass by pass.  A tile touched by more than SLR_ROW_CAP segments
+// (pathological flows) is scanned from ALL rows of its sample.  DESIGN.md 3.2.5b has the measurements behind every choice.
 constexpr int ROW_CAP = SLR_ROW_CAP;
 struct RowRec { uint32_t sy, sx_cnt; };     // row segment: image row | column octants of the tile it touches << 24, (x / 64) << 8 | its hits in the tile (<= 64)
 
@@ -664,6 +666,15 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
                 }
                 p |= (unsigned long long)(start | ((8u - start) << 4)) << (8 * np); ++np;
                 pcs[k] = p; ns[k] = np;
+#if SLR_ROWS_EVEN_FIRST
+                // (where plain halves / quarters already fit, take them: equal widths)
+                uint32_t q4[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q)
+                    q4[q] = (uint32_t)((((oh[k] >> (16 * q)) & 0xffull) * scale16) >> 16) + (uint32_t)((((oh[k] >> (16 * q + 8)) & 0xffull) * scale16) >> 16);
+                if (max(q4[0] + q4[1], q4[2] + q4[3]) <= limit) { pcs[k] = 0x40ull | (0x44ull << 8); ns[k] = 2; }
+                else if (max(max(q4[0], q4[1]), max(q4[2], q4[3])) <= limit && np >= 4) { pcs[k] = 0x20ull | (0x22ull << 8) | (0x24ull << 16) | (0x26ull << 24); ns[k] = 4; }
+#endif
             }
             xo[k] = (uint32_t)extra;
             extra += ns[k] ? ns[k] - 1u : 0u;
@@ -1277,12 +1288,12 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
         }
         return MODE == 0 ? cmask[64] : wcount;
     };
-    // ROWS: the entries of this piece of work from the tile's row-segment list.  A piece = the output rows [ra, rb) of the
-    // tile (plan: 1, 2, 4 or 8 pieces per tile): it owns its output pixels, so nothing is summed across pieces -- no partial
+    // ROWS: the entries of this piece of work from the tile's row-segment list.  A piece = a range of the tile's output columns
+    // (whole column octants, cut by the plan): it owns its output pixels, so nothing is summed across pieces -- no partial
     // tiles, no combine.  Entry slots:
     //   mode 0  (whole tile, <= SEG entries): the list's hit counts give every row segment its first slot (exclusive scan);
-    //   mode 1  (a row range, or a tile whose list overflowed and that walks ALL row segments of its sample): one LDS atomic per
-    //           wave and row segment; more than SEG hits -> the piece is handed to the pass-by-pass launch (WHOLE);
+    //   mode 1  (a column range, or a tile whose list overflowed and that walks ALL row segments of its sample): one LDS atomic
+    //           per wave and row segment; more than SEG hits -> the piece is handed to the pass-by-pass launch (WHOLE);
     //   mode 2  (WHOLE): ordinals (wave w takes segments w, w + 8, ...: hits of the waves before + own so far) after a count
     //           pass; pass si emits the ordinals [si * SEG, (si + 1) * SEG).
     const int p_oct = ROWS ? (int)min(max(it.nseg, 1u), 8u) : 8;             // the piece: p_oct column octants from octant it.seg
@@ -1365,7 +1376,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                     const uint32_t q = on ? ri : 0u;
                     const uint32_t syw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_sy[q]);
                     sy = (int)(syw & 0xffffffu);
-                    on = on && ((syw >> 24) & range_mask) != 0u;       // (a piece only loads the segments that touch its output rows)
+                    on = on && ((syw >> 24) & range_mask) != 0u;       // (a piece only loads the segments that touch its column octants)
                     stx = __builtin_amdgcn_readfirstlane((int)rl_sx[q]);
                     if (MODE == 0) base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl_base[q]);
                 }
@@ -1951,7 +1962,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
   }
     if (SCAN) {
         if (!w_piece) { SLR_STAMP(37); SLR_STAMP_RT(49); }
-        if (!ROWS && part) {                     // (rows front end: pieces own their output rows, nothing to sum)
+        if (!ROWS && part) {                     // (rows front end: pieces own their output pixels, nothing to sum)
             // every storing wave drains its write-through stores, then ONE arrival; the last segment to arrive combines
 #if SLR_SHARE_STORE == 2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
