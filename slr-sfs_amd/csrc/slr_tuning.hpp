@@ -96,10 +96,10 @@
 #define SLR_ROW_CAP 256         // row segments (64 source pixels of one image row) a tile's list holds; a tile touched by more is
 #endif                          // scanned from the whole flow instead (pathological flows only; identity ~30, Euler t=59 < 200)
 #ifndef SLR_ROWBIN_R
-#define SLR_ROWBIN_R 2          // source tiles (vertically adjacent) per workgroup of rowbin_kernel = row segments per wave
+#define SLR_ROWBIN_R 2          // source tiles (vertically adjacent) per workgroup of rowbin_kernel = row segments per wave.  1 / 2 / 4 (whole call, us): identity 153 / 148 / 148, Euler t=30 177 / 173 / 180, t=59 225 / 221 / 233
 #endif
 #ifndef SLR_ROW_CB
-#define SLR_ROW_CB 3            // row segments per wave whose flow loads are in flight together
+#define SLR_ROW_CB 3            // row segments per wave whose flow loads are in flight together (2 / 3 / 4: within 1 %; 4 needs 3 more registers)
 #endif
 #ifndef SLR_WAVES_ROWS
 #define SLR_WAVES_ROWS 6        // waves per SIMD the rows tile kernel is compiled for: 80 VGPRs = three workgroups per CU (two: +5..10 %)
@@ -114,7 +114,7 @@
 #define SLR_ROWS_GROUP 2        // narrow pieces: 0 one lane per output pixel; 1 groups of 8 / 4 lanes up to 16 columns; 2 also pairs up to 32 columns
 #endif
 #ifndef SLR_ROW_SORT
-#define SLR_ROW_SORT 1          // the tile kernel puts its row-segment list into image order before scanning (the appends arrive in any order)
+#define SLR_ROW_SORT 1          // the tile kernel puts its row-segment list into image order before scanning (the appends arrive in any order).  0: identity 148 -> 157 us, Euler t=30 173 -> 192, t=59 221 -> 249
 #endif
 #ifndef SLR_FRONT_END
 #define SLR_FRONT_END -1        // default of slr_splat_set_front_end: -1 = by grid size, 0 bins, 1 scan (boxes), 2 rows
