@@ -47,7 +47,7 @@ struct WsLayout {
     size_t off_nseg;      // uint32[nt]   segments per tile                (plan)
     size_t off_partoff;   // uint32[nt]   first partial slot of the tile   (plan)
     size_t off_multi;     // uint32[nt]   compact list of multi-segment tiles (plan)
-    size_t off_whole;     // uint32[nt]   work items that cover a whole over-budget tile (plan)
+    size_t off_whole;     // uint32[4*nt] work items that cover a whole over-budget tile (plan); rows front end: pieces of more than a segment
     size_t off_items;     // ItemDesc[items_cap] (32 B per work item)           (plan)
     size_t off_totals;    // uint32[4]    total items, total partial slots (plan)
     size_t off_box;       // SrcBox[nt]   destination box of every source tile (scan front end: no bins, no plan)
@@ -82,7 +82,7 @@ inline WsLayout ws_layout(int N, int C, int H, int W) {
     L.off_nseg = o;    o += al256((size_t)L.nt * 4);
     L.off_partoff = o; o += al256((size_t)L.nt * 4);
     L.off_multi = o;   o += al256((size_t)L.nt * 4);
-    L.off_whole = o;   o += al256((size_t)L.nt * 4);
+    L.off_whole = o;   o += al256((size_t)L.nt * 4 * 4);      // (rows front end: up to 4 * nt pieces may ask for the pass-by-pass launch)
     L.off_items = o;   o += al256((size_t)L.rows_items_cap * 32);
     L.off_totals = o;  o += 256;
     L.off_box = o;     o += al256((size_t)L.nt * 16);

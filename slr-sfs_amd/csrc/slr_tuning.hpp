@@ -107,6 +107,9 @@
 #ifndef SLR_KREG_ROWS
 #define SLR_KREG_ROWS 4         // register-resident records per output pixel in the rows tile kernel 
 #endif
+#ifndef SLR_EPT_DEFER
+#define SLR_EPT_DEFER 4         // entries per work-item and pass in the pass-by-pass launch of the rows front end (4: passes of 2048 entries, 86 KiB of LDS)
+#endif
 #ifndef SLR_ROWS_EVEN_FIRST
 #define SLR_ROWS_EVEN_FIRST 0   // plan: 1 = plain halves / quarters of a heavy tile where the histogram says they fit, the greedy cut otherwise (measured: t=30 166.0 vs 166.5, t=59 210 vs 215 us)
 #endif

@@ -1960,9 +1960,10 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
         SLR_CUT_AT(4);                                 // (after the first two chunks)
     }
   }
-    if (SCAN) {
+    if (ROWS) { SLR_STAMP(37); SLR_STAMP_RT(49); SLR_STAMP(38); SLR_STAMP_RT(50); }
+    if (SCAN && !ROWS) {                     // scan front end: partial tiles of shared segments, then the next piece of work
         if (!w_piece) { SLR_STAMP(37); SLR_STAMP_RT(49); }
-        if (!ROWS && part) {                     // (rows front end: pieces own their output pixels, nothing to sum)
+        if (part) {
             // every storing wave drains its write-through stores, then ONE arrival; the last segment to arrive combines
 #if SLR_SHARE_STORE == 2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -2023,7 +2024,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, tile_min_waves(EPT_MAX, WHOLE, FE)) 
                 }
             }
         }
-        if (ROWS || !a.ctl) break;                    // (rows: the plan cut the pieces, one per workgroup)
+        if (!a.ctl) break;
         // ---- next piece of work: claim a pushed segment (see the block comment above the kernel)
         if (tid == 0) {
             unsigned long long got = 0;
@@ -2429,7 +2430,7 @@ static int do_splat_rows(SplatArgs a, Ws &w0, hipStream_t st) {
     const uint32_t wgroups = (uint32_t)a.C / (2u * CHUNK_ONE) < 1u ? 1u : (uint32_t)a.C / (2u * CHUNK_ONE) > 8u ? 8u : (uint32_t)a.C / (2u * CHUNK_ONE);
     // (and with passes of 2048 entries -- 86 KiB of LDS, one workgroup per CU: most of these pieces are just over the 1024 of the
     // main kernel and finish in one pass)
-    constexpr int EPT_DEFER = 2 * EPT_SCAN;
+    constexpr int EPT_DEFER = SLR_EPT_DEFER;
     b.f[0].seg = EPT_DEFER * SPLAT_THREADS;
     const size_t lds_defer = lds_head_bytes(EPT_DEFER, true) + (size_t)CHUNK_ONE * (EPT_DEFER * SPLAT_THREADS + 1) * 4 + SLR_LDS_PAD;
     if (int e = launch_tile_variant<NORM, MAXOP, EPT_DEFER, CHUNK_ONE, true, 2>(b, b.end[0], wgroups, lds_defer, st)) return e;

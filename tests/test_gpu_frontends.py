@@ -229,3 +229,20 @@ def test_more_than_2048_source_tiles_per_sample(S, oracle, frontend):
     ref = oracle.softsplat_forward(x, flow)
     bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
     assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+
+
+def test_many_deferred_pieces(S, oracle, frontend):
+    """Partial collapses in a batch: dozens of tiles of every sample hold several thousand entries, so the rows front end hands
+    more pieces to its pass-by-pass launch than that launch has workgroups (found by tools/dev/fuzz_frontends.py: the launch
+    used to stop after one piece per workgroup)."""
+    H, W, C = 200, 480, 5
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    for seed, N in ((2, 2), (6, 3)):
+        rng = np.random.default_rng(seed)
+        flow = np.stack([np.stack([(W * rng.uniform(0, 1) - xx) * rng.uniform(0.5, 1.0), (H * rng.uniform(0, 1) - yy) * rng.uniform(0.5, 1.0)])
+                         for _ in range(N)]).astype(np.float32)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        out = host(S.FunctionSoftsplat(dev(x), dev(flow), None, "summation"))
+        ref = oracle.function_softsplat(x, flow, None, "summation")
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(out - ref).max()) < 2e-4 * scale, (seed, N, float(np.abs(out - ref).max()), scale)
