@@ -14,24 +14,30 @@ for it in range(n_cases):
     N = int(rng.choice([1, 1, 2, 3])); C = int(rng.choice([1, 3, 8, 17, 33, 65]))
     H = int(rng.choice([1, 5, 8, 9, 31, 64, 100, 200, 256])); W = int(rng.choice([1, 7, 63, 64, 65, 130, 200, 300, 480]))
     yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
-    fam = rng.integers(0, 7)
+    if it % 25 == 24:                                                   # now and then a big one
+        N, C, H, W = int(rng.choice([1, 2])), int(rng.choice([9, 65])), int(rng.choice([384, 768])), int(rng.choice([640, 1280]))
+        yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    fam = rng.integers(0, 10)
     if fam == 0: fl = rng.uniform(-8, 8, (N, 2, H, W))
     elif fam == 1: fl = np.stack([np.stack([3 * np.sin(xx / 17 + k) + 0.3 * yy / max(H, 1), 2 * np.cos(yy / 11 + k)]) for k in range(N)])
     elif fam == 2: fl = np.stack([np.stack([(W * rng.uniform(0, 1) - xx) * rng.uniform(0.5, 1.0), (H * rng.uniform(0, 1) - yy) * rng.uniform(0.5, 1.0)]) for _ in range(N)])
     elif fam == 3: fl = rng.uniform(-3 * W, 3 * W, (N, 2, H, W))
     elif fam == 4: fl = np.zeros((N, 2, H, W)) + rng.uniform(-1.5, 1.5, (N, 2, 1, 1))
     elif fam == 5: fl = np.stack([np.stack([(xx % 5) - xx + W // 2, (yy % 3) - yy + H // 2]) for _ in range(N)])        # onto a 5 x 3 patch
+    elif fam == 7: fl = np.stack([np.stack([W * rng.uniform(0.1, 0.9) - xx + (yy % 2), 0.3 * np.sin(yy / 9) + 0 * xx]) for _ in range(N)])   # onto a 2-pixel column
+    elif fam == 8: fl = np.stack([np.stack([1.7 * np.cos(xx / 13) + 0 * yy, H * rng.uniform(0.1, 0.9) - yy + (xx % 3)]) for _ in range(N)])   # onto 3 rows
+    elif fam == 9: fl = np.stack([np.stack([(xx - W / 2) * rng.uniform(-0.9, -0.3), (yy - H / 2) * rng.uniform(-0.4, 0.4)]) for _ in range(N)])  # squeeze / stretch
     else:
         fl = rng.uniform(-4, 4, (N, 2, H, W)); m = rng.random((N, 2, H, W)) < 0.01
         fl[m] = rng.choice([np.nan, np.inf, -np.inf, 3e9, -3e9], m.sum())
     fl = torch.from_numpy(np.ascontiguousarray(fl, dtype=np.float32)).cuda()
     x = torch.randn(N, C, H, W, device="cuda"); met = torch.randn(N, 1, H, W, device="cuda") * 0.7
-    mode = ["summation", "average", "linear", "softmax"][int(rng.integers(0, 4))]
-    m_ = None if mode in ("summation", "average") else (met.abs() + 0.1 if mode == "linear" else met)
+    mode = ["summation", "average", "linear", "softmax", "maximum"][int(rng.integers(0, 5))]
+    m_ = None if mode in ("summation", "average", "maximum") else (met.abs() + 0.1 if mode == "linear" else met)
     outs = {}
     for fe in (0, 1, 2):
         prev = L.slr_splat_set_front_end(fe)
-        outs[fe] = S.FunctionSoftsplat(x, fl, m_, mode)
+        outs[fe] = S.ModuleMaximumsplat()(x, fl) if mode == "maximum" else S.FunctionSoftsplat(x, fl, m_, mode)
         L.slr_splat_set_front_end(prev)
     ref = outs[0]
     scale = max(1.0, float(ref.abs().max()))
