@@ -116,7 +116,9 @@ int slr_splat_set_scan_max_tiles(int max_tiles);
  *          exactly the listed rows.  4 launches: zero, rows + plan, tile kernel, and a (normally empty) pass-by-pass
  *          launch for pieces that still hold more than 1024 entries.
  * front_end: 0 bins, 1 scan, 2 rows, anything else = automatic (the default): scan up to slr_splat_set_scan_max_tiles
- * tiles (single-digit rounds of workgroups: no plan to wait for), rows above (heavy tiles first, pieces in parallel).  Process-wide; returns the previous value (-1 = automatic).  All three are exact. */
+ * tiles (one or two rounds of workgroups: no plan to wait for), rows above (heavy tiles first, their pieces in parallel).
+ * Process-wide; returns the previous value (-1 = automatic).  All three are exact (floating-point summation order differs:
+ * results agree to rounding, ~1e-6 relative).  Images of 2^24 rows or more take bins instead of rows. */
 int slr_splat_set_front_end(int front_end);
 
 /* ------------------------------------------------------------------ splat: forward */
@@ -124,7 +126,7 @@ int slr_splat_set_front_end(int front_end);
 /* _FunctionSoftsplat.forward: summation splat.
  * Replaces kernel_Softsplat_updateOutput + its launcher, softsplat.py:157-202, 390-424.
  *   in [N,C,H,W], flow [N,2,H,W] -> out [N,C,H,W] (every element written; no pre-zeroing)
- * prebinned == 0: a self-contained call (front end chosen by slr_splat_set_scan_max_tiles; `ws` holds NO reusable bins
+ * prebinned == 0: a self-contained call (front end: slr_splat_set_front_end / slr_splat_set_scan_max_tiles; `ws` holds NO reusable bins
  * afterwards).  prebinned != 0: `ws` was filled by slr_splat_bin / slr_splat_bin_pair with this flow (bins shared by
  * several tensors splatted with the same flow). */
 int slr_softsplat_forward(const float *in, const float *flow, float *out,
