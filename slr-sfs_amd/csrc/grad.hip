@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in,
 // are then already coalesced), takes the direct gathers instead (decided per block).
 // Measured (768x1280, C = 65, tools/bwdbench.py; grad_kernel -> this kernel): Euler t=30 gradInput 254 -> 186 us, gradFlow
 // 242 -> 173, both gradients 279 -> 222 (0.35 -> 0.44 of 8 TB/s on 3C planes); t=59 both 346 -> 297; identity flow
-// gradInput 119 -> 129, both 165 -> 195 (the direct path carries this kernel's registers: 96 VGPRs).
+// gradInput 119 -> 129, both 165 -> 195 (the direct path carried this kernel's registers: 96 VGPRs).  Round 3, later: each path a
+// loop of its own and the direct gathers double-buffered in registers (next pass in flight under this pass's sums and stores):
+// 82 VGPRs; both gradients identity 188 -> 181 us, Euler t=30 217-222 -> 212-217, gradInput t=59 285 -> 260.
 constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
 #ifndef SLR_GRAD_BOX
 #define SLR_GRAD_BOX 2048                              // floats of LDS per channel (e.g. 20 rows x 100 columns); x U channels x 4 bytes = 32 KiB
@@ -191,33 +193,8 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
             for (int k = 0; k < NS; ++k) sv[k][u] = pl[soff[k]];
         }
     };
-    if (staged) issue(0);
-    for (int ch = 0; ch < C; ch += U) {
-        float a0[U], a1[U], a2[U], a3[U], v[U];
-        if (staged) {
-            __syncthreads();                                       // the previous pass has been gathered
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int idx = tid + k * GT_THREADS;
-                if (idx < nbox)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) box[u][idx] = sv[k][u];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (GFLOW) v[u] = ip[(size_t)min(ch + u, C - 1) * HW + i];
-            __syncthreads();
-            if (ch + U < C) issue(ch + U);                         // in flight under this pass's gathers, sums and stores
-#pragma unroll
-            for (int u = 0; u < U; ++u) { a0[u] = box[u][l0]; a1[u] = box[u][l1]; a2[u] = box[u][l2]; a3[u] = box[u][l3]; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const size_t po = (size_t)min(ch + u, C - 1) * HW;
-                a0[u] = gp[po + g0]; a1[u] = gp[po + g1]; a2[u] = gp[po + g2]; a3[u] = gp[po + g3];
-                if (GFLOW) v[u] = ip[po + i];
-            }
-        }
+    // one pass of U channels: the reference's terms in the reference's order (bit-identical on either path)
+    auto finish = [&](int ch, const float (&a0)[U], const float (&a1)[U], const float (&a2)[U], const float (&a3)[U], const float (&v)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool live = (ch + u < C) & live_px;
@@ -235,6 +212,49 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
                 gx += k1 ? t1 * dx[1] : 0.0f; gy += k1 ? t1 * dy[1] : 0.0f;
                 gx += k2 ? t2 * dx[2] : 0.0f; gy += k2 ? t2 * dy[2] : 0.0f;
                 gx += k3 ? t3 * dx[3] : 0.0f; gy += k3 ? t3 * dy[3] : 0.0f;
+            }
+        }
+    };
+    if (staged) {                                                  // (workgroup-uniform: each path is a loop of its own)
+        issue(0);
+        for (int ch = 0; ch < C; ch += U) {
+            float a0[U], a1[U], a2[U], a3[U], v[U];
+            __syncthreads();                                       // the previous pass has been gathered
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int idx = tid + k * GT_THREADS;
+                if (idx < nbox)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) box[u][idx] = sv[k][u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (GFLOW) v[u] = ip[(size_t)min(ch + u, C - 1) * HW + i];
+            __syncthreads();
+            if (ch + U < C) issue(ch + U);                         // in flight under this pass's gathers, sums and stores
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a0[u] = box[u][l0]; a1[u] = box[u][l1]; a2[u] = box[u][l2]; a3[u] = box[u][l3]; }
+            finish(ch, a0, a1, a2, a3, v);
+        }
+    } else {
+        // direct gathers, two register sets: the loads of the NEXT pass are issued before this pass's sums and stores (they used
+        // to be issued and waited for inside the same pass: one exposed memory round trip per pass of U channels)
+        float p0[U], p1[U], p2[U], p3[U], pv[U], q0[U], q1[U], q2[U], q3[U], qv[U];
+        auto load = [&](int ch, float (&a0)[U], float (&a1)[U], float (&a2)[U], float (&a3)[U], float (&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t po = (size_t)min(ch + u, C - 1) * HW;
+                a0[u] = gp[po + g0]; a1[u] = gp[po + g1]; a2[u] = gp[po + g2]; a3[u] = gp[po + g3];
+                if (GFLOW) v[u] = ip[po + i];
+            }
+        };
+        load(0, p0, p1, p2, p3, pv);
+        for (int ch = 0; ch < C; ch += 2 * U) {
+            load(ch + U, q0, q1, q2, q3, qv);                      // (past the last channel: re-reads channel C - 1, unused)
+            finish(ch, p0, p1, p2, p3, pv);
+            if (ch + U < C) {
+                load(ch + 2 * U, p0, p1, p2, p3, pv);
+                finish(ch + U, q0, q1, q2, q3, qv);
             }
         }
     }
