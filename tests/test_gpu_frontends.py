@@ -246,3 +246,15 @@ def test_many_deferred_pieces(S, oracle, frontend):
         ref = oracle.function_softsplat(x, flow, None, "summation")
         scale = max(1.0, float(np.abs(ref).max()))
         assert float(np.abs(out - ref).max()) < 2e-4 * scale, (seed, N, float(np.abs(out - ref).max()), scale)
+
+
+def test_differential_fuzz_of_the_front_ends(S):
+    """tools/dev/fuzz_frontends.py, a short run with a fixed seed: random shapes (ragged edges, one-pixel images, batches, a
+    768x1280 case), ten flow families (incoherent, collapsing onto points / lines, far outside, non-finite sprinkles, ...) and
+    all modes incl. the maximum splat; scan and rows against bins on the same inputs."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "fuzz_frontends.py")
+    r = subprocess.run([sys.executable, tool, "150", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
