@@ -647,7 +647,7 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
             pcs[k] = 0x80ull;                                                 // one piece: octants [0, 8)
             ns[k] = t0 + k >= nt ? 0u : 1u;
             if (ns[k] && cnt > seg) {
-                const uint32_t limit = seg - seg / 8u;
+                const uint32_t limit = (seg * (uint32_t)SLR_ROWS_FILL) / 8u;
                 // (the histogram is an estimate -- units of 16 entries, small appends left out -- scaled to the tile's count + 1/8
                 // for the entries that sit on an octant boundary and count twice)
                 uint32_t hsum = 0;
