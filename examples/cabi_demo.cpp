@@ -77,7 +77,9 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc(&ws, ws_bytes));
 
     SLR_OK(slr_euler_integrate(motion, H, W, nsteps, 1.0f, disp, vis, st));                        // a1
+    const int fe_before = slr_splat_set_front_end(2);                                                 // (the rows front end, whatever the grid size)
     SLR_OK(slr_softsplat_forward(in, disp, out_sum, 1, C, H, W, ws, ws_bytes, 0, st));              // a3 (self-contained call)
+    slr_splat_set_front_end(fe_before);
     SLR_OK(slr_splat_bin(disp, 1, C, H, W, ws, ws_bytes, st));                                      // bins of disp, made once ...
     SLR_OK(slr_softsplat_mode_forward(in, metric, disp, out_soft, 1, C, H, W, SLR_MODE_SOFTMAX,     // a4 ... and reused
                                       ws, ws_bytes, 1, st));
