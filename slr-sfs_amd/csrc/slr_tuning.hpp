@@ -107,6 +107,9 @@
 #ifndef SLR_KREG_ROWS
 #define SLR_KREG_ROWS 4         // register-resident records per output pixel in the rows tile kernel 
 #endif
+#ifndef SLR_ROWS_PLAN_PER
+#define SLR_ROWS_PLAN_PER 4     // tiles per work-item and round of the plan (the plan's registers set rowbin_kernel's occupancy)
+#endif
 #ifndef SLR_ROWS_FILL
 #define SLR_ROWS_FILL 7         // plan: a piece of a heavy tile may hold up to this many eighths of a segment by the (estimated) histogram.  6 / 5 / 4: Euler t=59 +0 / +2 / +8 %, t=45 +2 / +5 / +11 % (more, smaller pieces lose: every piece repeats the tile's list, sort and scan)
 #endif

@@ -606,8 +606,7 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
     // The words were written by other workgroups' agent-scope atomics (performed at the memory side, before their arrival
     // atomics); this XCD's L2 may still hold the zeros of rows_zero_kernel.  They are read with agent-scope (sc1) loads, all four
     // of a round in flight together (as __hip_atomic_load the compiler waits after each).
-    constexpr uint32_t PER = 4;
-    static_assert(PER == 4, "the load block below is written out for 4 words");
+    constexpr uint32_t PER = SLR_ROWS_PLAN_PER;
 #ifdef SLR_PLAN_STAMPS
 #define PSTAMP(k) do { if (threadIdx.x == 0) ((unsigned long long *)totals)[8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -626,8 +625,9 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
             asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:8 sc1"
                          : "=&v"(w[k]), "=&v"(oh[k]) : "v"(pw_) : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(oh[0]), "+v"(oh[1]), "+v"(oh[2]), "+v"(oh[3])
-                     :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) asm volatile("" : "+v"(w[k]), "+v"(oh[k]));      // (read only after the wait)
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) if (t0 + k >= nt) w[k] = 0ull;
         PSTAMP(1);
@@ -654,13 +654,14 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
 #pragma unroll
                 for (uint32_t o = 0; o < 8; ++o) hsum += (uint32_t)(oh[k] >> (8 * o)) & 0xffu;
                 const uint32_t osum = cnt + cnt / 8u;
-                const unsigned long long scale16 = ((unsigned long long)osum << 16) / (hsum ? hsum : 1u);
-                const uint32_t even = osum / ((osum + limit - 1u) / limit);        // pieces of about equal weight, not one full + a rest
+                // (float arithmetic: these are estimates, and 64-bit integer divisions cost the one planning workgroup 2.7 us)
+                const float scale = (float)osum / (float)(hsum ? hsum : 1u);
+                const uint32_t even = (uint32_t)((float)osum / ceilf((float)osum / (float)limit));   // pieces of about equal weight, not one full + a rest
                 uint32_t start = 0, sum = 0, np = 0;
                 unsigned long long p = 0;
 #pragma unroll
                 for (uint32_t o = 0; o < 8; ++o) {
-                    const uint32_t co = (uint32_t)((((oh[k] >> (8 * o)) & 0xffull) * scale16) >> 16);
+                    const uint32_t co = (uint32_t)((float)((uint32_t)(oh[k] >> (8 * o)) & 0xffu) * scale);
                     if ((sum + co > limit || sum + co / 2u >= even) && o > start) { p |= (unsigned long long)(start | ((o - start) << 4)) << (8 * np); ++np; start = o; sum = 0; }
                     sum += co;
                 }
@@ -671,7 +672,7 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
                 uint32_t q4[4];
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q)
-                    q4[q] = (uint32_t)((((oh[k] >> (16 * q)) & 0xffull) * scale16) >> 16) + (uint32_t)((((oh[k] >> (16 * q + 8)) & 0xffull) * scale16) >> 16);
+                    q4[q] = (uint32_t)((float)((uint32_t)(oh[k] >> (16 * q)) & 0xffu) * scale) + (uint32_t)((float)((uint32_t)(oh[k] >> (16 * q + 8)) & 0xffu) * scale);
                 if (max(q4[0] + q4[1], q4[2] + q4[3]) <= limit) { pcs[k] = 0x40ull | (0x44ull << 8); ns[k] = 2; }
                 else if (max(max(q4[0], q4[1]), max(q4[2], q4[3])) <= limit && np >= 4) { pcs[k] = 0x20ull | (0x22ull << 8) | (0x24ull << 16) | (0x26ull << 24); ns[k] = 4; }
 #endif
@@ -791,16 +792,22 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
             // in units of 16 entries with a pseudo-random rounding offset (unbiased: a tile's sum over its ~50 appends is what
             // matters; two 16-bit-per-octant words cost +7 us per call at 46 k appends).  Appends of fewer than 8 hits -- the
             // one-column overlaps into the neighbouring tile, half of all appends -- stay out of it.
+            // (This loop is what the kernel's time grows with -- a bent row touches up to ~8 tiles, 12 us per workgroup at Euler
+            // t=59 against 6 on the identity flow -- so the small appends take a short way: the union of <= 7 lanes' masks.)
             uint32_t rm = 0;
             unsigned long long hist = 0;
-            const uint32_t rnd = ((uint32_t)y * 2654435761u + (uint32_t)T * 40503u) >> 16;
+            if (c >= 8u) {                                   // (wave-uniform)
+                const uint32_t rnd = ((uint32_t)y * 2654435761u + (uint32_t)T * 40503u) >> 16;
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const uint32_t co = (uint32_t)__popcll(__ballot((lm >> o) & 1u));
-                rm |= co ? 1u << o : 0u;
-                hist |= (unsigned long long)((co + ((rnd >> o) & 15u)) >> 4) << (8 * o);
+                for (int o = 0; o < 8; ++o) {
+                    const uint32_t co = (uint32_t)__popcll(__ballot((lm >> o) & 1u));
+                    rm |= co ? 1u << o : 0u;
+                    hist |= (unsigned long long)((co + ((rnd >> o) & 15u)) >> 4) << (8 * o);
+                }
+            } else {
+                for (unsigned long long m = __ballot(h); m; m &= m - 1ull)
+                    rm |= (uint32_t)__builtin_amdgcn_readlane((int)lm, __ffsll((long long)m) - 1);
             }
-            if (c < 8u) hist = 0;
             if (t0 == T) t0 = -1;
             if (t1 == T) t1 = -1;
             if (t2 == T) t2 = -1;
