@@ -73,3 +73,26 @@ def test_frames_at_256_vs_reference_models(golden_dir):
     outs = _v1(golden_dir).cuda().synthesize(img, motion, N, frames=[t], keys=("PredImg", "FluidImg", "CompositeFluidAlpha"))
     for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
         _check(g, f"v1_{k}_t{t}", outs[k], tol_abs=1e-4)
+
+
+@pytest.mark.gpu
+def test_frames_at_native_768_vs_reference_models(golden_dir):
+    """The reference's own working size (test_animating/CLAW/test_v1.sh:19: W = 768, N = 60; test_v1_4eval_rawsize.py:233-239):
+    frames t = 1, 30, 59 of both animators (HIP kernels throughout -- the multi-tile 128 / 256-channel convolution variants that make
+    up two thirds of a timed clip, the fused splat kernel on 96 x 12 tiles) within 1e-4 max-abs of the frames the reference's own
+    models produce on the CPU from the same seeded weights, image and motion (tools/make_golden_large.py --native)."""
+    g = np.load(f"{golden_dir}/native_frames_768.npz")
+    S, N = int(g["S"]), int(g["N"])
+    assert (S, N) == (768, 60)
+    img, motion, _ = NF.e2e_inputs(S, N)
+    img, motion = torch.from_numpy(img).cuda(), torch.from_numpy(motion).cuda()
+    ts = [int(t) for t in g["ts"]]
+    frames = _baseline(golden_dir).cuda().synthesize(img, motion, N, frames=ts)
+    errs = [_check(g, f"baseline_PredImg_t{t}", frames[k:k + 1], tol_abs=1e-4) for k, t in enumerate(ts)]
+    v1_ts = [int(t) for t in g["v1_ts"]]
+    keys = ("PredImg", "FluidImg", "CompositeFluidAlpha")
+    outs = _v1(golden_dir).cuda().synthesize(img, motion, N, frames=v1_ts, keys=keys)
+    for i, t in enumerate(v1_ts):
+        for k in keys:
+            errs.append(_check(g, f"v1_{k}_t{t}", outs[k][i:i + 1], tol_abs=1e-4))
+    print("native 768 frames vs reference models: max abs", max(errs))

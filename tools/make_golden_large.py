@@ -35,7 +35,8 @@ def digest(g, tag, x):
     print(tag, x.shape, "absmax", float(np.abs(x).max()))
 
 
-def main():
+def main(S=S, N=8, ts=None, v1_ts=None, nets_too=True, out_name="large_nets_e2e.npz"):
+    """S x S grid, N-frame clip; ts / v1_ts: the frames whose digests are stored (baseline / 2-layer model)."""
     ss, eim = MG.load_reference()
 
     def stub(name, **kw):
@@ -85,7 +86,9 @@ def main():
         nets = {"encoder": (U.get_encoder, opt_v1), "projector": (U.get_decoder, opt_v1),
                 "net_alpha_decoder": (U.get_alpha_decoder, opt_v1)}
         built = {}
-        for name, (fn, opt) in nets.items():
+        if not nets_too:
+            built["net_alpha_decoder"] = build(U.get_alpha_decoder, "net_alpha_decoder", opt_v1)
+        for name, (fn, opt) in (nets.items() if nets_too else ()):
             net = built[name] = build(fn, name, opt)
             out = net(NF.net_input_large(name, S))
             out = out if isinstance(out, tuple) else (out,)
@@ -93,13 +96,15 @@ def main():
             for i, o in enumerate(out):
                 digest(g, f"{name}_out{i}", o.numpy())
         # ---- frames of both models (the runner flow of make_golden_e2e.py) at S x S
-        img, motion, N = NF.e2e_inputs(S, 8)
+        img, motion, N = NF.e2e_inputs(S, N)
         g["N"] = np.int32(N)
         enc, dec = build(U.get_encoder, "encoder", opt_base), build(U.get_decoder, "projector", opt_base)
         fs, Z = enc(torch.from_numpy(img))
         me = types.SimpleNamespace(opt=opt_base, softsplater=ss.ModuleSoftsplat("summation"), projector=dec)
-        ts = [1, N // 2, N - 1]
+        ts = [1, N // 2, N - 1] if ts is None else list(ts)
+        v1_ts = [N // 2] if v1_ts is None else list(v1_ts)
         g["ts"] = np.array(ts, np.int32)
+        g["v1_ts"] = np.array(v1_ts, np.int32)
         for t in ts:
             batch = {"features": [(cl(plain(fs)), cl(plain(Z)))], "images": [cl(img)], "motions": [cl(motion)],
                      "index": torch.tensor([[0, t, N - 1]])}
@@ -111,13 +116,13 @@ def main():
         bg = bgn(torch.from_numpy(img))
         me = types.SimpleNamespace(opt=opt_v1, softsplater=ss.ModuleSoftsplat("summation"), projector=dec1,
                                    net_alpha_decoder=adec, net_alpha_encoder=aenc)
-        t = N // 2
-        batch = {"features": [(cl(plain(fs1)), cl(plain(Z1)))], "images": [cl(img)], "motions": [cl(motion)],
-                 "index": torch.tensor([[0, t, N - 1]]), "BGImg": [cl(plain(bg))]}
-        pred = B.AnimatingSoftmaxSplatingJoint.forward_flow(me, batch)
-        for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
-            digest(g, f"v1_{k}_t{t}", plain(pred[k]))
-    p = os.path.join(ROOT, "tests", "golden", "large_nets_e2e.npz")
+        for t in v1_ts:
+            batch = {"features": [(cl(plain(fs1)), cl(plain(Z1)))], "images": [cl(img)], "motions": [cl(motion)],
+                     "index": torch.tensor([[0, t, N - 1]]), "BGImg": [cl(plain(bg))]}
+            pred = B.AnimatingSoftmaxSplatingJoint.forward_flow(me, batch)
+            for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
+                digest(g, f"v1_{k}_t{t}", plain(pred[k]))
+    p = os.path.join(ROOT, "tests", "golden", out_name)
     np.savez_compressed(p, **g)
     print("wrote", p, os.path.getsize(p) // 1024, "kB")
 
@@ -125,6 +130,10 @@ def main():
 if __name__ == "__main__":
     import shutil
     try:
-        main()
+        if "--native" in sys.argv[1:]:
+            # the reference's own working size (test_animating/CLAW/test_v1.sh:19: W = 768, N = 60), frames only
+            main(S=768, N=60, ts=[1, 30, 59], v1_ts=[1, 30, 59], nets_too=False, out_name="native_frames_768.npz")
+        else:
+            main()
     finally:
         shutil.rmtree(MG.TMP, ignore_errors=True)
