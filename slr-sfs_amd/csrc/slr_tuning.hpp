@@ -98,6 +98,9 @@
 #ifndef SLR_ROWBIN_R
 #define SLR_ROWBIN_R 2          // source tiles (vertically adjacent) per workgroup of rowbin_kernel = row segments per wave.  1 / 2 / 4 (whole call, us): identity 153 / 148 / 148, Euler t=30 177 / 173 / 180, t=59 225 / 221 / 233
 #endif
+#ifndef SLR_ROW_CB_CLIP
+#define SLR_ROW_CB_CLIP 4       // fused clip kernel: row segments per group of the walk (two groups' flow loads in flight: a tile of two flows has ~60 segments, 8 per wave)
+#endif
 #ifndef SLR_ROW_CB
 #define SLR_ROW_CB 3            // row segments per wave whose flow loads are in flight together (2 / 3 / 4: within 1 %; 4 needs 3 more registers)
 #endif

@@ -26,6 +26,7 @@
 // HBM traffic ~ C input planes read (x1.14 bin halo) + C output planes written + 4 B per bin entry,
 // i.e. about the algorithmic bytes, instead of ~2x that for the atomic formulation.
 #include "slr_common.hpp"
+#include "splat_types.hpp"
 
 #include <stdarg.h>
 #include <atomic>
@@ -35,9 +36,9 @@ namespace slr {
 
 static thread_local char g_err[512] = "";
 #ifdef SLR_TRACE
-static long long *g_trace;
+long long *g_trace;
 #endif
-static thread_local void *g_ev_start = nullptr, *g_ev_stop = nullptr;   // slr_splat_time_next
+thread_local void *g_ev_start = nullptr, *g_ev_stop = nullptr;   // slr_splat_time_next (also armed for splat_clip.hip's launches)
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -46,24 +47,6 @@ void set_error(const char *fmt, ...) {
 }
 
 // =========================================================================== binning
-
-// Tiles touched by the footprint of one source pixel: <= 2 tile columns x <= 2 tile rows.
-// (scalars, not arrays: dynamically indexed private arrays would be demoted to LDS/scratch)
-struct TileSet {
-    int txa, txb, tya, tyb;     // candidate tile columns / rows
-    bool vxa, vxb, vya, vyb;    // candidate valid (b only when distinct from a)
-};
-
-__device__ __forceinline__ TileSet footprint_tiles(const Corners &c, int H, int W) {
-    TileSet s;
-    const bool xa = c.ok & (c.x0 >= 0) & (c.x0 < W), xb = c.ok & (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
-    const bool ya = c.ok & (c.y0 >= 0) & (c.y0 < H), yb = c.ok & (c.y0 + 1 >= 0) & (c.y0 + 1 < H);
-    s.txa = c.x0 / TILE_W; s.txb = (c.x0 + 1) / TILE_W;      // only used when in range (>= 0)
-    s.tya = c.y0 / TILE_H; s.tyb = (c.y0 + 1) / TILE_H;
-    s.vxa = xa; s.vxb = xb & !(xa & (s.txb == s.txa));
-    s.vya = ya; s.vyb = yb & !(ya & (s.tyb == s.tya));
-    return s;
-}
 
 // Wave-aggregated append: lanes of the wave that target the same tile take consecutive
 // slots in lane order (so a bin stays sorted by source pixel inside every wave's chunk).
@@ -280,33 +263,6 @@ __global__ __launch_bounds__(256) void bin_kernel(BinSet b, int H, int W, int ti
                    b.list[blockIdx.z], blockIdx.y, H, W, tiles_x, tiles);
 }
 
-// ---- a whole clip at once ---------------------------------------------------------------------------------------
-// All displacement maps of a clip exist before its first frame (one all-frames Euler pass per direction), and the
-// binning kernels are latency-bound (flow load -> footprint -> reservation atomic -> list store): binning the 2 x n
-// maps of n frames in ONE launch each (count, scan, fill) costs about what a handful of per-frame launches cost.
-// Map m = d * nframes + i is the direction-d map of frame i: disp[d] + idx[d][i] * 2*H*W.  Per map: count[nt],
-// cursor[nt], listoff[nt + 1] (local exclusive prefix), mapbase[m] = where the map's lists start in the shared list
-// array (a second scan over the map totals): the lists of all maps are packed back to back.
-struct ClipMaps {
-    const float *disp[2];        // [*, 2, H, W] displacement maps of the two directions
-    const int *idx[2];           // [nframes] device arrays: which map of disp[d] frame i uses
-    uint32_t *count, *cursor, *listoff, *mapbase, *list;
-    uint32_t nframes, nt;
-};
-
-template <bool FILL>
-__global__ __launch_bounds__(256) void bin_clip_kernel(ClipMaps c, int H, int W, int tiles_x, int tiles) {
-    const uint32_t m = blockIdx.z, d = m >= c.nframes ? 1u : 0u, i = m - d * c.nframes;
-    const float *flow = c.disp[d] + (size_t)c.idx[d][i] * 2 * H * W;
-    bin_body<FILL, true>(flow, (FILL ? c.cursor : c.count) + (size_t)m * c.nt, c.listoff + (size_t)m * (c.nt + 1),
-                   FILL ? c.list + c.mapbase[m] : nullptr, 0, H, W, tiles_x, tiles);
-}
-
-__global__ __launch_bounds__(256) void zero_u32_kernel(uint32_t *__restrict__ p, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = 0;
-}
-
 // Block-wide exclusive scan helper (1024 threads), returns the block total.
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *excl, uint32_t *wsum /*[16]*/) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -346,51 +302,6 @@ __global__ __launch_bounds__(1024) void offsets_kernel(BinSet b, uint32_t nt) {
     }
     if (threadIdx.x == 0) listoff[nt] = run;
 }
-
-// One workgroup per map: local exclusive prefix of its tile counts, zeroed cursors, and the map's total.
-__global__ __launch_bounds__(1024) void offsets_clip_kernel(ClipMaps c, uint32_t *__restrict__ maptotal) {
-    const uint32_t m = blockIdx.x, nt = c.nt;
-    const uint32_t *__restrict__ count = c.count + (size_t)m * nt;
-    uint32_t *__restrict__ listoff = c.listoff + (size_t)m * (nt + 1);
-    uint32_t *__restrict__ cursor = c.cursor + (size_t)m * nt;
-    __shared__ uint32_t wsum[16];
-    uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < nt; b0 += 1024) {
-        uint32_t t = b0 + threadIdx.x;
-        uint32_t v = t < nt ? count[t] : 0;
-        uint32_t ex;
-        uint32_t tot = block_exscan(v, &ex, wsum);
-        if (t < nt) { listoff[t] = run + ex; cursor[t] = 0; }
-        run += tot;
-    }
-    if (threadIdx.x == 0) { listoff[nt] = run; maptotal[m] = run; }
-}
-
-// mapbase = exclusive prefix of the map totals (single workgroup; mapbase[nmaps] = all entries of the clip).
-__global__ __launch_bounds__(1024) void mapbase_kernel(const uint32_t *__restrict__ maptotal, uint32_t *__restrict__ mapbase,
-                                                       uint32_t nmaps) {
-    __shared__ uint32_t wsum[16];
-    uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < nmaps; b0 += 1024) {
-        uint32_t m = b0 + threadIdx.x;
-        uint32_t v = m < nmaps ? maptotal[m] : 0;
-        uint32_t ex;
-        uint32_t tot = block_exscan(v, &ex, wsum);
-        if (m < nmaps) mapbase[m] = run + ex;
-        run += tot;
-    }
-    if (threadIdx.x == 0) mapbase[nmaps] = run;
-}
-
-// Everything a tile workgroup needs to know about its work item, in ONE 32-byte record (one scalar
-// load instead of a chain of dependent lookups through items -> count/listoff/nseg/partoff).
-struct ItemDesc {
-    uint32_t tile, seg;          // tile index (n*tiles + tile), segment of its concatenated bin
-    uint32_t cnt0, cnt1;         // entries in the bin of flow 0 / flow 1
-    uint32_t off0, off1;         // where those bins start in list[0] / list[1]
-    uint32_t nseg, partoff;      // segments of the tile (0: this item covers the whole tile, segment by
-                                 // segment); first partial slot (multi-segment tiles)
-};
 
 constexpr uint32_t PLAN_SX = 4, PLAN_SY = SLR_PLAN_SY;   // super-tile of the work-item order (plan_kernel).  Measured with
 // PLAN_SY = 2 / XCD_GROUP = 8: -7 % HBM fetch (764 -> 708 MB per frame) but no time gain (+1 %): the kernel is not
@@ -488,23 +399,6 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
               nseg, partoff, items, multi, whole_items, totals);
 }
 
-// The work plans of all frames of a clip in one launch: workgroup i plans frame i (its forward + backward bins).
-struct ClipPlan {
-    uint32_t *nseg, *partoff, *multi, *whole_items, *totals;      // [nframes][nt] ... totals [nframes][CLIP_TOTALS]
-    ItemDesc *items;                                               // [nframes][items_cap]
-    uint32_t items_cap, part_slots;
-};
-constexpr uint32_t CLIP_TOTALS = 8;
-
-__global__ __launch_bounds__(1024) void plan_clip_kernel(ClipMaps c, ClipPlan p, uint32_t tiles_x, uint32_t tiles_y,
-                                                         uint32_t seg) {
-    const uint32_t i = blockIdx.x, nt = c.nt, m0 = i, m1 = c.nframes + i;
-    plan_body(c.count + (size_t)m0 * nt, c.count + (size_t)m1 * nt, c.listoff + (size_t)m0 * (nt + 1),
-              c.listoff + (size_t)m1 * (nt + 1), c.mapbase[m0], c.mapbase[m1], 0u, nt, tiles_x, tiles_y, seg, p.part_slots,
-              p.nseg + (size_t)i * nt, p.partoff + (size_t)i * nt, p.items + (size_t)i * p.items_cap,
-              p.multi + (size_t)i * nt, p.whole_items + (size_t)i * nt, p.totals + (size_t)i * CLIP_TOTALS);
-}
-
 // =========================================================================== scan front end (no bins)
 // Small grids (config C2 of BASELINE.json: 256x480) spend their time in the latency chains of seven tiny dependent
 // launches (zero, count, scan, fill, plan, whole, combine: ~35 us around a 30 us tile kernel, profiles/r2_c2_kernel_stats.txt).
@@ -565,8 +459,6 @@ __global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restr
 // no pass loop and no work loop: 80 VGPRs, three workgroups per CU.  A piece that still holds more than SEG entries is handed
 // to a second, normally empty launch (WHOLE) that walks it pass by pass.  A tile touched by more than SLR_ROW_CAP segments
 // (pathological flows) is scanned from ALL rows of its sample.  DESIGN.md 3.2.5b has the measurements behind every choice.
-constexpr int ROW_CAP = SLR_ROW_CAP;
-struct RowRec { uint32_t sy, sx_cnt; };     // row segment: image row | column octants of the tile it touches << 24, (x / 64) << 8 | its hits in the tile (<= 64)
 
 // Work plan from the per-tile (entries, row segments) words; run by ONE workgroup of TILE_PIX work-items (the last one of
 // rowbin_kernel) in ONE pass over the tiles.  A round covers 4 * TILE_PIX tiles: every work-item loads the words of 4
@@ -2464,51 +2356,6 @@ static int do_splat(SplatArgs a, Ws &w0, Ws *w1, hipStream_t st) {
     return run_plan<NORM, MAXOP>(a, w1 != nullptr, w0.L.items_cap, w0.L.nt, w0.L.part_slots, -1, -1, -1, st);
 }
 
-// ---- clip plans (all frames of a clip binned and planned by one set of launches) ---------------------------------
-struct ClipLayout {
-    int tiles_x, tiles_y, tiles;
-    uint32_t nt, nframes, nmaps, part_slots, items_cap;
-    size_t off_count, off_cursor, off_listoff, off_maptotal, off_mapbase, off_nseg, off_partoff, off_multi, off_whole,
-        off_items, off_totals, off_list, total;
-};
-
-static ClipLayout clip_layout(int nframes, int H, int W) {
-    ClipLayout L;
-    L.tiles_x = (W + TILE_W - 1) / TILE_W;
-    L.tiles_y = (H + TILE_H - 1) / TILE_H;
-    L.tiles = L.tiles_x * L.tiles_y;
-    L.nt = (uint32_t)L.tiles;
-    L.nframes = (uint32_t)nframes;
-    L.nmaps = 2u * L.nframes;
-    L.part_slots = L.nt < 64 ? 64 : L.nt;
-    L.items_cap = L.nt + L.part_slots;
-    size_t o = 0;
-    L.off_count = o;    o += al256((size_t)L.nmaps * L.nt * 4);
-    L.off_cursor = o;   o += al256((size_t)L.nmaps * L.nt * 4);
-    L.off_listoff = o;  o += al256((size_t)L.nmaps * (L.nt + 1) * 4);
-    L.off_maptotal = o; o += al256((size_t)L.nmaps * 4);
-    L.off_mapbase = o;  o += al256(((size_t)L.nmaps + 1) * 4);
-    L.off_nseg = o;     o += al256((size_t)L.nframes * L.nt * 4);
-    L.off_partoff = o;  o += al256((size_t)L.nframes * L.nt * 4);
-    L.off_multi = o;    o += al256((size_t)L.nframes * L.nt * 4);
-    L.off_whole = o;    o += al256((size_t)L.nframes * L.nt * 4);
-    L.off_items = o;    o += al256((size_t)L.nframes * L.items_cap * sizeof(ItemDesc));
-    L.off_totals = o;   o += al256((size_t)L.nframes * CLIP_TOTALS * 4);
-    L.off_list = o;     o += al256((size_t)4 * H * W * L.nmaps * 4);        // worst case: 4 bins per source pixel
-    L.total = o;
-    return L;
-}
-
-static int clip_check(int nframes, int H, int W, const char *who) {
-    // list offsets are 32-bit: 4 entries per source pixel and map must stay below 2^32 (plan longer clips in chunks)
-    if (nframes <= 0 || H <= 0 || W <= 0 || (long long)H * W >= (1LL << 29) ||
-        (long long)8 * nframes * H * W >= (1LL << 32)) {
-        set_error("%s: bad sizes nframes=%d H=%d W=%d (8*nframes*H*W must stay below 2^32)", who, nframes, H, W);
-        return SLR_E_BADARG;
-    }
-    return 0;
-}
-
 }  // namespace slr
 
 using namespace slr;
@@ -2674,169 +2521,3 @@ SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *o
     return do_splat<false, true>(a, w, nullptr, st);
 }
 
-// ------------------------------------------------------------------------------------------ clip plans (C ABI)
-
-SLR_EXPORT size_t slr_clip_plan_bytes(int nframes, int H, int W) {
-    if (nframes <= 0 || H <= 0 || W <= 0 || (long long)8 * nframes * H * W >= (1LL << 32)) return 0;
-    return clip_layout(nframes, H, W).total;
-}
-
-SLR_EXPORT size_t slr_splat_scratch_bytes(int C, int H, int W) {
-    if (C <= 0 || H <= 0 || W <= 0) return 0;
-    const ClipLayout L = clip_layout(1, H, W);
-    const size_t stride = (size_t)(C + 3) * TILE_PIX * 4;
-    return al256(stride) + al256((size_t)L.part_slots * stride);
-}
-
-SLR_EXPORT int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words) {
-    if (int e = clip_check(nframes, H, W, __func__)) return e;
-    SLR_CHECK_ARG(offset_bytes && stride_words, "null pointer");
-    *offset_bytes = clip_layout(nframes, H, W).off_totals;
-    *stride_words = (int)CLIP_TOTALS;
-    return 0;
-}
-
-SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp_p, const int *idx_p, int nframes,
-                                   int H, int W, void *plan, size_t plan_bytes, void *stream) {
-    SLR_CHECK_ARG(disp_f && idx_f && disp_p && idx_p && plan, "null pointer");
-    if (int e = clip_check(nframes, H, W, __func__)) return e;
-    const ClipLayout L = clip_layout(nframes, H, W);
-    if (((uintptr_t)plan & 15) || plan_bytes < L.total) {
-        set_error("%s: plan buffer needs %zu bytes (16-byte aligned), got %zu", __func__, L.total, plan_bytes);
-        return SLR_E_WORKSPACE;
-    }
-    char *b = (char *)plan;
-    hipStream_t st = (hipStream_t)stream;
-    ClipMaps c = {};
-    c.disp[0] = disp_f; c.disp[1] = disp_p; c.idx[0] = idx_f; c.idx[1] = idx_p;
-    c.count = (uint32_t *)(b + L.off_count); c.cursor = (uint32_t *)(b + L.off_cursor);
-    c.listoff = (uint32_t *)(b + L.off_listoff); c.mapbase = (uint32_t *)(b + L.off_mapbase);
-    c.list = (uint32_t *)(b + L.off_list);
-    c.nframes = L.nframes; c.nt = L.nt;
-    uint32_t *maptotal = (uint32_t *)(b + L.off_maptotal);
-    ClipPlan p = {};
-    p.nseg = (uint32_t *)(b + L.off_nseg); p.partoff = (uint32_t *)(b + L.off_partoff);
-    p.multi = (uint32_t *)(b + L.off_multi); p.whole_items = (uint32_t *)(b + L.off_whole);
-    p.totals = (uint32_t *)(b + L.off_totals); p.items = (ItemDesc *)(b + L.off_items);
-    p.items_cap = L.items_cap; p.part_slots = L.part_slots;
-    const size_t ncount = (size_t)L.nmaps * L.nt;
-    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ncount + 255) / 256)), dim3(256), 0, st, c.count, ncount);
-    // blockIdx.z carries the map: at most 65535 maps per launch (the 2^32 entry bound above is far tighter)
-    const dim3 grid((H * W + 256 * BIN_PPT - 1) / (256 * BIN_PPT), 1, L.nmaps);
-    hipLaunchKernelGGL(bin_clip_kernel<false>, grid, dim3(256), 0, st, c, H, W, L.tiles_x, L.tiles);
-    hipLaunchKernelGGL(offsets_clip_kernel, dim3(L.nmaps), dim3(1024), 0, st, c, maptotal);
-    hipLaunchKernelGGL(mapbase_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)maptotal, c.mapbase, L.nmaps);
-    hipLaunchKernelGGL(bin_clip_kernel<true>, grid, dim3(256), 0, st, c, H, W, L.tiles_x, L.tiles);
-    hipLaunchKernelGGL(plan_clip_kernel, dim3(L.nframes), dim3(1024), 0, st, c, p, (uint32_t)L.tiles_x, (uint32_t)L.tiles_y,
-                       (uint32_t)SEG_TWO);
-    SLR_CHECK_LAUNCH();
-    return 0;
-}
-
-// SplatArgs of frame `frame` of a clip plan (everything but the per-call tensors).
-static void clip_frame_args(SplatArgs &a, const ClipLayout &L, const void *plan, int frame, void *scratch, int slot, int C) {
-    const char *b = (const char *)plan;
-    const size_t i = (size_t)frame;
-    const size_t stride = (size_t)(C + 3) * TILE_PIX;        // value planes, normaliser, second group's sum and normaliser
-    const size_t slot_bytes = al256((size_t)L.part_slots * stride * 4);
-    a.tiles_x = L.tiles_x; a.tiles = L.tiles;
-    a.count[0] = (const uint32_t *)(b + L.off_count) + i * L.nt;
-    a.count[1] = (const uint32_t *)(b + L.off_count) + ((size_t)L.nframes + i) * L.nt;
-    a.list[0] = a.list[1] = (const uint32_t *)(b + L.off_list);       // ItemDesc.off0 / off1 are absolute (mapbase included)
-    a.nseg = (const uint32_t *)(b + L.off_nseg) + i * L.nt;
-    a.partoff = (const uint32_t *)(b + L.off_partoff) + i * L.nt;
-    a.multi = (const uint32_t *)(b + L.off_multi) + i * L.nt;
-    a.whole_items = (const uint32_t *)(b + L.off_whole) + i * L.nt;
-    a.items = (const ItemDesc *)(b + L.off_items) + i * L.items_cap;
-    a.totals = (const uint32_t *)(b + L.off_totals) + i * CLIP_TOTALS;
-    a.trash = (float *)scratch;                                        // shared by the frames of a batch (write-only sink)
-    a.partial = (float *)((char *)scratch + al256(stride * 4) + (size_t)slot * slot_bytes);
-    a.part_stride = stride;
-}
-
-static size_t clip_scratch_need(const ClipLayout &L, int C, int nb) {
-    const size_t stride = (size_t)(C + 3) * TILE_PIX;
-    return al256(stride * 4) + (size_t)nb * al256((size_t)L.part_slots * stride * 4);
-}
-
-SLR_EXPORT size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb) {
-    if (C <= 0 || H <= 0 || W <= 0 || nb <= 0 || nb > MAXB) return 0;
-    return clip_scratch_need(clip_layout(1, H, W), C, nb);
-}
-
-static int synth_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
-                            const float *values2, const float *wlogit2, int exp_weights2, float *const *out2,
-                            const float *const *disp_f, const float *const *disp_p, const float *alpha,
-                            float *const *out, float *const *norm_out, int C, int H, int W, float eps,
-                            const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                            void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
-    SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && alpha && out && plan && scratch && frame, "null pointer");
-    SLR_CHECK_ARG((!values2 && !wlogit2 && !out2) || (values2 && wlogit2 && out2), "the second group needs values, weights and outputs");
-    SLR_CHECK_ARG(nb >= 1 && nb <= MAXB, "1 <= nb <= 8 frames per launch");
-    if (int e = check_dims(1, C, H, W, __func__)) return e;
-    if (int e = clip_check(nframes, H, W, __func__)) return e;
-    const ClipLayout L = clip_layout(nframes, H, W);
-    const size_t need = clip_scratch_need(L, C, nb);
-    if (((uintptr_t)plan & 15) || plan_bytes < L.total || ((uintptr_t)scratch & 15) || scratch_bytes < need) {
-        set_error("%s: plan needs %zu bytes (got %zu), scratch %zu (got %zu), both 16-byte aligned", __func__, L.total,
-                  plan_bytes, need, scratch_bytes);
-        return SLR_E_WORKSPACE;
-    }
-    SplatBatch b = {};
-    PlanHint h[MAXB];
-    b.nb = (uint32_t)nb;
-    for (int k = 0; k < nb; ++k) {
-        SLR_CHECK_ARG(frame[k] >= 0 && frame[k] < nframes, "frame index");
-        SLR_CHECK_ARG(disp_f[k] && disp_p[k] && out[k], "null pointer");
-        SplatArgs &a = b.f[k];
-        a.in = values; a.mul = wlogit; a.mulmax = wmax;
-        a.flow[0] = disp_f[k]; a.flow[1] = disp_p[k];
-        a.scale[0] = alpha[k]; a.scale[1] = 1.0f - alpha[k];
-        a.out = out[k]; a.norm_out = norm_out ? norm_out[k] : nullptr;
-        a.N = 1; a.C = C; a.H = H; a.W = W;
-        a.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
-        a.norm_mode = SLR_NORM_CLAMP_EPS;
-        a.eps = eps;
-        if (values2) {
-            SLR_CHECK_ARG(out2[k], "null pointer");
-            a.in2 = values2; a.mul2 = wlogit2; a.out2 = out2[k];
-            a.mulmode2 = exp_weights2 ? MUL_EXP : MUL_PLANE;
-        }
-        clip_frame_args(a, L, plan, frame[k], scratch, k, C);
-        h[k].n_items = hints ? hints[3 * k] : -1;
-        h[k].n_multi = hints ? hints[3 * k + 1] : -1;
-        h[k].n_whole = hints ? hints[3 * k + 2] : -1;
-    }
-    return run_batch<true, false>(b, h, true, L.items_cap, L.nt, L.part_slots, (hipStream_t)stream);
-}
-
-SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
-                                          const float *const *disp_f, const float *const *disp_p, const float *alpha,
-                                          float *const *out, float *const *norm_out, int C, int H, int W, float eps,
-                                          const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                                          void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
-    return synth_clip_batch(values, wlogit, wmax, exp_weights, nullptr, nullptr, 0, nullptr, disp_f, disp_p, alpha, out, norm_out,
-                            C, H, W, eps, plan, plan_bytes, nframes, frame, nb, scratch, scratch_bytes, hints, stream);
-}
-
-SLR_EXPORT int slr_synth_two_groups_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
-                                               const float *values2, const float *wlogit2, int exp_weights2,
-                                               const float *const *disp_f, const float *const *disp_p, const float *alpha,
-                                               float *const *out, float *const *out2, int C, int H, int W, float eps,
-                                               const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                                               void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
-    SLR_CHECK_ARG(values2 && wlogit2 && out2, "null pointer");
-    return synth_clip_batch(values, wlogit, wmax, exp_weights, values2, wlogit2, exp_weights2, out2, disp_f, disp_p, alpha, out,
-                            nullptr, C, H, W, eps, plan, plan_bytes, nframes, frame, nb, scratch, scratch_bytes, hints, stream);
-}
-
-SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
-                                    const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
-                                    int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes,
-                                    int frame, void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole,
-                                    void *stream) {
-    const int hints[3] = {n_items, n_multi, n_whole};
-    return slr_synth_group_clip_batch(values, wlogit, wmax, exp_weights, &disp_f, &disp_p, &alpha, &out,
-                                      norm_out ? &norm_out : nullptr, C, H, W, eps, plan, plan_bytes, nframes, &frame, 1,
-                                      scratch, scratch_bytes, hints, stream);
-}

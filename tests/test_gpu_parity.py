@@ -415,7 +415,9 @@ def test_batched_launch_with_whole_tile_items(S, oracle):
     cs = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N)
     ts = [1, 0, 2]
     hints = [cs.plan.lookup(t)[3] for t in ts]
-    assert hints[0][2] > 0 and hints[1][2] == 0, hints              # frame 1 has whole-tile items, frame 0 has none
+    # (round 4: a piece of more than a segment is found by its workgroup at run time and walked by the pass-by-pass launch behind the
+    #  main one -- the plan no longer knows; frames 1 and 2 pile 4 x H x W entries and overflowing row lists into four tiles)
+    assert all(h[0] >= (H // 8) * (W // 64) for h in hints), hints
     out = torch.empty(len(ts), 5, H, W, device="cuda")
     cs.features_batch(ts, out)
     for k, t in enumerate(ts):
@@ -1164,7 +1166,7 @@ def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
     nb = len(ts)
     pbytes = int(L.slr_clip_plan_bytes(nb, H, W))
     assert pbytes > 0 and int(L.slr_clip_plan_bytes(0, H, W)) == 0
-    assert int(L.slr_clip_plan_bytes(70000, 768, 1280)) == 0              # 8 * nframes * H * W must stay below 2^32
+    assert int(L.slr_clip_plan_bytes(70000, 768, 1280)) == 0              # at most 16384 frames per plan
     plan = torch.empty(pbytes, dtype=torch.uint8, device="cuda")
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
     assert L.slr_clip_plan_build(ptr(disp_f), vp(idx_f), ptr(disp_p), vp(idx_p), nb, H, W, ptr(plan), pbytes // 2, st) == -2
@@ -1201,7 +1203,11 @@ def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
         np.testing.assert_allclose(host(outs[k:k + 1]), refs[k], rtol=2e-4, atol=2e-5)
     assert call(9, fr, sbytes) == -1 and b"frames per launch" in L.slr_last_error()
     assert call(nb, (ctypes.c_int * nb)(0, 1, 5), sbytes) == -1 and b"frame index" in L.slr_last_error()
-    assert call(nb, fr, 1024) == -2 and b"scratch" in L.slr_last_error()
+    assert call(nb, fr, 0) == 0                                            # (no scratch since the rows front end: pieces own their pixels)
+    for k in range(nb):
+        np.testing.assert_allclose(host(outs[k:k + 1]), refs[k], rtol=2e-4, atol=2e-5)
+    assert L.slr_synth_group_clip_batch(ptr(dfs), ptr(dZ), ptr(zmax), 1, df, dp, al, po, None, C, H, W, 1e-8, ptr(plan), pbytes // 2,
+                                        nb, fr, nb, None, 0, None, st) == -2 and b"plan needs" in L.slr_last_error()
 
 
 def test_splat_over_budget_tiles_whole_tile_path(S, oracle):
@@ -1344,7 +1350,6 @@ def test_two_weight_groups_whole_tile_items_and_underflowing_weights(S, oracle):
     abg = (1 / (1 + np.exp(-a[:, 0:1]))).astype(np.float32)
     cv = S.synthesis.ClipSynthesizer(dev(fs), dev(Z), dev(m), N, alpha_fluid_logit=dev(a[:, 1:2]), alpha_bg=dev(abg))
     ts = [1, 0, 2]
-    assert cv.plan.lookup(1)[3][2] > 0                                 # frame 1 has whole-tile items
     out, outa = torch.empty(3, 6, H, W, device="cuda"), torch.empty(3, 1, H, W, device="cuda")
     cv.features_batch(ts, out, outa)
     for k, t in enumerate(ts):
