@@ -701,6 +701,9 @@ __device__ __forceinline__ void stream_planes(const ClipShared &s, const ClipFra
             __builtin_amdgcn_sched_barrier(0);
         });
         if (c0 < 8 * C_CHUNK) C_STAMP(s, 11 + 6 * (c0 / C_CHUNK));
+        if (c0 < 8 * C_CHUNK) C_STAMP(s, 12 + 6 * (c0 / C_CHUNK));
+        __syncthreads();                              // val4 is overwritten by the next chunk (the stores below do not hold the others up)
+        if (c0 < 8 * C_CHUNK) C_STAMP(s, 13 + 6 * (c0 / C_CHUNK));
 #pragma unroll
         for (int u = 0; u < C_CHUNK; ++u) {
             if (FULL || c0 + u < s.C) {               // (scalar: only the last chunk of a plane count that is not a multiple of 4)
@@ -711,9 +714,6 @@ __device__ __forceinline__ void stream_planes(const ClipShared &s, const ClipFra
                 buf_st(rout, voff, soff, r);
             }
         }
-        if (c0 < 8 * C_CHUNK) C_STAMP(s, 12 + 6 * (c0 / C_CHUNK));
-        __syncthreads();                              // val4 is overwritten by the next chunk
-        if (c0 < 8 * C_CHUNK) C_STAMP(s, 13 + 6 * (c0 / C_CHUNK));
     };
     // (the loads of the first two chunks were issued in phase 1a, ~5 us ago: waiting for them here costs nothing, and with nothing
     //  pending at the loop's entry the compiler's counter bookkeeping inside the loop is exact -- merged with a non-empty entry state it

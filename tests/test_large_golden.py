@@ -75,12 +75,42 @@ def test_frames_at_256_vs_reference_models(golden_dir):
         _check(g, f"v1_{k}_t{t}", outs[k], tol_abs=1e-4)
 
 
+def _check_envelope(g, tag, x, tol_abs):
+    """Distance of x to the interval spanned by the reference's two own runs (plain and oneDNN CPU convolutions) at the sampled positions."""
+    x = np.ascontiguousarray(x.detach().cpu().numpy() if torch.is_tensor(x) else x, dtype=np.float32)
+    assert list(x.shape) == [int(v) for v in g[f"{tag}_shape"]], tag
+    pos = NF.digest_positions(tag, x.size, int(g["npos"]))
+    a, b = g[f"{tag}_val"], g[f"{tag}_val_onednn"]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    v = x.ravel()[pos]
+    dist = np.maximum(np.maximum(lo - v, v - hi), 0.0)
+    err = float(dist.max())
+    assert err <= tol_abs, (tag, err, tol_abs, float(np.abs(a - b).max()))
+    sums = x.reshape(-1, x.shape[-2] * x.shape[-1]).astype(np.float64).sum(1)
+    hw = x.shape[-2] * x.shape[-1]
+    assert float(np.abs(sums - g[f"{tag}_plane_sums"]).max()) <= tol_abs * hw * 0.05, tag          # (mean error per pixel << tol)
+    return err, float(min(np.abs(v - a).max(), np.abs(v - b).max()))
+
+
+def test_native_fixture_holds_both_reference_runs(golden_dir):
+    """The fixture itself: both runs of the reference present for every tensor, and the spread between them is what the header of
+    tools/make_golden_large.py says (max 2.0e-4 on frame 30 of the baseline model; everything else below 1e-4)."""
+    g = np.load(f"{golden_dir}/native_frames_768.npz")
+    tags = [k[:-4] for k in g.files if k.endswith("_val")]
+    assert len(tags) == 12
+    spread = {t: float(np.abs(g[t + "_val"] - g[t + "_val_onednn"]).max()) for t in tags}
+    assert 1.5e-4 < spread["baseline_PredImg_t30"] < 2.5e-4, spread
+    assert all(v < 1e-4 for t, v in spread.items() if t != "baseline_PredImg_t30"), spread
+
+
 @pytest.mark.gpu
 def test_frames_at_native_768_vs_reference_models(golden_dir):
     """The reference's own working size (test_animating/CLAW/test_v1.sh:19: W = 768, N = 60; test_v1_4eval_rawsize.py:233-239):
     frames t = 1, 30, 59 of both animators (HIP kernels throughout -- the multi-tile 128 / 256-channel convolution variants that make
-    up two thirds of a timed clip, the fused splat kernel on 96 x 12 tiles) within 1e-4 max-abs of the frames the reference's own
-    models produce on the CPU from the same seeded weights, image and motion (tools/make_golden_large.py --native)."""
+    up two thirds of a timed clip, the fused splat kernel on 96 x 12 tiles) against the frames the reference's own models produce on
+    the CPU from the same seeded weights, image and motion (tools/make_golden_large.py --native).  The reference's fp32 frames are
+    themselves only reproducible to 2.0e-4 at this size (its oneDNN and its plain CPU convolutions, both stored); every sampled value
+    has to lie within 1e-4 of the interval the two reference runs span."""
     g = np.load(f"{golden_dir}/native_frames_768.npz")
     S, N = int(g["S"]), int(g["N"])
     assert (S, N) == (768, 60)
@@ -88,11 +118,12 @@ def test_frames_at_native_768_vs_reference_models(golden_dir):
     img, motion = torch.from_numpy(img).cuda(), torch.from_numpy(motion).cuda()
     ts = [int(t) for t in g["ts"]]
     frames = _baseline(golden_dir).cuda().synthesize(img, motion, N, frames=ts)
-    errs = [_check(g, f"baseline_PredImg_t{t}", frames[k:k + 1], tol_abs=1e-4) for k, t in enumerate(ts)]
+    errs = [_check_envelope(g, f"baseline_PredImg_t{t}", frames[k:k + 1], 1e-4) for k, t in enumerate(ts)]
     v1_ts = [int(t) for t in g["v1_ts"]]
     keys = ("PredImg", "FluidImg", "CompositeFluidAlpha")
     outs = _v1(golden_dir).cuda().synthesize(img, motion, N, frames=v1_ts, keys=keys)
     for i, t in enumerate(v1_ts):
         for k in keys:
-            errs.append(_check(g, f"v1_{k}_t{t}", outs[k][i:i + 1], tol_abs=1e-4))
-    print("native 768 frames vs reference models: max abs", max(errs))
+            errs.append(_check_envelope(g, f"v1_{k}_t{t}", outs[k][i:i + 1], 1e-4))
+    print("native 768 frames: max distance to the reference's own interval", max(e[0] for e in errs),
+          "| max distance to the nearer single run", max(e[1] for e in errs))

@@ -1,4 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_large_golden.py -m gpu -q -s -k native 2>&1 | grep -E "Error|assert|native 768|passed|failed" | head
 python tools/dev/trace_clip.py 24 | head -5
-python tools/dev/stage_line.py 2>&1 | tail -1
-python tools/dev/stage_line.py 2>&1 | tail -1

@@ -33,7 +33,7 @@ print(f"frames {ts[0]}..{ts[-1]}: {len(t)} workgroups, life us mean {life.mean()
 def seg(a, b): return (t[:, b] - t[:, a]).mean() / clk
 print(f"  item->lists sorted {seg(0, 1):.2f} | rows walk {seg(1, 2):.2f} | entries read + prefetch issue {seg(2, 3):.2f} | Z + footprints + atomics {seg(3, 4):.2f} | "
       f"barrier {seg(4, 5):.2f} | scan + scatter {seg(5, 6):.2f} | lists + normaliser {seg(6, 7):.2f}")
-names = ["wait loads + stage", "barrier", "prefetch issue", "gather", "finish + stores", "barrier"]
+names = ["stores + wait loads + stage", "barrier", "-", "gather + loads", "-", "barrier"]
 for c in range(8):
     b0 = 8 + 6 * c
     prev = 7 if c == 0 else b0 - 1
