@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 
 H, W, NFRAMES = 768, 1280, 60
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = "r3_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh + tools/pmc_traffic.py) of the fused kernel; carries the
+TRAFFIC_FILE = "r4_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh + tools/pmc_traffic.py) of the fused kernel; carries the
                                            # hash of the kernel sources it was taken on (a figure from another build is labelled stale)
 
 
@@ -55,7 +55,7 @@ def csrc_hash():
     """sha256 (first 16 hex digits) over the sources of the splat kernels (the files the fused tile kernel is built from)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("slr_common.hpp", "slr_tuning.hpp", "splat.hip"):
+    for name in ("slr_common.hpp", "slr_tuning.hpp", "splat_types.hpp", "splat_core.hpp", "splat_clip.hip"):
         h.update(name.encode())
         h.update(open(os.path.join(ROOT, "slr-sfs_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]

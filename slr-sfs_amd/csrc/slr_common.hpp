@@ -108,10 +108,9 @@ struct Corners {
     bool ok;           // coordinate representable (finite, |.| < 2^30)
 };
 
-__device__ __forceinline__ Corners make_corners(float fx, float fy, int x, int y) {
+// (X, Y) = the target coordinate (float)x + fx, (float)y + fy of softsplat.py:169-170
+__device__ __forceinline__ Corners corners_at(float X, float Y) {
     Corners c;
-    float X = (float)x + fx;
-    float Y = (float)y + fy;
     c.ok = (fabsf(X) < 1073741824.0f) && (fabsf(Y) < 1073741824.0f);
     float flx = floorf(X), fly = floorf(Y);
     c.x0 = c.ok ? (int)flx : 0;
@@ -122,6 +121,10 @@ __device__ __forceinline__ Corners make_corners(float fx, float fy, int x, int y
     c.w[2] = (x1 - X) * (Y - y0f);
     c.w[3] = (X - x0f) * (Y - y0f);
     return c;
+}
+
+__device__ __forceinline__ Corners make_corners(float fx, float fy, int x, int y) {
+    return corners_at((float)x + fx, (float)y + fy);
 }
 
 __device__ __forceinline__ bool in_image(int cx, int cy, int H, int W) {

@@ -98,6 +98,15 @@
 #ifndef SLR_ROWBIN_R
 #define SLR_ROWBIN_R 2          // source tiles (vertically adjacent) per workgroup of rowbin_kernel = row segments per wave.  1 / 2 / 4 (whole call, us): identity 153 / 148 / 148, Euler t=30 177 / 173 / 180, t=59 225 / 221 / 233
 #endif
+#ifndef SLR_CLIP_MAXB
+#define SLR_CLIP_MAXB 16        // frames per launch of the fused clip kernel (kernel arguments: 16 x 112 bytes)
+#endif
+#ifndef SLR_CLIP_ALIGNED
+#define SLR_CLIP_ALIGNED 0      // clip plans: 1 = the first piece of tile t is item t in every frame (further pieces behind item nt - 1)
+#endif
+#ifndef SLR_CLIP_HEAVY
+#define SLR_CLIP_HEAVY 0        // clip plans: tiles with more than 7/8 of a segment's entries (and every tile cut into pieces) go first; 0 = one row-major pass (measured: 7/8 161.4-162.1 us per frame, 6/8 162.1-162.7, one pass 159.5-160.4: the spatial order is worth more than the shorter tail)
+#endif
 #ifndef SLR_ROW_CB_CLIP
 #define SLR_ROW_CB_CLIP 4       // fused clip kernel: row segments per group of the walk (two groups' flow loads in flight: a tile of two flows has ~60 segments, 8 per wave)
 #endif

@@ -30,14 +30,13 @@ constexpr int C_SEG = C_EPT * CT;                  // entries a workgroup stages
 constexpr int C_CHUNK = 4;                         // planes per pass of the chunk pipeline
 constexpr int C_KREG = SLR_KREG_TWO;               // records of an output pixel kept in registers across the chunks
 constexpr int C_RECCAP = 4 * C_SEG + CT;           // <= 4 records per entry + one pad per pixel (odd list lengths: bank spreading)
-constexpr int C_MAXB = SLR_MAXB;                   // frames per launch
+constexpr int C_MAXB = SLR_CLIP_MAXB;              // frames per launch
 constexpr uint32_t C_NULL = C_SEG;                 // staged-entry index of the all-zero slot
 constexpr int C_XCD = SLR_XCD_GROUP;
 constexpr uint32_t CLIP_TOTALS = 8;                // per frame: [0] items, [4] deferred pieces, [5] arrivals of the deferred launch
 constexpr uint32_t C_DEFER_WG = 16;                // workgroups per frame of the deferred launch
 static_assert(CT == 2 * ROW_CAP, "rows_setup loads the two row lists with one work-item per slot");
-static_assert(4 * C_SEG * 4 <= (C_SEG + 1) * 16, "the entry arrays live in the staging area");
-static_assert(3 * (2 * ROW_CAP) * 4 + 8 <= C_RECCAP * 8, "the row lists live in the record area");
+static_assert(2 * (2 * ROW_CAP) * 4 + C_SEG * 8 <= C_RECCAP * 8, "the row lists and the second group's entry words live in the record area");
 
 // ---- kernel arguments -------------------------------------------------------------------------------------------------------------
 struct ClipShared {                // the same for every frame of a launch
@@ -85,9 +84,9 @@ struct ClipLds {
     uint16_t *off;
     uint2 *rec;
     float4 *val4;
-    uint32_t *rl_sy, *rl_sx, *rl_base;
-    uint32_t *ent_pix, *ent_sy;
-    float *ent_fx, *ent_fy;
+    uint32_t *rl_sy, *rl_w1;       // the two row lists, compacted (direction 0, then direction 1): image row | octants, packed column / slot / hits
+    float4 *ent4;                  // entries: source pixel | direction << 31 (bits), target X, target Y, weight logit
+    float2 *ent2;                  // G2: second group's weight logit and value of the entry
 };
 constexpr size_t C_LDS_HEAD = (size_t)(CT + 16 + 16 + CT / 2) * 4;
 constexpr size_t C_LDS_BYTES = C_LDS_HEAD + (size_t)C_RECCAP * 8 + (size_t)(C_SEG + 1) * 16;
@@ -102,12 +101,9 @@ __device__ __forceinline__ ClipLds clip_lds(uint32_t *smem) {
     L.rec = reinterpret_cast<uint2 *>(smem + CT + 32 + CT / 2);
     L.val4 = reinterpret_cast<float4 *>(L.rec + C_RECCAP);
     L.rl_sy = reinterpret_cast<uint32_t *>(L.rec);
-    L.rl_sx = L.rl_sy + 2 * ROW_CAP;
-    L.rl_base = L.rl_sx + 2 * ROW_CAP;
-    L.ent_pix = reinterpret_cast<uint32_t *>(L.val4);
-    L.ent_sy = L.ent_pix + C_SEG;
-    L.ent_fx = reinterpret_cast<float *>(L.ent_sy + C_SEG);
-    L.ent_fy = L.ent_fx + C_SEG;
+    L.rl_w1 = L.rl_sy + 2 * ROW_CAP;
+    L.ent4 = L.val4;
+    L.ent2 = reinterpret_cast<float2 *>(L.rl_w1 + 2 * ROW_CAP);
     return L;
 }
 
@@ -222,6 +218,66 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
     //  tile and workgroup -- 8x fewer atomics, 1027 -> 1167 us per clip: the kernel is bound by its VALU work, not by the atomics)
 }
 
+// One wave per (map, tile): the tile's row-segment list into image order (the appends arrived in any order; image order is what the
+// staging loads and the record lists like best: unsorted +6..11 % on the one-flow operator), each segment with its first entry slot
+// (exclusive prefix of the hit counts: where its hits go when the whole tile is one piece).  Done once per clip instead of by every
+// workgroup that works on the tile (3.8 us of a 40 us workgroup life went into item -> lists -> sort -> scan).
+// Record after the sort: image row | octants << 24, (x / 64) << 18 | first slot << 7 | hits.
+constexpr uint32_t ROWW_STX = 18, ROWW_BASE = 7;
+__global__ __launch_bounds__(CT) void rows_sort_clip_kernel(ClipRows r) {
+    __shared__ uint32_t k_sy[CT / 64][ROW_CAP], k_sx[CT / 64][ROW_CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * (CT / 64) + w, m = blockIdx.y;
+    if (t >= r.nt) return;                                            // (whole waves; no barriers below)
+    const uint32_t n = min((uint32_t)r.rowcnt[((size_t)m * r.nt + t) * 4], (uint32_t)ROW_CAP);
+    RowRec *list = r.rowlist + ((size_t)m * r.nt + t) * ROW_CAP;
+    constexpr int PER = ROW_CAP / 64;
+    RowRec rec[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t q = (uint32_t)lane + 64u * i;
+        rec[i] = q < n ? list[q] : RowRec{0xffffffffu, 0xffffffffu};
+        k_sy[w][q] = rec[i].sy & 0xffffffu;
+        k_sx[w][q] = rec[i].sx_cnt >> 8;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    uint32_t rank[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) rank[i] = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const unsigned long long kj = ((unsigned long long)k_sy[w][j] << 24) | k_sx[w][j];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const unsigned long long ki = ((unsigned long long)(rec[i].sy & 0xffffffu) << 24) | (rec[i].sx_cnt >> 8);
+            rank[i] += kj < ki ? 1u : 0u;                              // (keys are distinct: one append per (segment, tile))
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // hit counts in sorted order -> exclusive prefix (lane l owns sorted positions PER * l .. PER * l + PER - 1)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t q = (uint32_t)lane + 64u * i;
+        if (q < n) k_sx[w][rank[i]] = rec[i].sx_cnt & 0xffu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t c[PER], mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const uint32_t q = (uint32_t)(PER * lane + i); c[i] = q < n ? k_sx[w][q] : 0u; mine += c[i]; }
+    uint32_t ex = wave_incl_scan(mine, lane) - mine;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { k_sy[w][PER * lane + i] = ex; ex += c[i]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t q = (uint32_t)lane + 64u * i;
+        if (q < n) {
+            const uint32_t base = min(k_sy[w][rank[i]], 0x7ffu);       // (meaningful only when the tile holds <= SEG entries)
+            list[rank[i]] = RowRec{rec[i].sy, ((rec[i].sx_cnt >> 8) << ROWW_STX) | (base << ROWW_BASE) | (rec[i].sx_cnt & 0xffu)};
+        }
+    }
+}
+
 // One workgroup per frame: the (entries, row segments, octant histogram) words of its two maps -> work items in row-major tile
 // order, the pieces of a heavy tile next to each other.  A piece = a range of the tile's 8 column octants (8 output columns each),
 // cut greedily so that no piece's octant counts add up to more than SEG (an entry on an octant boundary counts in both octants: the
@@ -241,13 +297,19 @@ __global__ __launch_bounds__(CT) void rows_plan_clip_kernel(ClipRows r, ClipPlan
     const unsigned long long *w0 = r.rowcnt + (size_t)fi * nt * 4, *w1 = r.rowcnt + (size_t)(r.nframes + fi) * nt * 4;
     ItemDesc *items = p.items + (size_t)fi * p.items_cap;
     uint32_t run = 0;
-    for (uint32_t b = 0; b < nt; b += CT) {
+    // Heavy tiles first (two passes over the same row-major order): the frames of a batch are interleaved, so the launch ends where
+    // all its frames end, and a ridge tile (long record lists: up to 90 us against a mean of 37) that starts there keeps the chip
+    // waiting.  Heavy = cut into pieces, or more than SLR_CLIP_HEAVY / 8 of a segment.
+    const uint32_t heavy_thr = (seg * (uint32_t)SLR_CLIP_HEAVY) / 8u;
+    for (uint32_t pb = 0; pb < (SLR_CLIP_HEAVY ? 2u : 1u) * ((nt + CT - 1) / CT) * CT; pb += CT) {
+        const uint32_t pass = pb / (((nt + CT - 1) / CT) * CT), b = pb - pass * (((nt + CT - 1) / CT) * CT);
         const uint32_t t = b + tid;
-        const bool on = t < nt;
+        bool on = t < nt;
         unsigned long long a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
         if (on) { a0 = w0[4 * (size_t)t]; a1 = w0[4 * (size_t)t + 1]; a2 = w0[4 * (size_t)t + 2];
                   b0 = w1[4 * (size_t)t]; b1 = w1[4 * (size_t)t + 1]; b2 = w1[4 * (size_t)t + 2]; }
         const uint32_t cnt = (uint32_t)(a0 >> 32) + (uint32_t)(b0 >> 32);
+        if (SLR_CLIP_HEAVY && on && (cnt > heavy_thr) != (pass == 0u)) on = false;      // not this pass's tile
         unsigned long long pcs = 0x80ull;                          // pieces: (first octant | octants << 4), 8 bits each; default: octants [0, 8)
         uint32_t ns = on ? 1u : 0u;
         if (on && cnt > seg) {
@@ -269,7 +331,10 @@ __global__ __launch_bounds__(CT) void rows_plan_clip_kernel(ClipRows r, ClipPlan
             q |= (unsigned long long)(start | ((8u - start) << 4)) << (8 * np); ++np;
             pcs = q; ns = np;
         }
-        const uint32_t ex = block_excl_scan(ns, wsum, tid);
+        // SLR_CLIP_ALIGNED: the first piece of tile t is item t in EVERY frame, further pieces follow behind item nt - 1: item i of the
+        // frames of an interleaved batch is then the same tile, their workgroups run side by side on one XCD and fetch the source
+        // region once (FETCH_SIZE per frame 514 -> ... MB); in line, a frame's items drift against its neighbours' by the extra pieces.
+        const uint32_t ex = block_excl_scan(SLR_CLIP_ALIGNED ? (ns ? ns - 1u : 0u) : ns, wsum, tid);
         uint32_t tot = 0;
 #pragma unroll
         for (int w = 0; w < CT / 64; ++w) tot += wsum[w];
@@ -283,11 +348,13 @@ __global__ __launch_bounds__(CT) void rows_plan_clip_kernel(ClipRows r, ClipPlan
                 const uint32_t pc = (uint32_t)(pcs >> (8 * k)) & 0xffu;
                 dsc.seg = pc & 0xfu;                                                    // first column octant of the piece
                 dsc.nseg = pc >> 4;                                                     // its octants (8 = the whole tile)
-                if (run + ex + k < p.items_cap) items[run + ex + k] = dsc;
+                const uint32_t at = !SLR_CLIP_ALIGNED ? run + ex + k : k == 0 ? t : nt + run + ex + k - 1u;
+                if (at < p.items_cap) items[at] = dsc;
             }
         }
         run += tot;
     }
+    if (SLR_CLIP_ALIGNED) run += nt;
     if (tid == 0) {
         uint32_t *tt = p.totals + (size_t)fi * CLIP_TOTALS;
         tt[0] = run < p.items_cap ? run : p.items_cap; tt[1] = 0; tt[2] = 0; tt[3] = 0; tt[4] = 0; tt[5] = 0; tt[6] = 0; tt[7] = 0;
@@ -307,32 +374,16 @@ struct Piece {                     // what one workgroup works on
     bool whole;                    // all 8 octants
 };
 
-// The two row-segment lists of the tile -> LDS in image order (the appends arrived in any order; image order is what the staging
-// loads and the record lists like best: unsorted +6..11 % on the one-flow operator), compacted (direction 0, then direction 1),
-// with the exclusive prefix of their hit counts (the first entry slot of every row segment when the whole tile is one piece).
+// The two row-segment lists of the tile (sorted by rows_sort_clip_kernel) -> LDS, compacted: direction 0, then direction 1.
 __device__ __forceinline__ void rows_setup(const ClipFrame &f, const ClipLds &L, const Piece &p, int tid) {
     const int d = tid >> 8, q = tid & (ROW_CAP - 1);
-    const uint32_t n1 = p.ovf1 ? 0u : p.len1;
-    const uint32_t nd = d ? n1 : p.n0;
-    RowRec r = {0u, 0u};
-    if ((uint32_t)q < nd) r = f.rowlist[d][(size_t)p.tile * ROW_CAP + q];
-    uint32_t *usy = L.rl_sy + d * ROW_CAP, *usx = L.rl_sx + d * ROW_CAP;
-    if ((uint32_t)q < nd) { usy[q] = r.sy; usx[q] = r.sx_cnt >> 8; }
-    __syncthreads();
-    const unsigned long long mykey = ((unsigned long long)(r.sy & 0xffffffu) << 24) | (r.sx_cnt >> 8);
-    uint32_t rank = 0;
-    if ((uint32_t)q < nd)
-        for (uint32_t j = 0; j < nd; ++j) {
-            const unsigned long long k2 = ((unsigned long long)(usy[j] & 0xffffffu) << 24) | usx[j];
-            rank += (k2 < mykey) ? 1u : 0u;                            // (keys are distinct: one append per (segment, tile))
-        }
-    __syncthreads();
-    const uint32_t pos = (d ? p.n0 : 0u) + rank;
-    if ((uint32_t)q < nd) { L.rl_sy[pos] = r.sy; L.rl_sx[pos] = r.sx_cnt >> 8; L.rl_base[pos] = r.sx_cnt & 0xffu; }
-    __syncthreads();
-    const uint32_t c = (uint32_t)tid < p.n0 + n1 ? L.rl_base[tid] : 0u;
-    const uint32_t ex = block_excl_scan(c, L.wsum, tid);
-    L.rl_base[tid] = ex;
+    const uint32_t nd = d ? (p.ovf1 ? 0u : p.len1) : p.n0;
+    if ((uint32_t)q < nd) {
+        const RowRec r = f.rowlist[d][(size_t)p.tile * ROW_CAP + q];
+        const uint32_t pos = (d ? p.n0 : 0u) + (uint32_t)q;
+        L.rl_sy[pos] = r.sy;
+        L.rl_w1[pos] = r.sx_cnt;
+    }
     __syncthreads();
 }
 
@@ -341,7 +392,7 @@ __device__ __forceinline__ void rows_setup(const ClipFrame &f, const ClipLds &L,
 //   MODE 1  a column range / an overflowed list: one LDS atomic per wave and row segment hands out the slots (L.misc[0]);
 //   MODE 2  ordinals (hits of the waves before + own so far, after a count pass): emits the ordinals in [lo, hi).
 // EMIT: write the entries (source pixel | direction << 31, image row, flow) to the entry arrays.
-template <int MODE, bool EMIT>
+template <int MODE, bool EMIT, bool G2>
 __device__ __forceinline__ uint32_t rows_walk(const ClipShared &s, const ClipFrame &f, const ClipLds &L, const Piece &p, int tid,
                                               uint32_t wave_base, uint32_t lo, uint32_t hi) {
     constexpr int CB = SLR_ROW_CB_CLIP;
@@ -351,7 +402,10 @@ __device__ __forceinline__ uint32_t rows_walk(const ClipShared &s, const ClipFra
     const uint32_t nseg = p.len0 + p.len1;
     const uint32_t my_n = nseg > wid ? (nseg - wid + (uint32_t)(CT / 64) - 1u) / (uint32_t)(CT / 64) : 0u;
     const uint32_t range_mask = ((1u << ((p.pcb - p.pca) >> 3)) - 1u) << (p.pca >> 3);      // the piece's column octants
-    struct Group { float fx[CB], fy[CB]; int sy[CB], stx[CB]; uint32_t b0[CB], d[CB]; };
+    // (the weight logits -- and the second group's logits and values -- of a row segment are loaded with its flow: coalesced, and the
+    //  dependent gather round trip they used to be, after the entries were known, is gone from phase 1)
+    struct Group { float fx[CB], fy[CB], z[CB], l2[G2 ? CB : 1], v2[G2 ? CB : 1]; int sy[CB], stx[CB]; uint32_t b0[CB], d[CB]; };
+    const bool has_mul = s.mulmode != MUL_ONE;
     auto issue = [&](Group &g, uint32_t j0) {
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
@@ -369,8 +423,9 @@ __device__ __forceinline__ uint32_t rows_walk(const ClipShared &s, const ClipFra
                 const uint32_t syw = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rl_sy[q]);
                 sy = (int)(syw & 0xffffffu);
                 on = on && ((syw >> 24) & range_mask) != 0u;           // (a piece only loads the segments that touch its column octants)
-                stx = __builtin_amdgcn_readfirstlane((int)L.rl_sx[q]);
-                if (MODE == 0) base = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rl_base[q]);
+                const uint32_t w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rl_w1[q]);
+                stx = (int)(w1 >> ROWW_STX);
+                if (MODE == 0) base = ((w1 >> ROWW_BASE) & 0x7ffu) + (d ? p.cnt0 : 0u);
             }
             g.sy[i] = on ? sy : -1;
             g.stx[i] = stx;
@@ -382,6 +437,8 @@ __device__ __forceinline__ uint32_t rows_walk(const ClipShared &s, const ClipFra
             const uint32_t q = in ? (uint32_t)(sy * s.W + sx) : 0u;
             g.fx[i] = fl[q];
             g.fy[i] = fl[(uint32_t)HW + q];
+            g.z[i] = has_mul ? s.mul[q] : 0.0f;
+            if (G2) { g.l2[i] = s.mul2[q]; g.v2[i] = s.in2[q]; }
         }
     };
     uint32_t wcount = 0;
@@ -390,7 +447,8 @@ __device__ __forceinline__ uint32_t rows_walk(const ClipShared &s, const ClipFra
         for (int i = 0; i < CB; ++i) {
             const int sy = g.sy[i], sx = g.stx[i] * TILE_W + lane;
             const bool in = (sy >= 0) & (sx < s.W);
-            const Corners c = make_corners(g.fx[i], g.fy[i], sx, sy);
+            const float X = (float)sx + g.fx[i], Y = (float)sy + g.fy[i];
+            const Corners c = corners_at(X, Y);
             const int lx = c.x0 - p.tx0, ly = c.y0 - p.ty0;
             const bool xa = (lx >= p.pca) & (lx < p.pcb) & (c.x0 < s.W), xb = (lx + 1 >= p.pca) & (lx + 1 < p.pcb) & (c.x0 + 1 < s.W);
             const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < s.H), yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < s.H);
@@ -408,10 +466,8 @@ __device__ __forceinline__ uint32_t rows_walk(const ClipShared &s, const ClipFra
             if (EMIT) {
                 const uint32_t slot = b0 + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
                 if (hit && slot >= lo && slot < hi) {
-                    L.ent_pix[slot - lo] = (uint32_t)(sy * s.W + sx) | (g.d[i] << 31);
-                    L.ent_sy[slot - lo] = (uint32_t)sy;
-                    L.ent_fx[slot - lo] = g.fx[i];
-                    L.ent_fy[slot - lo] = g.fy[i];
+                    L.ent4[slot - lo] = make_float4(__uint_as_float((uint32_t)(sy * s.W + sx) | (g.d[i] << 31)), X, Y, g.z[i]);
+                    if (G2) L.ent2[slot - lo] = make_float2(g.l2[i], g.v2[i]);
                 }
             }
         }
@@ -454,37 +510,28 @@ __device__ __forceinline__ void prefetch_planes(rsrc_t rin, const EntryRegs &e, 
 // when they are staged, and the entry's slot of a special chunk carries  m | in2 * m2 | m2  (gathered before the value planes).
 template <bool G2>
 __device__ __forceinline__ void build_records(const ClipShared &s, const ClipFrame &f, const ClipLds &L, const Piece &p, int tid,
-                                              uint32_t total, rsrc_t rin, uint32_t hw4, EntryRegs &e,
+                                              uint32_t total, rsrc_t rin, uint32_t hw4, float shift, float sc0, float sc1, EntryRegs &e,
                                               float (&preA)[C_EPT][C_CHUNK], float (&preB)[C_EPT][C_CHUNK]) {
-    uint32_t pix[C_EPT], esy[C_EPT], dir[C_EPT];
-    float fx[C_EPT], fy[C_EPT], mm[C_EPT], l2[C_EPT], v2[C_EPT];
+    uint32_t dir[C_EPT];
+    float X[C_EPT], Y[C_EPT], mm[C_EPT], l2[C_EPT], v2[C_EPT];
     bool val[C_EPT];
 #pragma unroll
     for (int j = 0; j < C_EPT; ++j) {
         const uint32_t k = (uint32_t)tid + (uint32_t)j * CT;
         val[j] = k < total;
-        const uint32_t pw = val[j] ? L.ent_pix[k] : 0u;
+        float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (val[j]) en = L.ent4[k];
+        const uint32_t pw = __float_as_uint(en.x);
         dir[j] = pw >> 31;
-        pix[j] = pw & 0x7fffffffu;
-        esy[j] = val[j] ? L.ent_sy[k] : 0u;
-        fx[j] = val[j] ? L.ent_fx[k] : 0.0f;
-        fy[j] = val[j] ? L.ent_fy[k] : 0.0f;
-        e.off[j] = pix[j] * 4u;
+        e.off[j] = (pw & 0x7fffffffu) * 4u;
         e.m[j] = 1.0f;
-    }
-    // (the weight gathers go out BEFORE the 24 plane loads of the first two chunks: memory operations return in order, and the
-    //  footprints wait for the weights only -- issued behind the planes they cost this phase 3.1 us instead of ... of a 40 us life)
-    const bool has_mul = s.mulmode != MUL_ONE;
-#pragma unroll
-    for (int j = 0; j < C_EPT; ++j) {
-        mm[j] = has_mul ? s.mul[pix[j]] : 0.0f;
-        if (G2) { l2[j] = s.mul2[pix[j]]; v2[j] = s.in2[pix[j]]; }
+        X[j] = en.y; Y[j] = en.z; mm[j] = en.w;
+        if (G2) { float2 e2 = make_float2(0.f, 0.f); if (val[j]) e2 = L.ent2[k]; l2[j] = e2.x; v2[j] = e2.y; }
     }
     prefetch_planes(rin, e, preA, 0, s.C - 1, hw4);
     prefetch_planes(rin, e, preB, C_CHUNK, s.C - 1, hw4);
     C_STAMP(s, 3);
-    if (G2) __syncthreads();                          // every entry has been read: the special chunk may overwrite the entry arrays
-    const float shift = (s.mulmode == MUL_EXP_SHIFT) ? s.mulmax[0] : 0.0f;
+    // (G2: a work-item's special-chunk slots are the entry slots it has just read itself: no hazard)
     uint32_t ts[C_EPT][4];                            // (output pixel << 16) | slot, 0xffffffff = corner not in the piece
     float w[C_EPT][4];
 #pragma unroll
@@ -493,13 +540,14 @@ __device__ __forceinline__ void build_records(const ClipShared &s, const ClipFra
         for (int k = 0; k < 4; ++k) { ts[j][k] = 0xffffffffu; w[j][k] = 0.0f; }
         if (G2 && !val[j]) L.val4[tid + j * CT] = make_float4(0.f, 0.f, 0.f, 0.f);      // (no record points here)
         if (!val[j]) continue;
-        const int y = (int)esy[j], x = (int)(pix[j] - esy[j] * (uint32_t)s.W);
-        const Corners c = make_corners(fx[j], fy[j], x, y);
-        float m = f.scale[dir[j]];
+        const Corners c = corners_at(X[j], Y[j]);
+        const float sc = dir[j] ? sc1 : sc0;          // (two scalars read at the kernel's start: taken from the frame's arguments here, by a
+                                                      //  per-lane index or select, they become a vector memory load behind the 24 plane loads)
+        float m = sc;
         if (s.mulmode == MUL_PLANE) m = mm[j] * m;
         else if (s.mulmode >= MUL_EXP) m = expf(mm[j] - shift) * m;
         if (G2) {
-            float m2 = f.scale[dir[j]];
+            float m2 = sc;
             m2 = s.mulmode2 == MUL_PLANE ? l2[j] * m2 : expf(l2[j]) * m2;
             L.val4[tid + j * CT] = make_float4(m, v2[j] * m2, m2, 0.0f);
             e.m[j] = m;
@@ -513,13 +561,16 @@ __device__ __forceinline__ void build_records(const ClipShared &s, const ClipFra
         const int oc = ly * TILE_W + lx - p.pca;      // (a piece's columns start at lane 0 of the row's wave)
         const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
         const int tg[4] = {oc, oc + 1, oc + TILE_W, oc + TILE_W + 1};
+        // all four reservations go out before the first result is looked at, without branches: a corner outside the piece adds 0 to
+        // this work-item's own counter (one LDS round trip per entry instead of four dependent ones inside exec-masked branches)
+        uint32_t slot[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (kb[k]) {
-                const uint32_t slot = atomicAdd(&L.cnt[tg[k]], 1u);           // ds_add_rtn_u32
-                ts[j][k] = ((uint32_t)tg[k] << 16) | slot;
-                w[j][k] = m * c.w[k];
-            }
+        for (int k = 0; k < 4; ++k) slot[k] = atomicAdd(&L.cnt[kb[k] ? tg[k] : tid], kb[k] ? 1u : 0u);      // ds_add_rtn_u32
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ts[j][k] = kb[k] ? ((uint32_t)tg[k] << 16) | slot[k] : 0xffffffffu;
+            w[j][k] = kb[k] ? m * c.w[k] : 0.0f;
+        }
     }
     C_STAMP(s, 4);
     __syncthreads();
@@ -772,6 +823,9 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
     const int tid = threadIdx.x;
     const uint32_t hw4 = (uint32_t)(s.H * s.W) * 4u;
     const rsrc_t rin = make_rsrc(s.in, (uint32_t)s.C * hw4);
+    const float shift = (s.mulmode == MUL_EXP_SHIFT) ? s.mulmax[0] : 0.0f;      // (a dependent scalar load: issued first, needed in phase 1a)
+    const float sc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(f.scale[0])));
+    const float sc1 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(f.scale[1])));
     if (!PASSES) {
         if (bx >= f.grid) return;                          // this frame has fewer groups than the longest of the batch
         // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Groups of C_XCD consecutive items (= neighbouring
@@ -787,11 +841,11 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
         C_STAMP(s, 1);
         uint32_t total;
         if (p.whole && !p.ovf0 && !p.ovf1 && p.cnt0 + p.cnt1 <= (uint32_t)C_SEG) {
-            rows_walk<0, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)C_SEG);
+            rows_walk<0, true, G2>(s, f, L, p, tid, 0u, 0u, (uint32_t)C_SEG);
             total = p.cnt0 + p.cnt1;
             __syncthreads();
         } else {
-            rows_walk<1, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)C_SEG);
+            rows_walk<1, true, G2>(s, f, L, p, tid, 0u, 0u, (uint32_t)C_SEG);
             __syncthreads();
             total = L.misc[0];
             if (total > (uint32_t)C_SEG) {                 // (uniform) more than one pass: the pass-by-pass launch takes the piece
@@ -803,7 +857,7 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
         C_NOTE(s, 60, total); C_NOTE(s, 61, p.len0 + p.len1); C_NOTE(s, 62, p.pcb - p.pca);
         EntryRegs e;
         float preA[C_EPT][C_CHUNK], preB[C_EPT][C_CHUNK];
-        build_records<G2>(s, f, L, p, tid, total, rin, hw4, e, preA, preB);
+        build_records<G2>(s, f, L, p, tid, total, rin, hw4, shift, sc0, sc1, e, preA, preB);
         C_STAMP(s, 6);
         PixelSums sums = {0.0f, 0.0f, 0.0f};
         stream_planes<G2, false>(s, f, L, p, tid, rin, hw4, e, preA, preB, sums, true, true);
@@ -814,7 +868,7 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
             const Piece p = make_piece(s, f.items[f.defer[k]]);
             rows_setup(f, L, p, tid);
             // ordinals: a count pass (hits per wave), then pass si emits the ordinals [si * SEG, (si + 1) * SEG)
-            const uint32_t wc = rows_walk<2, false>(s, f, L, p, tid, 0u, 0u, 0u);
+            const uint32_t wc = rows_walk<2, false, G2>(s, f, L, p, tid, 0u, 0u, 0u);
             if ((tid & 63) == 0) L.misc[1 + (tid >> 6)] = wc;
             __syncthreads();
             uint32_t all = 0, wb = 0;
@@ -827,11 +881,11 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
                 if (si > 0) rows_setup(f, L, p, tid);      // (the lists share LDS with the previous pass's records)
                 L.cnt[tid] = 0;
                 const uint32_t lo = si * (uint32_t)C_SEG;
-                rows_walk<2, true>(s, f, L, p, tid, wb, lo, lo + (uint32_t)C_SEG);
+                rows_walk<2, true, G2>(s, f, L, p, tid, wb, lo, lo + (uint32_t)C_SEG);
                 __syncthreads();
                 EntryRegs e;
                 float preA[C_EPT][C_CHUNK], preB[C_EPT][C_CHUNK];
-                build_records<G2>(s, f, L, p, tid, min((uint32_t)C_SEG, all - lo), rin, hw4, e, preA, preB);
+                build_records<G2>(s, f, L, p, tid, min((uint32_t)C_SEG, all - lo), rin, hw4, shift, sc0, sc1, e, preA, preB);
                 stream_planes<G2, true>(s, f, L, p, tid, rin, hw4, e, preA, preB, sums, si == 0, si + 1 == npass);
             }
             __syncthreads();
@@ -947,6 +1001,7 @@ SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const 
     hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, r.rowcnt, nwords);
     const dim3 grid((unsigned)(L.tiles_x * ((L.tiles_y + 1) / 2)), L.nmaps);      // (blockIdx.y carries the map: <= 32768 maps, see clip_check)
     hipLaunchKernelGGL(rowbin_clip_kernel, grid, dim3(CT), 0, st, r, H, W, L.tiles_x, L.tiles_y);
+    hipLaunchKernelGGL(rows_sort_clip_kernel, dim3((L.nt + CT / 64 - 1) / (CT / 64), L.nmaps), dim3(CT), 0, st, r);
     hipLaunchKernelGGL(rows_plan_clip_kernel, dim3(L.nframes), dim3(CT), 0, st, r, p, (uint32_t)C_SEG);
     SLR_CHECK_LAUNCH();
     return 0;
@@ -960,7 +1015,7 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
                             const int *hints, void *stream) {
     SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && alpha && out && plan && frame, "null pointer");
     SLR_CHECK_ARG((!values2 && !wlogit2 && !out2) || (values2 && wlogit2 && out2), "the second group needs values, weights and outputs");
-    SLR_CHECK_ARG(nb >= 1 && nb <= C_MAXB, "1 <= nb <= 8 frames per launch");
+    SLR_CHECK_ARG(nb >= 1 && nb <= C_MAXB, "1 <= nb <= 16 frames per launch");
     SLR_CHECK_ARG(C >= 1, "C");
     if (int e = clip_check(nframes, C, H, W, __func__)) return e;
     const ClipLayout L = clip_layout(nframes, H, W);

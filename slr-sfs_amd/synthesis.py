@@ -206,7 +206,7 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
     return (out, norm) if return_norm else out
 
 
-MAX_BATCH = min(8, max(1, int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "8"))))   # frames per launch of slr_synth_group_clip_batch (csrc: MAXB = 8)
+MAX_BATCH = min(16, max(1, int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "16"))))   # frames per launch of slr_synth_group_clip_batch (csrc: SLR_CLIP_MAXB = 16; 8 / 12 / 16: 158 / 153 / 151-153 us per frame of work)
 
 
 def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_weights=True, eps=1e-8, timed=False,

@@ -1179,7 +1179,7 @@ def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
     assert all(int(totals[i, 0]) >= tiles for i in range(nb))             # at least one work item per tile
     zmax = dZ.max().reshape(1).contiguous()
     sbytes = int(L.slr_splat_scratch_bytes_batch(C, H, W, nb))
-    assert sbytes >= int(L.slr_splat_scratch_bytes(C, H, W)) and int(L.slr_splat_scratch_bytes_batch(C, H, W, 9)) == 0
+    assert sbytes >= int(L.slr_splat_scratch_bytes(C, H, W)) and int(L.slr_splat_scratch_bytes_batch(C, H, W, 17)) == 0
     scratch = torch.empty(sbytes, dtype=torch.uint8, device="cuda")
     refs = [oracle.synth_baseline(fs, Z, m, t, N) for t in ts]
     alphas = [1.0 - t / N for t in ts]
@@ -1201,7 +1201,7 @@ def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
     assert call(nb, fr, sbytes) == 0
     for k in range(nb):
         np.testing.assert_allclose(host(outs[k:k + 1]), refs[k], rtol=2e-4, atol=2e-5)
-    assert call(9, fr, sbytes) == -1 and b"frames per launch" in L.slr_last_error()
+    assert call(17, fr, sbytes) == -1 and b"frames per launch" in L.slr_last_error()
     assert call(nb, (ctypes.c_int * nb)(0, 1, 5), sbytes) == -1 and b"frame index" in L.slr_last_error()
     assert call(nb, fr, 0) == 0                                            # (no scratch since the rows front end: pieces own their pixels)
     for k in range(nb):

@@ -1,3 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_large_golden.py -m gpu -q -s -k native 2>&1 | grep -E "Error|assert|native 768|passed|failed" | head
-python tools/dev/trace_clip.py 24 | head -5
+for i in 1 2; do
+python tools/dev/stage_line.py 2>&1 | tail -1
+for v in x2 x8 k8 k4 cb3; do SLR_SFS_AMD_LIB=$PWD/slr-sfs_amd/lib/var_$v.so python tools/dev/stage_line.py 2>&1 | tail -1; done
+done

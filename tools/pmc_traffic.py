@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import H, W, csrc_hash, splat_alg_bytes  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
-KERNEL = "splat_tile_kernel<true, false, 3, 4, false"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "clip_tile_kernel<false, false>"          # (v1: "clip_tile_kernel<true, false>")
 
 
 def mean_counter(sub, name):
@@ -30,13 +30,13 @@ def mean_counter(sub, name):
 
 fetch, n1 = mean_counter("fetch", "FETCH_SIZE")
 write, n2 = mean_counter("write", "WRITE_SIZE")
-fpl = 60.0 / 8.0                                   # 60 frames = 7 launches of 8 + one of 4 -> 7.5 frames per launch
+fpl = 60.0 / n1                                    # tools/splat_stage.py renders one 60-frame clip: 3 launches of 16 + one of 12 -> 15 per launch
 read_b, write_b = fetch * 1024 * 2.0 / fpl, write * 1024 / fpl
 out = {
     "_comment": "HBM-side traffic of the fused splat tile kernel: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate "
                 "passes on tools/splat_stage.py (tools/pmc_traffic.sh), summarised by tools/pmc_traffic.py; values per FRAME of work "
-                "(one launch = 7.5 frames on average).  FETCH_SIZE x2 on gfx950 (128-byte requests tallied at 64), WRITE_SIZE exact.",
-    "kernel": "slr::splat_tile_kernel<true,false,3,4,false>(SplatBatch)",
+                "(one launch = 60 / launches frames on average).  FETCH_SIZE x2 on gfx950 (128-byte requests tallied at 64), WRITE_SIZE exact.",
+    "kernel": "slr::" + KERNEL + "(ClipBatch)",
     "source_sha16": csrc_hash(),
     "frames_per_launch": fpl, "launches_seen": [n1, n2],
     "FETCH_SIZE_KiB_raw_per_launch": round(fetch, 1), "WRITE_SIZE_KiB_raw_per_launch": round(write, 1), "fetch_correction": 2.0,
