@@ -19,7 +19,7 @@ A step  : ONE 60-frame clip, everything included (both all-frames Euler passes, 
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     : the splat tile kernel (slr::splat_tile_kernel<true,false,...>, the kernel that does
+  roofline     : the fused clip kernel (slr::clip_tile_kernel<G2,false>, csrc/splat_clip.hip: the kernel that does
                  the exp-weighted two-direction splat + normalisation of one frame), timed
                  with HIP events on its launch stream inside the timed steps.
                  algorithmic bytes per launch = 2 * (2*65+2)*H*W*4 = 1038.1 MB at C3
@@ -157,7 +157,7 @@ def splat_roofline(kev, sev, c_splat, kernel):
             "note": "avg/min/max_us = launch duration / frames in the launch; achieved = alg_bytes_per_launch / launch_avg_us",
             "stage_us": round(stage_us, 1), "stage_frac": round(alg / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "stage_prep_us_per_clip": round(sum(prep) / max(1, len(prep)), 1),
-            "stage": "per frame: fused tile kernel + combine (+ the 2nd weight group for C4); per clip / frames: both "
+            "stage": "per frame: fused tile kernel + the (normally empty) pass-by-pass launch; per clip / frames: both "
                      "all-frames Euler passes + binning and planning of all displacement maps"}
 
 
@@ -209,7 +209,7 @@ def main():
     assert clip.shape == (NFRAMES, 3, H, W) and bool(torch.isfinite(clip).all())
 
     c_splat = 65 if a.workload == "c3" else 67              # planes per reference splat call (v1: 67)
-    roofline = splat_roofline(kev, sev, c_splat, "slr::splat_tile_kernel<true,false,3,4>")
+    roofline = splat_roofline(kev, sev, c_splat, "slr::clip_tile_kernel<false,false>" if a.workload == "c3" else "slr::clip_tile_kernel<true,false>")
 
     extra, cpu, parity = {}, None, None
     if world > 1 and (a.assembly, a.encoder) == ("final", "redundant"):
@@ -419,22 +419,37 @@ def context_measurements(workload, image, motion, dev):
                   "parity_err": parity_check(m2, image, motion, other, dev),
                   "workload": ("C4 SLR-v1 2-layer pipeline (fluid + background + alpha), " if other == "c4" else
                                "C3 baseline pipeline, ") + "768x1280, N=60",
-                  "roofline": splat_roofline(kev, sev, c2, "slr::splat_tile_kernel<true,false,3,4> (" +
+                  "roofline": splat_roofline(kev, sev, c2, "slr::clip_tile_kernel<G2,false> (" +
                                              ("64 features + the alpha group" if other == "c4" else "64 features") + ")")}
     del m2
-    # ---- the all-fp32 context: the same C3 pipeline with its convolutions through PyTorch-ROCm (MIOpen fp32)
+    # ---- the all-fp32 context: the same C3 clip with every convolution in the reference's arithmetic (fp32 operands, products and
+    # accumulation) -- on this package's fp32 matrix-core kernels (convs="fp32"), and through PyTorch-ROCm (MIOpen fp32, convs="torch")
     if workload == "c3":
+        out["roofline_conv_fp32"] = conv_roofline(dev, fp32=True)
         torch.manual_seed(0)
-        m3 = pipeline.BaselineAnimator(convs="fp32").to(dev).eval()      # the supported full-range route (nets.torch_convolutions)
+        m3 = pipeline.BaselineAnimator(convs="fp32").to(dev).eval()
+        m3.synthesize(image, motion, NFRAMES)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        c32 = m3.synthesize(image, motion, NFRAMES)
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        m3.convs = "torch"
         m3.synthesize(image, motion, NFRAMES, frames=range(0, 6), batch=1)        # MIOpen picks its kernels
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
+        ct = m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
         torch.cuda.synchronize()
-        out["fps_fp32_convs"] = {"value": round(20 / (time.perf_counter() - t1), 2), "unit": "frames/s",
-                                 "what": "same C3 clip (20 of its 60 frames) with BaselineAnimator(convs='fp32'): every convolution "
-                                         "of the encoder / decoder as torch.nn.functional.conv2d (MIOpen fp32) and the "
-                                         "elementwise stages as torch ops; the splat stage unchanged"}
+        dtt = time.perf_counter() - t1
+        out["fps_fp32_convs"] = {"value": round(NFRAMES / dt32, 2), "unit": "frames/s",
+                                 "what": "the same C3 clip (all 60 frames, one warm-up clip) with BaselineAnimator(convs='fp32'): every 3x3 / "
+                                         "1x1 convolution of the encoder / decoder on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 products, "
+                                         "fp32 accumulation: the reference's arithmetic; csrc/conv.hip, SLR_CONV_F32), every other stage "
+                                         "and the splat path unchanged",
+                                 "through_torch_miopen": {"value": round(20 / dtt, 2), "unit": "frames/s",
+                                                          "what": "convs='torch' (20 of the 60 frames): F.conv2d -> MIOpen fp32, elementwise "
+                                                                  "stages as torch ops"},
+                                 "frames_fp32_kernels_vs_torch_max_abs": float((c32[::3] - ct).abs().max())}
         del m3
     return out
 
@@ -550,7 +565,7 @@ def dropin_roofline(dev, motion):
     return res
 
 
-def conv_roofline(dev):
+def conv_roofline(dev, fp32=False):
     """Second kernel of the frame (and since the splat is fused, the dominant one by time): the
     matrix-core partial convolution, timed with HIP events on its launch stream (torch's current
     stream) on the decoder's heaviest layer shape, in the CHANNEL-BLOCKED instantiation the decoder actually
@@ -565,9 +580,18 @@ def conv_roofline(dev):
     sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.3
     nb = (torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.3)
     lay = nets.IN_B8 | nets.OUT_B8
+    flops = 2.0 * 9 * cin * cout * H * W
+    if fp32:                                             # the fp32 rung: same call, same layouts, products on v_mfma_f32_32x32x2_f32
+        with torch.no_grad(), nets.fp32_kernels():
+            avg, mn = _time_calls(lambda: pc(x, mask, next_bn=nb, pre_bn=(sc, sh), layout=lay), 15, warm=3)
+        ach = flops / (avg * 1e-6) / 1e12
+        return {"bound": "mfma", "kernel": "slr::conv3x3_split_kernel<1,4,true,true,F32> (128->128, 768x1280, channel-blocked in/out, BN+mask "
+                                           "prologue, partial-conv epilogue + next BN) on v_mfma_f32_32x32x2_f32",
+                "achieved": round(ach, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+                "avg_us": round(avg, 1), "min_us": round(mn, 1), "launches": 15,
+                "precision": "fp32 operands, fp32 products, fp32 accumulation (one MFMA per product): the reference's arithmetic"}
     with torch.no_grad():
         avg, mn = _time_calls(lambda: pc(x, mask, next_bn=nb, pre_bn=(sc, sh), layout=lay), 30, warm=5)
-    flops = 2.0 * 9 * cin * cout * H * W
     ach = flops / (avg * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "slr::conv3x3_split_kernel<1,4,true,true> (128->128, 768x1280, channel-blocked in/out, "
                                        "BN+mask prologue, partial-conv epilogue + next BN: the variant 14 of the decoder's 16 "

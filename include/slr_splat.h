@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 5
+#define SLR_ABI_VERSION 6
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -296,10 +296,18 @@ int slr_conv_saturation_record(unsigned *host_slot, void *stream);
 #define SLR_CONV_IN_B8  1      /* `in` / `x` is channel-blocked */
 #define SLR_CONV_OUT_B8 2      /* `out` is written channel-blocked */
 #define SLR_CONV_RES_B8 4      /* `residual` is channel-blocked (only together with SLR_CONV_OUT_B8) */
+/* The fp32 rung (ABI 6): with SLR_CONV_F32 in `layout` the same entry points run the convolution on v_mfma_f32_32x32x2_f32 --
+ * fp32 operands, fp32 products, fp32 accumulation: the arithmetic of the reference's own convolutions
+ * (models/layers/partialconv2d.py:61-74, models/layers/blocks.py:173-248), no pre-scale, no clamp, no limit on the magnitude of the
+ * activations -- at the rate of the fp32 matrix pipe (157 TFLOP/s, 1/16 of the f16 rate).  `wsplit` must then come from
+ * slr_conv3x3_f32_weights / slr_conv1x1_f32_weights (same byte counts as the split-f16 buffers), wscale = xscale = 1. */
+#define SLR_CONV_F32    8
 
 size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
 int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit, int Cout, int Cin,
                               float wscale, void *stream);
+int slr_conv3x3_f32_weights(const float *w /* [Cout,Cin,3,3] */, void *wfrag /* slr_conv3x3_weight_bytes */, int Cout, int Cin,
+                            void *stream);
 
 /* out = conv3x3(pre(in)) + bias + residual, pre(x) = relu(x*pre_scale[c] - pre_shift[c]) when pre_scale
  * is given (eval-mode noise-BN + ReLU in front of the convolution, models/layers/blocks.py:66-74 +
@@ -333,6 +341,8 @@ int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pr
 size_t slr_conv1x1_weight_bytes(int Cout, int Cin);
 int slr_conv1x1_split_weights(const float *w /* [Cout,Cin,1,1] */, void *wsplit, int Cout, int Cin,
                               float wscale, void *stream);
+int slr_conv1x1_f32_weights(const float *w /* [Cout,Cin,1,1] */, void *wfrag /* slr_conv1x1_weight_bytes */, int Cout, int Cin,
+                            void *stream);
 int slr_conv1x1_forward(const float *in, const void *wsplit, const float *bias /* [Cout] or NULL */, float *out,
                         int N, int Cin, int Cout, int H, int W, float wscale, float xscale, int layout, void *stream);
 

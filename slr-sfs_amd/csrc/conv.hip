@@ -91,10 +91,21 @@ __host__ __device__ inline int conv_cin_pad(int Cin) { return (Cin + 15) / 16 * 
 // INB8: the input tensor is channel-blocked, [N, Cin/8, H, W, 8] (what a previous call wrote with out_b8): the 8 channels of
 // a staging item are 32 contiguous bytes = two 16-byte loads instead of eight 4-byte loads.  A VMEM instruction costs
 // an in-order wave ~60-100 issue cycles; the 24 staging loads per chunk of the NCHW scheme are 14 % of the kernel.
-template <int CPW, int WCO, bool PRE, bool INB8>
+// F32: the fp32 rung -- operands stay fp32, products on v_mfma_f32_32x32x2_f32 (fp32 multiply, fp32 accumulate: the arithmetic of the
+// reference's convolutions, models/layers/partialconv2d.py:61-74; no pre-scale, no clamp, no magnitude limit) at the fp32 matrix
+// rate (157 TFLOP/s, 1/16 of the f16 rate: 64 cycles per MFMA and SIMD).  Same workgroup shape, prologue, epilogue and layouts;
+// the staged halo block is kept as [16 channels][halo pixel] floats (row stride 352: lanes 0-31 / 32-63 of a fragment read
+// -- pixel l & 31 of channels 2k / 2k + 1 -- fall on disjoint banks), a wave's A fragments are 8 floats per lane and tap
+// ([co tile][chunk][tap][lane][k pair]: two 16-byte loads), and one tap is 8 x PT MFMAs with ONE ds_read_b32 each: the loop is
+// bound by the matrix pipe alone.
+constexpr int CV_FSTR = 352;                       // F32: floats per channel row of the staged block
+template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
-    __shared__ h8 xs[2][2][2][CV_NPX];             // [buffer][hi|lo][8-channel group][halo pixel]
+    static_assert(!F32 || CPW == 1, "the fp32 rung runs one 32-channel tile per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char xraw[F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16];
+    h8 (*xs)[2][2][CV_NPX] = reinterpret_cast<h8 (*)[2][2][CV_NPX]>(xraw);             // [buffer][hi|lo][8-channel group][halo pixel]
+    float (*xf)[16][CV_FSTR] = reinterpret_cast<float (*)[16][CV_FSTR]>(xraw);          // F32: [buffer][channel][halo pixel]
     __shared__ float mpl[CV_NPX];                  // mask plane over the halo block (0 outside the image)
     __shared__ float mplB[2][CV_NPX - 256];        // derived mask: per-group counts of the round-2 pixels
     __shared__ float4 pss4[2][CV_MAXCIN / 4];      // prologue scale / shift (x CV_XSCALE) per (padded) input channel
@@ -114,8 +125,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     if (PRE) {
         float *pssw = reinterpret_cast<float *>(&pss4[0][0]);
         for (int i = tid; i < nchunk * 16; i += CV_THREADS) {       // padded channels: scale = shift = 0 -> 0
-            pssw[i] = i < a.Cin ? a.pre_scale[i] * a.xscale : 0.0f;
-            pssw[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] * a.xscale : 0.0f;
+            pssw[i] = i < a.Cin ? a.pre_scale[i] * (F32 ? 1.0f : a.xscale) : 0.0f;
+            pssw[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] * (F32 ? 1.0f : a.xscale) : 0.0f;
         }
     }
 
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     }
     // per-item multiplier: the [N,1,H,W] mask value (1 without a mask), 0 for the zero padding outside
     // the image; without a prologue it also carries the 2^6 pre-scale of the split
-    const float unit = PRE ? 1.0f : a.xscale;
+    const float unit = (PRE || F32) ? 1.0f : a.xscale;
     const float mvA = (a.mask && okA) ? a.mask[(size_t)n * HW + offA] : 0.0f;
     const float mvB = (a.mask && okB) ? a.mask[(size_t)n * HW + offB] : 0.0f;
     if (a.mask) {                                      // mask plane of the halo block, for the 3x3 box sum of the epilogue
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // prologue (normalization.py:231, ReLU, partialconv2d.py:69; 2^6 folded into scale / shift, which
     // commutes with the roundings) + split + LDS store: straight-line code, no selects on validity.
     // In three pieces (begin / one value / finish) so the main loop can slot the values between MFMAs.
-    struct Stage { int cb; float mk0, fresh, cnt; h8 hi, lo; };
+    struct Stage { int cb; float mk0, fresh, cnt; h8 hi, lo; float f[F32 ? 8 : 1]; };
     unsigned long long sat = 0ull;
     const float *pss = reinterpret_cast<const float *>(&pss4[0][0]);
     auto stage_begin = [&](auto R, int c, Stage &g) {
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         } else {
             v = x * g.mk0;
         }
+        if (F32) { g.f[j] = v; return; }                     // the fp32 rung stages the value as it is
         // f16 range guard (one v_med3): the split is exact-domain for |activation| < 2^16 / 2^6 = 1023;
         // larger values saturate there instead of becoming inf -> NaN (post-BN activations are O(1..10^2)).
         // A saturated value makes the frame WRONG, not just inexact: it is counted (one compare into a lane mask
@@ -214,6 +226,14 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     auto stage_finish = [&](auto R, int buf, const Stage &g) {
         cnt[R.value] += g.cnt * g.fresh;
         const int dst = R.value == 0 ? tid : (R.value == 1 ? CV_NPX + tid : gB * CV_NPX + pB);
+        if (F32) {
+            const int ch0 = R.value < 2 ? R.value * 8 : gB * 8, px = R.value < 2 ? tid : pB;
+            if (R.value < 2 || liveB) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[buf][ch0 + j][px] = g.f[j];
+            }
+            return;
+        }
         if (R.value < 2 || liveB) {
             (&xs[buf][0][0][0])[dst] = g.hi;
             (&xs[buf][1][0][0])[dst] = g.lo;
@@ -257,11 +277,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // Fragment (cot, chunk, tap, half) = 64 consecutive 16-byte vectors, lane l takes vector l.
     const size_t wtile = (size_t)nchunk * 9 * 2 * 64;            // vectors per 32-channel tile
     const h8 *wbase = a.w + (size_t)cot0 * wtile;                // wave-uniform
-    h8 a_cur[CPW][2], a_nxt[CPW][2];
+    h8 a_cur[CPW][2], a_nxt[CPW][2];                              // (F32: the same 8 registers hold the lane's 8 fp32 weights of a tap)
     auto load_a = [&](h8 (&dst)[CPW][2], int g /* chunk * 9 + tap */) {
 #pragma unroll
         for (int ct = 0; ct < CPW; ++ct) {
             const h8 *q = wbase + ct * wtile + (size_t)g * 128;     // uniform base, lane offset
+            if (F32) { dst[ct][0] = q[2u * (unsigned)lane]; dst[ct][1] = q[2u * (unsigned)lane + 1u]; continue; }   // 32 contiguous bytes per lane
             dst[ct][0] = q[(unsigned)lane];
             dst[ct][1] = q[(unsigned)lane + 64u];
         }
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         const int cn = min(c + 1, nchunk - 1);         // the chunk staged under this one's MFMAs (the last
                                                        // iteration re-stages its own chunk: harmless, and it keeps
                                                        // every load unconditional -> counted vmcnt waits)
-        const h8 *xh = &xs[buf][0][bgrp][0], *xl = &xs[buf][1][bgrp][0];
+        const h8 *xh = &xs[buf][0][bgrp][0], *xl = &xs[buf][1][bgrp][0];          // (split rung)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -313,6 +334,33 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             // (WCO = 4) makes two passes with the same A fragments.
             constexpr int PB = PT > 4 ? 4 : PT, NB = PT / PB;
             constexpr int NM = 3 * CPW * PT, NMB = 3 * CPW * PB;
+            if constexpr (F32) {
+                // 8 k-pairs x PT rows: MFMA (kp, row) multiplies the tap's weights of input channels 2kp, 2kp + 1 (lanes 0-31 / 32-63) with
+                // the row's 32 pixels of those two channels; consecutive MFMAs never touch the same accumulator
+                typedef float f8v __attribute__((ext_vector_type(8)));
+                union AW { h8 h[2]; f8v f; } aw;
+                aw.h[0] = a_cur[0][0]; aw.h[1] = a_cur[0][1];
+                constexpr int NMF = 8 * PT;
+#pragma unroll
+                for (int kp = 0; kp < 8; ++kp) {
+                    float bv[PT];
+#pragma unroll
+                    for (int k = 0; k < PT; ++k) bv[k] = xf[buf][2 * kp + bgrp][(wp * PT + k + kh) * CV_HW + kw + bcol];
+#pragma unroll
+                    for (int k = 0; k < PT; ++k) {
+                        acc[0][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.f[kp], bv[k], acc[0][k], 0, 0, 0);
+                        if (stage_tap) {
+                            const int i = kp * PT + k;
+                            const int j0 = i * 8 / NMF, j1 = (i + 1) * 8 / NMF;
+                            if (j1 > j0) {
+#pragma unroll
+                                for (int j = j0; j < j1; ++j) stage_value(j, sg, st);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int hb = 0; hb < NB; ++hb) {
                 h8 bh[PB], bl[PB];
@@ -356,7 +404,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         __syncthreads();
     }
 
-    if (a.sat && sat != 0ull && lane == 0) atomicAdd(a.sat, 1u);   // an activation left the f16 range (stage_value)
+    if (!F32 && a.sat && sat != 0ull && lane == 0) atomicAdd(a.sat, 1u);   // an activation left the f16 range (stage_value)
 
     if (pre == PRE_BN_NONZERO) {                       // mask plane = channel sum of (x != 0)  (architectures.py:369,
         mpl[tid] = cnt[0] + cnt[1];                    // partialconv2d.py:61 with a per-element mask)
@@ -385,7 +433,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     const bool vec = !a.out_b8 && (a.W % 4 == 0) && (x0 + CV_W <= a.W) &&
                      !(((uintptr_t)a.out | (uintptr_t)a.residual) & 15);
     constexpr int SCR_STRIDE = 36;                     // floats per channel row: 16-byte aligned, conflict-free
-    float *scr = reinterpret_cast<float *>(&xs[0][0][0][0]) + wave * (32 * SCR_STRIDE);
+    float *scr = reinterpret_cast<float *>(xraw) + wave * (32 * SCR_STRIDE);
     const int ox = x0 + bcol;
     const bool xin_img = ox < a.W;
     const int cout1 = a.Cout - 1;
@@ -520,7 +568,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #endif
 constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (streaming several was measured slower:
                                                    // the stores of a tile share vmcnt with the next tile's loads)
-template <int NCT, bool INB8>
+template <int NCT, bool INB8, bool F32 = false>
 __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restrict__ in, const h8 *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out,
                                                             int Cin, int Cout, int HW, int nchunk, float unscale, float xscale,
@@ -559,6 +607,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
 #pragma unroll
         for (int t = 0; t < NCT; ++t) {
             const h8 *q = wb + ((size_t)t * nchunk + c) * 128;
+            if (F32) { d[t][0] = q[lane]; d[t][1] = q[lane + 1]; continue; }     // (wb + lane + lane: the lane's 8 fp32 weights, 32 contiguous bytes)
             d[t][0] = q[0];
             d[t][1] = q[64];
         }
@@ -592,6 +641,24 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             load_x(x2, g + 2);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (F32) {
+                // fp32 rung: MFMA kp multiplies the weights of input channels 8 * (lane >> 5) + kp with this lane's pixel of that channel
+                typedef float f8v __attribute__((ext_vector_type(8)));
+                const float ok1 = ok ? 1.0f : 0.0f;
+#pragma unroll
+                for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) {
+                        union AW { h8 h[2]; f8v f; } aw;
+                        aw.h[0] = a_cur[t][0]; aw.h[1] = a_cur[t][1];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.f[kp], x0[kp] * ok1, acc[t], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { x0[j] = x1[j]; x1[j] = x2[j]; }
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) { a_cur[t][0] = a_nxt[t][0]; a_cur[t][1] = a_nxt[t][1]; }
+                continue;
+            }
             h8 bh, bl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -650,7 +717,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             }
         }
     }
-    if (sat_count && __ballot(sat) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(sat_count, 1u);
+    if (!F32 && sat_count && __ballot(sat) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(sat_count, 1u);
 }
 
 // w [Cout,Cin,k,k] fp32 (taps = k*k = 9 or 1) -> split f16 weights in fragment order over the PADDED
@@ -669,6 +736,24 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float *__
         const int within = ((ci & 15) >> 3) * 256 + (co & 31) * 8 + (ci & 7);     // [ci group][co][8 ci]
         ws[frag * 512 + within] = h;
         ws[(frag + 1) * 512 + within] = l;
+    }
+}
+
+// fp32 rung: w [Cout,Cin,k,k] fp32 -> fp32 weights in fragment order over the padded channel counts:
+// [co tile][chunk of 16 ci][tap][lane 64][k pair 8], lane = (co & 31) + 32 * g, and the lane's k-th value is input channel
+// chunk * 16 + (pair8 ? 8 * g + k : 2 * k + g): the 3x3 kernel pairs channels (2k, 2k + 1) (its LDS rows), the 1x1 kernel (k, 8 + k)
+// (what its 8 plane loads per lane deliver).  Same bytes as the split-f16 buffer.
+__global__ __launch_bounds__(256) void conv_f32_weights_kernel(const float *__restrict__ w, float *__restrict__ wf, int Cout, int Cin,
+                                                               int CoutP, int CinP, int taps, int pair8) {
+    const int total = CoutP * CinP * taps;
+    const int nchunk = CinP >> 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int tap = i % taps, ci = (i / taps) % CinP, co = i / (taps * CinP);
+        const float x = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.0f;
+        const int cl = ci & 15;
+        const int g = pair8 ? cl >> 3 : cl & 1, k = pair8 ? cl & 7 : cl >> 1;
+        const size_t frag = ((size_t)(co >> 5) * nchunk + (ci >> 4)) * taps + tap;
+        wf[frag * 512 + ((co & 31) + 32 * g) * 8 + k] = x;
     }
 }
 
@@ -770,6 +855,28 @@ SLR_EXPORT int slr_conv1x1_split_weights(const float *w, void *wsplit, int Cout,
     return 0;
 }
 
+SLR_EXPORT int slr_conv3x3_f32_weights(const float *w, void *wfrag, int Cout, int Cin, void *stream) {
+    SLR_CHECK_ARG(w && wfrag, "null pointer");
+    SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)conv_cout_pad(Cout) * conv_cin_pad(Cin) * 9 < (1LL << 30), "sizes");
+    const int CoutP = conv_cout_pad(Cout), CinP = conv_cin_pad(Cin);
+    const int total = CoutP * CinP * 9;
+    hipLaunchKernelGGL(conv_f32_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float *)wfrag,
+                       Cout, Cin, CoutP, CinP, 9, 0);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_conv1x1_f32_weights(const float *w, void *wfrag, int Cout, int Cin, void *stream) {
+    SLR_CHECK_ARG(w && wfrag, "null pointer");
+    SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)conv1x1_cout_pad(Cout) * conv_cin_pad(Cin) < (1LL << 30), "sizes");
+    const int CoutP = conv1x1_cout_pad(Cout), CinP = conv_cin_pad(Cin);
+    const int total = CoutP * CinP;
+    hipLaunchKernelGGL(conv_f32_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float *)wfrag,
+                       Cout, Cin, CoutP, CinP, 1, 1);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
 static int check_xscale(float xscale) {
     int ex = 0;
     SLR_CHECK_ARG(xscale > 0.0f && xscale <= CV_XSCALE && frexpf(xscale, &ex) == 0.5f, "xscale: a power of two in (0, 64]");
@@ -780,6 +887,9 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
                                    int Cout, int H, int W, float wscale, float xscale, int layout, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
     if (int e = check_xscale(xscale)) return e;
+    const bool f32 = (layout & SLR_CONV_F32) != 0;
+    SLR_CHECK_ARG(!f32 || (wscale == 1.0f && xscale == 1.0f), "the fp32 rung takes no operand scales (wscale = xscale = 1)");
+    layout &= ~SLR_CONV_F32;
     if (int e = conv_check_layout(layout & ~SLR_CONV_RES_B8, in, out, Cin, Cout, nullptr, false)) return e;
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8), "layout flags");
     SLR_CHECK_ARG(N > 0 && N < 65536 && Cin > 0 && Cout > 0 && Cout < (1 << 20) && H > 0 && W > 0 &&
@@ -793,7 +903,9 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
     if (int e = sat_counter(&satp)) return e;
 #define C1_LAUNCH(T)                                                                                                       \
     do {                                                                                                                   \
-        if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
+        if (f32 && (layout & SLR_CONV_IN_B8)) hipLaunchKernelGGL((conv1x1_split_kernel<T, true, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
+        else if (f32) hipLaunchKernelGGL((conv1x1_split_kernel<T, false, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
+        else if (layout & SLR_CONV_IN_B8) hipLaunchKernelGGL((conv1x1_split_kernel<T, true>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
         else hipLaunchKernelGGL((conv1x1_split_kernel<T, false>), grid, dim3(256), 0, st, in, (const h8 *)wsplit, bias, out, Cin, Cout, HW, nchunk, unscale, xscale, ob8, satp); \
     } while (0)
     if (nct == 4) C1_LAUNCH(4); else if (nct == 2) C1_LAUNCH(2); else C1_LAUNCH(1);
@@ -802,13 +914,22 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
     return 0;
 }
 
-static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, hipStream_t st) {
+template <bool F32>
+static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st);
+
+static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, bool f32, hipStream_t st) {
     if (int e = check_xscale(xscale)) return e;
+    SLR_CHECK_ARG(!f32 || (wscale == 1.0f && xscale == 1.0f), "the fp32 rung takes no operand scales (wscale = xscale = 1)");
     a.tiles_x = (a.W + CV_W - 1) / CV_W;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.xscale = xscale;
     a.unscale = 1.0f / (xscale * wscale);
     if (int e = sat_counter(&a.sat)) return e;
+    return f32 ? conv_launch_t<true>(a, in_b8, st) : conv_launch_t<false>(a, in_b8, st);
+}
+
+template <bool F32>
+static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
     const int tiles = a.tiles_x * ((a.H + CV_H - 1) / CV_H);
     int ct = conv_cout_tile(a.Cout);
     // NCHW input WITH a prologue and > 64 output channels: 24 scalar staging loads + the prologue table + 128
@@ -819,16 +940,16 @@ static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, hipS
     const dim3 grid(tiles, conv_cout_pad(a.Cout) / ct, a.N);
 #define CV_LAUNCH(CPW, WCO)                                                                                     \
     do {                                                                                                       \
-        if (a.pre != PRE_NONE && in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, true>), grid, dim3(CV_THREADS), 0, st, a);    \
-        else if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, false>), grid, dim3(CV_THREADS), 0, st, a);      \
-        else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, true>), grid, dim3(CV_THREADS), 0, st, a);                  \
-        else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, false>), grid, dim3(CV_THREADS), 0, st, a);                            \
+        if (a.pre != PRE_NONE && in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, true, F32>), grid, dim3(CV_THREADS), 0, st, a);    \
+        else if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, false, F32>), grid, dim3(CV_THREADS), 0, st, a);      \
+        else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, true, F32>), grid, dim3(CV_THREADS), 0, st, a);                  \
+        else hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, false, false, F32>), grid, dim3(CV_THREADS), 0, st, a);                            \
     } while (0)
     if (ct == 128) {                        // one 32-channel tile x all 8 rows per wave: a quarter of the weight-fragment
                                             // traffic of 4 x 2 tiles per wave would need, half of <2,2> (+3..5 % measured)
-        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true>), grid, dim3(CV_THREADS), 0, st, a);   // (in_b8)
-        else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true>), grid, dim3(CV_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, false>), grid, dim3(CV_THREADS), 0, st, a);
+        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, F32>), grid, dim3(CV_THREADS), 0, st, a);   // (in_b8)
+        else if (in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, F32>), grid, dim3(CV_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, false, F32>), grid, dim3(CV_THREADS), 0, st, a);
     }
     else if (ct == 64) CV_LAUNCH(1, 2);     // 1 tile x 4 rows per wave: half the weight-fragment loads of <2,1> (+4 %)
     else CV_LAUNCH(1, 1);
@@ -839,6 +960,7 @@ static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, hipS
 
 static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
                              bool derived_mask) {
+    layout &= ~SLR_CONV_F32;
     SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8 | SLR_CONV_RES_B8)) == 0, "layout flags");
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8) || ((layout & SLR_CONV_OUT_B8) && residual && !((uintptr_t)residual & 15)),
                   "a channel-blocked residual goes with a channel-blocked output");
@@ -871,7 +993,7 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.residual = residual;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
-    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
+    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream);
 }
 
 SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
@@ -897,5 +1019,5 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
-    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (hipStream_t)stream);
+    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream);
 }

@@ -32,7 +32,8 @@ from . import _lib
 _CPU_REFERENCE = False
 _TORCH_CONVS = False                     # inside torch_convolutions(): every stage through its torch definition (fp32)
 ACT_SCALE = 64.0                         # pre-scale of the activations in the split-f16 kernels (include/slr_splat.h: xscale)
-IN_B8, OUT_B8, RES_B8 = 1, 2, 4          # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8
+IN_B8, OUT_B8, RES_B8, CONV_F32 = 1, 2, 4, 8      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32
+_F32_KERNELS = False                     # inside fp32_kernels(): the convolutions on the fp32 matrix instructions (the fp32 rung)
 
 
 def _b8(x, channels):
@@ -59,6 +60,25 @@ class torch_convolutions:
     def __exit__(self, *exc):
         global _TORCH_CONVS
         _TORCH_CONVS = self._prev
+        return False
+
+
+class fp32_kernels:
+    """Context manager: the FULL-RANGE fp32 rung of these networks on this package's own kernels.  Inside it every 3x3 / 1x1
+    convolution runs on v_mfma_f32_32x32x2_f32 (csrc/conv.hip, SLR_CONV_F32): fp32 operands, fp32 products, fp32 accumulation --
+    the arithmetic of the reference's decoder (models/layers/partialconv2d.py:61-74, models/networks/architectures.py:345-375) with
+    no limit on the magnitude of the activations, at the fp32 matrix rate (157 TFLOP/s against the ~830 effective of the split-f16
+    rung); prologue, epilogue, mask update, layouts and every other kernel are the ones of the split-f16 rung.  The animators enter
+    it on request (convs="fp32") or by themselves when the split-f16 kernels report a clamped activation (convs="auto")."""
+
+    def __enter__(self):
+        global _F32_KERNELS
+        self._prev, _F32_KERNELS = _F32_KERNELS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _F32_KERNELS
+        _F32_KERNELS = self._prev
         return False
 
 
@@ -205,23 +225,31 @@ class Conv(nn.Module):
         return self.conv(x, self.bias, pre_bn, residual, layout)
 
     def _split_weights(self):
-        """Split-f16 weights of the matrix-core kernel (csrc/conv.hip), prepared once per device /
-        weight version: (buffer, wscale)."""
+        """Weights of the matrix-core kernels (csrc/conv.hip) in fragment order, prepared once per device / weight version and
+        arithmetic: (buffer, wscale, xscale, layout flag).  Split-f16 rung: hi / lo halves scaled by wscale; fp32 rung
+        (inside fp32_kernels()): the fp32 values themselves, no scales."""
         w = self.weight
+        f32 = _F32_KERNELS
         key = (w.data_ptr(), w._version, w.device)
-        c = self.__dict__.get("_wsplit")
+        name = "_wf32" if f32 else "_wsplit"
+        c = self.__dict__.get(name)
         if c is None or c[0] != key:
             L = _lib.lib()
-            amax = float(w.abs().max())
-            wscale = 2.0 ** math.floor(math.log2(4096.0 / amax)) if amax > 0 else 1.0
-            nbytes, split = ((L.slr_conv3x3_weight_bytes, L.slr_conv3x3_split_weights) if self.k == 3 else
-                             (L.slr_conv1x1_weight_bytes, L.slr_conv1x1_split_weights))
+            nbytes = L.slr_conv3x3_weight_bytes if self.k == 3 else L.slr_conv1x1_weight_bytes
             buf = torch.empty(nbytes(w.shape[0], w.shape[1]), dtype=torch.uint8, device=w.device)
             with torch.cuda.device(w.device):
-                _lib.check(split(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale, _lib.stream_of(w)),
-                           "slr_conv_split_weights")
-            c = self.__dict__["_wsplit"] = (key, buf, wscale)
-        return c[1], c[2]
+                if f32:
+                    prep = L.slr_conv3x3_f32_weights if self.k == 3 else L.slr_conv1x1_f32_weights
+                    wscale = 1.0
+                    _lib.check(prep(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], _lib.stream_of(w)), "slr_conv_f32_weights")
+                else:
+                    amax = float(w.abs().max())
+                    wscale = 2.0 ** math.floor(math.log2(4096.0 / amax)) if amax > 0 else 1.0
+                    split = L.slr_conv3x3_split_weights if self.k == 3 else L.slr_conv1x1_split_weights
+                    _lib.check(split(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale, _lib.stream_of(w)),
+                               "slr_conv_split_weights")
+            c = self.__dict__[name] = (key, buf, wscale)
+        return (c[1], 1.0, 1.0, CONV_F32) if f32 else (c[1], c[2], ACT_SCALE, 0)
 
     def conv(self, x, bias, pre_bn=None, residual=None, layout=0):
         """conv(relu(bn(x))) + bias + residual (``pre_bn`` = (scale, shift) of the BN in front, or None).
@@ -232,13 +260,13 @@ class Conv(nn.Module):
         if self.k == 3 and _fused_ok(x, *([] if residual is None else [residual])):
             cout, cin = self.weight.shape[:2]
             N, _, H, W = x.shape
-            buf, wscale = self._split_weights()
+            buf, wscale, xscale, arith = self._split_weights()
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             sc, sh = pre_bn if pre_bn is not None else (None, None)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out),
-                                                          N, cin, cout, H, W, wscale, ACT_SCALE, _lib.ptr(sc), _lib.ptr(sh),
-                                                          layout, _lib.stream_of(x)), "slr_conv3x3_forward")
+                                                          N, cin, cout, H, W, wscale, xscale, _lib.ptr(sc), _lib.ptr(sh),
+                                                          layout | arith, _lib.stream_of(x)), "slr_conv3x3_forward")
             return out
         assert layout == 0 or x.is_cuda        # the channel-blocked intermediate exists on the device path only
         if residual is not None:
@@ -259,11 +287,11 @@ class Conv(nn.Module):
         if self.k == 1 and _fused_ok(x):                 # the other 1x1 skip branches: split-f16 MFMA, HBM-bound
             N, cin, H, W = x.shape
             cout = self.weight.shape[0]
-            buf, wscale = self._split_weights()
+            buf, wscale, xscale, arith = self._split_weights()
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_conv1x1_forward(_lib.ptr(x), _lib.ptr(buf), _lib.ptr(bias), _lib.ptr(out),
-                                                          N, cin, cout, H, W, wscale, ACT_SCALE, layout, _lib.stream_of(x)),
+                                                          N, cin, cout, H, W, wscale, xscale, layout | arith, _lib.stream_of(x)),
                            "slr_conv1x1_forward")
             return out
         return F.conv2d(x, self.weight, bias, padding=self.pad)
@@ -291,16 +319,16 @@ class PartialConv(Conv):
         if self.k == 3 and _fused_ok(x, *([] if mask is None else [mask]), *([] if residual is None else [residual])):
             N, _, H, W = x.shape
             cout = self.weight.shape[0]
-            buf, wscale = self._split_weights()
+            buf, wscale, xscale, arith = self._split_weights()
             out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
             um = torch.empty(N, 1, H, W, device=x.device, dtype=x.dtype)
             psc, psh = pre_bn if pre_bn is not None else (None, None)
             nsc, nsh = next_bn if next_bn is not None else (None, None)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().slr_pconv3x3_forward(
-                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale, ACT_SCALE,
+                    _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale, xscale,
                     _lib.ptr(self.bias), _lib.ptr(residual), _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um),
-                    N, cin, cout, H, W, layout, _lib.stream_of(x)), "slr_pconv3x3_forward")
+                    N, cin, cout, H, W, layout | arith, _lib.stream_of(x)), "slr_pconv3x3_forward")
             return out, um
         assert layout == 0
         if mask is None:
@@ -539,11 +567,14 @@ class SaturationLog:
 
 def guarded(fn, device, policy, what, owner=None):
     """Run ``fn()`` (networks on split-f16 kernels) under the saturation policy of the animators:
-    "split": as is, raise if an activation was clamped; "fp32": inside torch_convolutions();
+    "split": as is, raise if an activation was clamped; "fp32": inside fp32_kernels(); "torch": inside torch_convolutions();
     "auto": split-f16 at the default activation scale; clamped -> again at scale 1 (exact up to 65472); clamped again ->
-    inside torch_convolutions().  ``owner`` (an animator) remembers the rung that worked, so later clips start there.
+    inside fp32_kernels() (the fp32 matrix instructions: no limit).  ``owner`` (an animator) remembers the rung that worked, so later clips start there.
     Synchronises with the device once per call (per rung tried)."""
     if policy == "fp32":
+        with fp32_kernels():
+            return fn()
+    if policy == "torch":
         with torch_convolutions():
             return fn()
     if policy == "split":
@@ -562,10 +593,10 @@ def guarded(fn, device, policy, what, owner=None):
             return out
         import warnings
         warnings.warn(f"slr_sfs_amd: activations of the {what} exceed the exact range of the split-f16 convolutions at "
-                      f"activation scale {scale:g}; rendering again " + ("at scale 1" if r == 0 else "with fp32 convolutions"))
+                      f"activation scale {scale:g}; rendering again " + ("at scale 1" if r == 0 else "on the fp32 rung"))
         if owner is not None:
             owner._conv_rung = r + 1
-    with torch_convolutions():
+    with fp32_kernels():
         return fn()
 
 

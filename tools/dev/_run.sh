@@ -1,5 +1,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-python tools/dev/stage_line.py 2>&1 | tail -1
-for v in x2 x8 k8 k4 cb3; do SLR_SFS_AMD_LIB=$PWD/slr-sfs_amd/lib/var_$v.so python tools/dev/stage_line.py 2>&1 | tail -1; done
-done
+mkdir -p gpurun_out/r4e
+python bench.py > gpurun_out/r4e/bench_default.json 2> gpurun_out/r4e/bench_default.err; tail -3 gpurun_out/r4e/bench_default.err; python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r4e/bench_default.json") if l.startswith("{")][-1])
+print({k:d[k] for k in ("value","ms_per_step")})
+print("fp32", d.get("fps_fp32_convs"))
+print("conv32", d.get("roofline_conv_fp32"))
+print("conv", {k:d["roofline_conv"][k] for k in ("achieved","avg_us","frac_issued")})
+PY
