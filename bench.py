@@ -77,7 +77,7 @@ def splat_alg_bytes(c_splat):
     return 2 * (2 * c_splat + 2) * H * W * 4
 
 
-def make_step(model, image, motion, rank, world, assembly, encoder):
+def make_step(model, image, motion, rank, world, assembly, encoder, frames_u8=False):
     from slr_sfs_amd import parallel
     mine = parallel.shard_frames(NFRAMES, rank, world)
     shard = (rank, world) if (world > 1 and encoder == "banded") else None
@@ -87,6 +87,8 @@ def make_step(model, image, motion, rank, world, assembly, encoder):
             return model.synthesize(image, motion, NFRAMES, frames=mine)
         if assembly == "final":          # north_star form: one all-gather of the finished clip
             local = model.synthesize(image, motion, NFRAMES, frames=mine, shard=shard)
+            if frames_u8:                # every rank converts its own frames; the collective moves 1 byte per sample
+                local = parallel.frames_for_assembly(local)
             return parallel.gather_clip(local, NFRAMES, rank, world)
         # one small asynchronous all-gather per round of `world` frames, under the next round's rendering
         asm = parallel.ClipAssembler(NFRAMES, rank, world)
@@ -172,6 +174,9 @@ def main():
     ap.add_argument("--assembly", default="final", choices=["rounds", "final"],
                     help="N>1: ONE all-gather of the finished clip (default, the north_star form) | all-gather per round of frames "
                          "under the next round")
+    ap.add_argument("--frames", default="fp32", choices=["fp32", "uint8"],
+                    help="N > 1, --assembly final: what the all-gather moves -- the fp32 frames (11.8 MB each), or the uint8 frames every "
+                         "rank made of its own (*0.5+0.5, *255, rounded: what the reference's writer saves; 2.95 MB each)")
     ap.add_argument("--encoder", default="redundant", choices=["banded", "redundant"],
                     help="N>1: every rank encodes the image (default) | per-clip encoder in row bands + one all-gather")
     a = ap.parse_args()
@@ -204,9 +209,10 @@ def main():
     image = torch.from_numpy(rng.uniform(-1, 1, (1, 3, H, W)).astype(np.float32)).to(dev)
     motion = torch.from_numpy(smooth_motion(H, W)).to(dev)
 
-    step = make_step(model, image, motion, rank, world, a.assembly, a.encoder)
+    u8 = world > 1 and a.frames == "uint8" and a.assembly == "final"
+    step = make_step(model, image, motion, rank, world, a.assembly, a.encoder, frames_u8=u8)
     dt, clip, kev, sev = timed_clips(step, a.steps, a.warmup, world, dev)
-    assert clip.shape == (NFRAMES, 3, H, W) and bool(torch.isfinite(clip).all())
+    assert clip.shape == ((NFRAMES, H, W, 3) if u8 else (NFRAMES, 3, H, W)) and (u8 or bool(torch.isfinite(clip).all()))
 
     c_splat = 65 if a.workload == "c3" else 67              # planes per reference splat call (v1: 67)
     roofline = splat_roofline(kev, sev, c_splat, "slr::clip_tile_kernel<false,false>" if a.workload == "c3" else "slr::clip_tile_kernel<true,false>")
@@ -219,6 +225,11 @@ def main():
         extra["value_rounds_banded"] = {"value": round(NFRAMES * max(1, min(a.steps, 3)) / dt2, 3), "unit": "frames/s",
                                         "form": "all-gather per round of frames under the next round + encoder in row bands"}
         del clip2
+    if world > 1:
+        # what the communicator says about this job: every rank reports its device and its own rate
+        my_frames = len(parallel.shard_frames(NFRAMES, rank, world)) * a.steps
+        extra["communicator"] = parallel.communicator_report(dev, my_frames, dt)
+        assert extra["communicator"]["world_size"] == world == dist.get_world_size()
     if rank == 0 and world == 1:
         parity = parity_check(model, image, motion, a.workload, dev)
     if rank == 0 and world == 1 and not a.no_extras:
@@ -242,6 +253,10 @@ def main():
                    else "ONE all-gather of the finished clip (north_star form)")
             par = f"frames t = r mod {world} per rank; {asm}; {enc}"
             rounds = parallel.frames_per_rank(NFRAMES, world)
+            if u8:
+                frame_bytes //= 4
+                asm += ", uint8 frames converted per rank"
+                par = f"frames t = r mod {world} per rank; {asm}; {enc}"
             moved = rounds * frame_bytes * (world - 1)              # received per rank for the clip assembly
             if a.encoder == "banded":
                 moved += 65 * H * W * 4 * (world - 1) // world      # + the other ranks' encoder bands
@@ -261,6 +276,7 @@ def main():
                                    ", 768x1280, N=60, random-init weights of the reference architecture",
                        "frames_per_step": NFRAMES, "H": H, "W": W, "parallelism": par,
                        "assembly": a.assembly if world > 1 else None, "encoder": a.encoder if world > 1 else None,
+                       "assembled_frames": ("uint8" if u8 else "fp32") if world > 1 else None,
                        "frames_rank0": mine, "collective_bytes_received_per_rank_per_clip": moved},
             "roofline": roofline, "parity_err": parity, "cpu_baseline": cpu,
         }

@@ -22,19 +22,55 @@ def frames_per_rank(N, world):
 
 
 def gather_clip(local_frames, N, rank, world, group=None):
-    """local_frames [len(shard_frames(N,rank,world)),3,H,W] -> [N,3,H,W] on every rank.
-    Shards are padded to ceil(N/world) frames so a single all_gather_into_tensor suffices."""
+    """local_frames [len(shard_frames(N,rank,world)), ...] -> [N, ...] on every rank (any dtype: fp32 frames [n,3,H,W], or the
+    uint8 [n,h,w,3] frames of frames_for_assembly).  ONE all_gather_into_tensor of shards of ceil(N/world) frames: a full shard is
+    sent as it is (no staging copy); a short one (N not divisible by world) is padded with rows that land behind frame N - 1 and are
+    cut off -- they are never read, so they are not initialised either."""
     if world == 1:
         return local_frames
     per = frames_per_rank(N, world)
-    C, H, W = local_frames.shape[1:]
-    send = local_frames.new_zeros(per, C, H, W)
-    send[:local_frames.shape[0]] = local_frames
-    recv = local_frames.new_empty(world * per, C, H, W)
+    n, tail = local_frames.shape[0], tuple(local_frames.shape[1:])
+    if n == per:
+        send = local_frames.contiguous()
+    else:
+        send = local_frames.new_empty((per,) + tail)
+        send[:n] = local_frames
+    recv = local_frames.new_empty((world * per,) + tail)
     dist.all_gather_into_tensor(recv, send, group=group)
-    # recv[r*per + i] is frame r + i*world  ->  clip order
-    clip = recv.view(world, per, C, H, W).transpose(0, 1).reshape(per * world, C, H, W)
+    # recv[r*per + i] is frame r + i*world  ->  clip order (the one reordering copy of the assembly; 2.95 MB per frame as uint8)
+    clip = recv.view((world, per) + tail).transpose(0, 1).reshape((per * world,) + tail)
     return clip[:N]
+
+
+def frames_for_assembly(frames, raw_hw=None):
+    """What a rank hands to the clip assembly when the clip's destination is image files (the reference's writer,
+    test_animating/test_baseline_4eval_rawsize.py:246-274): its frames resized to the raw size, * 0.5 + 0.5, * 255, rounded, as uint8
+    [n,h,w,3] -- done BY EVERY RANK on its own frames (io.frames_to_uint8), so the all-gather moves 1 byte per sample instead of 4
+    (2.95 instead of 11.8 MB per 768x1280 frame) and rank 0 has nothing left to do but write."""
+    from . import io
+    return io.frames_to_uint8(frames, raw_hw).contiguous()
+
+
+def communicator_report(device, frames, seconds, group=None):
+    """What the communicator itself says about the job, gathered from every rank (all_gather_object): backend, world size, and per
+    rank its device index, the GPU's name / PCI bus id / UUID, the frames it rendered and its own frames/s.  bench.py prints it in the
+    N > 1 line, so a scaling run proves which GPUs and how many RCCL ranks took part."""
+    world = dist.get_world_size(group)
+    props = torch.cuda.get_device_properties(device) if device.type == "cuda" else None
+    mine = {"rank": dist.get_rank(group), "device_index": device.index if device.type == "cuda" else None,
+            "device_name": getattr(props, "name", None), "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "pci_domain_id": getattr(props, "pci_domain_id", None), "uuid": str(getattr(props, "uuid", None)) if props else None,
+            "frames": int(frames), "fps_this_rank": round(frames / seconds, 3) if seconds > 0 else None}
+    everybody = [None] * world
+    dist.all_gather_object(everybody, mine, group=group)
+    rccl = None
+    if dist.get_backend(group) == "nccl":
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+    return {"backend": dist.get_backend(group), "rccl_version": rccl, "world_size": world, "ranks": everybody,
+            "distinct_devices": len({(r["pci_domain_id"], r["pci_bus_id"], r["uuid"], r["device_index"]) for r in everybody})}
 
 
 class ClipAssembler:

@@ -41,6 +41,11 @@ for name, cls in (("baseline", S.pipeline.BaselineAnimator), ("slr-v1", S.pipeli
         # the north_star form: redundant encoder, ONE all-gather of the finished clip (uneven shards: N = 7 over 2 ranks)
         one = parallel.gather_clip(an.synthesize(img, m, N, frames=mine), N, rank, world)
         assert one.shape == ref.shape and (one - ref).abs().max().item() < 1e-4, (name, N, rank)
+        # ... with the frames converted to uint8 by every rank before the collective (what the writer saves: 1 byte per sample moved)
+        from slr_sfs_amd import io
+        u8 = parallel.gather_clip(parallel.frames_for_assembly(an.synthesize(img, m, N, frames=mine)), N, rank, world)
+        want = io.frames_to_uint8(ref)
+        assert u8.dtype == torch.uint8 and u8.shape == want.shape and int((u8.int() - want.int()).abs().max()) <= 1, (name, N, rank)
         if name == "slr-v1":                                   # the runner's dict of outputs, every key gathered by every rank
             outs = an.synthesize(img, m, N, frames=mine, shard=(rank, world), keys=cls.KEYS)
             full = an.synthesize(img, m, N, keys=cls.KEYS)
@@ -52,6 +57,10 @@ for name, cls in (("baseline", S.pipeline.BaselineAnimator), ("slr-v1", S.pipeli
         fs0 = an.encoder(img)
         for got, want in zip(fs if isinstance(fs, tuple) else (fs,), fs0 if isinstance(fs0, tuple) else (fs0,)):
             assert torch.equal(got, want), (name, rank)
+rep = parallel.communicator_report(torch.device("cuda", torch.cuda.current_device()), 7, 1.0)
+assert rep["world_size"] == world and rep["backend"] == backend and [r["rank"] for r in rep["ranks"]] == list(range(world))
+if backend == "nccl":
+    assert rep["distinct_devices"] == world and rep["rccl_version"], rep
 dist.barrier()
 dist.destroy_process_group()
 print(f"RANK{rank} OK")

@@ -949,7 +949,7 @@ def test_two_ranks_on_rccl(S):
     _run_two_ranks("nccl")
 
 
-@pytest.mark.parametrize("form", [(), ("--assembly", "rounds", "--encoder", "banded")])
+@pytest.mark.parametrize("form", [(), ("--assembly", "rounds", "--encoder", "banded"), ("--frames", "uint8")])
 def test_bench_two_ranks_on_one_gpu(form):
     """bench.py's own multi-rank path, launched the way the driver launches it (torch.distributed.run, 2 ranks):
     warm-up, barrier-bracketed timed steps, MAX over ranks, rank 0's extra measurements while the other rank waits,
@@ -981,9 +981,15 @@ def test_bench_two_ranks_on_one_gpu(form):
     # all-gather of the finished clip), with the other form's figure beside it; explicit = per-round all-gathers + banded encoder
     cfg = d["config"]
     frame = 3 * 768 * 1280 * 4
-    if not form:
+    # ... and what the communicator itself reports: backend, world size, every rank's device and frames (ADVICE / VERDICT r3: a
+    # scaling line has to prove how many ranks took part)
+    com = d["communicator"]
+    assert com["world_size"] == 2 and com["backend"] == "gloo" and [r["rank"] for r in com["ranks"]] == [0, 1]
+    assert [r["frames"] for r in com["ranks"]] == [30, 30] and all(r["device_name"] for r in com["ranks"])
+    if not form or form[0] == "--frames":
         assert cfg["assembly"] == "final" and cfg["encoder"] == "redundant"
-        assert cfg["collective_bytes_received_per_rank_per_clip"] == 30 * frame
+        assert cfg["assembled_frames"] == ("uint8" if form else "fp32")
+        assert cfg["collective_bytes_received_per_rank_per_clip"] == 30 * frame // (4 if form else 1)
         assert d["value_rounds_banded"]["value"] > 0
     else:
         assert cfg["assembly"] == "rounds" and cfg["encoder"] == "banded"
