@@ -83,9 +83,15 @@ int slr_euler_backward(const float *motion, int H, int W, int nsteps, float sign
 
 /* ------------------------------------------------------------------ splat: binning */
 
+/* flags of the `prebinned` argument of the one-flow calls (0: a self-contained call on a workspace nothing is known about) */
+#define SLR_WS_PREBINNED 1   /* `ws` was filled by slr_splat_bin / slr_splat_bin_pair with this flow */
+#define SLR_WS_CLEAN     2   /* `ws` was zeroed by slr_splat_workspace_init and has only been used through this library since: the call
+                                skips the kernel that zeroes the binning counters (the binning leaves them zero again) */
+
 /* Bytes of scratch one flow field needs: tile bins (12 B per source pixel worst case), the
  * work plan, and partial-tile slots for splatting up to C value planes (C = 0: bins only). */
 size_t slr_splat_workspace_bytes(int N, int C, int H, int W);
+int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int C, int H, int W, void *stream);
 
 /* Sort the source pixels of `flow` [N,2,H,W] into per-output-tile bins inside `ws`.
  * Depends on the flow only -- every tensor splatted with this flow reuses the bins.

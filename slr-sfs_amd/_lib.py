@@ -8,12 +8,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
 ABI_VERSION = 6
+WS_PREBINNED, WS_CLEAN = 1, 2       # include/slr_splat.h: flags of the `prebinned` argument
 
 # every symbol include/slr_splat.h declares
 SYMBOLS = (
     "slr_abi_version", "slr_last_error", "slr_splat_time_next",
     "slr_euler_integrate", "slr_euler_integrate_all", "slr_euler_backward",
-    "slr_splat_workspace_bytes", "slr_splat_bin", "slr_splat_bin_pair", "slr_splat_set_scan_max_tiles",
+    "slr_splat_workspace_bytes", "slr_splat_workspace_init", "slr_splat_bin", "slr_splat_bin_pair", "slr_splat_set_scan_max_tiles",
     "slr_splat_set_front_end",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
@@ -77,6 +78,7 @@ def lib():
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_backward": [fp, i, i, i, f, fp, fp, vp],
+            "slr_splat_workspace_init": [vp, sz, i, i, i, i, vp],
             "slr_splat_bin": [fp, i, i, i, i, vp, sz, vp],
             "slr_splat_bin_pair": [fp, fp, i, i, i, i, vp, vp, sz, vp],
             "slr_softsplat_forward": [fp, fp, fp, i, i, i, i, vp, sz, i, vp],
@@ -175,6 +177,10 @@ def workspace(t, role, N, C, H, W, nbytes=None):
         while not capturing and len(_ws_cache) >= WS_CACHE_MAX:
             _ws_cache.popitem(last=False)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+        if role != "scratch":
+            # a splat workspace starts zeroed; the kernels leave its counters zero again, so the calls may say WS_CLEAN (no zero kernel)
+            with torch.cuda.device(t.device):
+                check(lib().slr_splat_workspace_init(ptr(ws), ws.numel(), N, C, H, W, ctypes.c_void_p(stream.cuda_stream)), "slr_splat_workspace_init")
         _ws_cache[key] = ws
     else:
         _ws_cache.move_to_end(key)

@@ -1,0 +1,810 @@
+// splat_op.hip -- the one-flow operator: _FunctionSoftsplat / FunctionSoftsplat (4 modes) / the maximum splat as ONE gather per call.
+//
+// Replaces models/softsplat.py:157-202 (kernel_Softsplat_updateOutput: one thread per ELEMENT, 4 global fp32 atomicAdds each into a
+// pre-zeroed output), its launcher :390-424, and the weighting / normalisation of FunctionSoftsplat :665-690.  Here the scatter is
+// turned around (owner computes): the flow is shared by all C channels, so it is sorted once per call, and every output tile's
+// workgroup gathers exactly the sources that land in it -- every output byte written once, never read, never zeroed, no global
+// atomics on the values (splat_tile.hpp has the two phases every tile kernel shares).  Two exact front ends find a tile's entries:
+//   rows  (grids of more than slr_splat_set_scan_max_tiles tiles; slr_splat_bin / prebinned calls): rowbin_kernel appends every
+//         64-pixel row segment of the flow to the few tiles its footprints touch -- one returning 64-bit atomic per (segment, tile) =
+//         list slot + the tile's exact entry count -- and its last workgroup writes the work plan: heavy tiles first, a tile of more
+//         than SEG entries cut into ranges of its OUTPUT COLUMNS (a piece owns its pixels: no partial tiles, no combine);
+//         op_rows_kernel walks exactly the listed rows (splat_rows.hpp).  3 launches: rows + plan, tile kernel, a normally empty
+//         pass-by-pass launch for pieces that still hold more than SEG entries (the workspace arrives zeroed: see slr_splat_bin);
+//   scan  (small grids): scan_box_kernel writes the destination box of every 8x64 block of source pixels; every output tile's
+//         workgroup tests the boxes, lists the rows of the blocks that touch it in LDS and walks them with the same code.  2
+//         launches, nothing to zero, no plan: a tile of more than SEG entries is walked pass by pass by its own workgroup.
+#include "splat_rows.hpp"
+#include "splat_ws.hpp"
+
+#include <stdarg.h>
+#include <atomic>
+
+namespace slr {
+
+static thread_local char g_err[512] = "";
+#ifdef SLR_TRACE
+long long *g_trace;
+#endif
+thread_local void *g_ev_start = nullptr, *g_ev_stop = nullptr;   // slr_splat_time_next (also armed for splat_clip.hip's launches)
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+using OpCfg = TileCfg<1, SLR_EPT_ONE, true, SLR_KREG_ROWS>;       // one flow: 1024 entries per workgroup, 6-byte records, 46 KiB of LDS
+constexpr int OP_SEG = OpCfg::SEG;
+constexpr uint32_t OP_DEFER_WG = 64;               // workgroups of the pass-by-pass launch (x channel groups)
+static_assert(4 * ROW_CAP * 4 + 2048 * 4 <= OpCfg::REC_BYTES, "row lists and the scan's candidate list live in the record area");
+
+// =========================================================================== rows front end: binning + plan
+// Work plan from the per-tile (entries, row segments) words; run by ONE workgroup of TILE_PIX work-items (the last one of
+// rowbin_kernel) in ONE pass over the tiles.  A round covers 4 * TILE_PIX tiles: every work-item loads the words of 4
+// CONSECUTIVE tiles together (one memory round trip per round), sums them locally, and two workgroup scans per round -- partial
+// slots, then (heavy | other) items packed in one 64-bit word -- place them (a scan is a chain of cross-lane steps and
+// barriers, ~0.5 us: one per tile and quantity made the plan 9.5 us of a 32 us kernel at 1920 tiles).
+// Tiles in row-major order; on grids of more than one round of workgroups the heavy tiles (more than SLR_PLAN_HEAVY / 4 of an
+// undisturbed tile's ~585 entries) go first: their items fill items[] from the front, everybody else's from the back
+// (items[cap - 1 - k]), and the tile kernel reads item i < totals[5] from the front.  Segments of `seg` entries; a tile whose
+// segments do not fit the partial-slot budget is left to one workgroup (nseg 0).
+template <typename V>
+__device__ __forceinline__ V exscan_tile_pix(V v, V *excl, V *wsum /*[TILE_PIX / 64]*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    V inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const V o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    V woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < TILE_PIX / 64; ++w) {
+        const V q = wsum[w];
+        if (w < wid) woff += q;
+        total += q;
+    }
+    __syncthreads();
+    *excl = woff + inc - v;
+    return total;
+}
+
+__device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__ rowcnt, unsigned long long *__restrict__ rowinfo, uint32_t nt, uint32_t seg, uint32_t heavy,
+                                          uint32_t items_cap, ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
+    __shared__ unsigned long long wsum[TILE_PIX / 64];
+    // The words were written by other workgroups' agent-scope atomics (performed at the memory side, before their arrival
+    // atomics); this XCD's L2 may still hold the zeros of rows_zero_kernel.  They are read with agent-scope (sc1) loads, all four
+    // of a round in flight together (as __hip_atomic_load the compiler waits after each).
+    constexpr uint32_t PER = SLR_ROWS_PLAN_PER;
+#ifdef SLR_PLAN_STAMPS
+#define PSTAMP(k) do { if (threadIdx.x == 0) ((unsigned long long *)totals)[8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+    PSTAMP(0);
+    const uint32_t heavy_thr = heavy ? (heavy * 585u) / 4u : 0xffffffffu;
+    uint32_t run_heavy = 0, run_light = 0, run_extra = 0;
+    const uint32_t extra_cap = items_cap - nt;                                // items beyond one per tile that items[] can hold
+    for (uint32_t b = 0; b < nt; b += PER * TILE_PIX) {
+        const uint32_t t0 = b + PER * threadIdx.x;
+        unsigned long long w[PER], oh[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {                  // 8 agent-scope loads in flight, one wait
+            const unsigned long long *pw_ = rowcnt + 2 * (size_t)(t0 + k < nt ? t0 + k : 0u);
+            asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:8 sc1"
+                         : "=&v"(w[k]), "=&v"(oh[k]) : "v"(pw_) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) asm volatile("" : "+v"(w[k]), "+v"(oh[k]));      // (read only after the wait)
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            if (t0 + k >= nt) w[k] = 0ull;
+            // (the words are left ZERO for the workspace's next binning: a call does not have to zero them first)
+            else {
+                rowinfo[2 * (size_t)(t0 + k)] = w[k]; rowinfo[2 * (size_t)(t0 + k) + 1] = oh[k];      // (kept for slr_synth_group's two-flow plan)
+                const_cast<unsigned long long *>(rowcnt)[2 * (size_t)(t0 + k)] = 0ull; const_cast<unsigned long long *>(rowcnt)[2 * (size_t)(t0 + k) + 1] = 0ull;
+            }
+        }
+        PSTAMP(1);
+        unsigned long long mine = 0;                                          // (heavy items << 32) | other items of my 4 tiles
+        uint32_t ns[PER], io[PER], xo[PER];
+        unsigned long long pcs[PER];                                          // pieces of the tile: (first octant | octants << 4), 8 bits each
+        bool hv[PER];
+        unsigned long long extra = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t cnt = (uint32_t)(w[k] >> 32);
+            // Pieces of a heavy tile = ranges of its 8 column octants (8 output columns each), cut greedily so that no piece's octant
+            // counts add up to more than 7/8 of a segment (an entry on an octant boundary counts in both: the sum bounds the piece
+            // from above).  Columns, not rows: a footprint is two pixels wide and two high, so 8 pieces by rows stage 1.78x the
+            // tile's entries, by columns 1.10x.  An octant that holds more than a segment by itself makes a piece that its workgroup
+            // finds too long and hands to the pass-by-pass launch.
+            pcs[k] = 0x80ull;                                                 // one piece: octants [0, 8)
+            ns[k] = t0 + k >= nt ? 0u : 1u;
+            if (ns[k] && cnt > seg) {
+                const uint32_t limit = (seg * (uint32_t)SLR_ROWS_FILL) / 8u;
+                // (the histogram is an estimate -- units of 16 entries, small appends left out -- scaled to the tile's count + 1/8
+                // for the entries that sit on an octant boundary and count twice)
+                uint32_t hsum = 0;
+#pragma unroll
+                for (uint32_t o = 0; o < 8; ++o) hsum += (uint32_t)(oh[k] >> (8 * o)) & 0xffu;
+                const uint32_t osum = cnt + cnt / 8u;
+                // (float arithmetic: these are estimates, and 64-bit integer divisions cost the one planning workgroup 2.7 us)
+                const float scale = (float)osum / (float)(hsum ? hsum : 1u);
+                const uint32_t even = (uint32_t)((float)osum / ceilf((float)osum / (float)limit));   // pieces of about equal weight, not one full + a rest
+                uint32_t start = 0, sum = 0, np = 0;
+                unsigned long long p = 0;
+#pragma unroll
+                for (uint32_t o = 0; o < 8; ++o) {
+                    const uint32_t co = (uint32_t)((float)((uint32_t)(oh[k] >> (8 * o)) & 0xffu) * scale);
+                    if ((sum + co > limit || sum + co / 2u >= even) && o > start) { p |= (unsigned long long)(start | ((o - start) << 4)) << (8 * np); ++np; start = o; sum = 0; }
+                    sum += co;
+                }
+                p |= (unsigned long long)(start | ((8u - start) << 4)) << (8 * np); ++np;
+                pcs[k] = p; ns[k] = np;
+#if SLR_ROWS_EVEN_FIRST
+                // (where plain halves / quarters already fit, take them: equal widths)
+                uint32_t q4[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q)
+                    q4[q] = (uint32_t)((float)((uint32_t)(oh[k] >> (16 * q)) & 0xffu) * scale) + (uint32_t)((float)((uint32_t)(oh[k] >> (16 * q + 8)) & 0xffu) * scale);
+                if (max(q4[0] + q4[1], q4[2] + q4[3]) <= limit) { pcs[k] = 0x40ull | (0x44ull << 8); ns[k] = 2; }
+                else if (max(max(q4[0], q4[1]), max(q4[2], q4[3])) <= limit && np >= 4) { pcs[k] = 0x20ull | (0x22ull << 8) | (0x24ull << 16) | (0x26ull << 24); ns[k] = 4; }
+#endif
+            }
+            xo[k] = (uint32_t)extra;
+            extra += ns[k] ? ns[k] - 1u : 0u;
+        }
+        unsigned long long xex;
+        const uint32_t xtot = (uint32_t)exscan_tile_pix<unsigned long long>(extra, &xex, wsum);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t cnt = (uint32_t)(w[k] >> 32);
+            if (ns[k] > 1u && run_extra + (uint32_t)xex + xo[k] + ns[k] - 1u > extra_cap) { ns[k] = 1u; pcs[k] = 0x80ull; }   // items[] is full: one piece (pass by pass)
+            hv[k] = ns[k] && cnt > heavy_thr;
+            io[k] = hv[k] ? (uint32_t)(mine >> 32) : (uint32_t)mine;
+            mine += hv[k] ? (unsigned long long)ns[k] << 32 : (unsigned long long)ns[k];
+        }
+        unsigned long long iex;
+        const unsigned long long itot = exscan_tile_pix<unsigned long long>(mine, &iex, wsum);
+        PSTAMP(3);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            if (!ns[k]) continue;
+            ItemDesc d;
+            d.tile = t0 + k; d.cnt0 = (uint32_t)(w[k] >> 32); d.cnt1 = (uint32_t)w[k]; d.off0 = 0; d.off1 = 0; d.partoff = 0;
+            const uint32_t at = hv[k] ? run_heavy + (uint32_t)(iex >> 32) + io[k] : run_light + (uint32_t)iex + io[k];
+            for (uint32_t q = 0; q < ns[k]; ++q) {
+                const uint32_t pc = (uint32_t)(pcs[k] >> (8 * q)) & 0xffu;
+                d.seg = pc & 0xfu;                                            // first column octant of the piece
+                d.nseg = pc >> 4;                                             // its octants (8 = the whole tile)
+                items[hv[k] ? at + q : items_cap - 1u - (at + q)] = d;
+            }
+        }
+        run_heavy += (uint32_t)(itot >> 32);
+        run_light += (uint32_t)itot;
+        run_extra += xtot;
+        PSTAMP(4);
+    }
+    // totals[4]: pieces that turn out to need more than one pass (appended by their workgroups, read by the WHOLE launch)
+    if (threadIdx.x == 0) { totals[0] = run_heavy + run_light; totals[1] = 0; totals[3] = 0; totals[4] = 0; totals[5] = run_heavy; totals[6] = 0; }
+}
+
+// grid: N * tiles_x * ceil(tiles_y / ROWBIN_R) workgroups; a workgroup covers ROWBIN_R vertically adjacent source tiles (wave w: rows
+// w, w + 8, ... of the block, all their flow loads in flight together, their appends in ONE atomic instruction): a wave's life is
+// one load round trip + one atomic round trip however many rows it carries, and 1920 one-tile workgroups took 2.5 rounds of that.
+constexpr int ROWBIN_R = SLR_ROWBIN_R;
+__global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restrict__ flow, unsigned long long *__restrict__ rowcnt, unsigned long long *__restrict__ rowinfo,
+                                                          RowRec *__restrict__ rowlist, int H, int W, int tiles_x, int tiles_y,
+                                                          uint32_t nt, uint32_t *__restrict__ ctl, uint32_t *__restrict__ arrive1,
+                                                          uint32_t seg, uint32_t heavy, uint32_t items_cap,
+                                                          ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
+    const int tiles = tiles_x * tiles_y, by_n = (tiles_y + ROWBIN_R - 1) / ROWBIN_R, per_n = tiles_x * by_n;
+    const int b = blockIdx.x, n = b / per_n, bl = b - n * per_n;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef SLR_PLAN_STAMPS
+    const unsigned long long k_entry = wall_clock64();
+    if (b == 0 && tid == 0) ((unsigned long long *)totals)[15] = k_entry;
+#endif
+    const int stx = bl % tiles_x, y_base = (bl / tiles_x) * ROWBIN_R * TILE_H + wid, x = stx * TILE_W + lane;
+    const float *fl = flow + (size_t)n * 2 * H * W;
+    float fx[ROWBIN_R], fy[ROWBIN_R];
+#pragma unroll
+    for (int r = 0; r < ROWBIN_R; ++r) {
+        const int y = y_base + r * TILE_H;
+        const size_t q = (y < H && x < W) ? (size_t)y * W + x : 0;
+        fx[r] = fl[q];
+        fy[r] = fl[(size_t)H * W + q];
+    }
+    // distinct tiles of a row's 64 footprints, one per round: the first lane with something left names a tile, a ballot counts the
+    // lanes that touch it; round k's (tile, row, hits) is parked in lane k and all appends go out as ONE atomic instruction
+    unsigned long long *cnt_n = rowcnt + 2 * (size_t)n * tiles;
+    RowRec *list_n = rowlist + (size_t)n * tiles * ROW_CAP;
+    int my_tile = -1, my_y = 0;
+    uint32_t my_cnt = 0;
+    unsigned long long my_hist = 0;                      // hits per column octant of the tile in units of 16, 8 bits each
+    int k = 0;
+    auto flush = [&]() {
+        if (my_tile >= 0) {
+            const unsigned long long old = atomicAdd(cnt_n + 2 * (size_t)my_tile, 1ull | ((unsigned long long)my_cnt << 32));
+            if (my_hist) atomicAdd(cnt_n + 2 * (size_t)my_tile + 1, my_hist);       // (no return value: fire and forget)
+            const uint32_t slot = (uint32_t)old;
+            if (slot < (uint32_t)ROW_CAP) list_n[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)my_y, ((uint32_t)stx << 8) | my_cnt};
+        }
+        my_tile = -1;
+        k = 0;
+    };
+#pragma unroll
+    for (int r = 0; r < ROWBIN_R; ++r) {
+        const int y = y_base + r * TILE_H;
+        if (y >= H) break;                                   // (wave-uniform)
+        int t0 = -1, t1 = -1, t2 = -1, t3 = -1;             // the <= 4 tiles this pixel's footprint touches
+        uint32_t cm_a = 0, cm_b = 0;                        // column octants (bits) it touches in the left / right of them
+        if (x < W) {
+            const Corners c = make_corners(fx[r], fy[r], x, y);
+            const TileSet q = footprint_tiles(c, H, W);
+            if (q.vxa & q.vya) t0 = q.tya * tiles_x + q.txa;
+            if (q.vxb & q.vya) t1 = q.tya * tiles_x + q.txb;
+            if (q.vxa & q.vyb) t2 = q.tyb * tiles_x + q.txa;
+            if (q.vxb & q.vyb) t3 = q.tyb * tiles_x + q.txb;
+            // tile column a holds corner column x0 (if in the image) and x0 + 1 when it lies in the same tile column; tile column b
+            // (valid only when distinct) holds x0 + 1.  Octant = 8 output columns (the finest piece of a heavy tile).
+            const bool x0in = c.ok & (c.x0 >= 0) & (c.x0 < W), x1in = c.ok & (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
+            if (q.vxa) cm_a = (x0in ? 1u << ((c.x0 & (TILE_W - 1)) >> 3) : 0u) |
+                              ((x1in && (c.x0 + 1) / TILE_W == q.txa) ? 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3) : 0u);
+            if (q.vxb) cm_b = 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3);
+        }
+        for (;;) {
+            const int cand = t0 >= 0 ? t0 : t1 >= 0 ? t1 : t2 >= 0 ? t2 : t3;
+            const unsigned long long pend = __ballot(cand >= 0);
+            if (!pend) break;
+            const int leader = __ffsll((long long)pend) - 1;
+            const int T = __builtin_amdgcn_readlane(cand, leader);
+            const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
+            const uint32_t c = (uint32_t)__popcll(__ballot(h));
+            const uint32_t lm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
+            // Column-octant histogram of the tile (what the plan cuts heavy tiles by): ONE more atomic per append, 8 bits per octant
+            // in units of 16 entries with a pseudo-random rounding offset (unbiased: a tile's sum over its ~50 appends is what
+            // matters; two 16-bit-per-octant words cost +7 us per call at 46 k appends).  Appends of fewer than 8 hits -- the
+            // one-column overlaps into the neighbouring tile, half of all appends -- stay out of it.
+            // (This loop is what the kernel's time grows with -- a bent row touches up to ~8 tiles, 12 us per workgroup at Euler
+            // t=59 against 6 on the identity flow -- so the small appends take a short way: the union of <= 7 lanes' masks.)
+            uint32_t rm = 0;
+            unsigned long long hist = 0;
+            if (c >= 8u) {                                   // (wave-uniform)
+                const uint32_t rnd = ((uint32_t)y * 2654435761u + (uint32_t)T * 40503u) >> 16;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const uint32_t co = (uint32_t)__popcll(__ballot((lm >> o) & 1u));
+                    rm |= co ? 1u << o : 0u;
+                    hist |= (unsigned long long)((co + ((rnd >> o) & 15u)) >> 4) << (8 * o);
+                }
+            } else {
+                for (unsigned long long m = __ballot(h); m; m &= m - 1ull)
+                    rm |= (uint32_t)__builtin_amdgcn_readlane((int)lm, __ffsll((long long)m) - 1);
+            }
+            if (t0 == T) t0 = -1;
+            if (t1 == T) t1 = -1;
+            if (t2 == T) t2 = -1;
+            if (t3 == T) t3 = -1;
+            if (lane == k) { my_tile = T; my_cnt = c; my_y = y | (int)(rm << 24); my_hist = hist; }
+            if (++k == 64) flush();
+        }
+    }
+    flush();
+    // ---- the last workgroup to get here plans the call (every append above has returned: its value was used)
+    // (two levels: thousands of returning atomics on ONE word are served one after the other -- 35 us at 1920 workgroups)
+    __shared__ uint32_t last;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t grp = blockIdx.x >> 6, ngrp = (gridDim.x + 63u) >> 6;
+        const uint32_t members = min(64u, gridDim.x - (grp << 6));
+        uint32_t l = 0;
+        if (atomicAdd(&arrive1[(size_t)grp * 32u], 1u) == members - 1u) l = atomicAdd(&ctl[0], 1u) == ngrp - 1u ? 1u : 0u;
+        last = l;
+    }
+    __syncthreads();
+    if (!last) return;
+#ifdef SLR_PLAN_STAMPS
+    if (tid == 0) { ((unsigned long long *)totals)[14] = k_entry; ((unsigned long long *)totals)[13] = (unsigned long long)wall_clock64(); }
+#endif
+    rows_plan(rowcnt, rowinfo, nt, seg, heavy, items_cap, items, totals);
+    // everybody has arrived: the arrival counters go back to zero for the workspace's next binning
+    for (uint32_t i = tid; i < ((gridDim.x + 63u) >> 6); i += TILE_PIX) arrive1[(size_t)i * 32u] = 0u;
+    if (tid == 0) ctl[0] = 0u;
+}
+
+// The counters rowbin_kernel adds to (rowcnt words, arrival counters).  rowbin_kernel's planning workgroup leaves them zero again, so a
+// workspace that was zeroed once (slr_splat_workspace_init) and is only used through this library never needs this kernel: calls that
+// say so (SLR_WS_CLEAN) skip it; for any other workspace -- the caller's memory, nothing can be assumed about it -- it runs first.
+__global__ __launch_bounds__(256) void rows_zero_kernel(unsigned long long *__restrict__ rowcnt, uint32_t nt, uint32_t *__restrict__ ctl,
+                                                        uint32_t *__restrict__ arrive1) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nt) { rowcnt[2 * (size_t)i] = 0ull; rowcnt[2 * (size_t)i + 1] = 0ull; }
+    if (i < (nt + 63u) / 64u) arrive1[(size_t)i * 32u] = 0u;    // first-level arrival counters of rowbin_kernel: one per 64
+                                                                 // workgroups, each on its own 128-byte line (atomics on one line are served
+                                                                 // one after the other: 1920 arrivals on one line cost 14 us)
+    if (i < 16u) ctl[i] = 0u;
+}
+
+
+// =========================================================================== scan front end: destination boxes
+// Small grids spend their time in the latency chains of dependent launches; the scan front end needs ONE small kernel before the tile
+// kernel: every 8x64 block of SOURCE pixels ("source tile") gets the bounding box of the NW corners its pixels splat to (no atomics,
+// nothing to zero, 3 us).  An output tile's workgroup then tests all boxes (16 bytes each, L2-resident) and walks the rows of the few
+// source tiles whose box touches it.  Any flow is handled exactly: a box that covers everything just means more candidates.
+__global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restrict__ flow, SrcBox *__restrict__ box, int H, int W,
+                                                            int tiles_x, int tiles) {
+    const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int y = (tl / tiles_x) * TILE_H + wid, x = (tl % tiles_x) * TILE_W + lane;
+    int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
+    if (y < H && x < W) {
+        const float *f = flow + (size_t)n * 2 * H * W + (size_t)y * W + x;
+        const Corners c = make_corners(f[0], f[(size_t)H * W], x, y);
+        // some corner of the footprint lies inside the image (the same test as footprint_tiles)
+        if (c.ok && c.x0 >= -1 && c.x0 <= W - 1 && c.y0 >= -1 && c.y0 <= H - 1) { bx0 = bx1 = c.x0; by0 = by1 = c.y0; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
+        by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
+    }
+    __shared__ int red[TILE_H][4];
+    if (lane == 0) { red[wid][0] = bx0; red[wid][1] = bx1; red[wid][2] = by0; red[wid][3] = by1; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < TILE_H; ++w) {
+            bx0 = min(bx0, red[w][0]); bx1 = max(bx1, red[w][1]); by0 = min(by0, red[w][2]); by1 = max(by1, red[w][3]);
+        }
+        SrcBox b; b.x0 = bx0; b.x1 = bx1; b.y0 = by0; b.y1 = by1;
+        box[t] = b;
+    }
+}
+
+// =========================================================================== tile kernels
+
+// planes [cb, ce) of this workgroup: on grids smaller than the chip (gridDim.y > 1) a tile's planes are dealt to 2-4 workgroups, each
+// builds the tile's records itself (phase 1 is the cheap part) -- a tile is one workgroup whose chunk pipeline nothing overlaps with
+// (256x480, C = 64: 37.5 -> 33.5 us with 2 groups; 128x240: 34 -> 21 us with 4).  Groups start on a multiple of 8 planes.
+__device__ __forceinline__ bool channel_group(int C, int &cb, int &ce) {
+    const int cper = (((C + (int)gridDim.y - 1) / (int)gridDim.y + 7) / 8) * 8;
+    cb = (int)blockIdx.y * cper;
+    ce = min(C, cb + cper);
+    return cb < C;
+}
+
+struct OpArgs { TileShared s; TileFrame f; };
+
+// rows front end.  grid.x: a multiple of 8 * SLR_XCD_GROUP blocks covering the plan's items (surplus workgroups exit at once).
+// PASSES = false: one piece per workgroup, no loop over work (80 VGPRs: three workgroups per CU); a piece of more than SEG entries is
+// appended to the deferred list.  PASSES = true: OP_DEFER_WG workgroups walk the deferred list pass by pass (normally it is empty).
+template <bool NORM, bool MAXOP, bool PASSES>
+__global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kernel(OpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const TileLds<OpCfg> L(smem);
+    const TileShared &s = a.s;
+    const TileFrame &f = a.f;
+    const int tid = threadIdx.x;
+    int cb, ce;
+    if (!channel_group(s.C, cb, ce)) return;
+    const TileScalars k = tile_scalars(s, f);
+    if (!PASSES) {
+        const uint32_t item = xcd_item(blockIdx.x);
+        if (item >= f.totals[0]) return;
+        const uint32_t nh = f.totals[5];                   // heavy items sit at the front of items[], the rest at its back
+        const uint32_t at = item < nh ? item : f.items_cap - 1u - (item - nh);
+        const Piece p = make_piece<OpCfg>(s, f.items[at]);
+        if (!rows_piece_once<OpCfg, false, NORM, MAXOP, false>(s, f, L, p, tid, k, cb, ce) && tid == 0 && blockIdx.y == 0)
+            f.defer[atomicAdd(f.totals + 4, 1u)] = at;     // (one entry per piece: every channel group gets here)
+    } else {
+        const uint32_t ndef = f.totals[4];
+        for (uint32_t q = blockIdx.x; q < ndef; q += gridDim.x)
+            rows_piece_passes<OpCfg, false, NORM, MAXOP, false>(s, f, L, make_piece<OpCfg>(s, f.items[f.defer[q]]), tid, k, cb, ce);
+        // the last workgroup to get here empties the deferred list for the plan's next use (prebinned calls share one plan)
+        __syncthreads();
+        if (tid == 0 && atomicAdd(f.totals + 6, 1u) == gridDim.x * gridDim.y - 1u) { f.totals[4] = 0u; f.totals[6] = 0u; }
+    }
+}
+
+// scan front end: one workgroup per output tile (x channel groups).  The boxes of all source tiles are tested 2048 at a time, the
+// rows of the candidates are listed in LDS 32 candidates at a time (wave w = row w of each: coalesced 256-byte loads) and walked by
+// rows_walk.  Optimistic first: one LDS atomic per wave and row hands out the entry slots; a tile that turns out to hold more than SEG
+// entries is walked again in passes of SEG entries with reproducible ordinals (a count walk, then one emitting walk per pass).
+template <int MODE, bool EMIT>
+__device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const TileFrame &f, const TileLds<OpCfg> &L, Piece &p, int tid,
+                                                 uint32_t wave_base, uint32_t lo, uint32_t hi) {
+    uint32_t *cmask = reinterpret_cast<uint32_t *>(L.off);         // [64] candidate bits of a block of 2048 source tiles (off[] is free until phase 1b)
+    uint32_t *clist = L.rl + 4 * ROW_CAP;                           // [2048] candidate source tiles of the block, in index order
+    const SrcBox *boxes = f.box + (size_t)p.n * s.tiles;
+    uint32_t wcount = 0;
+    for (int base = 0; base < s.tiles; base += 2048) {
+        SrcBox bx4[2048 / TT];
+#pragma unroll
+        for (int q = 0; q < 2048 / TT; ++q) {                       // the box loads do not depend on LDS: issue them first
+            const int st = base + tid + q * TT;
+            bx4[q] = boxes[st < s.tiles ? st : 0];
+        }
+        if (tid < 64) cmask[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2048 / TT; ++q) {
+            const int st = base + tid + q * TT;
+            const SrcBox b = bx4[q];
+            if (st < s.tiles && b.x1 >= p.tx0 - 1 && b.x0 <= p.tx0 + TILE_W - 1 && b.y1 >= p.ty0 - 1 && b.y0 <= p.ty0 + TILE_H - 1)
+                atomicOr(&cmask[(st - base) >> 5], 1u << (st & 31));
+        }
+        __syncthreads();
+        // the bit mask -> the ordered candidate list (lane l of wave 0 owns word l; a wave scan places its bits)
+        uint32_t nc = 0;
+        {
+            const int lane = tid & 63;
+            const uint32_t word = cmask[lane];
+            const uint32_t pc = (uint32_t)__popc(word);
+            const uint32_t inc = wave_incl_scan(pc, lane);
+            nc = (uint32_t)__shfl(inc, 63);
+            if (tid < 64) {
+                uint32_t w = word, at = inc - pc;
+                while (w) {
+                    const int bit = __ffs((int)w) - 1;
+                    w &= w - 1;
+                    clist[at++] = (uint32_t)(base + lane * 32 + bit);
+                }
+            }
+        }
+        __syncthreads();
+        // 32 candidates at a time: their 8 rows each as a row-segment list in LDS (index 8 * candidate + row: wave w walks row w of each)
+        for (uint32_t c0 = 0; c0 < nc; c0 += ROW_CAP / TILE_H) {
+            const uint32_t n = min(nc - c0, (uint32_t)(ROW_CAP / TILE_H));
+            if ((uint32_t)tid < n * TILE_H) {
+                const uint32_t st = clist[c0 + (uint32_t)tid / TILE_H];
+                const uint32_t sty = st / (uint32_t)s.tiles_x, stx = st - sty * (uint32_t)s.tiles_x;
+                const uint32_t sy = sty * TILE_H + (uint32_t)tid % TILE_H;
+                L.rl[tid] = sy < (uint32_t)s.H ? sy | 0xff000000u : 0u;          // (no octants: a row past the image is skipped)
+                L.rl[ROW_CAP + tid] = stx << ROWW_STX;
+            }
+            __syncthreads();
+            p.len0 = p.n0 = n * TILE_H;
+            wcount += rows_walk<OpCfg, MODE, EMIT, false>(s, f, L, p, tid, wave_base + wcount, lo, hi);
+            __syncthreads();
+        }
+    }
+    return wcount;
+}
+
+template <bool NORM, bool MAXOP>
+__global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const TileLds<OpCfg> L(smem);
+    const TileShared &s = a.s;
+    const TileFrame &f = a.f;
+    const int tid = threadIdx.x;
+    int cb, ce;
+    if (!channel_group(s.C, cb, ce)) return;
+    const uint32_t t = xcd_item(blockIdx.x);
+    if (t >= (uint32_t)s.N * (uint32_t)s.tiles) return;
+    const TileScalars k = tile_scalars(s, f);
+    ItemDesc it = {};
+    it.tile = t; it.nseg = 8;
+    Piece p = make_piece<OpCfg>(s, it);
+    L.cnt[tid] = 0;
+    if (tid == 0) L.misc[0] = 0;
+    __syncthreads();
+    scan_collect<1, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)OP_SEG);
+    const uint32_t total = L.misc[0];
+    const rsrc_t rin = sample_planes(s, p, k.hw4);
+    PixelSums sums = {0.0f, 0.0f, 0.0f};
+    if (total <= (uint32_t)OP_SEG) {
+        EntryRegs<OpCfg> e;
+        float preA[OpCfg::EPT][4], preB[OpCfg::EPT][4];
+        build_records<OpCfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+        stream_planes<OpCfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
+        return;
+    }
+    uint32_t wb;
+    const uint32_t all = wave_bases<OpCfg>(L, tid, scan_collect<2, false>(s, f, L, p, tid, 0u, 0u, 0u), wb);
+    const uint32_t npass = (all + (uint32_t)OP_SEG - 1u) / (uint32_t)OP_SEG;
+    for (uint32_t si = 0; si < npass; ++si) {
+        __syncthreads();
+        L.cnt[tid] = 0;
+        const uint32_t lo = si * (uint32_t)OP_SEG;
+        scan_collect<2, true>(s, f, L, p, tid, wb, lo, lo + (uint32_t)OP_SEG);
+        EntryRegs<OpCfg> e;
+        float preA[OpCfg::EPT][4], preB[OpCfg::EPT][4];
+        build_records<OpCfg, NORM, false>(s, L, p, tid, min((uint32_t)OP_SEG, all - lo), rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+        stream_planes<OpCfg, NORM, MAXOP, false, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, si == 0, si + 1 == npass);
+    }
+}
+
+// =========================================================================== small kernels
+
+__device__ __forceinline__ float finish(float s, float nrm, int norm_mode, float eps) {
+    if (norm_mode == SLR_NORM_ZERO_TO_ONE) return s / (nrm == 0.0f ? 1.0f : nrm);   // softsplat.py:684-686
+    return s / fmaxf(nrm, eps);                                                      // ...splating.py:923-924
+}
+
+
+// accum [N,C+1,H,W] (last channel = normaliser) -> out [N,C,H,W]
+__global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ accum, float *__restrict__ out,
+                                                        int C, int HW, int norm_mode, float eps) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float *ap = accum + (size_t)n * (C + 1) * HW;
+    float *op = out + (size_t)n * C * HW;
+    const float nrm = ap[(size_t)C * HW + i];
+    for (int c = 0; c < C; ++c) op[(size_t)c * HW + i] = finish(ap[(size_t)c * HW + i], nrm, norm_mode, eps);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+// two-stage max: stage 1 grid-stride -> partial[blocks]; stage 2 single block -> result[0]
+__global__ __launch_bounds__(256) void max_stage_kernel(const float *__restrict__ x, size_t n,
+                                                        float *__restrict__ dst) {
+    __shared__ float wm[4];
+    float m = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+}
+
+
+// =========================================================================== host side
+
+int op_ws_open(OpWs &w, int N, int H, int W, void *ws, size_t bytes, const char *who) {
+    w.L = op_layout(N, H, W);
+    if (!ws || ((uintptr_t)ws & 15) || bytes < w.L.total) {
+        set_error("%s: workspace needs %zu bytes (16-byte aligned), got %zu", who, w.L.total, bytes);
+        return SLR_E_WORKSPACE;
+    }
+    char *b = w.base = (char *)ws;
+    w.rowcnt = (unsigned long long *)(b + w.L.off_rowcnt);
+    w.rowinfo = (unsigned long long *)(b + w.L.off_rowinfo);
+    w.rowlist = (RowRec *)(b + w.L.off_rowlist);
+    w.rowlist2 = (RowRec *)(b + w.L.off_rowlist2);
+    w.items = (ItemDesc *)(b + w.L.off_items);
+    w.items2 = (ItemDesc *)(b + w.L.off_items2);
+    w.totals = (uint32_t *)(b + w.L.off_totals);
+    w.defer = (uint32_t *)(b + w.L.off_defer);
+    w.defer2 = (uint32_t *)(b + w.L.off_defer2);
+    w.ctl = (uint32_t *)(b + w.L.off_ctl);
+    w.arrive = (uint32_t *)(b + w.L.off_arrive);
+    w.box = b + w.L.off_box;
+    return 0;
+}
+
+int op_check_dims(int N, int C, int H, int W, const char *who) {
+    // image rows travel in 24 bits of a row-list entry; a sample's plane stack is addressed through one buffer descriptor (< 2^31 bytes)
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H >= (1 << 24) || (long long)N * H * W >= (1LL << 29) ||
+        (long long)C * H * W * 4 >= (1LL << 31)) {
+        set_error("%s: bad sizes N=%d C=%d H=%d W=%d (N*H*W < 2^29, C*H*W*4 < 2^31)", who, N, C, H, W);
+        return SLR_E_BADARG;
+    }
+    return 0;
+}
+
+static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_splat_set_scan_max_tiles
+static std::atomic<int> g_front_end{SLR_FRONT_END};                    // slr_splat_set_front_end
+
+// Front end of a one-flow call: 1 scan (boxes), 2 rows.  By default the grid decides: scan up to slr_splat_set_scan_max_tiles tiles
+// (single-round grids: no plan to wait for), rows above.  A prebinned workspace holds row lists: rows.
+static int front_end(int ws_flags, uint32_t nt) {
+    if (ws_flags & SLR_WS_PREBINNED) return 2;
+    int fe = g_front_end.load(std::memory_order_relaxed);
+    if (fe != 1 && fe != 2) fe = nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed) ? 1 : 2;
+    return fe;
+}
+
+static uint32_t channel_groups(uint32_t nt, int C) {
+    if (SLR_CSPLIT_MAX <= 1) return 1u;
+    const uint32_t fit = SLR_CSPLIT_SLOTS / (nt ? nt : 1u), byc = (uint32_t)C / 8u;
+    uint32_t groups = fit < (uint32_t)SLR_CSPLIT_MAX ? fit : (uint32_t)SLR_CSPLIT_MAX;
+    groups = groups < byc ? groups : byc;
+    return groups < 1u ? 1u : groups;
+}
+
+template <typename K>
+static int set_lds_attr(K kernel, bool (&done)[64]) {
+    int dev = 0;
+    SLR_CHECK_HIP(hipGetDevice(&dev));                  // (a process may drive several GPUs)
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return 0;
+}
+
+// rowbin + plan of one flow into its workspace (the binning of slr_splat_bin and of every self-contained rows call).
+static int do_rowbin(const float *flow, OpWs &w, int N, int H, int W, bool clean, hipStream_t st) {
+    const uint32_t nt = w.L.nt;
+    if (!clean) hipLaunchKernelGGL(rows_zero_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w.rowcnt, nt, w.ctl, w.arrive);
+    const uint32_t grid = (uint32_t)N * (uint32_t)w.L.tiles_x * (uint32_t)((w.L.tiles_y + ROWBIN_R - 1) / ROWBIN_R);
+    hipLaunchKernelGGL(rowbin_kernel, dim3(grid), dim3(TILE_PIX), 0, st, flow, w.rowcnt, w.rowinfo, w.rowlist, H, W, w.L.tiles_x, w.L.tiles_y, nt,
+                       w.ctl, w.arrive, (uint32_t)OP_SEG, nt > 512u ? (uint32_t)SLR_PLAN_HEAVY : 0u, w.L.items_cap, w.items, w.totals);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool NORM, bool MAXOP>
+static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
+    static bool attr_main[64] = {}, attr_pass[64] = {};
+    if (int e = set_lds_attr(op_rows_kernel<NORM, MAXOP, false>, attr_main)) return e;
+    if (int e = set_lds_attr(op_rows_kernel<NORM, MAXOP, true>, attr_pass)) return e;
+    a.f.rowlist[0] = w.rowlist; a.f.items = w.items; a.f.totals = w.totals; a.f.defer = w.defer; a.f.items_cap = w.L.items_cap;
+    // (the grid covers the bound on the plan's items; workgroups past totals[0] exit at once: measured free)
+    const uint32_t grid = ((w.L.items_cap + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
+    const uint32_t groups = channel_groups(w.L.nt, a.s.C);
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));      // slr_splat_time_next: the dominant kernel only
+    hipLaunchKernelGGL((op_rows_kernel<NORM, MAXOP, false>), dim3(grid, groups), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+    g_ev_start = g_ev_stop = nullptr;
+    // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass, their planes
+    // dealt to up to 8 workgroups each (these run after everybody else, on an empty chip)
+    const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > 8u ? 8u : (uint32_t)a.s.C / 8u;
+    hipLaunchKernelGGL((op_rows_kernel<NORM, MAXOP, true>), dim3(w.L.nt < OP_DEFER_WG ? w.L.nt : OP_DEFER_WG, wgroups), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool NORM, bool MAXOP>
+static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
+    static bool attr[64] = {};
+    if (int e = set_lds_attr(op_scan_kernel<NORM, MAXOP>, attr)) return e;
+    a.f.box = (const SrcBox *)w.box;
+    hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles);
+    const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, channel_groups(w.L.nt, a.s.C)), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+    g_ev_start = g_ev_stop = nullptr;
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+// One call of the operator: front end by grid size / flags, then the tile kernel(s).
+template <bool NORM, bool MAXOP>
+static int do_op(OpArgs &a, int ws_flags, void *ws, size_t ws_bytes, hipStream_t st, const char *who) {
+    OpWs w;
+    if (int e = op_ws_open(w, a.s.N, a.s.H, a.s.W, ws, ws_bytes, who)) return e;
+    a.s.tiles_x = w.L.tiles_x; a.s.tiles = w.L.tiles;
+    a.f.scale[0] = 1.0f; a.f.scale[1] = 0.0f;
+#ifdef SLR_TRACE
+    a.s.trace = g_trace;
+#endif
+    const int fe = front_end(ws_flags, w.L.nt);
+    if (fe == 1) return launch_scan<NORM, MAXOP>(a, w, st);
+    if (!(ws_flags & SLR_WS_PREBINNED))
+        if (int e = do_rowbin(a.f.flow[0], w, a.s.N, a.s.H, a.s.W, (ws_flags & SLR_WS_CLEAN) != 0, st)) return e;
+    return launch_rows<NORM, MAXOP>(a, w, st);
+}
+
+}  // namespace slr
+
+using namespace slr;
+
+SLR_EXPORT int slr_abi_version(void) { return SLR_ABI_VERSION; }
+SLR_EXPORT const char *slr_last_error(void) { return slr::g_err; }
+
+#ifdef SLR_TRACE
+SLR_EXPORT void slr_debug_trace(long long *buf) { g_trace = buf; }
+#endif
+#ifdef SLR_PLAN_STAMPS
+SLR_EXPORT size_t slr_debug_totals_offset(int N, int C, int H, int W) { return op_layout(N, H, W).off_totals; }
+#endif
+
+SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {
+    slr::g_ev_start = ev_start;
+    slr::g_ev_stop = ev_stop;
+}
+
+SLR_EXPORT int slr_splat_set_scan_max_tiles(int max_tiles) {
+    return slr::g_scan_max_tiles.exchange(max_tiles < 0 ? 0 : max_tiles);
+}
+
+SLR_EXPORT int slr_splat_set_front_end(int front_end) {
+    return slr::g_front_end.exchange(front_end == 1 || front_end == 2 ? front_end : -1);
+}
+
+SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C < 0 || H <= 0 || W <= 0) return 0;
+    return op_layout(N, H, W).total;
+}
+
+SLR_EXPORT int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int C, int H, int W, void *stream) {
+    if (int e = op_check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
+    OpWs w;
+    if (int e = op_ws_open(w, N, H, W, ws, ws_bytes, __func__)) return e;
+    // everything in front of the lists (counters, plans): zero.  A kernel of our own, not hipMemsetAsync: a captured memset node on a
+    // workspace from torch's graph-private pool made HIP-graph replays fault (tests/test_gpu_parity.py::test_frame_is_graph_capturable)
+    const uint32_t words = (uint32_t)(w.L.off_rowlist / 8);
+    hipLaunchKernelGGL(rows_zero_kernel, dim3((words / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)ws,
+                       words / 2, w.ctl, w.arrive);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream) {
+    SLR_CHECK_ARG(flow, "null flow");
+    if (int e = op_check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
+    OpWs w;
+    if (int e = op_ws_open(w, N, H, W, ws, ws_bytes, __func__)) return e;
+    return do_rowbin(flow, w, N, H, W, false, (hipStream_t)stream);
+}
+
+SLR_EXPORT int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W, void *ws_a,
+                                  void *ws_b, size_t ws_bytes, void *stream) {
+    SLR_CHECK_ARG(flow_a && flow_b, "null flow");
+    SLR_CHECK_ARG(ws_a != ws_b, "the two flows need separate workspaces");
+    if (int e = slr_splat_bin(flow_a, N, C, H, W, ws_a, ws_bytes, stream)) return e;
+    return slr_splat_bin(flow_b, N, C, H, W, ws_b, ws_bytes, stream);
+}
+
+SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *out, int N, int C, int H,
+                                     int W, void *ws, size_t ws_bytes, int prebinned, void *stream) {
+    SLR_CHECK_ARG(in && flow && out, "null pointer");
+    if (int e = op_check_dims(N, C, H, W, __func__)) return e;
+    OpArgs a = {};
+    a.s.in = in; a.f.flow[0] = flow; a.f.out = out;
+    a.s.N = N; a.s.C = C; a.s.H = H; a.s.W = W; a.s.mulmode = MUL_ONE;
+    return do_op<false, false>(a, prebinned, ws, ws_bytes, (hipStream_t)stream, __func__);
+}
+
+SLR_EXPORT int slr_softsplat_mode_forward(const float *in, const float *metric, const float *flow, float *out,
+                                          int N, int C, int H, int W, int mode, void *ws, size_t ws_bytes,
+                                          int prebinned, void *stream) {
+    SLR_CHECK_ARG(mode >= SLR_MODE_SUMMATION && mode <= SLR_MODE_SOFTMAX, "mode");
+    if (mode == SLR_MODE_SUMMATION)
+        return slr_softsplat_forward(in, flow, out, N, C, H, W, ws, ws_bytes, prebinned, stream);
+    SLR_CHECK_ARG(in && flow && out, "null pointer");
+    SLR_CHECK_ARG(mode == SLR_MODE_AVERAGE || metric, "metric required for linear/softmax");
+    if (int e = op_check_dims(N, C, H, W, __func__)) return e;
+    OpArgs a = {};
+    a.s.in = in; a.s.mul = metric; a.f.flow[0] = flow; a.f.out = out;
+    a.s.N = N; a.s.C = C; a.s.H = H; a.s.W = W;
+    a.s.mulmode = mode == SLR_MODE_AVERAGE ? MUL_ONE : mode == SLR_MODE_LINEAR ? MUL_PLANE : MUL_EXP;
+    a.s.norm_mode = SLR_NORM_ZERO_TO_ONE;
+    return do_op<true, false>(a, prebinned, ws, ws_bytes, (hipStream_t)stream, __func__);
+}
+
+SLR_EXPORT int slr_maxsplat_forward(const float *in, const float *flow, float *out, float init, int N, int C,
+                                    int H, int W, void *ws, size_t ws_bytes, int prebinned, void *stream) {
+    SLR_CHECK_ARG(in && flow && out, "null pointer");
+    if (int e = op_check_dims(N, C, H, W, __func__)) return e;
+    OpArgs a = {};
+    a.s.in = in; a.f.flow[0] = flow; a.f.out = out; a.s.init = init;
+    a.s.N = N; a.s.C = C; a.s.H = H; a.s.W = W; a.s.mulmode = MUL_ONE;
+    return do_op<false, true>(a, prebinned, ws, ws_bytes, (hipStream_t)stream, __func__);
+}
+
+SLR_EXPORT int slr_splat_normalize(const float *accum, float *out, int N, int C, int H, int W, int norm_mode,
+                                   float eps, void *stream) {
+    SLR_CHECK_ARG(accum && out, "null pointer");
+    SLR_CHECK_ARG(norm_mode == SLR_NORM_ZERO_TO_ONE || norm_mode == SLR_NORM_CLAMP_EPS, "norm_mode");
+    if (int e = op_check_dims(N, C, H, W, __func__)) return e;
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(normalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, accum, out, C, H * W, norm_mode, eps);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_global_max(const float *x, size_t n, float *result, float *scratch, void *stream) {
+    SLR_CHECK_ARG(x && result && scratch && n > 0, "null pointer / empty");
+    int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(max_stage_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+    hipLaunchKernelGGL(max_stage_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)scratch, (size_t)blocks, result);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,440 @@
+// splat_tile.hpp -- what every tile kernel does once the ENTRIES of its piece of work sit in LDS (gfx950):
+//   build_records   phase 1: per-OUTPUT-pixel lists of (entry, weight) records, built with integer LDS atomics (once per entry,
+//                   not per channel) -- the scatter turned into a gather inside the tile;
+//   stream_planes   phase 2: the chunk pipeline -- the entries' source values staged in LDS four planes at a time (plane loads
+//                   two chunks ahead, issued between the steps of the gather), every work-item accumulates its own output pixel in
+//                   registers, normalises with ONE reciprocal, stores: every output byte written once, never read, never zeroed.
+// A piece of work = an 8x64 OUTPUT tile, or a range of its columns (heavy tiles are cut by output columns: a piece owns its pixels,
+// nothing is summed across workgroups), of one sample.  An entry = a source pixel whose 2x2 bilinear footprint touches the piece:
+// (pixel | direction << 31, target X, target Y, weight logit) in the entry array `ent4` (+ the second weight group's logit and value).
+// Where the entries come from is the front end's business: row-segment lists (splat_rows.hpp; the clip kernel and the one-flow
+// operator on large grids) or a scan of the flow itself (splat_op.hip, small grids).
+// Replaces models/softsplat.py:157-202 (kernel_Softsplat_updateOutput), :390-424, :665-690 and the model-side weighting /
+// two-direction accumulation / normalisation of forward_flow (animating_softmax_splating.py:849-924).
+#pragma once
+#include "splat_core.hpp"
+
+#include <type_traits>
+
+namespace slr {
+
+constexpr int TT = TILE_PIX;                       // work-items per workgroup = output pixels of a tile
+
+enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
+
+// ---- shape of a kernel family -------------------------------------------------------------------------------------------------
+// NDIR flows per tile (the fused clip kernel: forward + backward displacement map), EPT entries per work-item (a workgroup stages
+// SEG = EPT * 512 entries at once), records as (u16 entry, f32 weight) in two arrays (REC6: 6 bytes) or as one 8-byte word, KREG
+// records of an output pixel kept in registers across the chunks.  LDS: counts | scan words | misc | offsets | records | staged
+// values (+ the all-zero slot).  One flow: EPT 2, REC6 -> 46 KiB, three workgroups per CU; two flows: EPT 3, 8-byte records
+// (their lists are twice as long: one ds_read_b64 per record beats two reads) -> 79 KiB, two per CU.
+template <int NDIR_, int EPT_, bool REC6_, int KREG_>
+struct TileCfg {
+    static constexpr int NDIR = NDIR_, EPT = EPT_, KREG = KREG_, CHUNK = 4;
+    static constexpr bool REC6 = REC6_;
+    static constexpr int SEG = EPT * TT;
+    static constexpr int RECCAP = 4 * SEG + TT;    // <= 4 records per entry + one pad per pixel (odd list lengths: bank spreading)
+    static constexpr uint32_t NULL_E = SEG;        // staged-entry index of the all-zero slot
+    static constexpr uint32_t NULLREC = RECCAP - 1;   // a record (all-zero slot, weight 0) that no list owns (the last pixel's pad)
+    static constexpr size_t HEAD = (size_t)(TT + 16 + 16 + TT / 2) * 4;
+    static constexpr size_t REC_BYTES = ((size_t)RECCAP * (REC6 ? 6 : 8) + 15) & ~(size_t)15;
+    static constexpr size_t LDS_BYTES = HEAD + REC_BYTES + (size_t)(SEG + 1) * 16;
+    static_assert(HEAD % 16 == 0, "records and staged values are 16-byte aligned");
+    static_assert(SEG < 65536, "entry indices travel in 16 bits");
+};
+
+// ---- kernel arguments ---------------------------------------------------------------------------------------------------------
+struct TileShared {                // the same for every frame of a launch
+    const float *in;               // [N,C,H,W] value planes
+    const float *mul;              // [N,1,H,W] weight plane (metric / Z), or nullptr
+    const float *mulmax;           // device scalar subtracted before exp (MUL_EXP_SHIFT), or nullptr
+    const float *in2, *mul2;       // second weight group: one value plane with its own weight logits (G2 instantiations)
+    int N, C, H, W, tiles_x, tiles;   // tiles per sample
+    int mulmode, mulmode2, norm_mode;
+    float eps, init;               // normaliser clamp; start value of the maximum splat
+    long long *trace;              // development builds (-DSLR_TRACE): 64 time stamps per workgroup, or nullptr
+};
+struct SrcBox { int x0, x1, y0, y1; };             // scan front end: inclusive range of a source tile's footprint NW corners; x0 > x1: none
+struct TileFrame {
+    const float *flow[2];                  // displacement map(s) [N,2,H,W]
+    const RowRec *rowlist[2];              // rows front end: [N * tiles][ROW_CAP]
+    const SrcBox *box;                     // scan front end: [N * tiles]
+    const ItemDesc *items;                 // the work plan
+    uint32_t *totals, *defer;              // [>= 8]: [0] items, [4] deferred pieces, [5] arrivals of the deferred launch, [6] heavy items; [items_cap]
+    float *out, *out2, *norm_out;          // [N,C,H,W], [N,1,H,W] (G2), [N,1,H,W] or nullptr
+    float scale[2];                        // alpha, 1 - alpha (one flow: 1)
+    uint32_t grid, items_cap;              // blocks of this frame (multiple of 8 * XCD group); size of items[]
+};
+
+#ifdef SLR_TRACE      // development aid: per-workgroup phase time stamps (shader clock) into TileShared.trace (tools/dev/trace_clip.py)
+#define T_STAMP(s_, slot) do { if ((s_).trace && threadIdx.x == 0) (s_).trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (slot)] = clock64(); } while (0)
+#define T_NOTE(s_, slot, v) do { if ((s_).trace && threadIdx.x == 0) (s_).trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (slot)] = (long long)(v); } while (0)
+#else
+#define T_STAMP(s_, slot) do { } while (0)
+#define T_NOTE(s_, slot, v) do { } while (0)
+#endif
+
+// ---- LDS ----------------------------------------------------------------------------------------------------------------------
+// Aliases: the row lists (and the second group's entry words) sit in the record area (dead before the records are written), the
+// entry array IS the staging area (dead before the first chunk is staged; a work-item's special-chunk slots are its own entry slots).
+template <class Cfg>
+struct TileLds {
+    uint32_t *cnt, *wsum, *misc;   // [TT] records per output pixel; [16] scan words; [16] counters
+    uint16_t *off;                 // [TT] exclusive prefix of the (padded) counts
+    uint2 *rec8;                   // !REC6: [RECCAP] (entry, weight bits)
+    float *rec_w;                  // REC6: [RECCAP] weights ...
+    uint16_t *rec_e;               // ... and [RECCAP] entry indices
+    float4 *val4;                  // [SEG + 1] staged values of 4 planes per entry
+    uint32_t *rl;                  // row-list words (splat_rows.hpp): [4][NDIR * ROW_CAP]
+    float4 *ent4;                  // entries (= val4)
+    float2 *ent2;                  // G2: (weight logit, value) of the second group per entry
+
+    __device__ __forceinline__ explicit TileLds(uint32_t *smem) {
+        cnt = smem;
+        wsum = smem + TT;
+        misc = smem + TT + 16;
+        off = reinterpret_cast<uint16_t *>(smem + TT + 32);
+        char *r = reinterpret_cast<char *>(smem) + Cfg::HEAD;
+        rec8 = reinterpret_cast<uint2 *>(r);
+        rec_w = reinterpret_cast<float *>(r);
+        rec_e = reinterpret_cast<uint16_t *>(rec_w + Cfg::RECCAP);
+        val4 = reinterpret_cast<float4 *>(r + Cfg::REC_BYTES);
+        rl = reinterpret_cast<uint32_t *>(r);
+        ent4 = val4;
+        ent2 = reinterpret_cast<float2 *>(rl + 4 * Cfg::NDIR * ROW_CAP);
+    }
+    __device__ __forceinline__ void rec_put(uint32_t i, uint32_t e, float w) const {
+        if constexpr (Cfg::REC6) { rec_e[i] = (uint16_t)e; rec_w[i] = w; } else rec8[i] = make_uint2(e, __float_as_uint(w));
+    }
+    __device__ __forceinline__ void rec_get(uint32_t i, uint32_t &e, float &w) const {
+        if constexpr (Cfg::REC6) { e = rec_e[i]; w = rec_w[i]; } else { const uint2 q = rec8[i]; e = q.x; w = __uint_as_float(q.y); }
+    }
+    __device__ __forceinline__ float rec_weight(uint32_t i) const {
+        if constexpr (Cfg::REC6) return rec_w[i]; else return __uint_as_float(rec8[i].y);
+    }
+};
+
+// ---- a piece of work ----------------------------------------------------------------------------------------------------------
+struct Piece {
+    uint32_t tile;                 // n * tiles + tile of the sample
+    int n;                         // sample
+    int ty0, tx0;                  // the tile's first output row / column
+    int pca, pcb;                  // the piece's output columns [pca, pcb) of the tile (tile-local)
+    uint32_t cnt0, cnt1;           // rows front end: exact entries of the TILE per direction
+    uint32_t len0, len1;           // ... row segments to walk per direction (the whole sample's if the list overflowed)
+    uint32_t n0;                   // ... list entries of direction 0 in LDS (direction 1 follows them)
+    bool ovf0, ovf1;               // ... the direction's list overflowed ROW_CAP: every row segment of the sample is scanned
+    bool whole;                    // all 8 column octants
+};
+
+// What a work-item keeps of its EPT entries for the chunk pipeline.
+template <class Cfg>
+struct EntryRegs {
+    uint32_t off[Cfg::EPT];        // byte offset of the source pixel inside a plane of its sample
+    float m[Cfg::EPT];             // G2: the first group's weight of the entry (applied when its values are staged)
+};
+
+template <class Cfg>
+__device__ __forceinline__ void prefetch_planes(rsrc_t rin, const EntryRegs<Cfg> &e, float (&pre)[Cfg::EPT][4], int c0, int cmax, uint32_t hw4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t soff = (uint32_t)min(c0 + u, cmax) * hw4;           // (planes past the last re-read it)
+#pragma unroll
+        for (int j = 0; j < Cfg::EPT; ++j) pre[j][u] = buf_ld(rin, e.off[j], soff);
+    }
+}
+
+// Phase 1: the piece's `total` entries (in the entry array) -> per-output-pixel record lists.
+//   1a  footprint of this work-item's entries, weight m = 1 | metric | exp(metric - max) (x alpha | 1 - alpha with two flows); one
+//       LDS atomic per corner reserves a slot in that output pixel's list -- all four of an entry go out before the first result is
+//       looked at, without branches (a corner outside the piece adds 0 to this work-item's own counter); the plane loads of the
+//       first two chunks [c0, c0 + 8) are issued as soon as the source pixels are known;
+//   1b  workgroup scan of the list lengths (padded to odd: the lanes' list walks then start on different banks);
+//   1c  the (entry, weight) records are scattered into the lists.
+// WEIGHTED: the record weights carry m (normalised / fused kernels); else m is not applied (plain summation, maximum splat: the
+// pure bilinear weights).  G2 (a second weight group shares the records): the records keep the PURE bilinear weights, m multiplies
+// the first group's values when they are staged, and the entry's slot of a special chunk carries  m | in2 * m2 | m2.
+template <class Cfg, bool WEIGHTED, bool G2>
+__device__ __forceinline__ void build_records(const TileShared &s, const TileLds<Cfg> &L, const Piece &p, int tid, uint32_t total,
+                                              rsrc_t rin, uint32_t hw4, int c0, int cmax, float shift, float sc0, float sc1,
+                                              EntryRegs<Cfg> &e, float (&preA)[Cfg::EPT][4], float (&preB)[Cfg::EPT][4]) {
+    constexpr int EPT = Cfg::EPT;
+    uint32_t dir[EPT];
+    float X[EPT], Y[EPT], mm[EPT], l2[EPT], v2[EPT];
+    bool val[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t k = (uint32_t)tid + (uint32_t)j * TT;
+        val[j] = k < total;
+        float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (val[j]) en = L.ent4[k];
+        const uint32_t pw = __float_as_uint(en.x);
+        dir[j] = pw >> 31;
+        e.off[j] = (pw & 0x7fffffffu) * 4u;
+        e.m[j] = 1.0f;
+        X[j] = en.y; Y[j] = en.z; mm[j] = en.w;
+        if (G2) { float2 e2 = make_float2(0.f, 0.f); if (val[j]) e2 = L.ent2[k]; l2[j] = e2.x; v2[j] = e2.y; }
+    }
+    prefetch_planes<Cfg>(rin, e, preA, c0, cmax, hw4);
+    prefetch_planes<Cfg>(rin, e, preB, c0 + 4, cmax, hw4);
+    T_STAMP(s, 3);
+    uint32_t ts[EPT][4];                              // (output pixel << 16) | slot, 0xffffffff = corner not in the piece
+    float w[EPT][4];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ts[j][k] = 0xffffffffu; w[j][k] = 0.0f; }
+        if (G2 && !val[j]) L.val4[tid + j * TT] = make_float4(0.f, 0.f, 0.f, 0.f);      // (no record points here)
+        if (!val[j]) continue;
+        const Corners c = corners_at(X[j], Y[j]);
+        // (two scalars read at the kernel's start: taken from the frame's arguments here, by a per-lane index or select, they
+        //  become a vector memory load behind the plane loads)
+        const float sc = (Cfg::NDIR > 1 && dir[j]) ? sc1 : sc0;
+        float m = sc;
+        if (WEIGHTED) {
+            if (s.mulmode == MUL_PLANE) m = mm[j] * m;
+            else if (s.mulmode >= MUL_EXP) m = expf(mm[j] - shift) * m;
+        }
+        if (G2) {
+            float m2 = sc;
+            m2 = s.mulmode2 == MUL_PLANE ? l2[j] * m2 : expf(l2[j]) * m2;
+            L.val4[tid + j * TT] = make_float4(m, v2[j] * m2, m2, 0.0f);
+            e.m[j] = m;
+            m = 1.0f;
+        }
+        const int lx = c.x0 - p.tx0, ly = c.y0 - p.ty0;
+        const bool xa = c.ok & (lx >= p.pca) & (lx < p.pcb) & (c.x0 < s.W);
+        const bool xb = c.ok & (lx + 1 >= p.pca) & (lx + 1 < p.pcb) & (c.x0 + 1 < s.W);
+        const bool ya = (ly >= 0) & (ly < TILE_H) & (c.y0 < s.H);
+        const bool yb = (ly + 1 >= 0) & (ly + 1 < TILE_H) & (c.y0 + 1 < s.H);
+        const int oc = ly * TILE_W + lx - p.pca;      // (a piece's columns start at lane 0 of the row's wave)
+        const bool kb[4] = {bool(xa & ya), bool(xb & ya), bool(xa & yb), bool(xb & yb)};
+        const int tg[4] = {oc, oc + 1, oc + TILE_W, oc + TILE_W + 1};
+        uint32_t slot[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) slot[k] = atomicAdd(&L.cnt[kb[k] ? tg[k] : tid], kb[k] ? 1u : 0u);      // ds_add_rtn_u32
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ts[j][k] = kb[k] ? ((uint32_t)tg[k] << 16) | slot[k] : 0xffffffffu;
+            w[j][k] = kb[k] ? ((WEIGHTED || Cfg::NDIR > 1) ? m * c.w[k] : c.w[k]) : 0.0f;
+        }
+    }
+    T_STAMP(s, 4);
+    __syncthreads();
+    T_STAMP(s, 5);
+    {                                                 // 1b
+        const uint32_t v = L.cnt[tid] | 1u;
+        const uint32_t ex = block_excl_scan(v, L.wsum, tid);
+        L.off[tid] = (uint16_t)ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)                     // 1c
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ts[j][k] != 0xffffffffu) L.rec_put(L.off[ts[j][k] >> 16] + (ts[j][k] & 0xffffu), (uint32_t)tid + (uint32_t)j * TT, w[j][k]);
+    if (tid == 0) { L.val4[Cfg::NULL_E] = make_float4(0.f, 0.f, 0.f, 0.f); L.rec_put(Cfg::NULLREC, Cfg::NULL_E, 0.0f); }
+    __syncthreads();
+}
+
+// The record list of this work-item's output pixel for the gather: the first KREG records live in registers for the whole chunk
+// loop (missing ones are the NULL record: all-zero slot, weight 0 -- fma(0, 0, acc) == acc, the gather has no selects); what is left
+// of a list far longer than the wave's average (a "sink" pixel) is walked by the whole wave, lane-strided, and wave-reduced.
+template <class Cfg>
+struct PixelList {
+    uint32_t r0, rl, r1;           // own records [r0, rl), cooperative rest [rl, r1)
+    unsigned long long heavy;      // lanes of this wave whose rest the wave walks together
+    uint32_t ce[Cfg::KREG];
+    float cw[Cfg::KREG];
+};
+
+template <class Cfg>
+__device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int tid) {
+    PixelList<Cfg> g;
+    g.r0 = L.off[tid];
+    g.r1 = g.r0 + L.cnt[tid];
+    uint32_t wave_recs = g.r1 - g.r0;                  // records of this wave's 64 output pixels
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wave_recs += __shfl_xor(wave_recs, d);
+    // own share: twice the wave's average list length (a uniformly compressed region stays per-lane), at least SLR_LMAX; what is left
+    // of a longer list goes to the whole wave once it exceeds SLR_HEAVY_SLACK records (a cooperative pass costs ~50 cross-lane
+    // operations per chunk, a lane walking alone ~10 per record while the other 63 wait)
+    const uint32_t own = max((uint32_t)SLR_LMAX, 2u * ((wave_recs + 63u) >> 6));
+    g.rl = (g.r1 - g.r0 >= own + (uint32_t)SLR_HEAVY_SLACK) ? g.r0 + own : g.r1;
+    g.heavy = __ballot(g.r1 > g.rl);
+    // (the cooperative passes run one after the other; with many long lists in one wave every lane walks its own)
+    if (__popcll(g.heavy) > SLR_HEAVY_MAX) { g.rl = g.r1; g.heavy = 0ull; }
+#pragma unroll
+    for (int k = 0; k < Cfg::KREG; ++k) L.rec_get(g.r0 + (uint32_t)k < g.rl ? g.r0 + (uint32_t)k : Cfg::NULLREC, g.ce[k], g.cw[k]);
+    return g;
+}
+
+template <bool MAXOP>
+__device__ __forceinline__ void accum4(float (&acc)[4], const float4 &v, float w, bool on) {
+    if (MAXOP) {
+        acc[0] = fmaxf(on ? v.x * w : -INFINITY, acc[0]); acc[1] = fmaxf(on ? v.y * w : -INFINITY, acc[1]);
+        acc[2] = fmaxf(on ? v.z * w : -INFINITY, acc[2]); acc[3] = fmaxf(on ? v.w * w : -INFINITY, acc[3]);
+    } else {
+        acc[0] = __builtin_fmaf(v.x, w, acc[0]); acc[1] = __builtin_fmaf(v.y, w, acc[1]);
+        acc[2] = __builtin_fmaf(v.z, w, acc[2]); acc[3] = __builtin_fmaf(v.w, w, acc[3]);
+    }
+}
+
+// acc[u] (+)= over the pixel's records of staged value[u] * weight, for the 4 planes staged in LDS (MAXOP: maximum).
+// between(k), k = 0..3: called at four points of the gather -- the chunk pipeline issues the plane loads of a later chunk there, a
+// few at a time: the waves of a workgroup run in step, and a burst of loads per wave waits for the texture addresser (0.28 us per
+// chunk, measured) while the LDS pipe idles, then the LDS reads of the gather queue up while the addresser idles.
+template <class Cfg, bool MAXOP, typename F>
+__device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane, float init, float (&acc)[4], F &&between) {
+    constexpr int RB = 4, KREG = Cfg::KREG;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = MAXOP ? init : 0.0f;
+    {
+        between(0);
+        float4 v[KREG];
+#pragma unroll
+        for (int k = 0; k < KREG; ++k) v[k] = L.val4[g.ce[k]];                    // ds_read_b128: 4 planes per LDS instruction
+        between(1);
+#pragma unroll
+        for (int k = 0; k < KREG; ++k) accum4<MAXOP>(acc, v[k], g.cw[k], g.ce[k] != Cfg::NULL_E);
+    }
+    between(2);
+    for (uint32_t r = g.r0 + (uint32_t)KREG; r < g.rl; r += RB) {
+        uint32_t e[RB];
+        float w[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) L.rec_get(r + (uint32_t)k < g.rl ? r + (uint32_t)k : Cfg::NULLREC, e[k], w[k]);
+        float4 v[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) v[k] = L.val4[e[k]];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) accum4<MAXOP>(acc, v[k], w[k], e[k] != Cfg::NULL_E);
+    }
+    between(3);
+    for (unsigned long long hv = g.heavy; hv; hv &= hv - 1) {                     // long lists, cooperatively
+        const int src = __ffsll((long long)hv) - 1;
+        const uint32_t hb = __shfl(g.rl, src), he = __shfl(g.r1, src);
+        float part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part[u] = MAXOP ? -INFINITY : 0.0f;
+        for (uint32_t r = hb + (uint32_t)lane; r < he; r += 64) {
+            uint32_t e;
+            float w;
+            L.rec_get(r, e, w);
+            accum4<MAXOP>(part, L.val4[e], w, true);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t = part[u];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(t, d); t = MAXOP ? fmaxf(t, o) : t + o; }
+            if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], t) : acc[u] + t;
+        }
+    }
+}
+
+// sum of the pixel's record weights (the normaliser when the weights carry m)
+template <class Cfg>
+__device__ __forceinline__ float weight_sum(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane) {
+    float nrm = 0.0f;
+    for (uint32_t r = g.r0; r < g.rl; ++r) nrm += L.rec_weight(r);
+    for (unsigned long long hv = g.heavy; hv; hv &= hv - 1) {
+        const int src = __ffsll((long long)hv) - 1;
+        const uint32_t hb = __shfl(g.rl, src), he = __shfl(g.r1, src);
+        float part = 0.0f;
+        for (uint32_t r = hb + (uint32_t)lane; r < he; r += 64) part += L.rec_weight(r);
+        part = wave_sum(part);
+        if (lane == src) nrm += part;
+    }
+    return nrm;
+}
+
+// What a work-item carries from pass to pass of a piece that needs several (one pass otherwise).
+struct PixelSums { float nrm, g2_sum, g2_nrm; };
+
+// Phase 2 for one pass over the planes [cb, ce) (the whole stack, or a channel group's share on small grids): [special chunk] ->
+// chunk pipeline.  first / last: the pass is the piece's first / last one (ACCUM kernels: a piece of several passes accumulates
+// through its own earlier stores and normalises in the last pass).
+template <class Cfg, bool NORM, bool MAXOP, bool G2, bool ACCUM>
+__device__ __forceinline__ void stream_planes(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, const Piece &p, int tid,
+                                              rsrc_t rin, uint32_t hw4, int cb, int ce, const EntryRegs<Cfg> &e,
+                                              float (&preA)[Cfg::EPT][4], float (&preB)[Cfg::EPT][4], PixelSums &sums, bool first, bool last) {
+    constexpr int EPT = Cfg::EPT;
+    const int lane = tid & 63;
+    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid);
+    const int ly = tid / TILE_W, lx = p.pca + tid - ly * TILE_W;
+    const int oy = p.ty0 + ly, ox = p.tx0 + lx;
+    const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb);
+    const uint32_t opix = (uint32_t)(oy * s.W + ox);
+    const uint32_t voff = inside ? opix * 4u : BUF_OOB;                   // (work-items outside the image / the piece: stores dropped)
+    const size_t hw = (size_t)s.H * s.W;
+    const rsrc_t rout = make_rsrc(f.out + (size_t)p.n * s.C * hw, (uint32_t)s.C * hw4);
+    float inv = 1.0f;
+    if (NORM) {
+        if (G2) {
+            // the special chunk (m | in2 * m2 | m2 per entry, staged in phase 1a): both normalisers and the second group's sum
+            float a2[4];
+            gather_chunk<Cfg, false>(L, g, lane, 0.0f, a2, [](int) {});
+            sums.nrm += a2[0]; sums.g2_sum += a2[1]; sums.g2_nrm += a2[2];
+            if (last && inside && cb == 0) f.out2[(size_t)p.n * hw + opix] = sums.g2_sum / norm_divisor(sums.g2_nrm, s.norm_mode, s.eps);
+            __syncthreads();                          // val4 is overwritten by the first value chunk
+        } else {
+            sums.nrm += weight_sum<Cfg>(L, g, lane);
+        }
+        if (last && inside && f.norm_out && cb == 0) f.norm_out[(size_t)p.n * hw + opix] = norm_divisor(sums.nrm, s.norm_mode, s.eps);
+        inv = 1.0f / norm_divisor(sums.nrm, s.norm_mode, s.eps);           // ONE division per output pixel
+    }
+    T_STAMP(s, 7);
+    T_NOTE(s, 63, g.r1 - g.r0);
+    const int cmax = ce - 1;
+    // FULL: all 4 planes exist -- every load and store of the body is unconditional, so the compiler knows how many memory
+    // operations are younger than the ones it has to wait for and emits s_waitcnt vmcnt(N) with N > 0 (a conditional store anywhere in
+    // the loop makes it drain the whole queue at the top of every chunk: the prefetch distance of two chunks becomes one)
+    auto chunk = [&](auto full_tag, float (&pre)[EPT][4], int c0) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            L.val4[tid + j * TT] = G2 ? make_float4(pre[j][0] * e.m[j], pre[j][1] * e.m[j], pre[j][2] * e.m[j], pre[j][3] * e.m[j])
+                                      : make_float4(pre[j][0], pre[j][1], pre[j][2], pre[j][3]);
+        if (c0 - cb < 32) T_STAMP(s, 8 + 6 * ((c0 - cb) / 4));
+        __syncthreads();
+        if (c0 - cb < 32) T_STAMP(s, 9 + 6 * ((c0 - cb) / 4));
+        float acc[4];
+        // the plane loads of the chunk after next (two chunks ahead), one plane at each of the gather's four stops
+        gather_chunk<Cfg, MAXOP>(L, g, lane, s.init, acc, [&](int u) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t soff = (uint32_t)min(c0 + 8 + u, cmax) * hw4;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) pre[j][u] = buf_ld(rin, e.off[j], soff);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));
+        __syncthreads();                              // val4 is overwritten by the next chunk (the stores below do not hold the others up)
+        if (c0 - cb < 32) T_STAMP(s, 13 + 6 * ((c0 - cb) / 4));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (FULL || c0 + u < ce) {                // (scalar: only the last chunk of a plane count that is not a multiple of 4)
+                const uint32_t soff = (uint32_t)(c0 + u) * hw4;
+                float r = acc[u];
+                if (ACCUM && !first) { const float o = buf_ld(rout, voff, soff); r = MAXOP ? fmaxf(r, o) : r + o; }   // earlier passes of this piece
+                if (NORM && (!ACCUM || last)) r *= inv;
+                buf_st(rout, voff, soff, r);
+            }
+        }
+    };
+    // (the loads of the first two chunks were issued in phase 1a, microseconds ago: waiting for them here costs nothing, and with
+    //  nothing pending at the loop's entry the compiler's counter bookkeeping inside the loop is exact -- merged with a non-empty entry
+    //  state it made every other chunk wait for the loads issued ONE chunk earlier: 1.84 against 1.59 us per chunk)
+    __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0)
+    int c0 = cb;
+    for (; c0 + 8 <= ce; c0 += 8) {
+        chunk(std::true_type{}, preA, c0);
+        chunk(std::true_type{}, preB, c0 + 4);
+    }
+    if (c0 < ce) {                                    // the last 1 .. 7 planes
+        chunk(std::false_type{}, preA, c0);
+        if (c0 + 4 < ce) chunk(std::false_type{}, preB, c0 + 4);
+    }
+}
+
+}  // namespace slr

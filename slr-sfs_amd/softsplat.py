@@ -7,7 +7,7 @@ Same public names, argument meaning, assertions and error behaviour as the refer
 import torch
 
 from . import _lib
-from ._lib import check, lib, ptr, require_device, stream_of, workspace
+from ._lib import WS_CLEAN, check, lib, ptr, require_device, stream_of, workspace
 
 _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 
@@ -30,7 +30,7 @@ def _splat_sum(input, flow):
     ws = workspace(input, "a", N, C, H, W)
     with torch.cuda.device(input.device):
         check(lib().slr_softsplat_forward(ptr(input), ptr(flow), ptr(out), N, C, H, W,
-                                          ptr(ws), ws.numel(), 0, stream_of(input)), "slr_softsplat_forward")
+                                          ptr(ws), ws.numel(), WS_CLEAN, stream_of(input)), "slr_softsplat_forward")
     return out
 
 
@@ -107,7 +107,7 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
     with torch.cuda.device(tenInput.device):
         check(lib().slr_softsplat_mode_forward(ptr(tenInput), ptr(tenMetric) if strType != 'average' else None,
                                                ptr(tenFlow), ptr(out), N, C, H, W, _MODES[strType],
-                                               ptr(ws), ws.numel(), 0, stream_of(tenInput)),
+                                               ptr(ws), ws.numel(), WS_CLEAN, stream_of(tenInput)),
               "slr_softsplat_mode_forward")
     return out
 
@@ -130,7 +130,7 @@ def _maxsplat(input, flow, init):
     ws = workspace(input, "a", N, C, H, W)
     with torch.cuda.device(input.device):
         check(lib().slr_maxsplat_forward(ptr(input), ptr(flow), ptr(out), float(init), N, C, H, W,
-                                         ptr(ws), ws.numel(), 0, stream_of(input)), "slr_maxsplat_forward")
+                                         ptr(ws), ws.numel(), WS_CLEAN, stream_of(input)), "slr_maxsplat_forward")
     return out
 
 
@@ -153,7 +153,7 @@ def _FunctionMaximumWarpNormsplat(input, flow):
     ws = workspace(input, "a", N, C, H, W)
     with torch.cuda.device(input.device):
         check(lib().slr_max_warp_norm(ptr(input), ptr(flow), ptr(scratch), ptr(out), N, C, H, W,
-                                      ptr(ws), ws.numel(), 0, stream_of(input)), "slr_max_warp_norm")
+                                      ptr(ws), ws.numel(), WS_CLEAN, stream_of(input)), "slr_max_warp_norm")
     return out
 
 

@@ -195,7 +195,7 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
         require_device(out)
         assert out.shape == values.shape and out.device == values.device
     norm = values.new_empty(1, 1, H, W) if return_norm else None
-    scratch = workspace(values, "clip", 1, C, H, W, nbytes=int(lib().slr_splat_scratch_bytes(C, H, W)))
+    scratch = workspace(values, "scratch", 1, C, H, W, nbytes=int(lib().slr_splat_scratch_bytes(C, H, W)))
     with torch.cuda.device(values.device):
         if timed and kernel_timing is not None:
             _arm_timer(values)
@@ -223,7 +223,7 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
     assert all(lk[0] is plan for lk in look), "frames of one launch must come from one chunk of the plan"
     nb = len(ts)
     L = lib()
-    scratch = workspace(values, "clipb", nb, C, H, W, nbytes=int(L.slr_splat_scratch_bytes_batch(C, H, W, nb)))
+    scratch = workspace(values, "scratch", nb, C, H, W, nbytes=int(L.slr_splat_scratch_bytes_batch(C, H, W, nb)))
     PP = ctypes.c_void_p * nb
     df = PP(*[mp.disp_f[t].data_ptr() for t in ts])
     dp = PP(*[mp.disp_p[mp.N - t].data_ptr() for t in ts])
