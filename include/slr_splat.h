@@ -81,50 +81,46 @@ int slr_euler_integrate_all(const float *motion, int H, int W, int nmax, float s
 int slr_euler_backward(const float *motion, int H, int W, int nsteps, float sign, const float *grad_disp,
                        float *grad_motion, void *stream);
 
-/* ------------------------------------------------------------------ splat: binning */
+/* ------------------------------------------------------------------ splat: workspace, binning, front ends */
 
 /* flags of the `prebinned` argument of the one-flow calls (0: a self-contained call on a workspace nothing is known about) */
 #define SLR_WS_PREBINNED 1   /* `ws` was filled by slr_splat_bin / slr_splat_bin_pair with this flow */
 #define SLR_WS_CLEAN     2   /* `ws` was zeroed by slr_splat_workspace_init and has only been used through this library since: the call
                                 skips the kernel that zeroes the binning counters (the binning leaves them zero again) */
 
-/* Bytes of scratch one flow field needs: tile bins (12 B per source pixel worst case), the
- * work plan, and partial-tile slots for splatting up to C value planes (C = 0: bins only). */
+/* Bytes of scratch one flow field needs: per-tile row-segment lists (256 records of 8 bytes per 8x64 output tile), work plans,
+ * destination boxes -- 12.7 MB at 768x1280.  C is accepted for compatibility and ignored (no partial tiles since ABI 6).
+ * slr_splat_workspace_init zeroes the counters of a fresh workspace (see SLR_WS_CLEAN). */
 size_t slr_splat_workspace_bytes(int N, int C, int H, int W);
 int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int C, int H, int W, void *stream);
 
-/* Sort the source pixels of `flow` [N,2,H,W] into per-output-tile bins inside `ws`.
- * Depends on the flow only -- every tensor splatted with this flow reuses the bins.
- * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199;
- * here each workgroup owns an output tile and gathers exactly the sources that land in it.) */
+/* Sort `flow` [N,2,H,W] for splatting, inside `ws`: every 64-pixel row segment of the flow is appended to the few 8x64 OUTPUT
+ * tiles its bilinear footprints touch (one 64-bit atomic per (segment, tile) = list slot + the tile's exact entry count), and the
+ * work plan is written by the same launch (heavy tiles first; a tile of more than 1024 entries cut into ranges of its output
+ * columns).  Depends on the flow only -- every tensor splatted with this flow reuses it (prebinned = SLR_WS_PREBINNED).
+ * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199; here each workgroup owns an output
+ * tile -- or a range of its columns -- and gathers exactly the sources that land in it.) */
 int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
 
-/* slr_splat_bin for two flow fields of the same shape at once (the forward and the backward
- * displacement map of a frame): same launches, about the time of one. */
+/* slr_splat_bin for two flow fields of the same shape (the forward and the backward displacement map of a frame). */
 int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W,
                        void *ws_a, void *ws_b, size_t ws_bytes, void *stream);
 
-/* Front end of the one-flow calls below (slr_softsplat_forward, slr_softsplat_mode_forward, slr_maxsplat_forward,
- * slr_max_warp_norm with prebinned == 0).  Exact front ends:
- *   bins : slr_splat_bin + a work plan + the tile kernel + combine (8 launches) -- what prebinned calls and the clip plans use;
- *   scan : one kernel writes the destination box of every 8x64 block of source pixels, then every output tile's
- *          workgroup scans the flow of the blocks whose box touches it (2 launches, no bins, no plan, no combine).
- * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64)); default 1024,
- * 0 = never scan, INT_MAX = always scan (larger grids: see slr_splat_set_front_end).  Process-wide; returns the previous value.
- * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199.) */
+/* Front end of the self-contained one-flow calls below (slr_softsplat_forward, slr_softsplat_mode_forward, slr_maxsplat_forward,
+ * slr_max_warp_norm without SLR_WS_PREBINNED).  Two exact front ends find an output tile's source pixels:
+ *   rows : slr_splat_bin's binning + plan, then the tile kernel walks exactly the listed rows of the flow; pieces of heavy tiles
+ *          run in parallel, each owning its output columns (no partial tiles, no combine).  3 launches (4 on a workspace that is not
+ *          SLR_WS_CLEAN): rows + plan, tile kernel, and a normally empty pass-by-pass launch for pieces that still hold more than
+ *          1024 entries;
+ *   scan : one kernel writes the destination box of every 8x64 block of source pixels, then every output tile's workgroup lists the
+ *          rows of the blocks whose box touches it and walks them with the same code (no plan: nothing to wait for on grids that fit
+ *          the chip in one or two rounds).  3 launches: boxes, tile kernel, and a normally empty launch that takes tiles of more
+ *          than 1024 entries as 8 column pieces each.
+ * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64); default 1024, 0 = never,
+ * INT_MAX = always) and `rows` above; slr_splat_set_front_end(1 | 2) forces scan | rows, anything else = automatic.  Process-wide;
+ * both return the previous value (-1 = automatic).  Both are exact (floating-point summation order differs: results agree to
+ * rounding, ~1e-6 relative).  (ABI <= 5 had a third front end, per-pixel bins with partial tiles and a combine pass: gone.) */
 int slr_splat_set_scan_max_tiles(int max_tiles);
-
-/* Third front end, and the explicit choice:
- *   rows : one kernel appends every row segment (64 consecutive source pixels of an image row) to the few tiles its
- *          footprints touch -- one 64-bit atomic per (segment, tile), which also sums the tile's exact entry count -- and
- *          its last workgroup writes the work plan: heavy tiles first, a tile of more than 1024 entries cut into ranges
- *          of output COLUMNS (each piece owns its output pixels: no partial tiles, no combine); the tile kernel scans
- *          exactly the listed rows.  4 launches: zero, rows + plan, tile kernel, and a (normally empty) pass-by-pass
- *          launch for pieces that still hold more than 1024 entries.
- * front_end: 0 bins, 1 scan, 2 rows, anything else = automatic (the default): scan up to slr_splat_set_scan_max_tiles
- * tiles (one or two rounds of workgroups: no plan to wait for), rows above (heavy tiles first, their pieces in parallel).
- * Process-wide; returns the previous value (-1 = automatic).  All three are exact (floating-point summation order differs:
- * results agree to rounding, ~1e-6 relative).  Images of 2^24 rows or more take bins instead of rows. */
 int slr_splat_set_front_end(int front_end);
 
 /* ------------------------------------------------------------------ splat: forward */
@@ -132,9 +128,9 @@ int slr_splat_set_front_end(int front_end);
 /* _FunctionSoftsplat.forward: summation splat.
  * Replaces kernel_Softsplat_updateOutput + its launcher, softsplat.py:157-202, 390-424.
  *   in [N,C,H,W], flow [N,2,H,W] -> out [N,C,H,W] (every element written; no pre-zeroing)
- * prebinned == 0: a self-contained call (front end: slr_splat_set_front_end / slr_splat_set_scan_max_tiles; `ws` holds NO reusable bins
- * afterwards).  prebinned != 0: `ws` was filled by slr_splat_bin / slr_splat_bin_pair with this flow (bins shared by
- * several tensors splatted with the same flow). */
+ * prebinned: 0 or SLR_WS_CLEAN = a self-contained call (front end: slr_splat_set_front_end / slr_splat_set_scan_max_tiles);
+ * SLR_WS_PREBINNED: `ws` was filled by slr_splat_bin / slr_splat_bin_pair with this flow (one binning shared by several tensors
+ * splatted with the same flow). */
 int slr_softsplat_forward(const float *in, const float *flow, float *out,
                           int N, int C, int H, int W,
                           void *ws, size_t ws_bytes, int prebinned, void *stream);
@@ -162,7 +158,8 @@ int slr_splat_normalize(const float *accum, float *out, int N, int C, int H, int
  * a = 1 - t/N) and ..._2layers_alpha_seperate.py:950-1045 (second group: values = alpha_fluid,
  * wlogit = CompositeFluidAlpha_I0).  One sample (the models run bs = 1 at inference).
  *   values [C,H,W]; wlogit [H,W]; wmax: device pointer to 1 float or NULL
- *   disp_f, disp_p [2,H,W]; ws_f, ws_p: workspaces ALREADY binned with disp_f / disp_p
+ *   disp_f, disp_p [2,H,W]; ws_f, ws_p: workspaces ALREADY binned with disp_f / disp_p (slr_splat_bin_pair); the call sorts copies
+ *   of their lists, writes a two-flow plan into ws_f and runs the fused kernel of the clip path on that one frame
  *   out [C,H,W]; norm_out [H,W] or NULL (the clamped normaliser, for alpha_fluid_mask :1039) */
 int slr_synth_group(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                     const float *disp_f, const float *disp_p, float alpha,
@@ -170,25 +167,27 @@ int slr_synth_group(const float *values, const float *wlogit, const float *wmax,
                     void *ws_f, void *ws_p, size_t ws_bytes, void *stream);
 
 /* ---- clip plans: all frames of a clip binned and planned by one set of launches ----
- * forward_flow integrates and splats per frame (animating_softmax_splating.py:847-848,884-921); every displacement
- * map of a clip exists before its first frame (slr_euler_integrate_all), and binning is latency-bound, so the 2 x n
- * maps of n frames are binned (count, scan, fill) and planned by ONE launch each instead of n x 6 launches.
- * Frame i uses disp_f[idx_f[i]] and disp_p[idx_p[i]] (idx_*: DEVICE int arrays; for frame t of an N-frame clip
- * idx_f = t, idx_p = N - t).  8*nframes*H*W must stay below 2^32 (plan longer clips in chunks).
- * slr_clip_plan_totals: where the per-frame totals sit inside the plan buffer (stride_words uint32 per frame:
- * [0] work items, [3] multi-segment tiles, [4] whole-tile items) -- read them back once per clip to pass exact
- * grids to slr_synth_group_clip (n_items / n_multi / n_whole; -1 = unknown: upper-bound grids, surplus exits). */
+ * forward_flow integrates and splats per frame (animating_softmax_splating.py:847-848,884-921); every displacement map of a clip
+ * exists before its first frame (slr_euler_integrate_all), so the 2 x n maps of n frames are binned by ONE launch (row segments
+ * per tile, exact column-octant histograms), their lists sorted by one, and one workgroup per frame writes the frame's work plan
+ * (tiles of more than 1536 entries of the two directions together cut into column pieces): 4 launches per clip.
+ * Frame i uses disp_f[idx_f[i]] and disp_p[idx_p[i]] (idx_*: DEVICE int arrays; for frame t of an N-frame clip idx_f = t,
+ * idx_p = N - t).  At most 16384 frames per plan; C*H*W*4 < 2^31.
+ * slr_clip_plan_totals: where the per-frame totals sit inside the plan buffer (stride_words uint32 per frame: [0] work items) --
+ * read them back once per clip to pass exact grids to the synthesis calls (n_items; -1 = unknown: upper-bound grids, surplus
+ * workgroups exit at once).  n_multi / n_whole of ABI <= 5 are accepted and ignored; the scratch arguments as well
+ * (slr_splat_scratch_bytes* return 256): pieces own their output pixels, nothing is summed across workgroups. */
 size_t slr_clip_plan_bytes(int nframes, int H, int W);
-size_t slr_splat_scratch_bytes(int C, int H, int W);      /* partial-tile scratch of one slr_synth_group_clip call */
+size_t slr_splat_scratch_bytes(int C, int H, int W);      /* 256 (kept for ABI <= 5 callers: no scratch is needed) */
 int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words);
 int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp_p, const int *idx_p, int nframes,
                         int H, int W, void *plan, size_t plan_bytes, void *stream);
-/* slr_synth_group for nb <= 8 frames of a built clip plan in ONE launch of the tile kernel (and one of combine):
- * consecutive kernels of a stream do not overlap, and the last round of a frame's ~2100 work items runs on a half-empty
- * chip; with the frames of a decoder batch in one grid the splat of a frame takes 190-200 us instead of 243.
+/* slr_synth_group for nb <= 16 frames of a built clip plan in ONE launch of the fused tile kernel (+ one normally empty launch for
+ * pieces of more than a segment): consecutive kernels of a stream do not overlap, and the last round of a frame's ~2100 work items
+ * runs on a half-empty chip; the frames' block groups are interleaved so that the same tile of consecutive frames runs side by
+ * side on one XCD and shares its L2.  Per frame of work at 768x1280: 239 us with 1 frame per launch, 158 with 8, 151 with 16.
  * Arrays of nb entries: disp_f / disp_p / out / norm_out (device pointers per frame; norm_out may be NULL), alpha,
- * frame (index into the plan); hints = nb x {n_items, n_multi, n_whole} or NULL (all unknown).
- * scratch: slr_splat_scratch_bytes_batch(C, H, W, nb) bytes (one partial-tile area per frame of the batch). */
+ * frame (index into the plan); hints = nb x {n_items, -, -} or NULL (all unknown). */
 size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb);
 int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                                const float *const *disp_f, const float *const *disp_p, const float *alpha,

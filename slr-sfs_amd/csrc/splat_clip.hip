@@ -24,6 +24,7 @@
 namespace slr {
 
 using ClipCfg = TileCfg<2, SLR_EPT_TWO, false, SLR_KREG_TWO>;      // two flows: 1536 entries per workgroup, 8-byte records, 79 KiB of LDS
+using ClipPassCfg = TileCfg<2, SLR_EPT_DEFER, false, SLR_KREG_TWO>; // the pass-by-pass launch: passes of 2048 entries, 103 KiB
 constexpr int CT = TT;                             // work-items per workgroup = output pixels of a tile
 constexpr int C_SEG = ClipCfg::SEG;                // entries a workgroup stages at once
 constexpr int C_MAXB = SLR_CLIP_MAXB;              // frames per launch
@@ -322,8 +323,9 @@ __global__ __launch_bounds__(CT) void rows_plan_pair_kernel(const unsigned long 
 // PASSES = true:  C_DEFER_WG workgroups per frame walk the deferred lists pass by pass.
 template <bool G2, bool PASSES>
 __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch b) {
+    using Cfg = std::conditional_t<PASSES, ClipPassCfg, ClipCfg>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const TileLds<ClipCfg> L(smem);
+    const TileLds<Cfg> L(smem);
     const TileShared &s = b.s;
     uint32_t bf, bx;
     if (PASSES) { bf = blockIdx.x / C_DEFER_WG; bx = blockIdx.x % C_DEFER_WG; }
@@ -345,13 +347,13 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
         if (bx >= f.grid) return;                          // this frame has fewer groups than the longest of the batch
         const uint32_t item = xcd_item(bx);
         if (item >= f.totals[0]) return;
-        const Piece p = make_piece<ClipCfg>(s, f.items[item]);
-        if (!rows_piece_once<ClipCfg, true, true, false, G2>(s, f, L, p, tid, k, 0, s.C) && tid == 0)
+        const Piece p = make_piece<Cfg>(s, f.items[item]);
+        if (!rows_piece_once<Cfg, true, true, false, G2>(s, f, L, p, tid, k, 0, s.C) && tid == 0)
             f.defer[atomicAdd(f.totals + 4, 1u)] = item;   // more than one pass: the pass-by-pass launch takes the piece
     } else {
         const uint32_t ndef = f.totals[4];
         for (uint32_t q = bx; q < ndef; q += C_DEFER_WG)
-            rows_piece_passes<ClipCfg, true, true, false, G2>(s, f, L, make_piece<ClipCfg>(s, f.items[f.defer[q]]), tid, k, 0, s.C);
+            rows_piece_passes<Cfg, true, true, false, G2>(s, f, L, make_piece<Cfg>(s, f.items[f.defer[q]]), tid, k, 0, s.C);
         // the last workgroup of the frame to get here empties the deferred list for the plan's next use (everybody has read it)
         __syncthreads();
         if (tid == 0 && atomicAdd(f.totals + 5, 1u) == C_DEFER_WG - 1u) { f.totals[4] = 0u; f.totals[5] = 0u; }
@@ -405,7 +407,7 @@ static int launch_clip_kernel(const ClipBatch &b, uint32_t grid, hipStream_t st)
         SLR_CHECK_HIP(hipFuncSetAttribute((const void *)clip_tile_kernel<G2, PASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((clip_tile_kernel<G2, PASSES>), dim3(grid), dim3(CT), ClipCfg::LDS_BYTES, st, b);
+    hipLaunchKernelGGL((clip_tile_kernel<G2, PASSES>), dim3(grid), dim3(CT), PASSES ? ClipPassCfg::LDS_BYTES : ClipCfg::LDS_BYTES, st, b);
     return 0;
 }
 

@@ -35,6 +35,8 @@ void set_error(const char *fmt, ...) {
 }
 
 using OpCfg = TileCfg<1, SLR_EPT_ONE, true, SLR_KREG_ROWS>;       // one flow: 1024 entries per workgroup, 6-byte records, 46 KiB of LDS
+using OpPassCfg = TileCfg<1, SLR_EPT_DEFER, true, SLR_KREG_ROWS>; // the pass-by-pass launches: passes of 2048 entries, 86 KiB (most deferred pieces
+                                                                  // are just over a segment and finish in one pass; these run on a near-empty chip)
 constexpr int OP_SEG = OpCfg::SEG;
 constexpr uint32_t OP_DEFER_WG = 64;               // workgroups of the pass-by-pass launch (x channel groups)
 static_assert(4 * ROW_CAP * 4 + 2048 * 4 <= OpCfg::REC_BYTES, "row lists and the scan's candidate list live in the record area");
@@ -338,9 +340,10 @@ __global__ __launch_bounds__(256) void rows_zero_kernel(unsigned long long *__re
 // nothing to zero, 3 us).  An output tile's workgroup then tests all boxes (16 bytes each, L2-resident) and walks the rows of the few
 // source tiles whose box touches it.  Any flow is handled exactly: a box that covers everything just means more candidates.
 __global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restrict__ flow, SrcBox *__restrict__ box, int H, int W,
-                                                            int tiles_x, int tiles) {
+                                                            int tiles_x, int tiles, uint32_t *__restrict__ totals) {
     const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (t == 0 && tid < 8) totals[tid] = 0u;          // the deferred list of the tile kernel that follows (a kernel boundary makes the zeros visible)
     const int y = (tl / tiles_x) * TILE_H + wid, x = (tl % tiles_x) * TILE_W + lane;
     int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
     if (y < H && x < W) {
@@ -386,8 +389,9 @@ struct OpArgs { TileShared s; TileFrame f; };
 // appended to the deferred list.  PASSES = true: OP_DEFER_WG workgroups walk the deferred list pass by pass (normally it is empty).
 template <bool NORM, bool MAXOP, bool PASSES>
 __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kernel(OpArgs a) {
+    using Cfg = std::conditional_t<PASSES, OpPassCfg, OpCfg>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const TileLds<OpCfg> L(smem);
+    const TileLds<Cfg> L(smem);
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
@@ -399,13 +403,13 @@ __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kerne
         if (item >= f.totals[0]) return;
         const uint32_t nh = f.totals[5];                   // heavy items sit at the front of items[], the rest at its back
         const uint32_t at = item < nh ? item : f.items_cap - 1u - (item - nh);
-        const Piece p = make_piece<OpCfg>(s, f.items[at]);
-        if (!rows_piece_once<OpCfg, false, NORM, MAXOP, false>(s, f, L, p, tid, k, cb, ce) && tid == 0 && blockIdx.y == 0)
+        const Piece p = make_piece<Cfg>(s, f.items[at]);
+        if (!rows_piece_once<Cfg, false, NORM, MAXOP, false>(s, f, L, p, tid, k, cb, ce) && tid == 0 && blockIdx.y == 0)
             f.defer[atomicAdd(f.totals + 4, 1u)] = at;     // (one entry per piece: every channel group gets here)
     } else {
         const uint32_t ndef = f.totals[4];
         for (uint32_t q = blockIdx.x; q < ndef; q += gridDim.x)
-            rows_piece_passes<OpCfg, false, NORM, MAXOP, false>(s, f, L, make_piece<OpCfg>(s, f.items[f.defer[q]]), tid, k, cb, ce);
+            rows_piece_passes<Cfg, false, NORM, MAXOP, false>(s, f, L, make_piece<Cfg>(s, f.items[f.defer[q]]), tid, k, cb, ce);
         // the last workgroup to get here empties the deferred list for the plan's next use (prebinned calls share one plan)
         __syncthreads();
         if (tid == 0 && atomicAdd(f.totals + 6, 1u) == gridDim.x * gridDim.y - 1u) { f.totals[4] = 0u; f.totals[6] = 0u; }
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kerne
 // rows of the candidates are listed in LDS 32 candidates at a time (wave w = row w of each: coalesced 256-byte loads) and walked by
 // rows_walk.  Optimistic first: one LDS atomic per wave and row hands out the entry slots; a tile that turns out to hold more than SEG
 // entries is walked again in passes of SEG entries with reproducible ordinals (a count walk, then one emitting walk per pass).
-template <int MODE, bool EMIT>
-__device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const TileFrame &f, const TileLds<OpCfg> &L, Piece &p, int tid,
+template <class Cfg, int MODE, bool EMIT>
+__device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, Piece &p, int tid,
                                                  uint32_t wave_base, uint32_t lo, uint32_t hi) {
     uint32_t *cmask = reinterpret_cast<uint32_t *>(L.off);         // [64] candidate bits of a block of 2048 source tiles (off[] is free until phase 1b)
     uint32_t *clist = L.rl + 4 * ROW_CAP;                           // [2048] candidate source tiles of the block, in index order
@@ -470,54 +474,86 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
             }
             __syncthreads();
             p.len0 = p.n0 = n * TILE_H;
-            wcount += rows_walk<OpCfg, MODE, EMIT, false>(s, f, L, p, tid, wave_base + wcount, lo, hi);
+            wcount += rows_walk<Cfg, MODE, EMIT, false>(s, f, L, p, tid, wave_base + wcount, lo, hi);
             __syncthreads();
         }
     }
     return wcount;
 }
 
-template <bool NORM, bool MAXOP>
-__global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
+// DEFER = false: one workgroup per output tile.  A tile that turns out to hold more than SEG entries is not walked pass by pass by its
+// own workgroup (on a small grid the rest of the chip would idle behind it): it is appended to the deferred list with the number of
+// pieces it should be cut into (2, 4 or 8 equal column ranges: ~1.25 x its entries / SEG).
+// DEFER = true (grid: SCAN_DEFER_WG x channel groups x 8): the second, normally empty launch -- every deferred tile's pieces (x channel
+// groups) in parallel, every piece re-scanning the tile's candidates for its own columns; a piece that still holds more than SEG
+// entries is walked in passes with reproducible ordinals (a count walk, then one emitting walk per pass).
+// (Measured and rejected: the deferred pieces as TAIL blocks of the same launch, waiting on an arrival counter of the tile blocks --
+//  no second launch, but the sleeping tail blocks and the larger kernel cost more than the 5.6 us of an empty launch: config C2
+//  37 -> 49.5 us, and with few tail slots a smooth flow's heavy tiles queue up behind each other: 177 -> 883 us.)
+constexpr uint32_t SCAN_DEFER_WG = 16;
+template <bool NORM, bool MAXOP, bool DEFER>
+__global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
+    using Cfg = OpCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const TileLds<OpCfg> L(smem);
+    const TileLds<Cfg> L(smem);
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
     int cb, ce;
     if (!channel_group(s.C, cb, ce)) return;
-    const uint32_t t = xcd_item(blockIdx.x);
-    if (t >= (uint32_t)s.N * (uint32_t)s.tiles) return;
     const TileScalars k = tile_scalars(s, f);
-    ItemDesc it = {};
-    it.tile = t; it.nseg = 8;
-    Piece p = make_piece<OpCfg>(s, it);
-    L.cnt[tid] = 0;
-    if (tid == 0) L.misc[0] = 0;
-    __syncthreads();
-    scan_collect<1, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)OP_SEG);
-    const uint32_t total = L.misc[0];
-    const rsrc_t rin = sample_planes(s, p, k.hw4);
-    PixelSums sums = {0.0f, 0.0f, 0.0f};
-    if (total <= (uint32_t)OP_SEG) {
-        EntryRegs<OpCfg> e;
-        float preA[OpCfg::EPT][4], preB[OpCfg::EPT][4];
-        build_records<OpCfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
-        stream_planes<OpCfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
-        return;
-    }
-    uint32_t wb;
-    const uint32_t all = wave_bases<OpCfg>(L, tid, scan_collect<2, false>(s, f, L, p, tid, 0u, 0u, 0u), wb);
-    const uint32_t npass = (all + (uint32_t)OP_SEG - 1u) / (uint32_t)OP_SEG;
-    for (uint32_t si = 0; si < npass; ++si) {
+    const uint32_t ndef = DEFER ? f.totals[4] : 1u;
+    for (uint32_t q = DEFER ? blockIdx.x : 0u; q < ndef; q += gridDim.x) {
+        ItemDesc it = {};
+        if (DEFER) {
+            const uint32_t w = f.defer[q], np = w >> 28;              // pieces: 2, 4 or 8 column ranges of 4, 2 or 1 octants
+            if (blockIdx.z >= np) continue;
+            it.tile = w & 0x0fffffffu; it.nseg = 8u / np; it.seg = blockIdx.z * it.nseg;
+        } else {
+            it.tile = xcd_item(blockIdx.x); it.nseg = 8;
+            if (it.tile >= (uint32_t)s.N * (uint32_t)s.tiles) return;
+        }
+        Piece p = make_piece<Cfg>(s, it);
         __syncthreads();
         L.cnt[tid] = 0;
-        const uint32_t lo = si * (uint32_t)OP_SEG;
-        scan_collect<2, true>(s, f, L, p, tid, wb, lo, lo + (uint32_t)OP_SEG);
-        EntryRegs<OpCfg> e;
-        float preA[OpCfg::EPT][4], preB[OpCfg::EPT][4];
-        build_records<OpCfg, NORM, false>(s, L, p, tid, min((uint32_t)OP_SEG, all - lo), rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
-        stream_planes<OpCfg, NORM, MAXOP, false, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, si == 0, si + 1 == npass);
+        if (tid == 0) L.misc[0] = 0;
+        __syncthreads();
+        scan_collect<Cfg, 1, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)Cfg::SEG);
+        const uint32_t total = L.misc[0];
+        const rsrc_t rin = sample_planes(s, p, k.hw4);
+        PixelSums sums = {0.0f, 0.0f, 0.0f};
+        if (total <= (uint32_t)Cfg::SEG) {
+            EntryRegs<Cfg> e;
+            float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
+            build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+            stream_planes<Cfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
+            continue;
+        }
+        if constexpr (!DEFER) {
+            if (tid == 0 && blockIdx.y == 0) {             // (one entry per tile: every channel group gets here)
+                const uint32_t want = (total + total / 4u + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG;
+                f.defer[atomicAdd(f.totals + 4, 1u)] = it.tile | ((want <= 2u ? 2u : want <= 4u ? 4u : 8u) << 28);
+            }
+            return;
+        } else {
+            uint32_t wb;
+            const uint32_t all = wave_bases<Cfg>(L, tid, scan_collect<Cfg, 2, false>(s, f, L, p, tid, 0u, 0u, 0u), wb);
+            const uint32_t npass = (all + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG;
+            for (uint32_t si = 0; si < npass; ++si) {
+                __syncthreads();
+                L.cnt[tid] = 0;
+                const uint32_t lo = si * (uint32_t)Cfg::SEG;
+                scan_collect<Cfg, 2, true>(s, f, L, p, tid, wb, lo, lo + (uint32_t)Cfg::SEG);
+                EntryRegs<Cfg> e;
+                float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
+                build_records<Cfg, NORM, false>(s, L, p, tid, min((uint32_t)Cfg::SEG, all - lo), rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+                stream_planes<Cfg, NORM, MAXOP, false, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, si == 0, si + 1 == npass);
+            }
+        }
+    }
+    if (DEFER) {        // the last workgroup to get here empties the deferred list
+        __syncthreads();
+        if (tid == 0 && atomicAdd(f.totals + 6, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u) { f.totals[4] = 0u; f.totals[6] = 0u; }
     }
 }
 
@@ -652,22 +688,27 @@ static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
     // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass, their planes
     // dealt to up to 8 workgroups each (these run after everybody else, on an empty chip)
     const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > 8u ? 8u : (uint32_t)a.s.C / 8u;
-    hipLaunchKernelGGL((op_rows_kernel<NORM, MAXOP, true>), dim3(w.L.nt < OP_DEFER_WG ? w.L.nt : OP_DEFER_WG, wgroups), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((op_rows_kernel<NORM, MAXOP, true>), dim3(w.L.nt < OP_DEFER_WG ? w.L.nt : OP_DEFER_WG, wgroups), dim3(TT), OpPassCfg::LDS_BYTES, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }
 
 template <bool NORM, bool MAXOP>
 static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
-    static bool attr[64] = {};
-    if (int e = set_lds_attr(op_scan_kernel<NORM, MAXOP>, attr)) return e;
-    a.f.box = (const SrcBox *)w.box;
-    hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles);
+    static bool attr[64] = {}, attr_d[64] = {};
+    if (int e = set_lds_attr(op_scan_kernel<NORM, MAXOP, false>, attr)) return e;
+    if (int e = set_lds_attr(op_scan_kernel<NORM, MAXOP, true>, attr_d)) return e;
+    a.f.box = (const SrcBox *)w.box; a.f.totals = w.totals; a.f.defer = w.defer;
+    hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
     const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, channel_groups(w.L.nt, a.s.C)), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, false>), dim3(grid, channel_groups(w.L.nt, a.s.C)), dim3(TT), OpCfg::LDS_BYTES, st, a);
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
+    // tiles of more than SEG entries (appended by their workgroups): 2 - 8 column pieces each x channel groups, pass by pass where needed
+    // (256 workgroups: an empty launch of them costs 5.6 us of config C2's 37; 2048 cost 25)
+    const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > 2u ? 2u : (uint32_t)a.s.C / 8u;
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, true>), dim3(w.L.nt < SCAN_DEFER_WG ? w.L.nt : SCAN_DEFER_WG, wgroups, 8), dim3(TT), OpCfg::LDS_BYTES, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }

@@ -240,33 +240,58 @@ __device__ __forceinline__ void build_records(const TileShared &s, const TileLds
 // The record list of this work-item's output pixel for the gather: the first KREG records live in registers for the whole chunk
 // loop (missing ones are the NULL record: all-zero slot, weight 0 -- fma(0, 0, acc) == acc, the gather has no selects); what is left
 // of a list far longer than the wave's average (a "sink" pixel) is walked by the whole wave, lane-strided, and wave-reduced.
+// A NARROW piece (<= 32 output columns: a cut of a ridge tile, 750 entries piled onto 64 pixels, lists of 150 records) keeps the tile's
+// shape -- wave w = output row w -- and gives every output pixel G = 2, 4 or 8 lanes (32, 16, 8 columns): lane g of a pixel takes
+// records g, g + G, ... of its list and the G partial sums are added up through log2(G) cross-lane steps.  One lane per pixel
+// walked such lists for 170-250 us while the rest of its wave sat idle; with G lanes the longest workgroup of Euler t=59 takes 81.
 template <class Cfg>
 struct PixelList {
-    uint32_t r0, rl, r1;           // own records [r0, rl), cooperative rest [rl, r1)
+    uint32_t r0, rl, r1;           // own records r0, r0 + G, ... < rl; cooperative rest [rl, r1)
     unsigned long long heavy;      // lanes of this wave whose rest the wave walks together
+    int g_log;                     // log2 of the lanes per output pixel
+    int pid;                       // the output pixel (index in the piece's 8 x 64 frame) this work-item serves
     uint32_t ce[Cfg::KREG];
     float cw[Cfg::KREG];
 };
 
+__device__ __forceinline__ int lane_group_log(const Piece &p) {
+    const int pw = p.pcb - p.pca;
+    return !SLR_ROWS_GROUP ? 0 : pw <= 8 ? 3 : pw <= 16 ? 2 : (pw <= 32 && SLR_ROWS_GROUP > 1) ? 1 : 0;
+}
+
 template <class Cfg>
-__device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int tid) {
+__device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int tid, int g_log) {
     PixelList<Cfg> g;
-    g.r0 = L.off[tid];
-    g.r1 = g.r0 + L.cnt[tid];
-    uint32_t wave_recs = g.r1 - g.r0;                  // records of this wave's 64 output pixels
+    g.g_log = g_log;
+    g.pid = (tid & ~63) | ((tid & 63) >> g_log);
+    const uint32_t first = L.off[g.pid];
+    g.r0 = first + ((uint32_t)tid & ((1u << g_log) - 1u));
+    g.r1 = first + L.cnt[g.pid];
+    uint32_t wave_recs = g.r1 - first;                 // records of this wave's output pixels (x G with lane groups: they walk their own)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) wave_recs += __shfl_xor(wave_recs, d);
     // own share: twice the wave's average list length (a uniformly compressed region stays per-lane), at least SLR_LMAX; what is left
     // of a longer list goes to the whole wave once it exceeds SLR_HEAVY_SLACK records (a cooperative pass costs ~50 cross-lane
     // operations per chunk, a lane walking alone ~10 per record while the other 63 wait)
     const uint32_t own = max((uint32_t)SLR_LMAX, 2u * ((wave_recs + 63u) >> 6));
-    g.rl = (g.r1 - g.r0 >= own + (uint32_t)SLR_HEAVY_SLACK) ? g.r0 + own : g.r1;
+    g.rl = (g.r1 - first >= own + (uint32_t)SLR_HEAVY_SLACK) ? first + own : g.r1;
     g.heavy = __ballot(g.r1 > g.rl);
-    // (the cooperative passes run one after the other; with many long lists in one wave every lane walks its own)
-    if (__popcll(g.heavy) > SLR_HEAVY_MAX) { g.rl = g.r1; g.heavy = 0ull; }
+    // (the cooperative passes run one after the other; with many long lists in one wave -- or lane groups -- every lane walks its own)
+    if (__popcll(g.heavy) > SLR_HEAVY_MAX || g_log) { g.rl = g.r1; g.heavy = 0ull; }
 #pragma unroll
-    for (int k = 0; k < Cfg::KREG; ++k) L.rec_get(g.r0 + (uint32_t)k < g.rl ? g.r0 + (uint32_t)k : Cfg::NULLREC, g.ce[k], g.cw[k]);
+    for (int k = 0; k < Cfg::KREG; ++k) {
+        const uint32_t r = g.r0 + ((uint32_t)k << g_log);
+        L.rec_get(r < g.rl ? r : Cfg::NULLREC, g.ce[k], g.cw[k]);
+    }
     return g;
+}
+
+template <bool MAXOP>
+__device__ __forceinline__ float group_reduce(float v, int g_log) {    // the G lanes of a pixel add up (every one of them ends up with the sum)
+    if (g_log >= 3) { const float o = __shfl_xor(v, 4); v = MAXOP ? fmaxf(v, o) : v + o; }
+    if (g_log >= 2) { const float o = __shfl_xor(v, 2); v = MAXOP ? fmaxf(v, o) : v + o; }
+    if (g_log >= 1) { const float o = __shfl_xor(v, 1); v = MAXOP ? fmaxf(v, o) : v + o; }
+    return v;
 }
 
 template <bool MAXOP>
@@ -299,11 +324,11 @@ __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelL
         for (int k = 0; k < KREG; ++k) accum4<MAXOP>(acc, v[k], g.cw[k], g.ce[k] != Cfg::NULL_E);
     }
     between(2);
-    for (uint32_t r = g.r0 + (uint32_t)KREG; r < g.rl; r += RB) {
+    for (uint32_t r = g.r0 + ((uint32_t)KREG << g.g_log); r < g.rl; r += (uint32_t)RB << g.g_log) {
         uint32_t e[RB];
         float w[RB];
 #pragma unroll
-        for (int k = 0; k < RB; ++k) L.rec_get(r + (uint32_t)k < g.rl ? r + (uint32_t)k : Cfg::NULLREC, e[k], w[k]);
+        for (int k = 0; k < RB; ++k) { const uint32_t q = r + ((uint32_t)k << g.g_log); L.rec_get(q < g.rl ? q : Cfg::NULLREC, e[k], w[k]); }
         float4 v[RB];
 #pragma unroll
         for (int k = 0; k < RB; ++k) v[k] = L.val4[e[k]];
@@ -331,13 +356,18 @@ __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelL
             if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], t) : acc[u] + t;
         }
     }
+    if (g.g_log) {                                     // (uniform)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = group_reduce<MAXOP>(acc[u], g.g_log);
+    }
 }
 
 // sum of the pixel's record weights (the normaliser when the weights carry m)
 template <class Cfg>
 __device__ __forceinline__ float weight_sum(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane) {
     float nrm = 0.0f;
-    for (uint32_t r = g.r0; r < g.rl; ++r) nrm += L.rec_weight(r);
+    for (uint32_t r = g.r0; r < g.rl; r += 1u << g.g_log) nrm += L.rec_weight(r);
+    if (g.g_log) nrm = group_reduce<false>(nrm, g.g_log);
     for (unsigned long long hv = g.heavy; hv; hv &= hv - 1) {
         const int src = __ffsll((long long)hv) - 1;
         const uint32_t hb = __shfl(g.rl, src), he = __shfl(g.r1, src);
@@ -361,10 +391,10 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
                                               float (&preA)[Cfg::EPT][4], float (&preB)[Cfg::EPT][4], PixelSums &sums, bool first, bool last) {
     constexpr int EPT = Cfg::EPT;
     const int lane = tid & 63;
-    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid);
-    const int ly = tid / TILE_W, lx = p.pca + tid - ly * TILE_W;
+    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid, lane_group_log(p));
+    const int ly = g.pid / TILE_W, lx = p.pca + g.pid - ly * TILE_W;
     const int oy = p.ty0 + ly, ox = p.tx0 + lx;
-    const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb);
+    const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb) & ((tid & ((1 << g.g_log) - 1)) == 0);      // (the first lane of a pixel's group stores)
     const uint32_t opix = (uint32_t)(oy * s.W + ox);
     const uint32_t voff = inside ? opix * 4u : BUF_OOB;                   // (work-items outside the image / the piece: stores dropped)
     const size_t hw = (size_t)s.H * s.W;

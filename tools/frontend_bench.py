@@ -35,7 +35,7 @@ def graph_us(fn, reps=20, iters=10):
 
 def measure(tag, x, fl, met, mode, alg):
     row = []
-    for fe, code in (("bins", 0), ("scan", 1), ("rows", 2)):
+    for fe, code in (("scan", 1), ("rows", 2)):
         prev = L.slr_splat_set_front_end(code)
         f = lambda: S.FunctionSoftsplat(x, fl, met, mode)
         synthesis.kernel_timing = []
