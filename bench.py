@@ -7,7 +7,7 @@ Workload: config C3 of BASELINE.json -- the full baseline pipeline
           64 features (both directions) + normalisation -> partial-conv decoder -> tanh]
           on a synthetic 768x1280 image + smooth motion field, random-init weights of the
           reference architecture, fp32.  (--workload c4: the 2-layer SLR v1 pipeline.)
-A step  : ONE 60-frame clip, everything included (both all-frames Euler passes, binning + planning of
+A step  : ONE 60-frame clip, everything included (both all-frames Euler passes, row lists + plan of
           all 120 displacement maps, encoder, 60 x (fused splat + decoder)), frames sharded round-robin
           over the ranks and assembled with ONE RCCL all-gather of the finished clip (the form north_star
           names: --assembly final --encoder redundant, the default) -> "scaling": "strong" (total work fixed).
@@ -24,13 +24,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                  with HIP events on its launch stream inside the timed steps.
                  algorithmic bytes per launch = 2 * (2*65+2)*H*W*4 = 1038.1 MB at C3
                  (B_sum per reference splat call x the 2 calls of one frame).
-                 stage_us / stage_frac: the WHOLE splat stage per frame inside the same steps -- the tile kernel,
-                 combine, and the per-clip motion work (Euler passes, binning, planning) divided by the frames.
+                 stage_us / stage_frac: the WHOLE splat stage per frame inside the same steps -- the tile kernel, the
+                 (normally empty) pass-by-pass launch, and the per-clip motion work (Euler passes, row lists, plan)
+                 divided by the frames.  traffic: static_traffic() -- PMC passes kept under profiles/.
   parity_err   : decoder input of one frame of the TIMED clip against the CPU oracle, and the fused kernel on the
                  seeded 768x1280 inputs against digests of the reference's own forward_flow (outside the timed region).
   cpu_baseline : the CPU oracle (oracle/, OpenMP over planes) on this box's host cores, same
                  hot path (Euler + 2 x 65-plane splat + normalise) on a sample of frames; plus one thread.
-  roofline_dropin / roofline_conv / c4 / fps_fp32_convs : context measured after the timed region (N = 1 only).
+  roofline_dropin / roofline_backward / roofline_conv / roofline_conv_fp32 / c4 / fps_fp32_convs : context measured after the timed
+                 region (N = 1 only).
 """
 import argparse
 import json
@@ -47,15 +49,34 @@ sys.path.insert(0, ROOT)
 
 H, W, NFRAMES = 768, 1280, 60
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = "r4_splat_traffic.json"     # PMC passes (tools/pmc_traffic.sh + tools/pmc_traffic.py) of the fused kernel; carries the
-                                           # hash of the kernel sources it was taken on (a figure from another build is labelled stale)
+TRAFFIC_ROUND = "r4"            # profiles/r4_traffic_<name>.json: PMC passes (tools/collect_profiles.sh -> tools/pmc_kernel_traffic.py) of one
+                                # kernel each; every file carries the hash of the kernel sources it was taken on
+
+
+def static_traffic(name, units):
+    """(HBM-side bytes of one launch doing `units` units of work, where the figure comes from) out of profiles/rN_traffic_<name>.json --
+    FETCH_SIZE x 2 + WRITE_SIZE per dispatch of that kernel, measured under rocprofv3 --pmc in separate passes, NOT in this run; a
+    figure taken on other kernel sources is labelled stale.  (None, None) without the file."""
+    rel = f"profiles/{TRAFFIC_ROUND}_traffic_{name}.json"
+    tf = os.path.join(ROOT, rel)
+    if not os.path.exists(tf):
+        return None, None
+    tj = json.load(open(tf))
+    if "traffic_bytes_per_unit" not in tj:
+        return None, None
+    same = tj.get("source_sha16") == csrc_hash()
+    src = (f"static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of {rel} per unit of work x the units of this launch, not measured in "
+           "this run; " + ("taken on these kernel sources" if same else
+                           "STALE: taken on other kernel sources (re-run tools/collect_profiles.sh)"))
+    return round(tj["traffic_bytes_per_unit"] * units), src
 
 
 def csrc_hash():
     """sha256 (first 16 hex digits) over the sources of the splat kernels (the files the fused tile kernel is built from)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("slr_common.hpp", "slr_tuning.hpp", "splat_types.hpp", "splat_core.hpp", "splat_clip.hip"):
+    for name in ("slr_common.hpp", "slr_tuning.hpp", "splat_types.hpp", "splat_core.hpp", "splat_tile.hpp", "splat_rows.hpp", "splat_ws.hpp",
+                 "splat_clip.hip", "splat_op.hip", "grad.hip"):
         h.update(name.encode())
         h.update(open(os.path.join(ROOT, "slr-sfs_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
@@ -141,15 +162,7 @@ def splat_roofline(kev, sev, c_splat, kernel):
     stage_us = (sum(us for us, _ in frames) + sum(prep)) / max(1, sum(nf for _, nf in frames))
     # the fused operator's own minimum traffic: 64 feature planes + Z + 2 x 2 displacement planes in, 64 planes out
     min_bytes = (c_splat - 1 + 1 + 4 + c_splat - 1) * H * W * 4
-    traffic, src = None, None
-    tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if c_splat == 65 and os.path.exists(tf):
-        tj = json.load(open(tf))
-        traffic = round(tj["traffic_bytes_per_launch"] * fpl)
-        same = tj.get("source_sha16") == csrc_hash()
-        src = (f"static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of profiles/{TRAFFIC_FILE} (per frame of work) x "
-               "frames_per_launch, not measured in this run; " +
-               ("taken on these kernel sources" if same else "STALE: taken on other kernel sources (re-run tools/pmc_traffic.sh)"))
+    traffic, src = static_traffic("clip_c3" if c_splat == 65 else "clip_c4", fpl)
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "alg_bytes_per_launch": round(alg * fpl), "frames_per_launch": round(fpl, 2), "launch_avg_us": round(l_avg, 1),
@@ -160,7 +173,7 @@ def splat_roofline(kev, sev, c_splat, kernel):
             "stage_us": round(stage_us, 1), "stage_frac": round(alg / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "stage_prep_us_per_clip": round(sum(prep) / max(1, len(prep)), 1),
             "stage": "per frame: fused tile kernel + the (normally empty) pass-by-pass launch; per clip / frames: both "
-                     "all-frames Euler passes + binning and planning of all displacement maps"}
+                     "all-frames Euler passes + row lists and plan of all displacement maps"}
 
 
 def main():
@@ -404,7 +417,7 @@ def context_measurements(workload, image, motion, dev):
     import slr_sfs_amd as S
     from slr_sfs_amd import pipeline, synthesis
     out = {}
-    # ---- splat stage alone (no networks): per clip Euler + bin + plan, per frame fused splat (+ combine)
+    # ---- splat stage alone (no networks): per clip Euler + row lists + plan, per frame the fused clip kernel
     fs = torch.randn(1, 64, H, W, device=dev)
     Z = torch.randn(1, 1, H, W, device=dev)
     best = 0.0
@@ -423,6 +436,7 @@ def context_measurements(workload, image, motion, dev):
     del g, cs
     out["roofline_dropin"] = dropin_roofline(dev, motion)
     out["roofline_conv"] = conv_roofline(dev)
+    out["roofline_backward"] = backward_roofline(dev, motion)
     # ---- the other pipeline of BASELINE.json (C4 when C3 is timed and vice versa), one warm-up + two clips
     other = "c4" if workload == "c3" else "c3"
     torch.manual_seed(0)
@@ -502,18 +516,20 @@ def dropin_roofline(dev, motion):
     """The operator the reference scripts reach unchanged -- ModuleSoftsplat('summation') / _FunctionSoftsplat
     (softsplat.py:157-202, 390-424): one flow, C = 65 planes, 768x1280, on Euler-integrated flows; algorithmic bytes
     B_sum = (2C+2)*H*W*4 = 519.0 MB per call.  `tile` = the tile kernel alone (events recorded by the library around that
-    launch), `call` = GPU time of EVERYTHING the call launches (front end + tile kernel + combine), measured by replaying a
+    launch), `call` = GPU time of EVERYTHING the call launches (front end + tile kernel + the pass-by-pass launch), measured by replaying a
     HIP graph of 20 calls; `call_eager_us` = the same call issued from Python with an event pair per call (host launch pace
     included).  Plus config C2 of BASELINE.json as stated (64 channels, 256x480, softmax mode, incoherent and smooth
     flow) and two more small grids.  `front_end` names what a call takes by default (include/slr_splat.h:
-    slr_splat_set_front_end: scan up to 1024 tiles, rows above); the other front ends are timed beside it."""
+    slr_splat_set_front_end: scan up to 1024 tiles, rows above); the other front end is timed beside it.  `traffic` (tile kernel, Euler
+    flows and C2): static_traffic()."""
     import slr_sfs_amd as S
     from slr_sfs_amd import synthesis
     L = S._lib.lib()
     C = 65
     x = torch.randn(1, C, H, W, device=dev)
     alg = (2 * C + 2) * H * W * 4
-    res = {"bound": "hbm", "kernel": "slr::splat_tile_kernel<false,false,2,4,false,FE>, FE = 2 rows (default at 1920 tiles) / 0 bins / 1 scan", "peak": HBM_PEAK_GBS,
+    res = {"bound": "hbm", "kernel": "slr::op_rows_kernel<false,false,false> (rows front end, the default at 1920 tiles); scan_front_end: "
+                                     "slr::op_scan_kernel<false,false,false>", "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "alg_bytes_per_call": alg, "flows": {},
            "call": "GPU time of all launches of one call (HIP graph of 20 calls replayed); call_eager_us: Python call, event pair per call"}
 
@@ -545,11 +561,12 @@ def dropin_roofline(dev, motion):
              ("identity", torch.zeros(1, 2, H, W, device=dev)), ("incoherent", torch.rand(1, 2, H, W, device=dev) * 16 - 8)]
     for name, flow in flows:
         r = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
-        r["front_end"] = "rows"                            # 1920 tiles > the scan threshold (1024): zero + rows/plan + tile kernel (+ deferred pieces)
-        for fe_name, fe in (("bins", 0), ("scan", 1)):
-            prev = L.slr_splat_set_front_end(fe)
-            r[fe_name + "_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
-            L.slr_splat_set_front_end(prev)
+        r["front_end"] = "rows"                            # 1920 tiles > the scan threshold (1024): rowbin (+ plan) -> tile kernel -> deferred pieces
+        if name.startswith("euler"):
+            r["traffic"], r["traffic_source"] = static_traffic("op_rows_" + name[6:], 1)
+        prev = L.slr_splat_set_front_end(1)
+        r["scan_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
+        L.slr_splat_set_front_end(prev)
         res["flows"][name] = r
         if name.startswith("euler") and (worst is None or r["tile_frac"] < worst["tile_frac"]):
             worst = r
@@ -566,18 +583,47 @@ def dropin_roofline(dev, motion):
         for fname, fl2 in cases.items():
             r = measure(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), alg2, tile=False)
             r.update({"workload": f"FunctionSoftsplat softmax, {c2} ch, {h2}x{w2}, {fname} flow", "alg_bytes": alg2,
-                      "front_end": "scan (box kernel + tile kernel: 2 launches)"})
-            for fe_name, fe in (("bins", 0), ("rows", 2)):
-                prev = L.slr_splat_set_front_end(fe)
-                try:
-                    r[fe_name + "_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
-                except Exception:
-                    r[fe_name + "_front_end_call_us"] = round(_time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 20)[0], 1)
-                L.slr_splat_set_front_end(prev)
+                      "front_end": "scan (box kernel + tile kernel + the pass-by-pass launch)"})
+            prev = L.slr_splat_set_front_end(2)
+            try:
+                r["rows_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
+            except Exception:
+                r["rows_front_end_call_us"] = round(_time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 20)[0], 1)
+            L.slr_splat_set_front_end(prev)
             small[tag if fname == "incoherent" else f"{tag}_{fname}"] = r
     res["c2"] = small.pop("c2")
     res["c2"]["workload"] = "C2: " + res["c2"]["workload"] + " U(-8,8)"
+    res["c2"]["traffic"], res["c2"]["traffic_source"] = static_traffic("op_scan_c2", 1)
     res["small_grids"] = small
+    return res
+
+
+@torch.no_grad()
+def backward_roofline(dev, motion):
+    """The reference's backward kernels (softsplat.py:204-326) as ONE gather kernel, 65 planes at 768x1280 on Euler-integrated flows:
+    gradInput + gradFlow in one launch; algorithmic bytes = gradOutput + input read, gradInput written = 3*C*H*W*4 (+ flow, gradFlow).
+    avg_us: the one launch of a call, 20 calls captured into a HIP graph and replayed (event pair around the replay); eager_us: event pair
+    around each Python call."""
+    import slr_sfs_amd as S
+    from slr_sfs_amd._lib import check, lib, ptr, stream_of
+    L = lib()
+    C = 65
+    x, go = torch.randn(1, C, H, W, device=dev), torch.randn(1, C, H, W, device=dev)
+    gi, gf = torch.empty_like(x), torch.empty(1, 2, H, W, device=dev)
+    alg = (3 * C + 4) * H * W * 4
+    res = {"bound": "hbm", "kernel": "slr::grad_tile_kernel<true,true> (gradInput + gradFlow, one launch)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "alg_bytes_per_launch": alg, "flows": {}}
+    for name, t in (("euler_t30", 30), ("euler_t59", 59), ("identity", 0)):
+        fl = S.euler_integration(motion, t)[0] if t else torch.zeros(1, 2, H, W, device=dev)
+        # (the library launches on the stream it is handed: inside _graph_call_us that is the capturing stream)
+        call = lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), 1, C, H, W, stream_of(x)), "backward")
+        eager, _ = _time_calls(call, 20)
+        avg = _graph_call_us(call)
+        r = {"avg_us": round(avg, 1), "eager_us": round(eager, 1), "achieved": round(alg / avg / 1e3, 1), "frac": round(alg / avg / 1e3 / HBM_PEAK_GBS, 4)}
+        if name == "euler_t30":
+            r["traffic"], r["traffic_source"] = static_traffic("grad_t30", 1)
+            res.update({"achieved": r["achieved"], "frac": r["frac"], "avg_us": r["avg_us"], "traffic": r["traffic"]})
+        res["flows"][name] = r
     return res
 
 

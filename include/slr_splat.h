@@ -122,6 +122,9 @@ int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, i
  * rounding, ~1e-6 relative).  (ABI <= 5 had a third front end, per-pixel bins with partial tiles and a combine pass: gone.) */
 int slr_splat_set_scan_max_tiles(int max_tiles);
 int slr_splat_set_front_end(int front_end);
+/* Tuning of the scan front end (process-wide, 0 = the built-in choice by grid size): column pieces per output tile in the first launch
+ * (1, 2, 4 or 8) x channel groups per piece; workgroups x channel groups of the pass-by-pass launch. */
+void slr_splat_set_scan_shape(int pieces, int groups, int defer_wg, int defer_groups);
 
 /* ------------------------------------------------------------------ splat: forward */
 

@@ -16,6 +16,7 @@ SYMBOLS = (
     "slr_euler_integrate", "slr_euler_integrate_all", "slr_euler_backward",
     "slr_splat_workspace_bytes", "slr_splat_workspace_init", "slr_splat_bin", "slr_splat_bin_pair", "slr_splat_set_scan_max_tiles",
     "slr_splat_set_front_end",
+    "slr_splat_set_scan_shape",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
     "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
@@ -62,6 +63,8 @@ def lib():
         L.slr_splat_set_scan_max_tiles.argtypes = [i]
         L.slr_splat_set_front_end.restype = i
         L.slr_splat_set_front_end.argtypes = [i]
+        L.slr_splat_set_scan_shape.restype = None
+        L.slr_splat_set_scan_shape.argtypes = [i, i, i, i]
         L.slr_splat_workspace_bytes.restype = sz
         L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
         L.slr_clip_plan_bytes.restype = sz

@@ -2,7 +2,9 @@
 // maximum-warp-norm splat.  All pure gathers: one work-item per source PIXEL, the flow and the
 // four corner weights are computed once and reused for every channel (the reference recomputes
 // them per element / per thread, models/softsplat.py:204-326, 84-155).
-#include "slr_common.hpp"
+#include "splat_core.hpp"
+
+#include <type_traits>
 
 namespace slr {
 
@@ -103,18 +105,33 @@ __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in,
 // gradInput 119 -> 129, both 165 -> 195 (the direct path carried this kernel's registers: 96 VGPRs).  Round 3, later: each path a
 // loop of its own and the direct gathers double-buffered in registers (next pass in flight under this pass's sums and stores):
 // 82 VGPRs; both gradients identity 188 -> 181 us, Euler t=30 217-222 -> 212-217, gradInput t=59 285 -> 260.
+// Round 4: passes whose U channels all exist store unconditionally (the tail pass is code of its own: counted waits inside both loops),
+// stores through a buffer descriptor, box 2048 -> 4096 floats per channel: both gradients identity 181 -> 165-171 us, Euler t=30
+// 214-219 -> 190-197 (0.50-0.52 of 8 TB/s), t=59 300-320 -> 248-255; gradInput alone t=30 178-190 -> 161-168, t=59 255-274 -> 217-226.
 constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
 #ifndef SLR_GRAD_BOX
-#define SLR_GRAD_BOX 2048                              // floats of LDS per channel (e.g. 20 rows x 100 columns); x U channels x 4 bytes = 32 KiB
-#endif
+#define SLR_GRAD_BOX 4096                              // floats of LDS per channel (e.g. 32 rows x 128 columns); x U channels x 4 bytes = 64 KiB: two workgroups
+#endif                                                 // per CU.  Round 4 (both gradients, identity / Euler t=30 / t=59): 2048: 169 / 201 / 290 us,
+                                                       // 3072: 169 / 196 / 271, 4096: 165-171 / 190-197 / 248-255, 5120 (40 staging registers): 184 / 253 / 279;
+                                                       // 2 channels per pass at 4096 / 6144 / 8192 / 10240: 170 / 189 / 274, 172 / 213 / 258, 171 / 253 / 273, 213 / 365 / 368
 #ifndef SLR_GRAD_TU
-#define SLR_GRAD_TU 4                                  // channels per pass of the tiled kernel (4 / 8 / 16 at box 2048 / 1536 / 1024: Euler t=30,
+#define SLR_GRAD_TU 4                                  // channels per pass of the tiled kernel (round 3, 4 / 8 / 16 at box 2048 / 1536 / 1024: Euler t=30,
 #endif                                                 // both gradients, 223 / 245 / 301 us; grad_kernel: 279)
 #ifndef SLR_GRAD_BENT
 #define SLR_GRAD_BENT 2                                // stage through LDS only where a wave's destinations spread over more rows than this
 #endif
 #ifndef SLR_GRAD_WAVES
 #define SLR_GRAD_WAVES 4                               // __launch_bounds__ waves per SIMD of the tiled kernel
+#endif
+#ifndef SLR_GRAD_BUF_LD
+#define SLR_GRAD_BUF_LD 0                              // 1: plane loads through buffer descriptors (plane offset in an SGPR, no 64-bit vector address sums).
+#endif                                                 // Measured SLOWER for these gathers although the loop then has ~25 % fewer VALU instructions: both gradients
+                                                       // identity / t=30 / t=59 169 / 204 / 310 us with global loads, 167 / 218 / 352 with buffer loads (box 2048)
+#ifndef SLR_GRAD_BUF_ST
+#define SLR_GRAD_BUF_ST 1                              // gradInput stores through a buffer descriptor (out-of-image work-items dropped by the range check, no
+#endif                                                 // exec-mask juggling around the stores): gradInput alone t=30 192 -> 176 us, t=59 295 -> 264; both: 204 -> 208 / 310 -> 297
+#ifndef SLR_GRAD_ENTRY_ST
+#define SLR_GRAD_ENTRY_ST 0                            // U dropped stores before the staged loop (the loop header then merges two equal wait states): no change
 #endif
 constexpr int GT_BOX = SLR_GRAD_BOX;
 
@@ -168,45 +185,60 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     const int g0 = k0 ? o : i, g1 = k1 ? o + 1 : i, g2 = k2 ? o + W : i, g3 = k3 ? o + W + 1 : i;
     const int lo = (c.y0 - by0) * bw + (c.x0 - bx0);
     const int l0 = k0 ? lo : 0, l1 = k1 ? lo + 1 : 0, l2 = k2 ? lo + bw : 0, l3 = k3 ? lo + bw + 1 : 0;
-    const float *ip = in + (size_t)n * C * HW;
-    const float *gp = gout + (size_t)n * C * HW;
+    // The gradInput stores go through a buffer descriptor (plane offset in an SGPR, one 32-bit pixel offset; work-items outside the image
+    // are dropped by its range check); the loads stay global loads (SLR_GRAD_BUF_LD above: the same gathers through a descriptor are slower).
+    const uint32_t hw4 = (uint32_t)HW * 4u;
+    const rsrc_t rg = make_rsrc(gout + (size_t)n * C * HW, (uint32_t)C * hw4);
+    const rsrc_t ri = make_rsrc(GFLOW ? in + (size_t)n * C * HW : gout, (uint32_t)C * hw4);
+    const rsrc_t ro = make_rsrc(GIN ? gin + (size_t)n * C * HW : gflow, GIN ? (uint32_t)C * hw4 : 0u);
+    const uint32_t vi = (uint32_t)i * 4u, vst = live_px ? vi : BUF_OOB;
+    const float *gp = gout + (size_t)n * C * HW, *ip = in + (size_t)n * C * HW;
     float *op = gin + (size_t)n * C * HW;
+    auto ld_g = [&](int plane, uint32_t voff) { return SLR_GRAD_BUF_LD ? buf_ld(rg, voff, (uint32_t)plane * hw4) : gp[(size_t)plane * HW + (voff >> 2)]; };
+    auto ld_i = [&](int plane, uint32_t voff) { return SLR_GRAD_BUF_LD ? buf_ld(ri, voff, (uint32_t)plane * hw4) : ip[(size_t)plane * HW + (voff >> 2)]; };
+    auto st_o = [&](int plane, float g) {
+        if (SLR_GRAD_BUF_ST) buf_st(ro, vst, (uint32_t)plane * hw4, g);
+        else if (live_px) op[(size_t)plane * HW + i] = g;
+    };
     float gx = 0.0f, gy = 0.0f;
     // staged path: the box is walked as ONE linear index range (dense wave loads across row ends); the values of the NEXT
     // pass are loaded into registers while this pass is gathered from LDS, and written to LDS after the barrier
     constexpr int NS = (GT_BOX + GT_THREADS - 1) / GT_THREADS;
     const int nbox = bw * bh;
-    int soff[NS];                                                  // global offset of this work-item's k-th box element
+    uint32_t soff[NS];                                             // byte offset of this work-item's k-th box element inside a plane
     const float inv_bw = 1.0f / (float)(bw > 0 ? bw : 1);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int idx = tid + k * GT_THREADS;
         const int r = (int)(((float)idx + 0.5f) * inv_bw);         // idx / bw, exact for idx < 2^22
-        soff[k] = (staged && idx < nbox) ? (by0 + r) * W + bx0 + (idx - r * bw) : 0;
+        soff[k] = (staged && idx < nbox) ? (uint32_t)((by0 + r) * W + bx0 + (idx - r * bw)) * 4u : 0u;
     }
     float sv[NS][U];
     auto issue = [&](int ch) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float *pl = gp + (size_t)min(ch + u, C - 1) * HW;
+            const int pl = min(ch + u, C - 1);
 #pragma unroll
-            for (int k = 0; k < NS; ++k) sv[k][u] = pl[soff[k]];
+            for (int k = 0; k < NS; ++k) sv[k][u] = ld_g(pl, soff[k]);
         }
     };
-    // one pass of U channels: the reference's terms in the reference's order (bit-identical on either path)
-    auto finish = [&](int ch, const float (&a0)[U], const float (&a1)[U], const float (&a2)[U], const float (&a3)[U], const float (&v)[U]) {
+    // one pass of U channels: the reference's terms in the reference's order (bit-identical on either path).  FULL: all U channels
+    // exist -- every store of the pass is unconditional (counted waits in the loop); the last pass of a channel count that is not a
+    // multiple of U branches around the missing ones.
+    auto finish = [&](auto full_tag, int ch, const float (&a0)[U], const float (&a1)[U], const float (&a2)[U], const float (&a3)[U], const float (&v)[U]) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool live = (ch + u < C) & live_px;
+            if (!FULL && ch + u >= C) continue;                    // (scalar)
             if (GIN) {
                 float g = 0.0f;
                 g += k0 ? a0[u] * c.w[0] : 0.0f;
                 g += k1 ? a1[u] * c.w[1] : 0.0f;
                 g += k2 ? a2[u] * c.w[2] : 0.0f;
                 g += k3 ? a3[u] * c.w[3] : 0.0f;
-                if (live) op[(size_t)(ch + u) * HW + i] = g;
+                st_o(ch + u, g);
             }
-            if (GFLOW && live) {
+            if (GFLOW) {                                           // (work-items outside the image: k0..k3 are false, +0.0 everywhere)
                 const float t0 = v[u] * a0[u], t1 = v[u] * a1[u], t2 = v[u] * a2[u], t3 = v[u] * a3[u];
                 gx += k0 ? t0 * dx[0] : 0.0f; gy += k0 ? t0 * dy[0] : 0.0f;
                 gx += k1 ? t1 * dx[1] : 0.0f; gy += k1 ? t1 * dy[1] : 0.0f;
@@ -216,8 +248,8 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
         }
     };
     if (staged) {                                                  // (workgroup-uniform: each path is a loop of its own)
-        issue(0);
-        for (int ch = 0; ch < C; ch += U) {
+        const uint32_t b0 = (uint32_t)l0, b1 = (uint32_t)l1, b2 = (uint32_t)l2, b3 = (uint32_t)l3;
+        auto pass = [&](auto full_tag, int ch) {
             float a0[U], a1[U], a2[U], a3[U], v[U];
             __syncthreads();                                       // the previous pass has been gathered
 #pragma unroll
@@ -229,33 +261,45 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (GFLOW) v[u] = ip[(size_t)min(ch + u, C - 1) * HW + i];
+                if (GFLOW) v[u] = ld_i(min(ch + u, C - 1), vi);
             __syncthreads();
-            if (ch + U < C) issue(ch + U);                         // in flight under this pass's gathers, sums and stores
+            issue(ch + U);                                         // in flight under this pass's gathers, sums and stores (past the last
+                                                                   // channel: re-reads channel C - 1, unused)
 #pragma unroll
-            for (int u = 0; u < U; ++u) { a0[u] = box[u][l0]; a1[u] = box[u][l1]; a2[u] = box[u][l2]; a3[u] = box[u][l3]; }
-            finish(ch, a0, a1, a2, a3, v);
-        }
+            for (int u = 0; u < U; ++u) { a0[u] = box[u][b0]; a1[u] = box[u][b1]; a2[u] = box[u][b2]; a3[u] = box[u][b3]; }
+            finish(full_tag, ch, a0, a1, a2, a3, v);
+        };
+        issue(0);
+        if (SLR_GRAD_ENTRY_ST && GIN)
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf_st(ro, BUF_OOB, 0u, 0.0f);
+        int ch = 0;
+        for (; ch + U <= C; ch += U) pass(std::true_type{}, ch);
+        if (ch < C) pass(std::false_type{}, ch);
     } else {
-        // direct gathers, two register sets: the loads of the NEXT pass are issued before this pass's sums and stores (they used
-        // to be issued and waited for inside the same pass: one exposed memory round trip per pass of U channels)
+        // direct gathers, two register sets: the loads of the NEXT pass are issued before this pass's sums and stores
+        const uint32_t v0 = (uint32_t)g0 * 4u, v1 = (uint32_t)g1 * 4u, v2 = (uint32_t)g2 * 4u, v3 = (uint32_t)g3 * 4u;
         float p0[U], p1[U], p2[U], p3[U], pv[U], q0[U], q1[U], q2[U], q3[U], qv[U];
         auto load = [&](int ch, float (&a0)[U], float (&a1)[U], float (&a2)[U], float (&a3)[U], float (&v)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const size_t po = (size_t)min(ch + u, C - 1) * HW;
-                a0[u] = gp[po + g0]; a1[u] = gp[po + g1]; a2[u] = gp[po + g2]; a3[u] = gp[po + g3];
-                if (GFLOW) v[u] = ip[po + i];
+                const int pl = min(ch + u, C - 1);
+                a0[u] = ld_g(pl, v0); a1[u] = ld_g(pl, v1); a2[u] = ld_g(pl, v2); a3[u] = ld_g(pl, v3);
+                if (GFLOW) v[u] = ld_i(pl, vi);
             }
         };
         load(0, p0, p1, p2, p3, pv);
-        for (int ch = 0; ch < C; ch += 2 * U) {
-            load(ch + U, q0, q1, q2, q3, qv);                      // (past the last channel: re-reads channel C - 1, unused)
-            finish(ch, p0, p1, p2, p3, pv);
-            if (ch + U < C) {
-                load(ch + 2 * U, p0, p1, p2, p3, pv);
-                finish(ch + U, q0, q1, q2, q3, qv);
-            }
+        int ch = 0;
+        for (; ch + 2 * U <= C; ch += 2 * U) {
+            load(ch + U, q0, q1, q2, q3, qv);
+            finish(std::true_type{}, ch, p0, p1, p2, p3, pv);
+            load(ch + 2 * U, p0, p1, p2, p3, pv);                  // (past the last channel: re-reads channel C - 1, unused)
+            finish(std::true_type{}, ch + U, q0, q1, q2, q3, qv);
+        }
+        if (ch < C) {                                              // the last 1 .. 2U - 1 channels
+            load(ch + U, q0, q1, q2, q3, qv);
+            finish(std::false_type{}, ch, p0, p1, p2, p3, pv);
+            if (ch + U < C) finish(std::false_type{}, ch + U, q0, q1, q2, q3, qv);
         }
     }
     if (GFLOW && live_px) {
@@ -303,18 +347,20 @@ SLR_EXPORT int slr_softsplat_backward(const float *in, const float *flow, const 
     SLR_CHECK_ARG(!grad_flow || in, "input required for grad_flow");
     SLR_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && (long long)N * H * W < (1LL << 29), "sizes");
     hipStream_t st = (hipStream_t)stream;
-#if SLR_GRAD_TILED
+    // the tiled kernel addresses one sample's C planes through a 32-bit buffer descriptor
+    const bool tiled = SLR_GRAD_TILED && (long long)C * H * W * 4 < (1LL << 31);
+    if (tiled) {
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     dim3 grid(tiles_x * tiles_y, N);
     if (grad_in && grad_flow) hipLaunchKernelGGL((grad_tile_kernel<true, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
     else if (grad_in) hipLaunchKernelGGL((grad_tile_kernel<true, false>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
     else if (grad_flow) hipLaunchKernelGGL((grad_tile_kernel<false, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
-#else
+    } else {
     dim3 grid((H * W + 255) / 256, N);
     if (grad_in && grad_flow) hipLaunchKernelGGL((grad_kernel<true, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
     else if (grad_in) hipLaunchKernelGGL((grad_kernel<true, false>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
     else if (grad_flow) hipLaunchKernelGGL((grad_kernel<false, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
-#endif
+    }
     SLR_CHECK_LAUNCH();
     return 0;
 }

@@ -74,6 +74,12 @@
 #ifndef SLR_CSPLIT_SLOTS
 #define SLR_CSPLIT_SLOTS 512    // workgroup slots of the chip the groups may fill (256 CUs x 2).  1024 / 8 groups: config C2 39 -> 54 us
 #endif
+#ifndef SLR_SCAN_DEFER_WG
+#define SLR_SCAN_DEFER_WG 32     // pass-by-pass launch of the scan front end: workgroups along the deferred list x SLR_SCAN_DEFER_GROUPS channel groups x 8 column
+#endif                          // sub-pieces.  Round 4 (empty workgroups end after one scalar load; before, each added to an arrival counter and 2048 of them cost 25 us):
+#ifndef SLR_SCAN_DEFER_GROUPS   // config C2 incoherent / smooth t=30 and 384x640 incoherent / t=30, call us: 16 x 2: 35.7 / 176 and 60.7 / 178; 32 x 2: 35.5 / 134 and
+#define SLR_SCAN_DEFER_GROUPS 4 // 61.0 / 157; 32 x 4: 35.0 / 135 and 61.2 / 146; 64 x 4: 35.0 / 140 and 61.5 / 145; 64 x 8: 35.8 / 195 and 62.6 / 152
+#endif
 #ifndef SLR_SCAN_MAX_TILES
 #define SLR_SCAN_MAX_TILES 1024 // default of slr_splat_set_scan_max_tiles: one-flow calls on grids of at most this many tiles take the scan front end,
 #endif                          // larger ones the rows front end (config C2, 240 tiles: bins 56 / scan 39 / rows 56 us; 384x640, 960 tiles: incoherent
@@ -97,6 +103,9 @@
 #endif                          // scanned from the whole flow instead (pathological flows only; identity ~30, Euler t=59 < 200)
 #ifndef SLR_ROWBIN_R
 #define SLR_ROWBIN_R 2          // source tiles (vertically adjacent) per workgroup of rowbin_kernel = row segments per wave.  1 / 2 / 4 (whole call, us): identity 153 / 148 / 148, Euler t=30 177 / 173 / 180, t=59 225 / 221 / 233
+#endif
+#ifndef SLR_PREFETCH_BURST_ONE
+#define SLR_PREFETCH_BURST_ONE 0 // one-flow kernels: 1 = the plane loads of the chunk after next in one burst right behind the barrier; 0 = one plane at each stop of the gather
 #endif
 #ifndef SLR_CLIP_MAXB
 #define SLR_CLIP_MAXB 16        // frames per launch of the fused clip kernel (kernel arguments: 16 x 112 bytes)

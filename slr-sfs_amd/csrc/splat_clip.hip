@@ -342,6 +342,7 @@ __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch
     }
     const TileFrame &f = b.f[bf];
     const int tid = threadIdx.x;
+    if (PASSES && f.totals[4] == 0u) return;               // the normal case: nothing deferred in this frame, nothing to reset
     const TileScalars k = tile_scalars(s, f);
     if (!PASSES) {
         if (bx >= f.grid) return;                          // this frame has fewer groups than the longest of the batch

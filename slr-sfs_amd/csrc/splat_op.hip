@@ -395,6 +395,7 @@ __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kerne
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
+    if (PASSES && f.totals[4] == 0u) return;               // the normal case: an empty launch whose workgroups do one scalar load (nothing to reset)
     int cb, ce;
     if (!channel_group(s.C, cb, ce)) return;
     const TileScalars k = tile_scalars(s, f);
@@ -440,7 +441,8 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
         for (int q = 0; q < 2048 / TT; ++q) {
             const int st = base + tid + q * TT;
             const SrcBox b = bx4[q];
-            if (st < s.tiles && b.x1 >= p.tx0 - 1 && b.x0 <= p.tx0 + TILE_W - 1 && b.y1 >= p.ty0 - 1 && b.y0 <= p.ty0 + TILE_H - 1)
+            // (against the piece's own columns: where a flow contracts -- the pile-ups that get cut into pieces -- source boxes are narrow)
+            if (st < s.tiles && b.x1 >= p.tx0 + p.pca - 1 && b.x0 <= p.tx0 + p.pcb - 1 && b.y1 >= p.ty0 - 1 && b.y0 <= p.ty0 + TILE_H - 1)
                 atomicOr(&cmask[(st - base) >> 5], 1u << (st & 31));
         }
         __syncthreads();
@@ -462,6 +464,7 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
             }
         }
         __syncthreads();
+        if (base == 0) { T_STAMP(s, 1); T_NOTE(s, 61, nc); }
         // 32 candidates at a time: their 8 rows each as a row-segment list in LDS (index 8 * candidate + row: wave w walks row w of each)
         for (uint32_t c0 = 0; c0 < nc; c0 += ROW_CAP / TILE_H) {
             const uint32_t n = min(nc - c0, (uint32_t)(ROW_CAP / TILE_H));
@@ -481,16 +484,16 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
     return wcount;
 }
 
-// DEFER = false: one workgroup per output tile.  A tile that turns out to hold more than SEG entries is not walked pass by pass by its
-// own workgroup (on a small grid the rest of the chip would idle behind it): it is appended to the deferred list with the number of
-// pieces it should be cut into (2, 4 or 8 equal column ranges: ~1.25 x its entries / SEG).
+// DEFER = false: one workgroup per output tile, or per column piece of it (grid.z).  A piece that turns out to hold more than SEG entries
+// is not walked pass by pass by its own workgroup (on a small grid the rest of the chip would idle behind it): it is appended to the
+// deferred list with the number of sub-pieces it should be cut into (2, 4 or 8 equal column ranges: ~1.25 x its entries / SEG).
 // DEFER = true (grid: SCAN_DEFER_WG x channel groups x 8): the second, normally empty launch -- every deferred tile's pieces (x channel
 // groups) in parallel, every piece re-scanning the tile's candidates for its own columns; a piece that still holds more than SEG
 // entries is walked in passes with reproducible ordinals (a count walk, then one emitting walk per pass).
 // (Measured and rejected: the deferred pieces as TAIL blocks of the same launch, waiting on an arrival counter of the tile blocks --
 //  no second launch, but the sleeping tail blocks and the larger kernel cost more than the 5.6 us of an empty launch: config C2
 //  37 -> 49.5 us, and with few tail slots a smooth flow's heavy tiles queue up behind each other: 177 -> 883 us.)
-constexpr uint32_t SCAN_DEFER_WG = 16;
+constexpr uint32_t SCAN_DEFER_WG = SLR_SCAN_DEFER_WG;
 template <bool NORM, bool MAXOP, bool DEFER>
 __global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     using Cfg = OpCfg;
@@ -499,40 +502,50 @@ __global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
+    const uint32_t ndef = DEFER ? f.totals[4] : 1u;
+    if (DEFER && ndef == 0u) return;                       // the normal case: an empty launch whose workgroups do one scalar load
     int cb, ce;
     if (!channel_group(s.C, cb, ce)) return;
     const TileScalars k = tile_scalars(s, f);
-    const uint32_t ndef = DEFER ? f.totals[4] : 1u;
     for (uint32_t q = DEFER ? blockIdx.x : 0u; q < ndef; q += gridDim.x) {
         ItemDesc it = {};
         if (DEFER) {
-            const uint32_t w = f.defer[q], np = w >> 28;              // pieces: 2, 4 or 8 column ranges of 4, 2 or 1 octants
+            // a deferred piece (tile | first octant << 20 | log2 octants << 23) and the number of sub-pieces it is cut into (<< 28)
+            const uint32_t w = f.defer[q], np = w >> 28, noct = 1u << ((w >> 23) & 3u);
             if (blockIdx.z >= np) continue;
-            it.tile = w & 0x0fffffffu; it.nseg = 8u / np; it.seg = blockIdx.z * it.nseg;
+            it.tile = w & 0xfffffu; it.nseg = noct / np; it.seg = ((w >> 20) & 7u) + blockIdx.z * it.nseg;
         } else {
-            it.tile = xcd_item(blockIdx.x); it.nseg = 8;
+            // grid.z column pieces per tile (1, 2, 4 or 8: on a grid smaller than the chip the spare workgroup slots go to column ranges
+            // first -- every piece builds and streams only its own records -- and to channel groups after that)
+            it.tile = xcd_item(blockIdx.x); it.nseg = 8u / gridDim.z; it.seg = blockIdx.z * it.nseg;
             if (it.tile >= (uint32_t)s.N * (uint32_t)s.tiles) return;
         }
         Piece p = make_piece<Cfg>(s, it);
+        T_STAMP(s, 0);
         __syncthreads();
         L.cnt[tid] = 0;
         if (tid == 0) L.misc[0] = 0;
         __syncthreads();
         scan_collect<Cfg, 1, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)Cfg::SEG);
         const uint32_t total = L.misc[0];
+        T_STAMP(s, 2);
+        T_NOTE(s, 60, total);
         const rsrc_t rin = sample_planes(s, p, k.hw4);
         PixelSums sums = {0.0f, 0.0f, 0.0f};
         if (total <= (uint32_t)Cfg::SEG) {
             EntryRegs<Cfg> e;
             float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
             build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+            T_STAMP(s, 6);
             stream_planes<Cfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
+            T_STAMP(s, 59);
             continue;
         }
         if constexpr (!DEFER) {
-            if (tid == 0 && blockIdx.y == 0) {             // (one entry per tile: every channel group gets here)
+            if (tid == 0 && blockIdx.y == 0) {             // (one entry per piece: every channel group gets here)
                 const uint32_t want = (total + total / 4u + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG;
-                f.defer[atomicAdd(f.totals + 4, 1u)] = it.tile | ((want <= 2u ? 2u : want <= 4u ? 4u : 8u) << 28);
+                const uint32_t np = min(want <= 2u ? 2u : want <= 4u ? 4u : 8u, it.nseg);
+                f.defer[atomicAdd(f.totals + 4, 1u)] = it.tile | (it.seg << 20) | ((uint32_t)(31 - __clz((int)it.nseg)) << 23) | (np << 28);
             }
             return;
         } else {
@@ -551,10 +564,7 @@ __global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel
             }
         }
     }
-    if (DEFER) {        // the last workgroup to get here empties the deferred list
-        __syncthreads();
-        if (tid == 0 && atomicAdd(f.totals + 6, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u) { f.totals[4] = 0u; f.totals[6] = 0u; }
-    }
+    // (the deferred list is emptied by the next call's scan_box_kernel: the scan front end has no prebinned form)
 }
 
 // =========================================================================== small kernels
@@ -639,6 +649,7 @@ static int front_end(int ws_flags, uint32_t nt) {
     if (ws_flags & SLR_WS_PREBINNED) return 2;
     int fe = g_front_end.load(std::memory_order_relaxed);
     if (fe != 1 && fe != 2) fe = nt <= (uint32_t)g_scan_max_tiles.load(std::memory_order_relaxed) ? 1 : 2;
+    if (nt >= (1u << 20)) fe = 2;                        // (the scan front end's deferred list carries tile indices in 20 bits)
     return fe;
 }
 
@@ -648,6 +659,16 @@ static uint32_t channel_groups(uint32_t nt, int C) {
     uint32_t groups = fit < (uint32_t)SLR_CSPLIT_MAX ? fit : (uint32_t)SLR_CSPLIT_MAX;
     groups = groups < byc ? groups : byc;
     return groups < 1u ? 1u : groups;
+}
+
+// scan front end: column pieces x channel groups per tile (slr_splat_set_scan_shape; 0 = by grid size)
+static std::atomic<int> g_scan_pieces{0}, g_scan_groups{0}, g_scan_defer_wg{0}, g_scan_defer_groups{0};
+static void scan_shape(uint32_t nt, int C, uint32_t &pieces, uint32_t &groups) {
+    const int sp = g_scan_pieces.load(), sg = g_scan_groups.load();
+    pieces = sp == 1 || sp == 2 || sp == 4 || sp == 8 ? (uint32_t)sp : 1u;
+    groups = sg > 0 ? (uint32_t)sg : channel_groups(nt * pieces, C);
+    const uint32_t byc = (uint32_t)C / 8u < 1u ? 1u : (uint32_t)C / 8u;
+    groups = groups < byc ? groups : byc;
 }
 
 template <typename K>
@@ -702,13 +723,18 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
     const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, false>), dim3(grid, channel_groups(w.L.nt, a.s.C)), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    uint32_t pieces, groups;
+    scan_shape(w.L.nt, a.s.C, pieces, groups);
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, false>), dim3(grid, groups, pieces), dim3(TT), OpCfg::LDS_BYTES, st, a);
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
-    // tiles of more than SEG entries (appended by their workgroups): 2 - 8 column pieces each x channel groups, pass by pass where needed
-    // (256 workgroups: an empty launch of them costs 5.6 us of config C2's 37; 2048 cost 25)
-    const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > 2u ? 2u : (uint32_t)a.s.C / 8u;
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, true>), dim3(w.L.nt < SCAN_DEFER_WG ? w.L.nt : SCAN_DEFER_WG, wgroups, 8), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    // pieces of more than SEG entries (appended by their workgroups): 2 - 8 column sub-pieces each x channel groups, pass by pass where needed
+    // (an empty launch: every workgroup does one scalar load and ends -- 256 or 4096 of them cost the same 2 - 3 us)
+    const int dwg = g_scan_defer_wg.load(), dgr = g_scan_defer_groups.load();
+    const uint32_t gmax = dgr > 0 ? (uint32_t)dgr : (uint32_t)SLR_SCAN_DEFER_GROUPS;
+    const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > gmax ? gmax : (uint32_t)a.s.C / 8u;
+    const uint32_t dw = dwg > 0 ? (uint32_t)dwg : SCAN_DEFER_WG;
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, true>), dim3(w.L.nt * pieces < dw ? w.L.nt * pieces : dw, wgroups, 8), dim3(TT), OpCfg::LDS_BYTES, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }
@@ -755,6 +781,10 @@ SLR_EXPORT int slr_splat_set_scan_max_tiles(int max_tiles) {
 
 SLR_EXPORT int slr_splat_set_front_end(int front_end) {
     return slr::g_front_end.exchange(front_end == 1 || front_end == 2 ? front_end : -1);
+}
+
+SLR_EXPORT void slr_splat_set_scan_shape(int pieces, int groups, int defer_wg, int defer_groups) {
+    slr::g_scan_pieces.store(pieces); slr::g_scan_groups.store(groups); slr::g_scan_defer_wg.store(defer_wg); slr::g_scan_defer_groups.store(defer_groups);
 }
 
 SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {

@@ -432,6 +432,14 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
         float acc[4];
         // the plane loads of the chunk after next (two chunks ahead), one plane at each of the gather's four stops
         gather_chunk<Cfg, MAXOP>(L, g, lane, s.init, acc, [&](int u) {
+            if (SLR_PREFETCH_BURST_ONE && Cfg::NDIR == 1) {      // one flow: all planes' loads at the first stop (its chunks are short: every load
+                if (u == 0) {                                     // as early as possible)
+                    __builtin_amdgcn_sched_barrier(0);
+                    prefetch_planes<Cfg>(rin, e, pre, c0 + 8, cmax, hw4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t soff = (uint32_t)min(c0 + 8 + u, cmax) * hw4;
 #pragma unroll

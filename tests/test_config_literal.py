@@ -35,7 +35,7 @@ def test_oracle_vs_reference_operators(oracle, golden_dir, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("front_end", ["bins", "scan", "rows"])
+@pytest.mark.parametrize("front_end", ["auto", "scan", "rows"])
 @pytest.mark.parametrize("tag", TAGS)
 def test_hip_operators_vs_reference_operators(golden_dir, tag, front_end):
     import slr_sfs_amd as S
@@ -43,7 +43,7 @@ def test_hip_operators_vs_reference_operators(golden_dir, tag, front_end):
     g = np.load(f"{golden_dir}/config_literal.npz")
     x, metric, motion, steps, flow = config_inputs(tag)
     d = lambda a: torch.from_numpy(a).cuda()
-    prev = L.slr_splat_set_front_end({"bins": 0, "scan": 1, "rows": 2}[front_end])
+    prev = L.slr_splat_set_front_end({"auto": -1, "scan": 1, "rows": 2}[front_end])
     try:
         fl = d(flow) if flow is not None else S.euler_integration(d(motion), steps)[0]
         if flow is None:

@@ -1,7 +1,8 @@
-"""The three front ends of the one-flow operator (include/slr_splat.h: slr_splat_set_front_end) against the oracle:
-`bins` (bin -> plan -> tile kernel -> combine), `scan` (source-tile destination boxes, the tile kernel builds its
-entry list itself) and `rows` (row segments binned per tile + the plan in one launch, the tile kernel scans the listed
-rows).  Every case runs with the front end FORCED, so all are covered at every size -- including
+"""The front ends of the one-flow operator (include/slr_splat.h: slr_splat_set_front_end) against the oracle:
+`scan` (source-tile destination boxes, the tile kernel lists and walks the candidate rows itself), `rows` (row segments binned per
+tile + the plan in one launch, the tile kernel walks the listed rows) and `prebinned` (slr_splat_bin once, then the call with
+SLR_WS_PREBINNED: the rows machinery on a shared binning).  Every case runs with the front end FORCED, so all are covered at every
+size -- including
 BASELINE.json's config C2 as it is stated (FunctionSoftsplat(..., 'softmax'), 64 channels, 256x480, incoherent U(-8,8)
 and smooth flow; models/softsplat.py:665-690)."""
 import numpy as np
@@ -20,7 +21,7 @@ def S():
     return slr_sfs_amd
 
 
-FRONT_ENDS = {"bins": 0, "scan": 1, "rows": 2}
+FRONT_ENDS = {"auto": -1, "scan": 1, "rows": 2}
 
 
 @pytest.fixture(params=list(FRONT_ENDS))
@@ -106,7 +107,7 @@ def test_config_c2_literal(S, oracle, frontend, flowkind):
 
 @pytest.mark.parametrize("shape", [(1, 65, 256, 480), (2, 7, 45, 131), (1, 16, 100, 64), (3, 1, 17, 70), (1, 5, 300, 700)])
 def test_sum_vs_oracle_piled_up_euler_flow(S, oracle, frontend, shape):
-    """Strong Euler-integrated flow: tiles with several times SEG entries (bins: segments + combine; scan: passes)."""
+    """Strong Euler-integrated flow: tiles with several times SEG entries (rows: column pieces + the pass-by-pass launch; scan: deferred column pieces)."""
     N, C, H, W = shape
     rng = np.random.default_rng(C)
     flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=3.0), 40 + n)[0] for n in range(N)])
@@ -251,7 +252,7 @@ def test_many_deferred_pieces(S, oracle, frontend):
 def test_differential_fuzz_of_the_front_ends(S):
     """tools/dev/fuzz_frontends.py, a short run with a fixed seed: random shapes (ragged edges, one-pixel images, batches, a
     768x1280 case), ten flow families (incoherent, collapsing onto points / lines, far outside, non-finite sprinkles, ...) and
-    all modes incl. the maximum splat; scan and rows against bins on the same inputs."""
+    all modes incl. the maximum splat; the scan and the rows front end against the CPU oracle on the same inputs."""
     import os
     import subprocess
     import sys

@@ -1,4 +1,4 @@
-"""Timing of the backward kernels (development aid)."""
+"""Timing of the backward kernels at 65x768x1280 (identity / Euler t=30 / t=59 flow):  python tools/bwdbench.py [flow name: only that one]."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import slr_sfs_amd as S
@@ -9,7 +9,10 @@ x = torch.randn(1, C, H, W, device="cuda"); go = torch.randn(1, C, H, W, device=
 m = smooth_motion(H, W); dall, _ = S.euler_integration_all(m, 60)
 gi = torch.empty_like(x); gf = torch.empty(1, 2, H, W, device="cuda")
 L = lib(); st = stream_of(x)
+only = sys.argv[1] if len(sys.argv) > 1 else None
 for name, fl in (("identity", torch.zeros(1, 2, H, W, device="cuda")), ("t30", dall[30:31].contiguous()), ("t59", dall[59:60].contiguous())):
+    if only and name != only:
+        continue
     t1 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), None, 1, C, H, W, st), "b"), 10)
     t2 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), None, ptr(gf), 1, C, H, W, st), "b"), 10)
     t3 = timeit(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), 1, C, H, W, st), "b"), 10)

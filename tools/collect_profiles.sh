@@ -1,8 +1,9 @@
 #!/bin/bash
 # Everything profiles/rN_* is made from, in one run on the GPU box (from the repo root):
-#   tools/collect_profiles.sh gpurun_out/r3final
-# bench lines, rocprofv3 kernel traces (per-kernel summaries via tools/trace_csv_stats.py), stand-alone kernel benches.
-# (The PMC traffic passes are separate: tools/pmc_traffic.sh.)
+#   tools/collect_profiles.sh gpurun_out/r4final
+# bench lines, rocprofv3 kernel traces (per-kernel summaries via tools/trace_csv_stats.py), PMC passes (SQ / TCC counters, FETCH_SIZE and
+# WRITE_SIZE in separate runs, kernel-trace only) for the fused clip kernel (C3 and C4), the one-flow operator (rows at 768x1280, scan at
+# config C2) and the backward kernel, stand-alone kernel benches.
 out=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $out
@@ -22,9 +23,23 @@ trace bench_c3 python bench.py --no-extras --no-cpu-baseline
 trace splat_stage python tools/splat_stage.py 3
 trace splat_stage_v1 python tools/splat_stage.py 3 v1
 trace c2 python tools/c2_bench.py c2
+trace frontends python tools/dev/fe_one.py 2
+trace bwd python tools/bwdbench.py
+pmc() {     # name, kernel pattern, units of work per dispatch, command...
+    local name=$1 pat=$2 units=$3; shift 3
+    bash tools/pmc_run.sh $out/pmc_$name "$@"
+    python tools/pmc_summary.py $out/pmc_$name "$pat" > $out/pmc_${name}_counters.txt
+    python tools/pmc_kernel_traffic.py $out/pmc_$name "$pat" $out/traffic_$name.json $units
+    find $out/pmc_$name -name "*.csv" -delete; find $out/pmc_$name -name "*.log" -delete
+}
+pmc clip_c3 "clip_tile_kernel<false, false>" 15 python tools/splat_stage.py
+pmc clip_c4 "clip_tile_kernel<true, false>" 15 python tools/splat_stage.py v1
+pmc op_rows_t30 "op_rows_kernel<false, false, false>" 1 python tools/dev/fe_one.py 2 t30
+pmc op_rows_t59 "op_rows_kernel<false, false, false>" 1 python tools/dev/fe_one.py 2 t59
+pmc op_scan_c2 "op_scan_kernel<true, false, false>" 1 python tools/dev/fe_one.py 1 c2
+pmc grad_t30 "grad_tile_kernel<true, true>" 1 python tools/bwdbench.py t30
 python tools/kbench.py > $out/kbench.txt 2>&1
-python tools/dropin_bench.py > $out/dropin_bench.txt 2>&1
-python tools/c2_bench.py > $out/c2_bench.txt 2>&1
 python tools/frontend_bench.py > $out/frontend_bench.txt 2>&1
 python tools/bwdbench.py > $out/bwdbench.txt 2>&1
-tail -3 $out/pytest.log; cat $out/smoke.log | tail -1; cut -c1-200 $out/bench_default.json
+python tools/dev/convbench_f32.py > $out/convbench_f32.txt 2>&1
+tail -3 $out/pytest.log; cat $out/smoke.log | tail -2; cut -c1-200 $out/bench_default.json

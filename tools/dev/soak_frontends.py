@@ -22,7 +22,7 @@ for (C, H, W, steps, amp) in ((65, 768, 1280, 59, 1.5), (64, 256, 480, 30, 1.5),
 bad = 0
 t0 = time.time()
 for ci, (x, fl, met) in enumerate(cases):
-    L.slr_splat_set_front_end(0)
+    L.slr_splat_set_front_end(3 - fe_under_test)          # the OTHER front end is the reference (1 scan <-> 2 rows)
     ref_sum = S.FunctionSoftsplat(x, fl, None, "summation")
     ref_soft = S.FunctionSoftsplat(x, fl, met, "softmax")
     L.slr_splat_set_front_end(fe_under_test)
