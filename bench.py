@@ -507,6 +507,9 @@ def _graph_call_us(fn, reps=20, iters=10):
             e1.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3 / reps)
     torch.cuda.synchronize()
+    del g                                                 # the graph is gone: the workspaces pinned for it may go as well
+    import slr_sfs_amd as S
+    S._lib.clear_workspaces(include_captured=True)
     ts.sort()
     return ts[len(ts) // 2]
 
@@ -531,7 +534,8 @@ def dropin_roofline(dev, motion):
     res = {"bound": "hbm", "kernel": "slr::op_rows_kernel<false,false,false> (rows front end, the default at 1920 tiles); scan_front_end: "
                                      "slr::op_scan_kernel<false,false,false>", "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "alg_bytes_per_call": alg, "flows": {},
-           "call": "GPU time of all launches of one call (HIP graph of 20 calls replayed); call_eager_us: Python call, event pair per call"}
+           "call": "call_us = call_graph_us = GPU time of all launches of one call (HIP graph of 20 calls replayed; since round 3 -- rounds 1 and 2 "
+                   "printed the eager figure under call_us); call_eager_us: Python call, event pair per call"}
 
     def measure(f, alg_bytes, tile=True):
         r = {}
@@ -552,7 +556,7 @@ def dropin_roofline(dev, motion):
         except Exception as e:                           # (a capture that fails must not cost the line: eager timing instead)
             call, r["call_note"] = eager, f"graph capture failed ({type(e).__name__}): call_us is the eager figure"
             torch.cuda.synchronize()
-        r.update({"call_us": round(call, 1), "call_frac": round(alg_bytes / call / 1e3 / HBM_PEAK_GBS, 4),
+        r.update({"call_us": round(call, 1), "call_graph_us": round(call, 1), "call_frac": round(alg_bytes / call / 1e3 / HBM_PEAK_GBS, 4),
                   "call_eager_us": round(eager, 1), "call_eager_frac": round(alg_bytes / eager / 1e3 / HBM_PEAK_GBS, 4)})
         return r
 
@@ -565,8 +569,10 @@ def dropin_roofline(dev, motion):
         if name.startswith("euler"):
             r["traffic"], r["traffic_source"] = static_traffic("op_rows_" + name[6:], 1)
         prev = L.slr_splat_set_front_end(1)
-        r["scan_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
-        L.slr_splat_set_front_end(prev)
+        try:
+            r["scan_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
+        finally:
+            L.slr_splat_set_front_end(prev)
         res["flows"][name] = r
         if name.startswith("euler") and (worst is None or r["tile_frac"] < worst["tile_frac"]):
             worst = r
@@ -586,10 +592,12 @@ def dropin_roofline(dev, motion):
                       "front_end": "scan (box kernel + tile kernel + the pass-by-pass launch)"})
             prev = L.slr_splat_set_front_end(2)
             try:
-                r["rows_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
-            except Exception:
-                r["rows_front_end_call_us"] = round(_time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 20)[0], 1)
-            L.slr_splat_set_front_end(prev)
+                try:
+                    r["rows_front_end_call_us"] = round(_graph_call_us(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax")), 1)
+                except Exception:
+                    r["rows_front_end_call_us"] = round(_time_calls(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), 20)[0], 1)
+            finally:
+                L.slr_splat_set_front_end(prev)
             small[tag if fname == "incoherent" else f"{tag}_{fname}"] = r
     res["c2"] = small.pop("c2")
     res["c2"]["workload"] = "C2: " + res["c2"]["workload"] + " U(-8,8)"

@@ -172,7 +172,8 @@ def workspace(t, role, N, C, H, W, nbytes=None):
     ws = _ws_captured.get(key)
     if ws is not None:
         return ws
-    capturing = torch.cuda.is_current_stream_capturing()
+    with torch.cuda.device(t.device):                    # (the capture status of t's device, not of the current one)
+        capturing = torch.cuda.is_current_stream_capturing()
     ws = _ws_cache.get(key)
     if ws is None:
         if nbytes is None:

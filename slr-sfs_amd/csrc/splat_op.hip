@@ -51,6 +51,11 @@ static_assert(4 * ROW_CAP * 4 + 2048 * 4 <= OpCfg::REC_BYTES, "row lists and the
 // undisturbed tile's ~585 entries) go first: their items fill items[] from the front, everybody else's from the back
 // (items[cap - 1 - k]), and the tile kernel reads item i < totals[5] from the front.  Segments of `seg` entries; a tile whose
 // segments do not fit the partial-slot budget is left to one workgroup (nseg 0).
+// (Round 4, measured and rejected: "tail fill" -- the item count rounded up to a multiple of the chip's 768 workgroup slots by cutting the
+//  last whole tiles of the launch order into column halves, so that the last round of workgroups is full and short.  The traced lives say
+//  the slots are 65 - 80 % busy (identity: 1920 lives of 34 us = 85 us of slot time in a 130 us kernel), but two halves cost 1.3 tiles
+//  and the dispatcher refills slots one by one, not in rounds: call identity / t=30 / t=59 / incoherent 141-148 / 160-169 / 203-211 /
+//  208-211 us without, 156 / 176 / 224 / 224 with.)
 template <typename V>
 __device__ __forceinline__ V exscan_tile_pix(V v, V *excl, V *wsum /*[TILE_PIX / 64]*/) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -135,6 +140,10 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
 #pragma unroll
                 for (uint32_t o = 0; o < 8; ++o) hsum += (uint32_t)(oh[k] >> (8 * o)) & 0xffu;
                 const uint32_t osum = cnt + cnt / 8u;
+                // (8 bits per octant: an octant byte that passed 255 units -- more than ~4000 entries -- has carried into its neighbour
+                // and the histogram no longer adds up to the tile's exact count: cut such a tile into its 8 octants, the pieces that
+                // are still too long go pass by pass)
+                const bool hist_ok = hsum * 32u >= cnt;
                 // (float arithmetic: these are estimates, and 64-bit integer divisions cost the one planning workgroup 2.7 us)
                 const float scale = (float)osum / (float)(hsum ? hsum : 1u);
                 const uint32_t even = (uint32_t)((float)osum / ceilf((float)osum / (float)limit));   // pieces of about equal weight, not one full + a rest
@@ -147,6 +156,7 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
                     sum += co;
                 }
                 p |= (unsigned long long)(start | ((8u - start) << 4)) << (8 * np); ++np;
+                if (!hist_ok) { p = 0x1716151413121110ull; np = 8; }
                 pcs[k] = p; ns[k] = np;
 #if SLR_ROWS_EVEN_FIRST
                 // (where plain halves / quarters already fit, take them: equal widths)
@@ -301,6 +311,7 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
     // ---- the last workgroup to get here plans the call (every append above has returned: its value was used)
     // (two levels: thousands of returning atomics on ONE word are served one after the other -- 35 us at 1920 workgroups)
     __shared__ uint32_t last;
+    __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0): the fire-and-forget histogram adds have been performed at the memory side too
     __syncthreads();
     if (tid == 0) {
         const uint32_t grp = blockIdx.x >> 6, ngrp = (gridDim.x + 63u) >> 6;
@@ -395,18 +406,31 @@ __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kerne
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
+#ifdef SLR_TRACE
+    const long long t_entry = (long long)wall_clock64();
+#endif
     if (PASSES && f.totals[4] == 0u) return;               // the normal case: an empty launch whose workgroups do one scalar load (nothing to reset)
     int cb, ce;
     if (!channel_group(s.C, cb, ce)) return;
     const TileScalars k = tile_scalars(s, f);
     if (!PASSES) {
+        // One workgroup per item, no loop over work.  (Round 4, traced with the constant clock: a slot stays empty for ~4.5 us between the end
+        // of one workgroup and the first instruction of the next, and the new one needs 2.5 us to know its item -- 630-680 of the 768 slots
+        // are occupied in the steady state.  As many workgroups as the chip holds, each walking items blockIdx.x, + grid.x, ... was measured
+        // and rejected: the loop's live kernel arguments cost 19 spilled registers and the static shares lose the dispatcher's balancing --
+        // call identity / t=30 / t=59 / incoherent 150 / 183 / 224 / 223 us against 146-153 / 171-180 / 216-224 / 214-219.)
         const uint32_t item = xcd_item(blockIdx.x);
         if (item >= f.totals[0]) return;
         const uint32_t nh = f.totals[5];                   // heavy items sit at the front of items[], the rest at its back
         const uint32_t at = item < nh ? item : f.items_cap - 1u - (item - nh);
         const Piece p = make_piece<Cfg>(s, f.items[at]);
+        T_NOTE(s, 56, wall_clock64());                     // (the constant 100 MHz clock: comparable across XCDs, unlike the shader clock of T_STAMP)
+#ifdef SLR_TRACE
+        T_NOTE(s, 58, t_entry);
+#endif
         if (!rows_piece_once<Cfg, false, NORM, MAXOP, false>(s, f, L, p, tid, k, cb, ce) && tid == 0 && blockIdx.y == 0)
             f.defer[atomicAdd(f.totals + 4, 1u)] = at;     // (one entry per piece: every channel group gets here)
+        T_NOTE(s, 57, wall_clock64());
     } else {
         const uint32_t ndef = f.totals[4];
         for (uint32_t q = blockIdx.x; q < ndef; q += gridDim.x)

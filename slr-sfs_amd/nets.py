@@ -22,6 +22,8 @@ Own definitions, folded for inference (reference file:line cited 
 """
 import math
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -29,11 +31,20 @@ import torch.nn.functional as F
 from . import _lib
 
 
-_CPU_REFERENCE = False
-_TORCH_CONVS = False                     # inside torch_convolutions(): every stage through its torch definition (fp32)
-ACT_SCALE = 64.0                         # pre-scale of the activations in the split-f16 kernels (include/slr_splat.h: xscale)
 IN_B8, OUT_B8, RES_B8, CONV_F32 = 1, 2, 4, 8      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32
-_F32_KERNELS = False                     # inside fp32_kernels(): the convolutions on the fp32 matrix instructions (the fp32 rung)
+
+
+class _Route(threading.local):
+    """What the context managers below switch, per HOST THREAD (two animators on two threads do not see each other's route or
+    activation scale).  The saturation counter they react to is one per DEVICE (include/slr_splat.h: slr_conv_saturation_count):
+    its attribution to a batch assumes one renderer per device at a time."""
+    cpu_reference = False
+    torch_convs = False                  # inside torch_convolutions(): every stage through its torch definition (fp32)
+    act_scale = 64.0                     # pre-scale of the activations in the split-f16 kernels (include/slr_splat.h: xscale)
+    f32_kernels = False                  # inside fp32_kernels(): the convolutions on the fp32 matrix instructions (the fp32 rung)
+
+
+_S = _Route()
 
 
 def _b8(x, channels):
@@ -41,7 +52,7 @@ def _b8(x, channels):
     in memory, carried in a tensor of the logical shape [N,C,H,W]): all its producers and consumers are our kernels,
     which then move 16 bytes per lane and instruction instead of 4.  The networks' inputs and outputs (3-, 65-, 2-channel
     ends, the splat's feature planes) stay NCHW; no torch op ever touches a blocked tensor."""
-    return x.is_cuda and channels % 8 == 0 and not _TORCH_CONVS
+    return x.is_cuda and channels % 8 == 0 and not _S.torch_convs
 
 
 class torch_convolutions:
@@ -53,13 +64,11 @@ class torch_convolutions:
     kernels report a clamped activation (convs="auto", pipeline.py)."""
 
     def __enter__(self):
-        global _TORCH_CONVS
-        self._prev, _TORCH_CONVS = _TORCH_CONVS, True
+        self._prev, _S.torch_convs = _S.torch_convs, True
         return self
 
     def __exit__(self, *exc):
-        global _TORCH_CONVS
-        _TORCH_CONVS = self._prev
+        _S.torch_convs = self._prev
         return False
 
 
@@ -72,13 +81,11 @@ class fp32_kernels:
     it on request (convs="fp32") or by themselves when the split-f16 kernels report a clamped activation (convs="auto")."""
 
     def __enter__(self):
-        global _F32_KERNELS
-        self._prev, _F32_KERNELS = _F32_KERNELS, True
+        self._prev, _S.f32_kernels = _S.f32_kernels, True
         return self
 
     def __exit__(self, *exc):
-        global _F32_KERNELS
-        _F32_KERNELS = self._prev
+        _S.f32_kernels = self._prev
         return False
 
 
@@ -93,13 +100,11 @@ class activation_scale:
         self.scale = float(scale)
 
     def __enter__(self):
-        global ACT_SCALE
-        self._prev, ACT_SCALE = ACT_SCALE, self.scale
+        self._prev, _S.act_scale = _S.act_scale, self.scale
         return self
 
     def __exit__(self, *exc):
-        global ACT_SCALE
-        ACT_SCALE = self._prev
+        _S.act_scale = self._prev
         return False
 
 
@@ -111,13 +116,11 @@ class cpu_reference:
     also enters it, to TIME the decoder on the host cores for its reported CPU figure -- never a product path.)"""
 
     def __enter__(self):
-        global _CPU_REFERENCE
-        self._prev, _CPU_REFERENCE = _CPU_REFERENCE, True
+        self._prev, _S.cpu_reference = _S.cpu_reference, True
         return self
 
     def __exit__(self, *exc):
-        global _CPU_REFERENCE
-        _CPU_REFERENCE = self._prev
+        _S.cpu_reference = self._prev
         return False
 
 
@@ -127,10 +130,10 @@ def _fused_ok(*ts):
     unless the caller is inside ``cpu_reference()`` (validation of these definitions against the
     reference classes): then they take the torch composition, which IS the definition the kernels are
     tested against (tests/test_gpu_parity.py)."""
-    if _TORCH_CONVS and all(t.is_cuda for t in ts):
+    if _S.torch_convs and all(t.is_cuda for t in ts):
         return False                                       # the supported fp32 route (torch_convolutions)
     if not any(t.is_cuda for t in ts):
-        if not _CPU_REFERENCE:
+        if not _S.cpu_reference:
             raise NotImplementedError("slr_sfs_amd.nets run on ROCm device tensors only (no CPU path); the torch "
                                       "definition used for validation is available inside nets.cpu_reference()")
         return False
@@ -229,7 +232,7 @@ class Conv(nn.Module):
         arithmetic: (buffer, wscale, xscale, layout flag).  Split-f16 rung: hi / lo halves scaled by wscale; fp32 rung
         (inside fp32_kernels()): the fp32 values themselves, no scales."""
         w = self.weight
-        f32 = _F32_KERNELS
+        f32 = _S.f32_kernels
         key = (w.data_ptr(), w._version, w.device)
         name = "_wf32" if f32 else "_wsplit"
         c = self.__dict__.get(name)
@@ -249,7 +252,7 @@ class Conv(nn.Module):
                     _lib.check(split(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale, _lib.stream_of(w)),
                                "slr_conv_split_weights")
             c = self.__dict__[name] = (key, buf, wscale)
-        return (c[1], 1.0, 1.0, CONV_F32) if f32 else (c[1], c[2], ACT_SCALE, 0)
+        return (c[1], 1.0, 1.0, CONV_F32) if f32 else (c[1], c[2], _S.act_scale, 0)
 
     def conv(self, x, bias, pre_bn=None, residual=None, layout=0):
         """conv(relu(bn(x))) + bias + residual (``pre_bn`` = (scale, shift) of the BN in front, or None).
@@ -530,7 +533,7 @@ def check_saturation(device, what="convolution", reset=True):
     never silent.  (The animators do better than raising: pipeline.py, convs="auto".)"""
     n = saturation_count(device, reset)
     if n:
-        raise RuntimeError(f"slr_sfs_amd: {n} wave(s) of the {what} kernels met activations >= {65472.0 / ACT_SCALE:.0f} in "
+        raise RuntimeError(f"slr_sfs_amd: {n} wave(s) of the {what} kernels met activations >= {65472.0 / _S.act_scale:.0f} in "
                            f"magnitude, outside the exact range of the split-f16 matrix-core convolution; the result is not "
                            f"valid (use a smaller nets.activation_scale, nets.torch_convolutions(), or the animators' "
                            f"convs='auto')")

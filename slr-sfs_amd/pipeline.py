@@ -125,7 +125,8 @@ def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_b
       "auto"  split-f16 kernels; every decoder batch leaves an asynchronous record of the device's saturation counter
               (no host synchronisation inside the loop); after the last batch the records are read and the batches in
               which an activation was clamped are rendered again one rung up (activation scale 1, then fp32) -- the
-              clip that comes back never contains a clamped frame.  The animator remembers the rung (``_conv_rung``).
+              clip that comes back never contains a clamped frame.  The animator remembers the rung (``_conv_rung``; see _ConvRung:
+              ``reset_conv_rung()``, and rung 0 is tried again every RUNG_RETRY_CLIPS clips).
     With ``on_frame`` (frames leave the rank while the clip is still being rendered) a batch is checked before its
     frames are handed on: one host synchronisation per batch."""
     decode_batch, store = decode
@@ -199,6 +200,25 @@ def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_b
         _warn_rung(rung)
 
 
+RUNG_RETRY_CLIPS = 16     # convs="auto": an animator that stepped up tries rung 0 again after this many clips (0 = never)
+
+
+class _ConvRung:
+    """The rung of convs="auto" an animator is on (0 split-f16 at activation scale 64, 1 at scale 1, 2 fp32 kernels): a step up is
+    per animator (and per rank) and shared by its encoder and decoder; it is NOT for good -- ``reset_conv_rung()`` goes back to
+    rung 0 at once, and every RUNG_RETRY_CLIPS clips rendered on a raised rung the next clip starts at rung 0 again (its clamped
+    batches are rendered again one rung up as always: one outlier clip does not leave a long-running service on the slow rung)."""
+
+    def reset_conv_rung(self):
+        self._conv_rung, self._rung_clips = 0, 0
+
+    def _clip_begins(self):
+        if getattr(self, "_conv_rung", 0) > 0 and RUNG_RETRY_CLIPS > 0:
+            self._rung_clips = getattr(self, "_rung_clips", 0) + 1
+            if self._rung_clips > RUNG_RETRY_CLIPS:
+                self.reset_conv_rung()
+
+
 def _warn_rung(rung):
     import warnings
     warnings.warn("slr_sfs_amd: decoder activations exceed the exact range of the split-f16 convolutions; rendering the "
@@ -257,7 +277,7 @@ def splat_options(opts, two_layer):
     return kw
 
 
-class BaselineAnimator(torch.nn.Module):
+class BaselineAnimator(torch.nn.Module, _ConvRung):
     def __init__(self, encoder=None, decoder=None, clamp_z=None, softmax_v1=False, softmax_v2=False, opts=None, convs="auto"):
         """clamp_z / softmax_v1 / softmax_v2: see ClipSynthesizer; ``opts`` (the checkpoint's pickled Namespace)
         sets them the way the reference's forward_flow reads them (splat_options).  convs: arithmetic of the encoder /
@@ -306,6 +326,7 @@ class BaselineAnimator(torch.nn.Module):
         frames = list(range(N) if frames is None else frames)
         policy = self.convs if convs is None else convs
         assert policy in CONV_POLICIES
+        self._clip_begins()
         clip = self.begin_clip(image, motion, N, shard, frames, convs=policy)
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         batch = DECODE_BATCH if batch is None else max(1, int(batch))
@@ -338,7 +359,7 @@ def blur_alpha_region(alpha_region, W):
     return torch.nn.functional.conv2d(x, g)
 
 
-class SLRv1Animator(torch.nn.Module):
+class SLRv1Animator(torch.nn.Module, _ConvRung):
     KEYS = ("PredImg", "BGImg", "FluidImg", "CompositeFluidAlpha")
 
     def __init__(self, encoder=None, decoder=None, net_bg=None, alpha_encoder=None, alpha_decoder=None,
@@ -460,6 +481,7 @@ class SLRv1Animator(torch.nn.Module):
         frames = list(range(N) if frames is None else frames)
         policy = self.convs if convs is None else convs
         assert policy in CONV_POLICIES
+        self._clip_begins()
         want = ("PredImg",) if keys is None else tuple(keys)
         once = ("BGImg", "AlphaRegionMask")
         channels = {"PredImg": 3, "FluidImg": 3, "CompositeFluidAlpha": 1, "EditedCompositeFluidAlpha": 1}

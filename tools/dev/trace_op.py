@@ -28,6 +28,15 @@ t = t[(t[:, 59] > 0) & (t[:, 0] > 0)]
 clk = 2.2e3
 life = (t[:, 59] - t[:, 0]) / clk
 print(f"{which}: {len(t)} workgroups, life us mean {life.mean():.1f} p50 {np.median(life):.1f} p90 {np.percentile(life, 90):.1f} max {life.max():.1f}; sum {life.sum() / 1e3:.1f} ms = {life.sum() / 768:.1f} us on 768 slots")
+tw = t[t[:, 57] > 0]
+st, en = (tw[:, 56] - tw[:, 56].min()) / 100.0, (tw[:, 57] - tw[:, 56].min()) / 100.0          # wall clock, 100 ticks per us
+edges = np.arange(0, min(en.max(), 400.0) + 10, 10.0)
+print("  workgroups running at t = 0, 10, 20, ... us: " + " ".join(str(int(((st <= e) & (en > e)).sum())) for e in edges))
+pro = (tw[:, 56] - tw[:, 58]) / 100.0
+en0 = (tw[:, 58] - tw[:, 56].min()) / 100.0
+print("  workgroups resident (entry .. end) at the same times:  " + " ".join(str(int(((en0 <= e) & (en > e)).sum())) for e in edges))
+print(f"  kernel entry -> item known: mean {pro.mean():.2f} p50 {np.median(pro):.2f} p90 {np.percentile(pro, 90):.2f} max {pro.max():.2f} us")
+print(f"  starts: 768th start at {np.sort(st)[min(767, len(st) - 1)]:.1f} us; last start {st.max():.1f}; last end {en.max():.1f}; lives by wall clock mean {(en - st).mean():.1f}")
 def seg(a, b): return (t[:, b] - t[:, a]).mean() / clk
 print(f"  item->lists sorted {seg(0, 1):.2f} | rows walk {seg(1, 2):.2f} | entries read + prefetch issue {seg(2, 3):.2f} | footprints + atomics {seg(3, 4):.2f} | "
       f"barrier {seg(4, 5):.2f} | scan + scatter {seg(5, 6):.2f} | lists {seg(6, 7):.2f}")
