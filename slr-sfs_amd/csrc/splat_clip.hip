@@ -10,7 +10,7 @@
 //                                   SEG entries is one item, a heavier one is cut into ranges of its OUTPUT COLUMNS (whole octants,
 //                                   by the exact histogram) -- a piece stages every entry that touches its columns and owns its
 //                                   output pixels: no partial tiles, no combine pass, nothing summed across workgroups;
-//   per batch  clip_tile_kernel     one workgroup = one piece of one frame (up to 8 frames per launch, their block groups
+//   per batch  clip_tile_kernel     one workgroup = one piece of one frame (up to 16 frames per launch, their block groups
 //                                   interleaved so the same tile of consecutive frames shares an XCD's L2): the two row-segment
 //                                   lists -> the flow rows (coalesced) -> entries in LDS -> per-output-pixel records -> chunk pipeline;
 //              clip_tile_kernel<.., PASSES>  a piece that still holds more than SEG entries (an octant that is a sink by itself; any
