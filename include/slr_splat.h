@@ -310,6 +310,9 @@ int slr_conv_saturation_record(unsigned *host_slot, void *stream);
  * activations -- at the rate of the fp32 matrix pipe (157 TFLOP/s, 1/16 of the f16 rate).  `wsplit` must then come from
  * slr_conv3x3_f32_weights / slr_conv1x1_f32_weights (same byte counts as the split-f16 buffers), wscale = xscale = 1. */
 #define SLR_CONV_F32    8
+/* Cout <= 4 (the 128 -> 3 end of the decoders): the 3x3 entry points run a kernel of their own on EITHER rung -- fp32 FMAs on the vector
+ * ALUs (csrc/conv_few.hpp; the narrowest matrix-core tile would compute 32 channels for 3), i.e. the reference's arithmetic: both
+ * weight-preparation calls then write plain fp32 weights into the buffer, wscale / xscale are accepted and unused, nothing saturates. */
 
 size_t slr_conv3x3_weight_bytes(int Cout, int Cin);
 int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit, int Cout, int Cin,

@@ -86,6 +86,10 @@ __host__ __device__ inline int conv_cout_tile(int Cout) { return Cout > 64 ? 128
 __host__ __device__ inline int conv_cout_pad(int Cout) { const int t = conv_cout_tile(Cout); return (Cout + t - 1) / t * t; }
 __host__ __device__ inline int conv_cin_pad(int Cin) { return (Cin + 15) / 16 * 16; }
 
+}  // namespace slr
+#include "conv_few.hpp"
+namespace slr {
+
 // CPW: 32-channel output tiles per wave; WCO: waves along the output channels (workgroup covers
 // 32*CPW*WCO channels); the other 4/WCO wave rows split the 8 block rows.
 // INB8: the input tensor is channel-blocked, [N, Cin/8, H, W, 8] (what a previous call wrote with out_b8): the 8 channels of
@@ -813,6 +817,26 @@ SLR_EXPORT int slr_conv_saturation_record(unsigned *host_slot, void *stream) {
     return 0;
 }
 
+// Cout <= 4: the weight buffer holds plain fp32 weights [ci padded to 8][tap][4] on either rung (conv_few.hpp); it fits the split layout's bytes
+static int conv_few_weights(const float *w, void *wbuf, int Cout, int Cin, hipStream_t st) {
+    const int CinP = conv_few_cin_pad(Cin);
+    static_assert(36 * sizeof(float) * 8 <= 32 * 16 * 9 * 2 * sizeof(_Float16), "8 input channels of plain weights fit 16 of the split layout");
+    hipLaunchKernelGGL(conv_few_weights_kernel, dim3((CinP * 36 + 255) / 256), dim3(256), 0, st, w, (float *)wbuf, Cout, Cin, CinP);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NCO>
+static int conv_few_launch(ConvArgs &a, bool in_b8, hipStream_t st) {
+    const dim3 grid(((a.W + CF_BW - 1) / CF_BW) * ((a.H + CF_BH - 1) / CF_BH), 1, a.N);
+    if (a.pre != PRE_NONE && in_b8) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, true, true>), grid, dim3(CF_THREADS), 0, st, a);
+    else if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, true, false>), grid, dim3(CF_THREADS), 0, st, a);
+    else if (in_b8) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, false, true>), grid, dim3(CF_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_few_kernel<NCO, false, false>), grid, dim3(CF_THREADS), 0, st, a);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
 SLR_EXPORT size_t slr_conv3x3_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
     return (size_t)conv_cout_pad(Cout) * conv_cin_pad(Cin) * 9 * 2 * sizeof(_Float16);
@@ -822,6 +846,7 @@ SLR_EXPORT int slr_conv3x3_split_weights(const float *w, void *wsplit, int Cout,
     SLR_CHECK_ARG(w && wsplit, "null pointer");
     SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)conv_cout_pad(Cout) * conv_cin_pad(Cin) * 9 < (1LL << 30), "sizes");
     SLR_CHECK_ARG(wscale > 0.0f, "wscale");
+    if (Cout <= CF_MAXCO) return conv_few_weights(w, wsplit, Cout, Cin, (hipStream_t)stream);      // (plain fp32 weights: conv_few.hpp)
     const int CoutP = conv_cout_pad(Cout), CinP = conv_cin_pad(Cin);
     const int total = CoutP * CinP * 9;
     hipLaunchKernelGGL(conv_split_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
@@ -858,6 +883,7 @@ SLR_EXPORT int slr_conv1x1_split_weights(const float *w, void *wsplit, int Cout,
 SLR_EXPORT int slr_conv3x3_f32_weights(const float *w, void *wfrag, int Cout, int Cin, void *stream) {
     SLR_CHECK_ARG(w && wfrag, "null pointer");
     SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)conv_cout_pad(Cout) * conv_cin_pad(Cin) * 9 < (1LL << 30), "sizes");
+    if (Cout <= CF_MAXCO) return conv_few_weights(w, wfrag, Cout, Cin, (hipStream_t)stream);
     const int CoutP = conv_cout_pad(Cout), CinP = conv_cin_pad(Cin);
     const int total = CoutP * CinP * 9;
     hipLaunchKernelGGL(conv_f32_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float *)wfrag,
@@ -920,6 +946,14 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st);
 static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, bool f32, hipStream_t st) {
     if (int e = check_xscale(xscale)) return e;
     SLR_CHECK_ARG(!f32 || (wscale == 1.0f && xscale == 1.0f), "the fp32 rung takes no operand scales (wscale = xscale = 1)");
+    if (a.Cout <= CF_MAXCO) {                           // fp32 FMAs on the vector ALUs on either rung: no operand scales, nothing saturates
+        switch (a.Cout) {
+            case 1: return conv_few_launch<1>(a, in_b8, st);
+            case 2: return conv_few_launch<2>(a, in_b8, st);
+            case 3: return conv_few_launch<3>(a, in_b8, st);
+            default: return conv_few_launch<4>(a, in_b8, st);
+        }
+    }
     a.tiles_x = (a.W + CV_W - 1) / CV_W;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.xscale = xscale;
