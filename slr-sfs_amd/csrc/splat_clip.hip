@@ -321,6 +321,10 @@ __global__ __launch_bounds__(CT) void rows_plan_pair_kernel(const unsigned long 
 // grid: per frame a multiple of 8 * C_XCD blocks, the frames' groups interleaved (see launch); CT work-items; ClipCfg::LDS_BYTES of LDS.
 // PASSES = false: one piece per workgroup, no loops over work; a piece of more than SEG entries goes to the frame's deferred list.
 // PASSES = true:  C_DEFER_WG workgroups per frame walk the deferred lists pass by pass.
+// (Round 4, measured and rejected: as many workgroups as the chip holds, each walking virtual blocks w, w + grid, ... -- a slot idles ~7 us
+//  between two workgroups of ~75 us.  The loop keeps the by-value kernel arguments live around the whole body: 80 spilled SGPRs, and the
+//  kernel went from 152 to 190 us per frame of work even with one round per workgroup, 202 us with 512 persistent ones.  It needs the
+//  per-frame arguments in memory, read per item, first.)
 template <bool G2, bool PASSES>
 __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_kernel(ClipBatch b) {
     using Cfg = std::conditional_t<PASSES, ClipPassCfg, ClipCfg>;

@@ -331,13 +331,13 @@ class BaselineAnimator(torch.nn.Module, _ConvRung):
         out = image.new_empty(len(frames), 3, image.shape[2], image.shape[3])
         batch = DECODE_BATCH if batch is None else max(1, int(batch))
 
-        def store(pos, frames_out):
-            if pos and pos[-1] - pos[0] + 1 == len(pos):
-                out[pos[0]:pos[0] + len(pos)] = frames_out
+        def store(pos, raw):                              # raw = the projector's output: the tanh writes the frames where they belong
+            if pos and pos[-1] - pos[0] + 1 == len(pos):   # (no intermediate tensor, no 47 MB device copy per batch)
+                torch.tanh(raw, out=out[pos[0]:pos[0] + len(pos)])
             else:
-                out[torch.as_tensor(pos, device=out.device)] = frames_out
+                out[torch.as_tensor(pos, device=out.device)] = torch.tanh(raw)
 
-        _render(self, clip, frames, batch, overlap, (lambda gen, afl: torch.tanh(self.projector(gen)), store), policy,
+        _render(self, clip, frames, batch, overlap, (lambda gen, afl: self.projector(gen), store), policy,
                 None if on_frame is None else (lambda p_: on_frame(out[p_])), one_by_one=overlap or batch == 1)
         return out
 
