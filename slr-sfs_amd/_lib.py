@@ -181,7 +181,9 @@ def workspace(t, role, N, C, H, W, nbytes=None):
         while not capturing and len(_ws_cache) >= WS_CACHE_MAX:
             _ws_cache.popitem(last=False)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
-        if role != "scratch":
+        if role == "scratch":
+            ws.zero_()                                   # ticket counters of the persistent tile kernel: zero once, every launch leaves them zero
+        else:
             # a splat workspace starts zeroed; the kernels leave its counters zero again, so the calls may say WS_CLEAN (no zero kernel)
             with torch.cuda.device(t.device):
                 check(lib().slr_splat_workspace_init(ptr(ws), ws.numel(), N, C, H, W, ctypes.c_void_p(stream.cuda_stream)), "slr_splat_workspace_init")

@@ -12,6 +12,14 @@
 #include "slr_common.hpp"
 #include "splat_types.hpp"
 
+// Tile kernels carry the packed-fp32 feature (the rest of the library is built without it, csrc/Makefile): accum4's inline
+// v_pk_fma_f32 needs it to assemble.  Device pass only (the host pass does not know the feature).
+#if defined(__HIP_DEVICE_COMPILE__) && SLR_PK_FMA
+#define SLR_TILE_KERNEL __attribute__((target("packed-fp32-ops")))
+#else
+#define SLR_TILE_KERNEL
+#endif
+
 namespace slr {
 
 // ---- memory access through buffer descriptors ------------------------------------------------------------------------------
@@ -27,7 +35,7 @@ __device__ __forceinline__ float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) 
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, SLR_STORE_AUX);
 }
 
 // ---- scans --------------------------------------------------------------------------------------------------------------------

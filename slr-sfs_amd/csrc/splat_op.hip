@@ -15,10 +15,12 @@
 //         workgroup tests the boxes, lists the rows of the blocks that touch it in LDS and walks them with the same code.  2
 //         launches, nothing to zero, no plan: a tile of more than SEG entries is walked pass by pass by its own workgroup.
 #include "splat_rows.hpp"
+#include "splat_queue.hpp"
 #include "splat_ws.hpp"
 
 #include <stdarg.h>
 #include <atomic>
+#include <stdlib.h>
 
 namespace slr {
 
@@ -399,7 +401,7 @@ struct OpArgs { TileShared s; TileFrame f; };
 // PASSES = false: one piece per workgroup, no loop over work (80 VGPRs: three workgroups per CU); a piece of more than SEG entries is
 // appended to the deferred list.  PASSES = true: OP_DEFER_WG workgroups walk the deferred list pass by pass (normally it is empty).
 template <bool NORM, bool MAXOP, bool PASSES>
-__global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kernel(OpArgs a) {
+SLR_TILE_KERNEL __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kernel(OpArgs a) {
     using Cfg = std::conditional_t<PASSES, OpPassCfg, OpCfg>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
@@ -439,6 +441,43 @@ __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kerne
         __syncthreads();
         if (tid == 0 && atomicAdd(f.totals + 6, 1u) == gridDim.x * gridDim.y - 1u) { f.totals[4] = 0u; f.totals[6] = 0u; }
     }
+}
+
+// rows front end, persistent form (SLR_PERSIST_ROWS; splat_queue.hpp): as many workgroups as the chip holds pull (item, channel group)
+// units from per-XCD ticket counters -- the per-item launch leaves 20 - 35 % of its 768 slots empty (traced in round 4: relaunch gaps and a
+// 30 - 40 us tail behind 2.5 rounds of workgroups).  Pieces of more than SEG entries still go to the deferred list (the second launch).
+template <bool NORM, bool MAXOP>
+SLR_TILE_KERNEL __global__ __launch_bounds__(TT, SLR_WAVES_ROWS) void op_rows_pull_kernel(OpArgs a, uint32_t *queues, uint32_t groups) {
+    using Cfg = OpCfg;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const TileLds<Cfg> L(smem);
+    int tid = threadIdx.x;
+    const uint32_t units = a.f.totals[0] * groups;
+    Puller P;
+    pull_begin(P, queues, tickets_per_queue(units, 1u), tid);
+    uint32_t k, q;
+    while (pull_next(P, &L.misc[15], tid, k, q)) {
+        uint32_t zero;                                     // (see clip_pull_kernel: an item's code compiled as if it stood alone)
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        asm volatile("" : "+v"(tid));
+        const OpArgs &aa = (&a)[zero];
+        const TileShared &s = aa.s;
+        const TileFrame &f = aa.f;
+        uint32_t fr, unit;
+        ticket_item(k, q, 1u, 0u, fr, unit);
+        if (unit >= units) continue;
+        const uint32_t item = unit / groups, g = unit - item * groups;
+        const int cper = (((s.C + (int)groups - 1) / (int)groups + 7) / 8) * 8;      // (channel_group with the group from the ticket)
+        const int cb = (int)g * cper, ce = min(s.C, cb + cper);
+        if (cb >= s.C) continue;
+        const TileScalars sc = tile_scalars(s, f);
+        const uint32_t nh = f.totals[5];                   // heavy items sit at the front of items[], the rest at its back
+        const uint32_t at = item < nh ? item : f.items_cap - 1u - (item - nh);
+        const Piece p = make_piece<Cfg>(s, f.items[at]);
+        if (!rows_piece_once<Cfg, false, NORM, MAXOP, false>(s, f, L, p, tid, sc, cb, ce) && tid == 0 && g == 0u)
+            f.defer[atomicAdd(f.totals + 4, 1u)] = at;
+    }
+    pull_end(P, tid, gridDim.x);
 }
 
 // scan front end: one workgroup per output tile (x channel groups).  The boxes of all source tiles are tested 2048 at a time, the
@@ -519,7 +558,7 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
 //  37 -> 49.5 us, and with few tail slots a smooth flow's heavy tiles queue up behind each other: 177 -> 883 us.)
 constexpr uint32_t SCAN_DEFER_WG = SLR_SCAN_DEFER_WG;
 template <bool NORM, bool MAXOP, bool DEFER>
-__global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
+SLR_TILE_KERNEL __global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     using Cfg = OpCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
@@ -650,18 +689,30 @@ int op_ws_open(OpWs &w, int N, int H, int W, void *ws, size_t bytes, const char 
     w.defer2 = (uint32_t *)(b + w.L.off_defer2);
     w.ctl = (uint32_t *)(b + w.L.off_ctl);
     w.arrive = (uint32_t *)(b + w.L.off_arrive);
+    w.queue = (uint32_t *)(b + w.L.off_queue);
     w.box = b + w.L.off_box;
     return 0;
 }
 
 int op_check_dims(int N, int C, int H, int W, const char *who) {
-    // image rows travel in 24 bits of a row-list entry; a sample's plane stack is addressed through one buffer descriptor (< 2^31 bytes)
-    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H >= (1 << 24) || (long long)N * H * W >= (1LL << 29) ||
-        (long long)C * H * W * 4 >= (1LL << 31)) {
-        set_error("%s: bad sizes N=%d C=%d H=%d W=%d (N*H*W < 2^29, C*H*W*4 < 2^31)", who, N, C, H, W);
+    // image rows travel in 24 bits of a row-list entry, pixel indices in 29 bits; 8 planes of a sample fit one buffer descriptor (a
+    // larger plane stack is rendered plane group by plane group: plane_group)
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H >= (1 << 24) || (long long)N * H * W >= (1LL << 29) || (long long)H * W >= (1LL << 26)) {
+        set_error("%s: bad sizes N=%d C=%d H=%d W=%d (N*H*W < 2^29, H*W < 2^26)", who, N, C, H, W);
         return SLR_E_BADARG;
     }
     return 0;
+}
+
+// Planes of a sample one launch covers.  A launch addresses the planes of a sample through ONE buffer descriptor (32-bit byte offsets; the
+// offset 2^31 is the one no descriptor covers: dropped stores).  The reference indexes up to 2^31 ELEMENTS per tensor (softsplat.py:163,
+// 408-416: `int` indices over output.nelement()); a stack of C * H * W * 4 >= 2^31 bytes -- 65 planes of a 4K frame -- is rendered by
+// several launches of the tile kernel, each over a group of planes (a multiple of 8, the channel groups' unit) of at most 2^31 - 1
+// bytes: the binning / plan is made once, the records of a tile are rebuilt per group.
+int plane_group(int C, int H, int W) {
+    const long long plane = (long long)H * W * 4, fit = ((1LL << 31) - 1) / plane;
+    if (fit >= C) return C;
+    return (int)(fit / 8 * 8);                          // (>= 8: H * W < 2^26, op_check_dims)
 }
 
 static std::atomic<int> g_scan_max_tiles{SLR_SCAN_MAX_TILES};          // slr_splat_set_scan_max_tiles
@@ -727,7 +778,24 @@ static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
     const uint32_t grid = ((w.L.items_cap + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
     const uint32_t groups = channel_groups(w.L.nt, a.s.C);
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));      // slr_splat_time_next: the dominant kernel only
+#if SLR_PERSIST_ROWS
+    {
+        static bool attr_pull[64] = {};
+        if (int e = set_lds_attr(op_rows_pull_kernel<NORM, MAXOP>, attr_pull)) return e;
+        static std::atomic<int> cus_known{0};
+        int cus = cus_known.load();
+        if (!cus) { int dev = 0; SLR_CHECK_HIP(hipGetDevice(&dev)); SLR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); cus_known.store(cus); }
+        const int by_lds = (int)((size_t)160 * 1024 / OpCfg::LDS_BYTES), by_waves = 32 / (TT / 64);
+        int per_cu = by_lds < by_waves ? by_lds : by_waves;
+        if (const char *e = getenv("SLR_DEBUG_WG_PER_CU")) per_cu = atoi(e);
+        uint32_t wgs = (uint32_t)cus * (uint32_t)per_cu;
+        const uint32_t bound = w.L.items_cap * groups;
+        if (wgs > bound) wgs = bound;
+        hipLaunchKernelGGL((op_rows_pull_kernel<NORM, MAXOP>), dim3(wgs), dim3(TT), OpCfg::LDS_BYTES, st, a, w.queue, groups);
+    }
+#else
     hipLaunchKernelGGL((op_rows_kernel<NORM, MAXOP, false>), dim3(grid, groups), dim3(TT), OpCfg::LDS_BYTES, st, a);
+#endif
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
     // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass, their planes
@@ -763,7 +831,8 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     return 0;
 }
 
-// One call of the operator: front end by grid size / flags, then the tile kernel(s).
+// One call of the operator: front end by grid size / flags, then the tile kernel(s) -- once per plane group (plane_group: one group unless
+// the sample's plane stack reaches 2 GiB).
 template <bool NORM, bool MAXOP>
 static int do_op(OpArgs &a, int ws_flags, void *ws, size_t ws_bytes, hipStream_t st, const char *who) {
     OpWs w;
@@ -774,10 +843,19 @@ static int do_op(OpArgs &a, int ws_flags, void *ws, size_t ws_bytes, hipStream_t
     a.s.trace = g_trace;
 #endif
     const int fe = front_end(ws_flags, w.L.nt);
-    if (fe == 1) return launch_scan<NORM, MAXOP>(a, w, st);
-    if (!(ws_flags & SLR_WS_PREBINNED))
+    if (fe != 1 && !(ws_flags & SLR_WS_PREBINNED))
         if (int e = do_rowbin(a.f.flow[0], w, a.s.N, a.s.H, a.s.W, (ws_flags & SLR_WS_CLEAN) != 0, st)) return e;
-    return launch_rows<NORM, MAXOP>(a, w, st);
+    const int C = a.s.C, gp = plane_group(C, a.s.H, a.s.W);
+    const size_t hw = (size_t)a.s.H * a.s.W;
+    const float *in = a.s.in;
+    float *out = a.f.out;
+    a.s.Cs = C;
+    for (int pb = 0; pb < C; pb += gp) {
+        a.s.in = in + (size_t)pb * hw; a.f.out = out + (size_t)pb * hw;
+        a.s.C = C - pb < gp ? C - pb : gp;
+        if (int e = fe == 1 ? launch_scan<NORM, MAXOP>(a, w, st) : launch_rows<NORM, MAXOP>(a, w, st)) return e;
+    }
+    return 0;
 }
 
 }  // namespace slr

@@ -46,7 +46,8 @@ __device__ __forceinline__ void rows_setup_sorted(const TileFrame &f, const Tile
     if (d < Cfg::NDIR) {
         const uint32_t nd = d ? (p.ovf1 ? 0u : p.len1) : p.n0;
         if ((uint32_t)q < nd) {
-            const RowRec r = f.rowlist[d][(size_t)p.tile * ROW_CAP + q];
+            const RowRec *list = d ? f.rowlist[Cfg::NDIR - 1] : f.rowlist[0];      // (a select, not an index: the frame's arguments may live in registers)
+            const RowRec r = list[(size_t)p.tile * ROW_CAP + q];
             const uint32_t pos = (d ? p.n0 : 0u) + (uint32_t)q;
             L.rl[pos] = r.sy;
             L.rl[Cfg::NDIR * ROW_CAP + pos] = r.sx_cnt;
@@ -212,7 +213,7 @@ __device__ __forceinline__ TileScalars tile_scalars(const TileShared &s, const T
     return k;
 }
 __device__ __forceinline__ rsrc_t sample_planes(const TileShared &s, const Piece &p, uint32_t hw4) {
-    return make_rsrc(s.in + (size_t)p.n * s.C * ((size_t)s.H * s.W), (uint32_t)s.C * hw4);
+    return make_rsrc(s.in + (size_t)p.n * s.Cs * ((size_t)s.H * s.W), (uint32_t)s.C * hw4);
 }
 
 // A piece in ONE pass (the main kernels: no loop over work): lists -> entries -> records -> planes [cb, ce).  Returns false, with

@@ -20,6 +20,9 @@ namespace slr {
 
 constexpr int TT = TILE_PIX;                       // work-items per workgroup = output pixels of a tile
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f2 WRec;                                   // a record in registers: .x weight, .y the staged entry's byte offset (bits)
+
 enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
 
 // ---- shape of a kernel family -------------------------------------------------------------------------------------------------
@@ -35,6 +38,7 @@ struct TileCfg {
     static constexpr int SEG = EPT * TT;
     static constexpr int RECCAP = 4 * SEG + TT;    // <= 4 records per entry + one pad per pixel (odd list lengths: bank spreading)
     static constexpr uint32_t NULL_E = SEG;        // staged-entry index of the all-zero slot
+    static_assert(!REC6_ || (EPT_ * TILE_PIX + 1) * 16 <= 65536, "byte offsets of staged entries travel in 16 bits (6-byte records)");
     static constexpr uint32_t NULLREC = RECCAP - 1;   // a record (all-zero slot, weight 0) that no list owns (the last pixel's pad)
     static constexpr size_t HEAD = (size_t)(TT + 16 + 16 + TT / 2) * 4;
     static constexpr size_t REC_BYTES = ((size_t)RECCAP * (REC6 ? 6 : 8) + 15) & ~(size_t)15;
@@ -50,6 +54,7 @@ struct TileShared {                // the same for every frame of a launch
     const float *mulmax;           // device scalar subtracted before exp (MUL_EXP_SHIFT), or nullptr
     const float *in2, *mul2;       // second weight group: one value plane with its own weight logits (G2 instantiations)
     int N, C, H, W, tiles_x, tiles;   // tiles per sample
+    int Cs;                        // planes of a sample IN MEMORY (its stride): C, or more when a launch covers a plane group of a larger stack
     int mulmode, mulmode2, norm_mode;
     float eps, init;               // normaliser clamp; start value of the maximum splat
     long long *trace;              // development builds (-DSLR_TRACE): 64 time stamps per workgroup, or nullptr
@@ -103,14 +108,22 @@ struct TileLds {
         ent4 = val4;
         ent2 = reinterpret_cast<float2 *>(rl + 4 * Cfg::NDIR * ROW_CAP);
     }
+    // A record = (weight, BYTE offset of the staged entry in val4): the weight comes first -- an 8-byte record read lands in an even
+    // register pair with the weight in its LOW register, the one operand form in which v_pk_fma_f32 may broadcast it (see accum4).
     __device__ __forceinline__ void rec_put(uint32_t i, uint32_t e, float w) const {
-        if constexpr (Cfg::REC6) { rec_e[i] = (uint16_t)e; rec_w[i] = w; } else rec8[i] = make_uint2(e, __float_as_uint(w));
+        if constexpr (Cfg::REC6) { rec_e[i] = (uint16_t)(e * 16u); rec_w[i] = w; } else rec8[i] = make_uint2(__float_as_uint(w), e * 16u);
     }
-    __device__ __forceinline__ void rec_get(uint32_t i, uint32_t &e, float &w) const {
-        if constexpr (Cfg::REC6) { e = rec_e[i]; w = rec_w[i]; } else { const uint2 q = rec8[i]; e = q.x; w = __uint_as_float(q.y); }
+    __device__ __forceinline__ WRec rec_get(uint32_t i) const {
+        WRec r;
+        if constexpr (Cfg::REC6) { r.x = rec_w[i]; r.y = __uint_as_float((uint32_t)rec_e[i]); }
+        else { const uint2 q = rec8[i]; r.x = __uint_as_float(q.x); r.y = __uint_as_float(q.y); }
+        return r;
     }
     __device__ __forceinline__ float rec_weight(uint32_t i) const {
-        if constexpr (Cfg::REC6) return rec_w[i]; else return __uint_as_float(rec8[i].y);
+        if constexpr (Cfg::REC6) return rec_w[i]; else return __uint_as_float(rec8[i].x);
+    }
+    __device__ __forceinline__ float4 staged(const WRec &r) const {       // the 4 staged planes of the record's entry: one ds_read_b128
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(val4) + __float_as_uint(r.y));
     }
 };
 
@@ -250,8 +263,7 @@ struct PixelList {
     unsigned long long heavy;      // lanes of this wave whose rest the wave walks together
     int g_log;                     // log2 of the lanes per output pixel
     int pid;                       // the output pixel (index in the piece's 8 x 64 frame) this work-item serves
-    uint32_t ce[Cfg::KREG];
-    float cw[Cfg::KREG];
+    WRec rc[Cfg::KREG];            // the first KREG records of the list
 };
 
 __device__ __forceinline__ int lane_group_log(const Piece &p) {
@@ -281,8 +293,23 @@ __device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int 
 #pragma unroll
     for (int k = 0; k < Cfg::KREG; ++k) {
         const uint32_t r = g.r0 + ((uint32_t)k << g_log);
-        L.rec_get(r < g.rl ? r : Cfg::NULLREC, g.ce[k], g.cw[k]);
+        g.rc[k] = L.rec_get(r < g.rl ? r : Cfg::NULLREC);
     }
+#if SLR_REC_SORT
+    // The register-resident records in the order of their staged entries (the slots of a list are handed out in the arrival order of
+    // LDS atomics): neighbouring output pixels then read neighbouring entries with the same instruction of the gather -- consecutive
+    // 16-byte slots, different banks -- instead of a random one of their ~8 sources each (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.28
+    // before).  Once per piece, in registers: KREG (KREG - 1) / 2 compare-exchanges.  The all-zero slot has the highest offset: pads last.
+#pragma unroll
+    for (int round = 0; round < Cfg::KREG; ++round)
+#pragma unroll
+        for (int k = round & 1; k + 1 < Cfg::KREG; k += 2) {
+            const bool sw = __float_as_uint(g.rc[k].y) > __float_as_uint(g.rc[k + 1].y);
+            const WRec a = g.rc[k], c = g.rc[k + 1];
+            g.rc[k].x = sw ? c.x : a.x; g.rc[k].y = sw ? c.y : a.y;
+            g.rc[k + 1].x = sw ? a.x : c.x; g.rc[k + 1].y = sw ? a.y : c.y;
+        }
+#endif
     return g;
 }
 
@@ -294,14 +321,37 @@ __device__ __forceinline__ float group_reduce(float v, int g_log) {    // the G 
     return v;
 }
 
+// Four planes' accumulators as two register pairs.  acc (+)= staged value * weight; the sum is two v_pk_fma_f32 (two FMAs each, the
+// same single rounding as v_fma_f32) with the record's weight broadcast from the LOW register of its pair (op_sel_hi:[1,0,1]).  That is
+// the operand form measured correct next to another wave's MFMAs; the high-register broadcast (op_sel:[0,1,0]), which is what the
+// compiler's own pairing of scalar FMAs produces for every second weight, is the one that returned wrong low halves (DESIGN.md 3.2,
+// tools/ubench/pkfma_repro.hip) -- the library is built without SLP vectorisation, and tests/test_abi_and_host.py disassembles the
+// code objects: every packed-fp32 instruction in them must be this form.
+struct Acc4 { f2 lo, hi; };
+
 template <bool MAXOP>
-__device__ __forceinline__ void accum4(float (&acc)[4], const float4 &v, float w, bool on) {
+__device__ __forceinline__ Acc4 acc4_init(float init) {
+    Acc4 a;
+    a.lo.x = a.lo.y = a.hi.x = a.hi.y = MAXOP ? init : 0.0f;
+    return a;
+}
+
+template <bool MAXOP>
+__device__ __forceinline__ void accum4(Acc4 &a, const float4 &v, const WRec &r, bool on) {
     if (MAXOP) {
-        acc[0] = fmaxf(on ? v.x * w : -INFINITY, acc[0]); acc[1] = fmaxf(on ? v.y * w : -INFINITY, acc[1]);
-        acc[2] = fmaxf(on ? v.z * w : -INFINITY, acc[2]); acc[3] = fmaxf(on ? v.w * w : -INFINITY, acc[3]);
+        const float w = r.x;
+        a.lo.x = fmaxf(on ? v.x * w : -INFINITY, a.lo.x); a.lo.y = fmaxf(on ? v.y * w : -INFINITY, a.lo.y);
+        a.hi.x = fmaxf(on ? v.z * w : -INFINITY, a.hi.x); a.hi.y = fmaxf(on ? v.w * w : -INFINITY, a.hi.y);
     } else {
-        acc[0] = __builtin_fmaf(v.x, w, acc[0]); acc[1] = __builtin_fmaf(v.y, w, acc[1]);
-        acc[2] = __builtin_fmaf(v.z, w, acc[2]); acc[3] = __builtin_fmaf(v.w, w, acc[3]);
+#if SLR_PK_FMA
+        const f2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a.lo) : "v"(vlo), "v"(r));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a.hi) : "v"(vhi), "v"(r));
+#else
+        const float w = r.x;
+        a.lo.x = __builtin_fmaf(v.x, w, a.lo.x); a.lo.y = __builtin_fmaf(v.y, w, a.lo.y);
+        a.hi.x = __builtin_fmaf(v.z, w, a.hi.x); a.hi.y = __builtin_fmaf(v.w, w, a.hi.y);
+#endif
     }
 }
 
@@ -312,50 +362,51 @@ __device__ __forceinline__ void accum4(float (&acc)[4], const float4 &v, float w
 template <class Cfg, bool MAXOP, typename F>
 __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane, float init, float (&acc)[4], F &&between) {
     constexpr int RB = 4, KREG = Cfg::KREG;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = MAXOP ? init : 0.0f;
+    constexpr uint32_t NULL_B = Cfg::NULL_E * 16u;
+    Acc4 a = acc4_init<MAXOP>(init);
     {
         between(0);
         float4 v[KREG];
 #pragma unroll
-        for (int k = 0; k < KREG; ++k) v[k] = L.val4[g.ce[k]];                    // ds_read_b128: 4 planes per LDS instruction
+        for (int k = 0; k < KREG; ++k) v[k] = (SLR_SKIP & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : L.staged(g.rc[k]);     // ds_read_b128: 4 planes per LDS instruction
         between(1);
 #pragma unroll
-        for (int k = 0; k < KREG; ++k) accum4<MAXOP>(acc, v[k], g.cw[k], g.ce[k] != Cfg::NULL_E);
+        for (int k = 0; k < KREG; ++k) accum4<MAXOP>(a, v[k], g.rc[k], __float_as_uint(g.rc[k].y) != NULL_B);
     }
     between(2);
-    for (uint32_t r = g.r0 + ((uint32_t)KREG << g.g_log); r < g.rl; r += (uint32_t)RB << g.g_log) {
-        uint32_t e[RB];
-        float w[RB];
+    for (uint32_t r = g.r0 + ((uint32_t)KREG << g.g_log); r < g.rl && !(SLR_SKIP & 8); r += (uint32_t)RB << g.g_log) {
+        WRec q[RB];
 #pragma unroll
-        for (int k = 0; k < RB; ++k) { const uint32_t q = r + ((uint32_t)k << g.g_log); L.rec_get(q < g.rl ? q : Cfg::NULLREC, e[k], w[k]); }
+        for (int k = 0; k < RB; ++k) { const uint32_t i = r + ((uint32_t)k << g.g_log); q[k] = L.rec_get(i < g.rl ? i : Cfg::NULLREC); }
         float4 v[RB];
 #pragma unroll
-        for (int k = 0; k < RB; ++k) v[k] = L.val4[e[k]];
+        for (int k = 0; k < RB; ++k) v[k] = L.staged(q[k]);
 #pragma unroll
-        for (int k = 0; k < RB; ++k) accum4<MAXOP>(acc, v[k], w[k], e[k] != Cfg::NULL_E);
+        for (int k = 0; k < RB; ++k) accum4<MAXOP>(a, v[k], q[k], __float_as_uint(q[k].y) != NULL_B);
     }
     between(3);
     for (unsigned long long hv = g.heavy; hv; hv &= hv - 1) {                     // long lists, cooperatively
         const int src = __ffsll((long long)hv) - 1;
         const uint32_t hb = __shfl(g.rl, src), he = __shfl(g.r1, src);
-        float part[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = MAXOP ? -INFINITY : 0.0f;
+        Acc4 part = acc4_init<MAXOP>(-INFINITY);
         for (uint32_t r = hb + (uint32_t)lane; r < he; r += 64) {
-            uint32_t e;
-            float w;
-            L.rec_get(r, e, w);
-            accum4<MAXOP>(part, L.val4[e], w, true);
+            const WRec q = L.rec_get(r);
+            accum4<MAXOP>(part, L.staged(q), q, true);
         }
+        float pt[4] = {part.lo.x, part.lo.y, part.hi.x, part.hi.y}, tot[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            float t = part[u];
+            float t = pt[u];
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(t, d); t = MAXOP ? fmaxf(t, o) : t + o; }
-            if (lane == src) acc[u] = MAXOP ? fmaxf(acc[u], t) : acc[u] + t;
+            tot[u] = t;
+        }
+        if (lane == src) {
+            a.lo.x = MAXOP ? fmaxf(a.lo.x, tot[0]) : a.lo.x + tot[0]; a.lo.y = MAXOP ? fmaxf(a.lo.y, tot[1]) : a.lo.y + tot[1];
+            a.hi.x = MAXOP ? fmaxf(a.hi.x, tot[2]) : a.hi.x + tot[2]; a.hi.y = MAXOP ? fmaxf(a.hi.y, tot[3]) : a.hi.y + tot[3];
         }
     }
+    acc[0] = a.lo.x; acc[1] = a.lo.y; acc[2] = a.hi.x; acc[3] = a.hi.y;
     if (g.g_log) {                                     // (uniform)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = group_reduce<MAXOP>(acc[u], g.g_log);
@@ -398,7 +449,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
     const uint32_t opix = (uint32_t)(oy * s.W + ox);
     const uint32_t voff = inside ? opix * 4u : BUF_OOB;                   // (work-items outside the image / the piece: stores dropped)
     const size_t hw = (size_t)s.H * s.W;
-    const rsrc_t rout = make_rsrc(f.out + (size_t)p.n * s.C * hw, (uint32_t)s.C * hw4);
+    const rsrc_t rout = make_rsrc(f.out + (size_t)p.n * s.Cs * hw, (uint32_t)s.C * hw4);
     float inv = 1.0f;
     if (NORM) {
         if (G2) {
@@ -422,12 +473,14 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
     // the loop makes it drain the whole queue at the top of every chunk: the prefetch distance of two chunks becomes one)
     auto chunk = [&](auto full_tag, float (&pre)[EPT][4], int c0) {
         constexpr bool FULL = decltype(full_tag)::value;
+        if (!(SLR_SKIP & 2)) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
             L.val4[tid + j * TT] = G2 ? make_float4(pre[j][0] * e.m[j], pre[j][1] * e.m[j], pre[j][2] * e.m[j], pre[j][3] * e.m[j])
                                       : make_float4(pre[j][0], pre[j][1], pre[j][2], pre[j][3]);
+        }
         if (c0 - cb < 32) T_STAMP(s, 8 + 6 * ((c0 - cb) / 4));
-        __syncthreads();
+        if (!(SLR_SKIP & 32)) __syncthreads();
         if (c0 - cb < 32) T_STAMP(s, 9 + 6 * ((c0 - cb) / 4));
         float acc[4];
         // the plane loads of the chunk after next (two chunks ahead), one plane at each of the gather's four stops
@@ -440,6 +493,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
                 }
                 return;
             }
+            if (SLR_SKIP & 1) return;
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t soff = (uint32_t)min(c0 + 8 + u, cmax) * hw4;
 #pragma unroll
@@ -447,7 +501,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
             __builtin_amdgcn_sched_barrier(0);
         });
         if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));
-        __syncthreads();                              // val4 is overwritten by the next chunk (the stores below do not hold the others up)
+        if (!(SLR_SKIP & 32)) __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up)
         if (c0 - cb < 32) T_STAMP(s, 13 + 6 * ((c0 - cb) / 4));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -456,7 +510,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
                 float r = acc[u];
                 if (ACCUM && !first) { const float o = buf_ld(rout, voff, soff); r = MAXOP ? fmaxf(r, o) : r + o; }   // earlier passes of this piece
                 if (NORM && (!ACCUM || last)) r *= inv;
-                buf_st(rout, voff, soff, r);
+                if (!(SLR_SKIP & 16) || c0 == cb) buf_st(rout, voff, soff, r);
             }
         }
     };

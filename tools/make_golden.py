@@ -39,6 +39,7 @@ import torch
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 TMP = tempfile.mkdtemp(prefix="slr_golden_")
+FP64 = False        # tools/make_golden_large.py --native --fp64: the reference's kernel text compiled with every `float` a double
 
 _PROLOGUE = r"""
 #include <cmath>
@@ -47,6 +48,7 @@ struct dim3_ { int x, y, z; };
 static dim3_ blockIdx = {0,0,0}, blockDim = {1,1,1}, threadIdx = {0,0,0}, gridDim = {1,1,1};
 #define __global__
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline int   atomicCAS(int* p, int cmp, int val) { int o = *p; if (o == cmp) *p = val; return o; }
 static inline int   __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i)   { float f; memcpy(&f, &i, 4); return f; }
@@ -59,16 +61,20 @@ class CudaLike(torch.Tensor):
 
 
 def cudalike(a):
-    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).clone()
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64 if FP64 else np.float32)).clone()
     return t.as_subclass(CudaLike)
 
 
 def _host_launch(strFunction, strKernel):
     """Stand-in for softsplat.cupy_launch: compile the expanded kernel text for the host."""
-    key = hashlib.sha1((strFunction + strKernel).encode()).hexdigest()[:16]
+    key = hashlib.sha1((strFunction + strKernel + ("fp64" if FP64 else "")).encode()).hexdigest()[:16]
     so = os.path.join(TMP, f"{strFunction}_{key}.so")
     if not os.path.exists(so):
         cpp = so[:-3] + ".cpp"
+        if FP64:        # every `float` of the kernel text a double (the summation kernels use no bit casts)
+            import re
+            assert "__float_as_int" not in strKernel and "__int_as_float" not in strKernel, strFunction
+            strKernel = re.sub(r"\bfloat\b", "double", strKernel)
         with open(cpp, "w") as f:
             f.write(_PROLOGUE + strKernel)
         subprocess.check_call(["g++", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-w", cpp, "-o", so])

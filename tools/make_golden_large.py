@@ -26,10 +26,10 @@ NPOS = 4096
 
 
 def digest(g, tag, x):
-    x = np.ascontiguousarray(x, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float64 if MG.FP64 else np.float32)
     pos = NF.digest_positions(tag, x.size, NPOS)
     g[f"{tag}_shape"] = np.array(x.shape, np.int64)
-    g[f"{tag}_val"] = x.ravel()[pos]
+    g[f"{tag}_val"] = x.ravel()[pos].astype(np.float32)
     g[f"{tag}_plane_sums"] = x.reshape(-1, x.shape[-2] * x.shape[-1]).astype(np.float64).sum(1)
     g[f"{tag}_absmax"] = np.float32(np.abs(x).max())
     print(tag, x.shape, "absmax", float(np.abs(x).max()))
@@ -80,7 +80,33 @@ def main(S=S, N=8, ts=None, v1_ts=None, nets_too=True, out_name="large_nets_e2e.
 
     g = {"S": np.int32(S), "npos": np.int32(NPOS)}
     cl = MG.cudalike
-    plain = lambda t: t.detach().as_subclass(torch.Tensor).numpy().astype(np.float32)
+    # fp64 run: the motion field and euler_integration stay fp32 -- the reference's integration is fp32 by definition (its `.float()` state
+    # and round-half-even lookups, euler_integration_manipulator.py:27-38); the displacement maps are widened exactly before the splat
+    cl_motion = (lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).clone().as_subclass(MG.CudaLike)) if MG.FP64 else cl
+    splatter = ss.ModuleSoftsplat("summation")
+    if MG.FP64:
+        class Splat64(torch.nn.Module):
+            def forward(self, tenInput, tenFlow, tenMetric):
+                return ss.FunctionSoftsplat(tenInput, tenFlow.double().contiguous().as_subclass(MG.CudaLike),
+                                            None if tenMetric is None else tenMetric.double().as_subclass(MG.CudaLike), "summation")
+        splatter = Splat64()
+        # the reference's hard-coded fp32 casts (`mask = (x != 0).float()`, architectures.py:369; `float_x = x.float()` in its batch
+        # norms, normalization.py:238,321; the alpha scalars, animating_softmax_splating.py:585) widened as well -- everywhere except
+        # inside euler_integration, which runs with the real Tensor.float
+        real_float = torch.Tensor.float
+        widen = lambda self, *a, **k: self.double()
+        torch.Tensor.float = widen
+
+        def euler32(*a, **k):
+            torch.Tensor.float = real_float
+            try:
+                return eim.euler_integration(*a, **k)
+            finally:
+                torch.Tensor.float = widen
+        A.euler_integration = B.euler_integration = euler32
+    npdt = np.float64 if MG.FP64 else np.float32
+    plain = lambda t: t.detach().as_subclass(torch.Tensor).numpy().astype(npdt)
+    tin = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=npdt))
     with torch.no_grad():
         # ---- the network classes by themselves
         nets = {"encoder": (U.get_encoder, opt_v1), "projector": (U.get_decoder, opt_v1),
@@ -99,25 +125,25 @@ def main(S=S, N=8, ts=None, v1_ts=None, nets_too=True, out_name="large_nets_e2e.
         img, motion, N = NF.e2e_inputs(S, N)
         g["N"] = np.int32(N)
         enc, dec = build(U.get_encoder, "encoder", opt_base), build(U.get_decoder, "projector", opt_base)
-        fs, Z = enc(torch.from_numpy(img))
-        me = types.SimpleNamespace(opt=opt_base, softsplater=ss.ModuleSoftsplat("summation"), projector=dec)
+        fs, Z = enc(tin(img))
+        me = types.SimpleNamespace(opt=opt_base, softsplater=splatter, projector=dec)
         ts = [1, N // 2, N - 1] if ts is None else list(ts)
         v1_ts = [N // 2] if v1_ts is None else list(v1_ts)
         g["ts"] = np.array(ts, np.int32)
         g["v1_ts"] = np.array(v1_ts, np.int32)
         for t in ts:
-            batch = {"features": [(cl(plain(fs)), cl(plain(Z)))], "images": [cl(img)], "motions": [cl(motion)],
+            batch = {"features": [(cl(plain(fs)), cl(plain(Z)))], "images": [cl(img)], "motions": [cl_motion(motion)],
                      "index": torch.tensor([[0, t, N - 1]])}
             digest(g, f"baseline_PredImg_t{t}", plain(A.AnimatingSoftmaxSplating.forward_flow(me, batch)["PredImg"]))
         bgn, aenc, adec = (build(U.get_net_bg, "net_bg", opt_v1), build(U.get_alpha_encoder, "net_alpha_encoder", opt_v1),
                            built["net_alpha_decoder"])
         enc1, dec1 = build(U.get_encoder, "encoder", opt_v1), build(U.get_decoder, "projector", opt_v1)
-        fs1, Z1 = enc1(torch.from_numpy(img))
-        bg = bgn(torch.from_numpy(img))
-        me = types.SimpleNamespace(opt=opt_v1, softsplater=ss.ModuleSoftsplat("summation"), projector=dec1,
+        fs1, Z1 = enc1(tin(img))
+        bg = bgn(tin(img))
+        me = types.SimpleNamespace(opt=opt_v1, softsplater=splatter, projector=dec1,
                                    net_alpha_decoder=adec, net_alpha_encoder=aenc)
         for t in v1_ts:
-            batch = {"features": [(cl(plain(fs1)), cl(plain(Z1)))], "images": [cl(img)], "motions": [cl(motion)],
+            batch = {"features": [(cl(plain(fs1)), cl(plain(Z1)))], "images": [cl(img)], "motions": [cl_motion(motion)],
                      "index": torch.tensor([[0, t, N - 1]]), "BGImg": [cl(plain(bg))]}
             pred = B.AnimatingSoftmaxSplatingJoint.forward_flow(me, batch)
             for k in ("PredImg", "FluidImg", "CompositeFluidAlpha"):
@@ -130,7 +156,22 @@ def main(S=S, N=8, ts=None, v1_ts=None, nets_too=True, out_name="large_nets_e2e.
 if __name__ == "__main__":
     import shutil
     try:
-        if "--native" in sys.argv[1:]:
+        if "--native" in sys.argv[1:] and "--fp64" in sys.argv[1:]:
+            # The single-valued arbiter at the native size: the SAME reference classes, forward_flow, euler_integration and
+            # splat kernel text run in float64 throughout (torch default dtype float64; the kernel text compiled with -Dfloat=double) --
+            # rounding noise 1e-13 instead of the 2e-4 spread of the two fp32 runs.  Stored beside them as `*_val_fp64` /
+            # `*_plane_sums_fp64` (values rounded to fp32 for storage: 6e-8).
+            MG.FP64 = True
+            torch.set_default_dtype(torch.float64)
+            main(S=768, N=60, ts=[1, 30, 59], v1_ts=[1, 30, 59], nets_too=False, out_name="native_frames_768_fp64.npz")
+            gd = os.path.join(ROOT, "tests", "golden")
+            a, b = dict(np.load(os.path.join(gd, "native_frames_768_fp64.npz"))), dict(np.load(os.path.join(gd, "native_frames_768.npz")))
+            for k in list(a):
+                if k.endswith("_val") or k.endswith("_plane_sums"):
+                    b[k + "_fp64"] = a[k]
+            np.savez_compressed(os.path.join(gd, "native_frames_768.npz"), **b)
+            os.remove(os.path.join(gd, "native_frames_768_fp64.npz"))
+        elif "--native" in sys.argv[1:]:
             # the reference's own working size (test_animating/CLAW/test_v1.sh:19: W = 768, N = 60), frames only -- run TWICE, with
             # torch's oneDNN convolutions and with its plain ones (im2col + sgemm): at this size the reference's OWN fp32 frames differ
             # by up to 2.0e-4 between the two (frame 30 of the baseline model: 4 of 4096 sampled values apart by more than 1e-4), i.e.
