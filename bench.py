@@ -464,20 +464,22 @@ def context_measurements(workload, image, motion, dev):
         c32 = m3.synthesize(image, motion, NFRAMES)
         torch.cuda.synchronize()
         dt32 = time.perf_counter() - t1
-        m3.convs = "torch"
-        m3.synthesize(image, motion, NFRAMES, frames=range(0, 6), batch=1)        # MIOpen picks its kernels
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ct = m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
-        torch.cuda.synchronize()
-        dtt = time.perf_counter() - t1
+        from slr_sfs_amd import nets as _nets
+        m3.convs = "split"                                                         # (inside torch_convolutions() no kernel of ours runs: nothing to clamp)
+        with _nets.torch_convolutions():                                           # the validation route, timed beside the product's fp32 rung
+            m3.synthesize(image, motion, NFRAMES, frames=range(0, 6), batch=1)    # MIOpen picks its kernels
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ct = m3.synthesize(image, motion, NFRAMES, frames=range(0, NFRAMES, 3), batch=1)
+            torch.cuda.synchronize()
+            dtt = time.perf_counter() - t1
         out["fps_fp32_convs"] = {"value": round(NFRAMES / dt32, 2), "unit": "frames/s",
                                  "what": "the same C3 clip (all 60 frames, one warm-up clip) with BaselineAnimator(convs='fp32'): every 3x3 / "
                                          "1x1 convolution of the encoder / decoder on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 products, "
                                          "fp32 accumulation: the reference's arithmetic; csrc/conv.hip, SLR_CONV_F32), every other stage "
                                          "and the splat path unchanged",
                                  "through_torch_miopen": {"value": round(20 / dtt, 2), "unit": "frames/s",
-                                                          "what": "convs='torch' (20 of the 60 frames): F.conv2d -> MIOpen fp32, elementwise "
+                                                          "what": "inside nets.torch_convolutions() (validation route; 20 of the 60 frames): F.conv2d -> MIOpen fp32, elementwise "
                                                                   "stages as torch ops"},
                                  "frames_fp32_kernels_vs_torch_max_abs": float((c32[::3] - ct).abs().max())}
         del m3

@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
     HIP_OK(hipMemcpyAsync(metric, h_metric.data(), hw * 4, hipMemcpyHostToDevice, st));
 
     // caller-owned scratch: the library allocates nothing
-    const size_t ws_bytes = slr_splat_workspace_bytes(1, C, H, W);
+    const size_t ws_bytes = slr_splat_workspace_bytes(1, H, W);
     void *ws;
     HIP_OK(hipMalloc(&ws, ws_bytes));
 
@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
     const int fe_before = slr_splat_set_front_end(2);                                                 // (the rows front end, whatever the grid size)
     SLR_OK(slr_softsplat_forward(in, disp, out_sum, 1, C, H, W, ws, ws_bytes, 0, st));              // a3 (self-contained call)
     slr_splat_set_front_end(fe_before);
-    SLR_OK(slr_splat_bin(disp, 1, C, H, W, ws, ws_bytes, st));                                      // bins of disp, made once ...
+    SLR_OK(slr_splat_bin(disp, 1, H, W, ws, ws_bytes, st));                                         // bins of disp, made once ...
     SLR_OK(slr_softsplat_mode_forward(in, metric, disp, out_soft, 1, C, H, W, SLR_MODE_SOFTMAX,     // a4 ... and reused
                                       ws, ws_bytes, 1, st));
     // argument errors come back as codes + message, nothing is launched
@@ -107,10 +107,9 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc(&idx_p, sizeof h_idx_p));
     HIP_OK(hipMemcpyAsync(idx_f, h_idx_f, sizeof h_idx_f, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(idx_p, h_idx_p, sizeof h_idx_p, hipMemcpyHostToDevice, st));
-    const size_t plan_bytes = slr_clip_plan_bytes(NB, H, W), scratch_bytes = slr_splat_scratch_bytes_batch(C, H, W, NB);
-    void *plan, *scratch;
+    const size_t plan_bytes = slr_clip_plan_bytes(NB, H, W);
+    void *plan;
     HIP_OK(hipMalloc(&plan, plan_bytes));
-    HIP_OK(hipMalloc(&scratch, scratch_bytes));
     SLR_OK(slr_clip_plan_build(disp_f, idx_f, disp_p, idx_p, NB, H, W, plan, plan_bytes, st));      // bins + plans of all frames
     const float *pf[NB], *pp[NB];
     float *po[NB], alpha[NB];
@@ -123,7 +122,7 @@ int main(int argc, char **argv) {
         frame[k] = k;
     }
     SLR_OK(slr_synth_group_clip_batch(in, metric, zmax, 1, pf, pp, alpha, po, nullptr, C, H, W, 1e-8f, plan, plan_bytes,
-                                      NB, frame, NB, scratch, scratch_bytes, nullptr /* totals not read back */, st));
+                                      NB, frame, NB, nullptr /* totals not read back: upper-bound grids */, st));
     HIP_OK(hipStreamSynchronize(st));
     if (!write_f32(prefix, "frames", frames_out, (size_t)NB * C * hw)) {
         std::fprintf(stderr, "cannot write the outputs\n");

@@ -13,8 +13,10 @@
  *     contract the reference asserts (softsplat.py:397-402);
  *   - `stream` is a hipStream_t (NULL = default stream) that belongs to the CURRENT device;
  *     all work is enqueued on it, nothing synchronises the host, nothing is allocated;
- *   - scratch memory is caller-owned: `ws` must hold slr_splat_workspace_bytes(N,C,H,W) bytes,
- *     16-byte aligned (C = the widest tensor splatted with it), and must not be shared by calls in flight on different streams;
+ *   - scratch memory is caller-owned: `ws` must hold slr_splat_workspace_bytes(N,H,W) bytes, 16-byte aligned (it depends on the
+ *     flow's shape only, not on the planes splatted with it), and must not be shared by calls in flight on different streams;
+ *   - sizes: H < 2^24, H*W < 2^26, N*H*W < 2^29; the plane count C is free -- a sample's plane stack of 2 GiB or more (the reference
+ *     indexes up to 2^31 ELEMENTS per tensor, softsplat.py:163,408-416) is rendered by several launches over plane groups;
  *   - return value 0 = success; >0 = hipError_t; <0 = SLR_E_* argument error.
  *     slr_last_error() returns a thread-local description of the last failure.
  *   - a non-finite or |.| >= 2^30 target coordinate drops all four corners (reference: UB).
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 6
+#define SLR_ABI_VERSION 7
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -88,11 +90,10 @@ int slr_euler_backward(const float *motion, int H, int W, int nsteps, float sign
 #define SLR_WS_CLEAN     2   /* `ws` was zeroed by slr_splat_workspace_init and has only been used through this library since: the call
                                 skips the kernel that zeroes the binning counters (the binning leaves them zero again) */
 
-/* Bytes of scratch one flow field needs: per-tile row-segment lists (256 records of 8 bytes per 8x64 output tile), work plans,
- * destination boxes -- 12.7 MB at 768x1280.  C is accepted for compatibility and ignored (no partial tiles since ABI 6).
- * slr_splat_workspace_init zeroes the counters of a fresh workspace (see SLR_WS_CLEAN). */
-size_t slr_splat_workspace_bytes(int N, int C, int H, int W);
-int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int C, int H, int W, void *stream);
+/* Bytes of scratch one flow field [N,2,H,W] needs: per-tile row-segment lists (256 records of 8 bytes per 8x64 output tile), work
+ * plans, destination boxes -- 12.7 MB at 768x1280.  slr_splat_workspace_init zeroes the counters of a fresh workspace (see SLR_WS_CLEAN). */
+size_t slr_splat_workspace_bytes(int N, int H, int W);
+int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int H, int W, void *stream);
 
 /* Sort `flow` [N,2,H,W] for splatting, inside `ws`: every 64-pixel row segment of the flow is appended to the few 8x64 OUTPUT
  * tiles its bilinear footprints touch (one 64-bit atomic per (segment, tile) = list slot + the tile's exact entry count), and the
@@ -100,10 +101,10 @@ int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int C, int H, int
  * columns).  Depends on the flow only -- every tensor splatted with this flow reuses it (prebinned = SLR_WS_PREBINNED).
  * (No reference counterpart: the reference scatters with global atomics, softsplat.py:186-199; here each workgroup owns an output
  * tile -- or a range of its columns -- and gathers exactly the sources that land in it.) */
-int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
+int slr_splat_bin(const float *flow, int N, int H, int W, void *ws, size_t ws_bytes, void *stream);
 
 /* slr_splat_bin for two flow fields of the same shape (the forward and the backward displacement map of a frame). */
-int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W,
+int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int H, int W,
                        void *ws_a, void *ws_b, size_t ws_bytes, void *stream);
 
 /* Front end of the self-contained one-flow calls below (slr_softsplat_forward, slr_softsplat_mode_forward, slr_maxsplat_forward,
@@ -119,7 +120,7 @@ int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, i
  * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64); default 1024, 0 = never,
  * INT_MAX = always) and `rows` above; slr_splat_set_front_end(1 | 2) forces scan | rows, anything else = automatic.  Process-wide;
  * both return the previous value (-1 = automatic).  Both are exact (floating-point summation order differs: results agree to
- * rounding, ~1e-6 relative).  (ABI <= 5 had a third front end, per-pixel bins with partial tiles and a combine pass: gone.) */
+ * rounding, ~1e-6 relative). */
 int slr_splat_set_scan_max_tiles(int max_tiles);
 int slr_splat_set_front_end(int front_end);
 /* Tuning of the scan front end (process-wide, 0 = the built-in choice by grid size): column pieces per output tile in the first launch
@@ -175,13 +176,13 @@ int slr_synth_group(const float *values, const float *wlogit, const float *wmax,
  * per tile, exact column-octant histograms), their lists sorted by one, and one workgroup per frame writes the frame's work plan
  * (tiles of more than 1536 entries of the two directions together cut into column pieces): 4 launches per clip.
  * Frame i uses disp_f[idx_f[i]] and disp_p[idx_p[i]] (idx_*: DEVICE int arrays; for frame t of an N-frame clip idx_f = t,
- * idx_p = N - t).  At most 16384 frames per plan; C*H*W*4 < 2^31.
+ * idx_p = N - t).  At most 16384 frames per plan.
  * slr_clip_plan_totals: where the per-frame totals sit inside the plan buffer (stride_words uint32 per frame: [0] work items) --
- * read them back once per clip to pass exact grids to the synthesis calls (n_items; -1 = unknown: upper-bound grids, surplus
- * workgroups exit at once).  n_multi / n_whole of ABI <= 5 are accepted and ignored; the scratch arguments as well
- * (slr_splat_scratch_bytes* return 256): pieces own their output pixels, nothing is summed across workgroups. */
+ * read them back once per clip to pass exact grids to the synthesis calls (n_items; -1 or a NULL array = unknown: upper-bound grids,
+ * surplus workgroups exit at once).
+ * The synthesis calls WRITE into the plan (a frame's list of pieces that turned out to hold more than a segment, emptied again by the
+ * same call): one synthesis call at a time per plan -- not from two streams at once -- and no frame twice in one batch. */
 size_t slr_clip_plan_bytes(int nframes, int H, int W);
-size_t slr_splat_scratch_bytes(int C, int H, int W);      /* 256 (kept for ABI <= 5 callers: no scratch is needed) */
 int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words);
 int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp_p, const int *idx_p, int nframes,
                         int H, int W, void *plan, size_t plan_bytes, void *stream);
@@ -190,13 +191,12 @@ int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp
  * runs on a half-empty chip; the frames' block groups are interleaved so that the same tile of consecutive frames runs side by
  * side on one XCD and shares its L2.  Per frame of work at 768x1280: 239 us with 1 frame per launch, 158 with 8, 151 with 16.
  * Arrays of nb entries: disp_f / disp_p / out / norm_out (device pointers per frame; norm_out may be NULL), alpha,
- * frame (index into the plan); hints = nb x {n_items, -, -} or NULL (all unknown). */
-size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb);
+ * frame (index into the plan, every frame at most once); n_items = nb work-item counts (slr_clip_plan_totals) or NULL (all unknown). */
 int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                                const float *const *disp_f, const float *const *disp_p, const float *alpha,
                                float *const *out, float *const *norm_out, int C, int H, int W, float eps,
-                               const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                               void *scratch, size_t scratch_bytes, const int *hints, void *stream);
+                               void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                               const int *n_items, void *stream);
 
 /* slr_synth_group_clip_batch with a SECOND WEIGHT GROUP splatted by the same launch: ONE more value plane with its own
  * weight plane -- the alpha plane of the 2-layer model, which the reference splats with CompositeFluidAlpha_I0 as weights
@@ -211,13 +211,13 @@ int slr_synth_two_groups_clip_batch(const float *values, const float *wlogit, co
                                     const float *values2, const float *wlogit2, int exp_weights2,
                                     const float *const *disp_f, const float *const *disp_p, const float *alpha,
                                     float *const *out, float *const *out2, int C, int H, int W, float eps,
-                                    const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                                    void *scratch, size_t scratch_bytes, const int *hints, void *stream);
+                                    void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                    const int *n_items, void *stream);
 /* slr_synth_group for frame `frame` of a built clip plan (disp_f / disp_p: that frame's two maps). */
 int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                          const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
-                         int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes, int frame,
-                         void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole, void *stream);
+                         int C, int H, int W, float eps, void *plan, size_t plan_bytes, int nframes, int frame,
+                         int n_items, void *stream);
 
 /* Global max of a tensor (Z.max(), animating_softmax_splating.py:855) -> result[0].
  * scratch: 1024 floats of device memory. */

@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 6
+ABI_VERSION = 7
 WS_PREBINNED, WS_CLEAN = 1, 2       # include/slr_splat.h: flags of the `prebinned` argument
 
 # every symbol include/slr_splat.h declares
@@ -19,8 +19,8 @@ SYMBOLS = (
     "slr_splat_set_scan_shape",
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
-    "slr_clip_plan_bytes", "slr_splat_scratch_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
-    "slr_splat_scratch_bytes_batch", "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch",
+    "slr_clip_plan_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
+    "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
@@ -66,13 +66,9 @@ def lib():
         L.slr_splat_set_scan_shape.restype = None
         L.slr_splat_set_scan_shape.argtypes = [i, i, i, i]
         L.slr_splat_workspace_bytes.restype = sz
-        L.slr_splat_workspace_bytes.argtypes = [i, i, i, i]
+        L.slr_splat_workspace_bytes.argtypes = [i, i, i]
         L.slr_clip_plan_bytes.restype = sz
         L.slr_clip_plan_bytes.argtypes = [i, i, i]
-        L.slr_splat_scratch_bytes.restype = sz
-        L.slr_splat_scratch_bytes.argtypes = [i, i, i]
-        L.slr_splat_scratch_bytes_batch.restype = sz
-        L.slr_splat_scratch_bytes_batch.argtypes = [i, i, i, i]
         L.slr_conv3x3_weight_bytes.restype = sz
         L.slr_conv3x3_weight_bytes.argtypes = [i, i]
         L.slr_conv1x1_weight_bytes.restype = sz
@@ -81,9 +77,9 @@ def lib():
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_backward": [fp, i, i, i, f, fp, fp, vp],
-            "slr_splat_workspace_init": [vp, sz, i, i, i, i, vp],
-            "slr_splat_bin": [fp, i, i, i, i, vp, sz, vp],
-            "slr_splat_bin_pair": [fp, fp, i, i, i, i, vp, vp, sz, vp],
+            "slr_splat_workspace_init": [vp, sz, i, i, i, vp],
+            "slr_splat_bin": [fp, i, i, i, vp, sz, vp],
+            "slr_splat_bin_pair": [fp, fp, i, i, i, vp, vp, sz, vp],
             "slr_softsplat_forward": [fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_softsplat_mode_forward": [fp, fp, fp, fp, i, i, i, i, i, vp, sz, i, vp],
             "slr_splat_normalize": [fp, fp, i, i, i, i, i, f, vp],
@@ -91,9 +87,9 @@ def lib():
             "slr_global_max": [fp, sz, fp, fp, vp],
             "slr_clip_plan_totals": [i, i, i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)],
             "slr_clip_plan_build": [fp, vp, fp, vp, i, i, i, vp, sz, vp],
-            "slr_synth_group_clip": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, sz, i, i, vp, sz, i, i, i, vp],
-            "slr_synth_group_clip_batch": [fp, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, sz, vp, vp],
-            "slr_synth_two_groups_clip_batch": [fp, fp, fp, i, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, sz, vp, vp],
+            "slr_synth_group_clip": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, sz, i, i, i, vp],
+            "slr_synth_group_clip_batch": [fp, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, vp],
+            "slr_synth_two_groups_clip_batch": [fp, fp, fp, i, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, vp],
             "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
@@ -125,6 +121,10 @@ def lib():
 def check(rc, what):
     if rc != 0:
         msg = lib().slr_last_error()
+        # A failed call may have left the counters of its workspace dirty (a launch error in flight): the calls that follow say
+        # SLR_WS_CLEAN and would trust them.  Drop every cached workspace -- the next call gets a freshly initialised one.
+        if rc > 0:                                       # (a hipError_t; argument errors, rc < 0, launch nothing)
+            clear_workspaces()
         raise RuntimeError(f"slr_sfs_amd: {what} failed (rc={rc}): {msg.decode() if msg else ''}")
 
 
@@ -177,16 +177,13 @@ def workspace(t, role, N, C, H, W, nbytes=None):
     ws = _ws_cache.get(key)
     if ws is None:
         if nbytes is None:
-            nbytes = int(lib().slr_splat_workspace_bytes(N, C, H, W))
+            nbytes = int(lib().slr_splat_workspace_bytes(N, H, W))
         while not capturing and len(_ws_cache) >= WS_CACHE_MAX:
             _ws_cache.popitem(last=False)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
-        if role == "scratch":
-            ws.zero_()                                   # ticket counters of the persistent tile kernel: zero once, every launch leaves them zero
-        else:
-            # a splat workspace starts zeroed; the kernels leave its counters zero again, so the calls may say WS_CLEAN (no zero kernel)
-            with torch.cuda.device(t.device):
-                check(lib().slr_splat_workspace_init(ptr(ws), ws.numel(), N, C, H, W, ctypes.c_void_p(stream.cuda_stream)), "slr_splat_workspace_init")
+        # a splat workspace starts zeroed; the kernels leave its counters zero again, so the calls may say WS_CLEAN (no zero kernel)
+        with torch.cuda.device(t.device):
+            check(lib().slr_splat_workspace_init(ptr(ws), ws.numel(), N, H, W, ctypes.c_void_p(stream.cuda_stream)), "slr_splat_workspace_init")
         _ws_cache[key] = ws
     else:
         _ws_cache.move_to_end(key)

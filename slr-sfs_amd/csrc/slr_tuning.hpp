@@ -26,13 +26,6 @@
 #ifndef SLR_REC_SORT
 #define SLR_REC_SORT 0          // 1: the register-resident records of an output pixel sorted by staged entry (splat_tile.hpp: pixel_list).  Round 5: no gain
 #endif                          // (159.9 sorted / 158.2 unsorted us per frame on the same box): the gather is not where the time is (see SLR_SKIP)
-#ifndef SLR_PERSIST
-#define SLR_PERSIST 0           // 1: the fused clip kernel as persistent workgroups pulling items from per-XCD ticket counters (splat_queue.hpp), pieces of more than a
-#endif                          // segment walked in place.  Round 5: 153.7 / 155.7 us per frame against 153.2 / 155.5 for one workgroup per item (same box): the slots are
-                                // 95 % busy either way (traced: sum of workgroup lives 144.8 us per frame on 512 slots)
-#ifndef SLR_PERSIST_ROWS
-#define SLR_PERSIST_ROWS 0      // 1: the rows tile kernel of the one-flow operator as persistent workgroups (splat_op.hip: op_rows_pull_kernel)
-#endif
 #ifndef SLR_PK_FMA
 #define SLR_PK_FMA 0            // 1: the gather's FMAs as v_pk_fma_f32 with the weight broadcast from the LOW register of the record's pair (splat_tile.hpp: accum4):
 #endif                          // -14 % VALU instructions per frame, no gain in time (152.7 vs 151.3 us per frame): the kernel is not VALU-bound
@@ -168,6 +161,9 @@
 #endif
 
 // ---- development aids
+#ifndef SLR_SKIP
+#define SLR_SKIP 0              // deletion experiments on the chunk pipeline (WRONG results; timing only): 1 no plane loads, 2 no staging stores,
+#endif                          // 4 no register-record reads, 8 no list loop, 16 no output stores (first chunk excepted), 32 no barriers
 #ifndef SLR_SKIP
 #define SLR_SKIP 0              // deletion experiments on the chunk pipeline (WRONG results; timing only): 1 no plane loads, 2 no staging stores,
 #endif                          // 4 no register-record reads, 8 no list loop, 16 no output stores (first chunk excepted), 32 no barriers

@@ -19,11 +19,8 @@
 // Round 3 did this with per-pixel bins (two passes over all maps with one atomic per footprint: 29 us per frame amortised), partial
 // tiles for multi-segment tiles and a combine pass (17 us per frame): stage 230 us per frame around a 180 us kernel.
 #include "splat_rows.hpp"
-#include "splat_queue.hpp"
 #include "splat_ws.hpp"
 
-#include <atomic>
-#include <stdlib.h>
 
 namespace slr {
 
@@ -41,8 +38,6 @@ struct ClipBatch {
     TileShared s;
     TileFrame f[C_MAXB];
     uint32_t nb, interleave;
-    uint32_t *queues;              // persistent kernel: the ticket counters (splat_queue.hpp), zero between launches
-    uint32_t rcp_nb;               // ceil(2^32 / nb)
 };
 static_assert(sizeof(ClipBatch) <= 4096, "kernel arguments are limited to 4 KiB");
 
@@ -371,51 +366,6 @@ SLR_TILE_KERNEL __global__ __launch_bounds__(CT, PASSES ? 1 : 4) void clip_tile_
     }
 }
 
-// The persistent form (SLR_PERSIST, splat_queue.hpp): as many workgroups as the chip holds, each pulling (frame, item) tickets from its
-// XCD's queue -- the frames' groups of SLR_XCD_GROUP items interleaved exactly as the per-item launch interleaved its block groups.  A
-// piece that turns out to hold more than SEG entries is walked pass by pass right here, by the workgroup that found out: no deferred
-// list, no second launch, and the plan is read-only.  The per-frame arguments are read from the kernel-argument segment with the
-// frame index of the ticket (scalar loads through the constant cache), per item: nothing of a frame stays live around the loop.
-// (the rare piece of more than SEG entries: a function of its own, so that its registers are not the persistent loop's)
-template <bool G2>
-SLR_TILE_KERNEL __device__ __attribute__((noinline)) void clip_piece_passes(const TileShared s, const TileFrame f, uint32_t *smem, const Piece p, int tid, const TileScalars sc) {
-    const TileLds<ClipCfg> L(smem);
-    rows_piece_passes<ClipCfg, true, true, false, G2>(s, f, L, p, tid, sc, 0, s.C);
-}
-
-template <bool G2>
-SLR_TILE_KERNEL __global__ __launch_bounds__(CT, 4) void clip_pull_kernel(ClipBatch b) {
-    using Cfg = ClipCfg;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const TileLds<Cfg> L(smem);
-    int tid = threadIdx.x;
-    uint32_t most = 0;                                     // the longest plan of the batch bounds the tickets of a queue
-    for (uint32_t i = 0; i < b.nb; ++i) most = max(most, b.f[i].totals[0]);
-    Puller P;
-    pull_begin(P, b.queues, tickets_per_queue(most, b.nb), tid);
-    uint32_t k, q;
-    while (pull_next(P, &L.misc[15], tid, k, q)) {
-        // An item's code is compiled as if it stood alone: the shared and the per-frame arguments are read from the kernel-argument
-        // segment HERE, at an offset the compiler cannot see through (always 0), and nothing derived from them or from the work-item
-        // index is carried around the loop (hoisted, the address arithmetic and constants of all phases at once need more registers
-        // than the kernel has: 19 - 80 spilled registers in the round-4 attempts).  Scalar loads through the constant cache, per item.
-        uint32_t zero;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-        asm volatile("" : "+v"(tid));
-        const ClipBatch &bb = (&b)[zero];
-        uint32_t fr, item;
-        ticket_item(k, q, bb.nb, bb.rcp_nb, fr, item);
-        const TileShared &s = bb.s;
-        const TileFrame &f = bb.f[fr];
-        if (item >= f.totals[0]) continue;                 // (a frame with fewer items than the batch's longest)
-        const TileScalars sc = tile_scalars(s, f);
-        const Piece p = make_piece<Cfg>(s, f.items[item]);
-        if (!rows_piece_once<Cfg, true, true, false, G2>(s, f, L, p, tid, sc, 0, s.C))
-            { if (!SLR_NO_INPLACE) rows_piece_passes<Cfg, true, true, false, G2>(s, f, L, p, tid, sc, 0, s.C); }
-    }
-    pull_end(P, tid, gridDim.x);
-}
-
 // =========================================================================== host side
 
 struct ClipLayout {
@@ -466,47 +416,6 @@ static int launch_clip_kernel(const ClipBatch &b, uint32_t grid, hipStream_t st)
     return 0;
 }
 
-// workgroups the chip holds of a persistent kernel (per device, asked once)
-template <typename K>
-static int resident_workgroups(K kernel, size_t lds_bytes, uint32_t &wgs) {
-    static std::atomic<uint32_t> known[64] = {};
-    int dev = 0;
-    SLR_CHECK_HIP(hipGetDevice(&dev));
-    uint32_t v = (dev >= 0 && dev < 64) ? known[dev].load(std::memory_order_relaxed) : 0u;
-    if (!v) {
-        int cus = 0, per_cu = 0;
-        SLR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        SLR_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kernel, CT, lds_bytes));
-        // (a CU of gfx950 has 160 KiB of LDS; an answer computed for 64 KiB would leave half the chip empty.  One workgroup too many per
-        //  CU merely waits for a slot, one too few idles a slot for the whole launch.)
-        const int by_lds = (int)((size_t)160 * 1024 / (lds_bytes ? lds_bytes : 1)), by_waves = 32 / (CT / 64);
-        const int fit = by_lds < by_waves ? by_lds : by_waves;
-        if (getenv("SLR_DEBUG_OCC")) fprintf(stderr, "resident_workgroups: cus %d, occupancy API %d, by LDS %d\n", cus, per_cu, by_lds);
-        if (per_cu < fit) per_cu = fit;
-        if (const char *e = getenv("SLR_DEBUG_WG_PER_CU")) per_cu = atoi(e);
-        v = (uint32_t)(cus > 0 ? cus : 1) * (uint32_t)(per_cu > 0 ? per_cu : 1);
-        if (dev >= 0 && dev < 64) known[dev].store(v, std::memory_order_relaxed);
-    }
-    wgs = v;
-    return 0;
-}
-
-template <bool G2>
-static int launch_clip_pull(const ClipBatch &b, uint32_t items_bound, hipStream_t st) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    SLR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)clip_pull_kernel<G2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-    uint32_t wgs = 0;
-    if (int e = resident_workgroups(clip_pull_kernel<G2>, ClipCfg::LDS_BYTES, wgs)) return e;
-    if (wgs > items_bound) wgs = items_bound ? items_bound : 1u;
-    hipLaunchKernelGGL((clip_pull_kernel<G2>), dim3(wgs), dim3(CT), ClipCfg::LDS_BYTES, st, b);
-    return 0;
-}
-
 extern thread_local void *g_ev_start, *g_ev_stop;          // slr_splat_time_next (splat.hip)
 #ifdef SLR_TRACE
 extern long long *g_trace;                                 // slr_debug_trace (splat.hip)
@@ -519,14 +428,6 @@ using namespace slr;
 SLR_EXPORT size_t slr_clip_plan_bytes(int nframes, int H, int W) {
     if (nframes <= 0 || nframes > 16384 || H <= 0 || W <= 0 || H >= (1 << 24) || (long long)H * W >= (1LL << 26)) return 0;
     return clip_layout(nframes, H, W).total;
-}
-
-SLR_EXPORT size_t slr_splat_scratch_bytes(int C, int H, int W) {
-    return (C <= 0 || H <= 0 || W <= 0) ? 0 : 1024;         // the ticket counters of the persistent tile kernel (splat_queue.hpp)
-}
-
-SLR_EXPORT size_t slr_splat_scratch_bytes_batch(int C, int H, int W, int nb) {
-    return (C <= 0 || H <= 0 || W <= 0 || nb <= 0 || nb > C_MAXB) ? 0 : 1024;
 }
 
 SLR_EXPORT int slr_clip_plan_totals(int nframes, int H, int W, size_t *offset_bytes, int *stride_words) {
@@ -569,19 +470,45 @@ SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const 
     return 0;
 }
 
+// The fused kernel (+ the pass-by-pass launch) over the frames of `b`, once per plane group (plane_group, splat_op.hip: one group unless
+// the plane stack reaches 2 GiB).  Groups after the first take the kernel without the second weight group and write no normaliser.
+static int launch_clip_groups(ClipBatch &b, uint32_t grid, bool g2, hipStream_t st) {
+    const int C = b.s.C, gp = plane_group(C, b.s.H, b.s.W);
+    const size_t hw = (size_t)b.s.H * b.s.W;
+    const float *values = b.s.in;
+    float *outs[C_MAXB];
+    for (uint32_t k = 0; k < b.nb; ++k) outs[k] = b.f[k].out;
+    b.s.Cs = C;
+    for (int pb = 0; pb < C; pb += gp) {
+        b.s.in = values + (size_t)pb * hw;
+        b.s.C = C - pb < gp ? C - pb : gp;
+        for (uint32_t k = 0; k < b.nb; ++k) {
+            b.f[k].out = outs[k] + (size_t)pb * hw;
+            if (pb) { b.f[k].norm_out = nullptr; b.f[k].out2 = nullptr; }
+        }
+        const bool two = g2 && pb == 0;
+        if (pb == 0 && g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));        // slr_splat_time_next: the dominant kernel only
+        if (grid) {
+            if (two) { if (int e = launch_clip_kernel<true, false>(b, grid, st)) return e; }
+            else if (int e = launch_clip_kernel<false, false>(b, grid, st)) return e;
+        }
+        if (pb == 0 && g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+        if (pb == 0) g_ev_start = g_ev_stop = nullptr;
+        // pieces of more than SEG entries (none for ordinary flows): pass by pass
+        if (two) { if (int e = launch_clip_kernel<true, true>(b, b.nb * C_DEFER_WG, st)) return e; }
+        else if (int e = launch_clip_kernel<false, true>(b, b.nb * C_DEFER_WG, st)) return e;
+    }
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
 static int synth_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                             const float *values2, const float *wlogit2, int exp_weights2, float *const *out2,
                             const float *const *disp_f, const float *const *disp_p, const float *alpha,
                             float *const *out, float *const *norm_out, int C, int H, int W, float eps,
-                            const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                            void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+                            void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                            const int *n_items, void *stream) {
     SLR_CHECK_ARG(values && wlogit && disp_f && disp_p && alpha && out && plan && frame, "null pointer");
-#if SLR_PERSIST
-    if (!scratch || ((uintptr_t)scratch & 63) || scratch_bytes < QUEUE_BYTES) {
-        set_error("%s: scratch needs %zu bytes (64-byte aligned, zero before its first use), got %zu", __func__, (size_t)QUEUE_BYTES, scratch_bytes);
-        return SLR_E_WORKSPACE;
-    }
-#endif
     SLR_CHECK_ARG((!values2 && !wlogit2 && !out2) || (values2 && wlogit2 && out2), "the second group needs values, weights and outputs");
     SLR_CHECK_ARG(nb >= 1 && nb <= C_MAXB, "1 <= nb <= 16 frames per launch");
     SLR_CHECK_ARG(C >= 1, "C");
@@ -592,7 +519,7 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
         return SLR_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const char *pb = (const char *)plan;
+    char *pb = (char *)plan;
     ClipBatch b = {};
     b.s.in = values; b.s.mul = wlogit; b.s.mulmax = wmax; b.s.in2 = values2; b.s.mul2 = wlogit2;
     b.s.N = 1; b.s.C = C; b.s.H = H; b.s.W = W; b.s.tiles_x = L.tiles_x; b.s.tiles = L.tiles;
@@ -608,6 +535,7 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
     uint32_t gsum = 0, gmax = 0;
     for (int k = 0; k < nb; ++k) {
         SLR_CHECK_ARG(frame[k] >= 0 && frame[k] < nframes, "frame index");
+        for (int j = 0; j < k; ++j) SLR_CHECK_ARG(frame[j] != frame[k], "a frame twice in one batch (its deferred list would be shared)");
         SLR_CHECK_ARG(disp_f[k] && disp_p[k] && out[k], "null pointer");
         TileFrame &f = b.f[k];
         const size_t i = (size_t)frame[k];
@@ -615,14 +543,14 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
         f.rowlist[0] = (const RowRec *)(pb + L.off_rowlist) + i * L.nt * ROW_CAP;
         f.rowlist[1] = (const RowRec *)(pb + L.off_rowlist) + ((size_t)L.nframes + i) * L.nt * ROW_CAP;
         f.items = (const ItemDesc *)(pb + L.off_items) + i * L.items_cap;
-        f.totals = (uint32_t *)(const_cast<char *>(pb) + L.off_totals) + i * CLIP_TOTALS;
-        f.defer = (uint32_t *)(const_cast<char *>(pb) + L.off_defer) + i * L.items_cap;
+        f.totals = (uint32_t *)(pb + L.off_totals) + i * CLIP_TOTALS;
+        f.defer = (uint32_t *)(pb + L.off_defer) + i * L.items_cap;
         f.items_cap = L.items_cap;
         f.out = out[k]; f.norm_out = norm_out ? norm_out[k] : nullptr;
         if (values2) { SLR_CHECK_ARG(out2[k], "null pointer"); f.out2 = out2[k]; }
         f.scale[0] = alpha[k]; f.scale[1] = 1.0f - alpha[k];
         // what the host knows of the plan (read back once per clip); unknown: the grid covers the bound, surplus workgroups exit at once
-        const int ni = hints ? hints[3 * k] : -1;
+        const int ni = n_items ? n_items[k] : -1;
         const uint32_t cover = ni >= 0 && (uint32_t)ni < L.items_cap ? (uint32_t)ni : L.items_cap;
         f.grid = ((cover + 8 * C_XCD - 1) / (8 * C_XCD)) * 8 * C_XCD;
         gsum += f.grid;
@@ -632,28 +560,7 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
     // of frame k.  With the groups of 8 * C_XCD blocks dealt round-robin over the frames they run side by side on the same XCD and
     // share its L2 (frames with fewer groups leave a few empty blocks).
     const uint32_t grid = b.interleave ? gmax * b.nb : gsum;
-    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));        // slr_splat_time_next: the dominant kernel only
-#if SLR_PERSIST
-    (void)grid;
-    b.queues = (uint32_t *)scratch;
-    b.rcp_nb = (uint32_t)((0x100000000ull + b.nb - 1u) / b.nb);
-    if (values2) { if (int e = launch_clip_pull<true>(b, gsum, st)) return e; }
-    else if (int e = launch_clip_pull<false>(b, gsum, st)) return e;
-    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
-    g_ev_start = g_ev_stop = nullptr;
-#else
-    if (grid) {
-        if (values2) { if (int e = launch_clip_kernel<true, false>(b, grid, st)) return e; }
-        else if (int e = launch_clip_kernel<false, false>(b, grid, st)) return e;
-    }
-    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
-    g_ev_start = g_ev_stop = nullptr;
-    // pieces of more than SEG entries (none for ordinary flows): pass by pass
-    if (values2) { if (int e = launch_clip_kernel<true, true>(b, b.nb * C_DEFER_WG, st)) return e; }
-    else if (int e = launch_clip_kernel<false, true>(b, b.nb * C_DEFER_WG, st)) return e;
-#endif
-    SLR_CHECK_LAUNCH();
-    return 0;
+    return launch_clip_groups(b, grid, values2 != nullptr, st);
 }
 
 // slr_synth_group: one frame from two workspaces that slr_splat_bin / slr_splat_bin_pair filled (no clip plan).  Their row lists are
@@ -696,49 +603,34 @@ SLR_EXPORT int slr_synth_group(const float *values, const float *wlogit, const f
     f.out = out; f.norm_out = norm_out;
     f.scale[0] = alpha; f.scale[1] = 1.0f - alpha;
     f.grid = ((wf.L.items2_cap + 8 * C_XCD - 1) / (8 * C_XCD)) * 8 * C_XCD;
-    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
-#if SLR_PERSIST
-    b.queues = wf.queue; b.rcp_nb = 0u;
-    if (int e = launch_clip_pull<false>(b, wf.L.items2_cap, st)) return e;
-    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
-    g_ev_start = g_ev_stop = nullptr;
-#else
-    if (int e = launch_clip_kernel<false, false>(b, f.grid, st)) return e;
-    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
-    g_ev_start = g_ev_stop = nullptr;
-    if (int e = launch_clip_kernel<false, true>(b, C_DEFER_WG, st)) return e;
-#endif
-    SLR_CHECK_LAUNCH();
-    return 0;
+    return launch_clip_groups(b, f.grid, false, st);
 }
 
 SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                                           const float *const *disp_f, const float *const *disp_p, const float *alpha,
                                           float *const *out, float *const *norm_out, int C, int H, int W, float eps,
-                                          const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                                          void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+                                          void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                          const int *n_items, void *stream) {
     return synth_clip_batch(values, wlogit, wmax, exp_weights, nullptr, nullptr, 0, nullptr, disp_f, disp_p, alpha, out, norm_out,
-                            C, H, W, eps, plan, plan_bytes, nframes, frame, nb, scratch, scratch_bytes, hints, stream);
+                            C, H, W, eps, plan, plan_bytes, nframes, frame, nb, n_items, stream);
 }
 
 SLR_EXPORT int slr_synth_two_groups_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                                                const float *values2, const float *wlogit2, int exp_weights2,
                                                const float *const *disp_f, const float *const *disp_p, const float *alpha,
                                                float *const *out, float *const *out2, int C, int H, int W, float eps,
-                                               const void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
-                                               void *scratch, size_t scratch_bytes, const int *hints, void *stream) {
+                                               void *plan, size_t plan_bytes, int nframes, const int *frame, int nb,
+                                               const int *n_items, void *stream) {
     SLR_CHECK_ARG(values2 && wlogit2 && out2, "null pointer");
     return synth_clip_batch(values, wlogit, wmax, exp_weights, values2, wlogit2, exp_weights2, out2, disp_f, disp_p, alpha, out,
-                            nullptr, C, H, W, eps, plan, plan_bytes, nframes, frame, nb, scratch, scratch_bytes, hints, stream);
+                            nullptr, C, H, W, eps, plan, plan_bytes, nframes, frame, nb, n_items, stream);
 }
 
 SLR_EXPORT int slr_synth_group_clip(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                                     const float *disp_f, const float *disp_p, float alpha, float *out, float *norm_out,
-                                    int C, int H, int W, float eps, const void *plan, size_t plan_bytes, int nframes,
-                                    int frame, void *scratch, size_t scratch_bytes, int n_items, int n_multi, int n_whole,
-                                    void *stream) {
-    const int hints[3] = {n_items, n_multi, n_whole};
+                                    int C, int H, int W, float eps, void *plan, size_t plan_bytes, int nframes,
+                                    int frame, int n_items, void *stream) {
     return slr_synth_group_clip_batch(values, wlogit, wmax, exp_weights, &disp_f, &disp_p, &alpha, &out,
                                       norm_out ? &norm_out : nullptr, C, H, W, eps, plan, plan_bytes, nframes, &frame, 1,
-                                      scratch, scratch_bytes, hints, stream);
+                                      &n_items, stream);
 }

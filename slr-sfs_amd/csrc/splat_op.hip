@@ -15,12 +15,10 @@
 //         workgroup tests the boxes, lists the rows of the blocks that touch it in LDS and walks them with the same code.  2
 //         launches, nothing to zero, no plan: a tile of more than SEG entries is walked pass by pass by its own workgroup.
 #include "splat_rows.hpp"
-#include "splat_queue.hpp"
 #include "splat_ws.hpp"
 
 #include <stdarg.h>
 #include <atomic>
-#include <stdlib.h>
 
 namespace slr {
 
@@ -347,6 +345,12 @@ __global__ __launch_bounds__(256) void rows_zero_kernel(unsigned long long *__re
 }
 
 
+// Everything in front of the row lists (counters, plans, boxes) of a fresh workspace: zero.
+__global__ __launch_bounds__(256) void ws_zero_kernel(unsigned long long *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 // =========================================================================== scan front end: destination boxes
 // Small grids spend their time in the latency chains of dependent launches; the scan front end needs ONE small kernel before the tile
 // kernel: every 8x64 block of SOURCE pixels ("source tile") gets the bounding box of the NW corners its pixels splat to (no atomics,
@@ -413,7 +417,8 @@ SLR_TILE_KERNEL __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) vo
 #endif
     if (PASSES && f.totals[4] == 0u) return;               // the normal case: an empty launch whose workgroups do one scalar load (nothing to reset)
     int cb, ce;
-    if (!channel_group(s.C, cb, ce)) return;
+    const bool has_planes = channel_group(s.C, cb, ce);
+    if (!PASSES && !has_planes) return;                    // (PASSES: a workgroup without planes still ARRIVES below -- the reset counts the whole grid)
     const TileScalars k = tile_scalars(s, f);
     if (!PASSES) {
         // One workgroup per item, no loop over work.  (Round 4, traced with the constant clock: a slot stays empty for ~4.5 us between the end
@@ -434,50 +439,15 @@ SLR_TILE_KERNEL __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) vo
             f.defer[atomicAdd(f.totals + 4, 1u)] = at;     // (one entry per piece: every channel group gets here)
         T_NOTE(s, 57, wall_clock64());
     } else {
-        const uint32_t ndef = f.totals[4];
+        const uint32_t ndef = has_planes ? f.totals[4] : 0u;
         for (uint32_t q = blockIdx.x; q < ndef; q += gridDim.x)
             rows_piece_passes<Cfg, false, NORM, MAXOP, false>(s, f, L, make_piece<Cfg>(s, f.items[f.defer[q]]), tid, k, cb, ce);
-        // the last workgroup to get here empties the deferred list for the plan's next use (prebinned calls share one plan)
+        // the last workgroup to get here empties the deferred list for the plan's next use (prebinned calls share one plan).  EVERY
+        // workgroup of the grid arrives -- also those whose channel group is empty (C = 36, 65, 72, 80 with 8 groups): counting only some
+        // of them left the list in place for the next prebinned call, which then walked the same pieces again
         __syncthreads();
         if (tid == 0 && atomicAdd(f.totals + 6, 1u) == gridDim.x * gridDim.y - 1u) { f.totals[4] = 0u; f.totals[6] = 0u; }
     }
-}
-
-// rows front end, persistent form (SLR_PERSIST_ROWS; splat_queue.hpp): as many workgroups as the chip holds pull (item, channel group)
-// units from per-XCD ticket counters -- the per-item launch leaves 20 - 35 % of its 768 slots empty (traced in round 4: relaunch gaps and a
-// 30 - 40 us tail behind 2.5 rounds of workgroups).  Pieces of more than SEG entries still go to the deferred list (the second launch).
-template <bool NORM, bool MAXOP>
-SLR_TILE_KERNEL __global__ __launch_bounds__(TT, SLR_WAVES_ROWS) void op_rows_pull_kernel(OpArgs a, uint32_t *queues, uint32_t groups) {
-    using Cfg = OpCfg;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const TileLds<Cfg> L(smem);
-    int tid = threadIdx.x;
-    const uint32_t units = a.f.totals[0] * groups;
-    Puller P;
-    pull_begin(P, queues, tickets_per_queue(units, 1u), tid);
-    uint32_t k, q;
-    while (pull_next(P, &L.misc[15], tid, k, q)) {
-        uint32_t zero;                                     // (see clip_pull_kernel: an item's code compiled as if it stood alone)
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-        asm volatile("" : "+v"(tid));
-        const OpArgs &aa = (&a)[zero];
-        const TileShared &s = aa.s;
-        const TileFrame &f = aa.f;
-        uint32_t fr, unit;
-        ticket_item(k, q, 1u, 0u, fr, unit);
-        if (unit >= units) continue;
-        const uint32_t item = unit / groups, g = unit - item * groups;
-        const int cper = (((s.C + (int)groups - 1) / (int)groups + 7) / 8) * 8;      // (channel_group with the group from the ticket)
-        const int cb = (int)g * cper, ce = min(s.C, cb + cper);
-        if (cb >= s.C) continue;
-        const TileScalars sc = tile_scalars(s, f);
-        const uint32_t nh = f.totals[5];                   // heavy items sit at the front of items[], the rest at its back
-        const uint32_t at = item < nh ? item : f.items_cap - 1u - (item - nh);
-        const Piece p = make_piece<Cfg>(s, f.items[at]);
-        if (!rows_piece_once<Cfg, false, NORM, MAXOP, false>(s, f, L, p, tid, sc, cb, ce) && tid == 0 && g == 0u)
-            f.defer[atomicAdd(f.totals + 4, 1u)] = at;
-    }
-    pull_end(P, tid, gridDim.x);
 }
 
 // scan front end: one workgroup per output tile (x channel groups).  The boxes of all source tiles are tested 2048 at a time, the
@@ -689,7 +659,6 @@ int op_ws_open(OpWs &w, int N, int H, int W, void *ws, size_t bytes, const char 
     w.defer2 = (uint32_t *)(b + w.L.off_defer2);
     w.ctl = (uint32_t *)(b + w.L.off_ctl);
     w.arrive = (uint32_t *)(b + w.L.off_arrive);
-    w.queue = (uint32_t *)(b + w.L.off_queue);
     w.box = b + w.L.off_box;
     return 0;
 }
@@ -778,24 +747,7 @@ static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
     const uint32_t grid = ((w.L.items_cap + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
     const uint32_t groups = channel_groups(w.L.nt, a.s.C);
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));      // slr_splat_time_next: the dominant kernel only
-#if SLR_PERSIST_ROWS
-    {
-        static bool attr_pull[64] = {};
-        if (int e = set_lds_attr(op_rows_pull_kernel<NORM, MAXOP>, attr_pull)) return e;
-        static std::atomic<int> cus_known{0};
-        int cus = cus_known.load();
-        if (!cus) { int dev = 0; SLR_CHECK_HIP(hipGetDevice(&dev)); SLR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); cus_known.store(cus); }
-        const int by_lds = (int)((size_t)160 * 1024 / OpCfg::LDS_BYTES), by_waves = 32 / (TT / 64);
-        int per_cu = by_lds < by_waves ? by_lds : by_waves;
-        if (const char *e = getenv("SLR_DEBUG_WG_PER_CU")) per_cu = atoi(e);
-        uint32_t wgs = (uint32_t)cus * (uint32_t)per_cu;
-        const uint32_t bound = w.L.items_cap * groups;
-        if (wgs > bound) wgs = bound;
-        hipLaunchKernelGGL((op_rows_pull_kernel<NORM, MAXOP>), dim3(wgs), dim3(TT), OpCfg::LDS_BYTES, st, a, w.queue, groups);
-    }
-#else
     hipLaunchKernelGGL((op_rows_kernel<NORM, MAXOP, false>), dim3(grid, groups), dim3(TT), OpCfg::LDS_BYTES, st, a);
-#endif
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
     // pieces that hold more than SEG entries (none for ordinary flows; appended by their workgroups above): pass by pass, their planes
@@ -889,38 +841,37 @@ SLR_EXPORT void slr_splat_set_scan_shape(int pieces, int groups, int defer_wg, i
     slr::g_scan_pieces.store(pieces); slr::g_scan_groups.store(groups); slr::g_scan_defer_wg.store(defer_wg); slr::g_scan_defer_groups.store(defer_groups);
 }
 
-SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int C, int H, int W) {
-    if (N <= 0 || C < 0 || H <= 0 || W <= 0) return 0;
+SLR_EXPORT size_t slr_splat_workspace_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
     return op_layout(N, H, W).total;
 }
 
-SLR_EXPORT int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int C, int H, int W, void *stream) {
-    if (int e = op_check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
+SLR_EXPORT int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int H, int W, void *stream) {
+    if (int e = op_check_dims(N, 1, H, W, __func__)) return e;
     OpWs w;
     if (int e = op_ws_open(w, N, H, W, ws, ws_bytes, __func__)) return e;
     // everything in front of the lists (counters, plans): zero.  A kernel of our own, not hipMemsetAsync: a captured memset node on a
     // workspace from torch's graph-private pool made HIP-graph replays fault (tests/test_gpu_parity.py::test_frame_is_graph_capturable)
-    const uint32_t words = (uint32_t)(w.L.off_rowlist / 8);
-    hipLaunchKernelGGL(rows_zero_kernel, dim3((words / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)ws,
-                       words / 2, w.ctl, w.arrive);
+    const size_t words = w.L.off_rowlist / 8;
+    hipLaunchKernelGGL(ws_zero_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)ws, words);
     SLR_CHECK_LAUNCH();
     return 0;
 }
 
-SLR_EXPORT int slr_splat_bin(const float *flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream) {
+SLR_EXPORT int slr_splat_bin(const float *flow, int N, int H, int W, void *ws, size_t ws_bytes, void *stream) {
     SLR_CHECK_ARG(flow, "null flow");
-    if (int e = op_check_dims(N, C > 0 ? C : 1, H, W, __func__)) return e;
+    if (int e = op_check_dims(N, 1, H, W, __func__)) return e;
     OpWs w;
     if (int e = op_ws_open(w, N, H, W, ws, ws_bytes, __func__)) return e;
     return do_rowbin(flow, w, N, H, W, false, (hipStream_t)stream);
 }
 
-SLR_EXPORT int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int C, int H, int W, void *ws_a,
+SLR_EXPORT int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int H, int W, void *ws_a,
                                   void *ws_b, size_t ws_bytes, void *stream) {
     SLR_CHECK_ARG(flow_a && flow_b, "null flow");
     SLR_CHECK_ARG(ws_a != ws_b, "the two flows need separate workspaces");
-    if (int e = slr_splat_bin(flow_a, N, C, H, W, ws_a, ws_bytes, stream)) return e;
-    return slr_splat_bin(flow_b, N, C, H, W, ws_b, ws_bytes, stream);
+    if (int e = slr_splat_bin(flow_a, N, H, W, ws_a, ws_bytes, stream)) return e;
+    return slr_splat_bin(flow_b, N, H, W, ws_b, ws_bytes, stream);
 }
 
 SLR_EXPORT int slr_softsplat_forward(const float *in, const float *flow, float *out, int N, int C, int H,

@@ -18,7 +18,6 @@ struct OpLayout {
     size_t off_defer;     // uint32[items_cap]  pieces of more than a segment (appended by their workgroups)
     size_t off_box;       // SrcBox[nt]  scan front end: destination box of every source tile
     size_t off_ctl;       // uint32[64]  arrival counter (second level) of rowbin_kernel
-    size_t off_queue;     // uint32[9][16]  ticket counters of the persistent tile kernels (splat_queue.hpp)
     size_t off_arrive;    // uint32[ceil(nt / 64)][32]  first-level arrival counters, one per 128-byte line
     size_t off_rowlist2;  // RowRec[2][nt][ROW_CAP]  slr_synth_group: sorted copies of this and the other workspace's lists
     size_t off_items2;    // ItemDesc[items2_cap]  slr_synth_group's two-flow plan
@@ -39,7 +38,6 @@ inline OpLayout op_layout(int N, int H, int W) {
     L.off_rowinfo = o;  o += al256((size_t)L.nt * 16);
     L.off_totals = o;   o += 256;
     L.off_ctl = o;      o += 256;
-    L.off_queue = o;    o += 1024;
     L.off_arrive = o;   o += al256((size_t)((L.nt + 63) / 64) * 128);
     L.off_box = o;      o += al256((size_t)L.nt * 16);
     L.off_items = o;    o += al256((size_t)L.items_cap * sizeof(ItemDesc));
@@ -58,7 +56,7 @@ struct OpWs {
     unsigned long long *rowcnt, *rowinfo;
     RowRec *rowlist, *rowlist2;
     ItemDesc *items, *items2;
-    uint32_t *totals, *defer, *defer2, *ctl, *arrive, *queue;
+    uint32_t *totals, *defer, *defer2, *ctl, *arrive;
     void *box;
 };
 

@@ -56,12 +56,11 @@ def _b8(x, channels):
 
 
 class torch_convolutions:
-    """Context manager: the FULL-RANGE fp32 route of these networks on a device.  Inside it every stage runs the torch
-    composition that defines it (nets.py: F.conv2d -> MIOpen fp32 on ROCm, elementwise stages as torch ops) -- the
-    arithmetic the reference's decoder uses (models/layers/partialconv2d.py:61-74, models/networks/architectures.py:345-375),
-    with no limit on the magnitude of the activations.  About 4.6x slower than the split-f16 kernels at 768x1280
-    (bench.py: fps_fp32_convs).  The animators enter it on request (convs="fp32") or by themselves when the split-f16
-    kernels report a clamped activation (convs="auto", pipeline.py)."""
+    """VALIDATION AID, not a product route: no animator policy selects it (pipeline.CONV_POLICIES = auto | split | fp32, all on this
+    package's kernels).  Inside it every stage runs the torch composition that DEFINES it (nets.py: F.conv2d -> MIOpen fp32 on ROCm,
+    elementwise stages as torch ops) -- the arithmetic the reference's decoder uses (models/layers/partialconv2d.py:61-74,
+    models/networks/architectures.py:345-375).  The GPU tests compare the HIP stages with it, and bench.py times it beside the fp32
+    rung (fps_fp32_convs.through_torch_miopen)."""
 
     def __enter__(self):
         self._prev, _S.torch_convs = _S.torch_convs, True
@@ -535,7 +534,7 @@ def check_saturation(device, what="convolution", reset=True):
     if n:
         raise RuntimeError(f"slr_sfs_amd: {n} wave(s) of the {what} kernels met activations >= {65472.0 / _S.act_scale:.0f} in "
                            f"magnitude, outside the exact range of the split-f16 matrix-core convolution; the result is not "
-                           f"valid (use a smaller nets.activation_scale, nets.torch_convolutions(), or the animators' "
+                           f"valid (use a smaller nets.activation_scale, nets.fp32_kernels(), or the animators' "
                            f"convs='auto')")
     return 0
 
@@ -570,15 +569,12 @@ class SaturationLog:
 
 def guarded(fn, device, policy, what, owner=None):
     """Run ``fn()`` (networks on split-f16 kernels) under the saturation policy of the animators:
-    "split": as is, raise if an activation was clamped; "fp32": inside fp32_kernels(); "torch": inside torch_convolutions();
+    "split": as is, raise if an activation was clamped; "fp32": inside fp32_kernels();
     "auto": split-f16 at the default activation scale; clamped -> again at scale 1 (exact up to 65472); clamped again ->
     inside fp32_kernels() (the fp32 matrix instructions: no limit).  ``owner`` (an animator) remembers the rung that worked, so later clips start there.
     Synchronises with the device once per call (per rung tried)."""
     if policy == "fp32":
         with fp32_kernels():
-            return fn()
-    if policy == "torch":
-        with torch_convolutions():
             return fn()
     if policy == "split":
         out = fn()

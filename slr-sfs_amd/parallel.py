@@ -21,12 +21,13 @@ def frames_per_rank(N, world):
     return (N + world - 1) // world
 
 
-def gather_clip(local_frames, N, rank, world, group=None):
+def gather_clip(local_frames, N, rank, world, group=None, always_collective=False):
     """local_frames [len(shard_frames(N,rank,world)), ...] -> [N, ...] on every rank (any dtype: fp32 frames [n,3,H,W], or the
     uint8 [n,h,w,3] frames of frames_for_assembly).  ONE all_gather_into_tensor of shards of ceil(N/world) frames: a full shard is
     sent as it is (no staging copy); a short one (N not divisible by world) is padded with rows that land behind frame N - 1 and are
-    cut off -- they are never read, so they are not initialised either."""
-    if world == 1:
+    cut off -- they are never read, so they are not initialised either.  always_collective: enter the collective at world size 1 too
+    (the single-GPU pre-flight of the RCCL path, tests/test_gpu_parity.py::test_multi_gpu_preflight_on_rccl)."""
+    if world == 1 and not always_collective:
         return local_frames
     per = frames_per_rank(N, world)
     n, tail = local_frames.shape[0], tuple(local_frames.shape[1:])
@@ -165,9 +166,10 @@ def encode_band(encoder, image, rank, world, halo=None, guard=None):
     return band, [o.shape[1] for o in outs]
 
 
-def encode_banded(encoder, image, rank, world, group=None, halo=None, guard=None):
-    """encoder(image) computed in row bands across the ranks + one all-gather; same return type as encoder(image)."""
-    if world == 1:
+def encode_banded(encoder, image, rank, world, group=None, halo=None, guard=None, always_collective=False):
+    """encoder(image) computed in row bands across the ranks + one all-gather; same return type as encoder(image).
+    always_collective: band + collective at world size 1 too (pre-flight of the RCCL path on one GPU)."""
+    if world == 1 and not always_collective:
         return encoder(image) if guard is None else guard(lambda: encoder(image))
     H, W = image.shape[2:]
     rows = -(-H // world)

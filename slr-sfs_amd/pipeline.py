@@ -9,8 +9,10 @@ the frame loop of its test scripts, with the frame-invariant work hoisted out of
 
 Per clip (once): encoder (and for v1: background net, alpha encoder -- the reference recomputes
 the alpha encoder every frame although its input is frame-invariant, :938), Z.max(), the two
-all-frames Euler passes.  Per frame: bin + fused splat (HIP), decoder(s) (PyTorch-ROCm), tanh /
-compositing.  Nothing syncs the host inside the loop; frames stay on the device.
+all-frames Euler passes, row lists and plans of all displacement maps.  Per batch of frames: the fused splat kernel
+(HIP), the decoder(s) -- every 3x3 / 1x1 (partial) convolution, resampling and normalisation stage on this package's own
+HIP kernels (csrc/conv.hip: split-f16 or fp32 matrix-core kernels; PyTorch only holds the tensors) --, tanh / compositing.
+Nothing syncs the host inside the loop; frames stay on the device.
 """
 import math
 
@@ -106,7 +108,7 @@ def _encode(encoder, image, shard, policy="split", owner=None, what="encoder"):
     return parallel.encode_banded(encoder, image, shard[0], shard[1], shard[2] if len(shard) > 2 else None, guard=guard)
 
 
-CONV_POLICIES = ("auto", "split", "fp32", "torch")
+CONV_POLICIES = ("auto", "split", "fp32")
 _RUNG_SCALE = (64.0, 1.0)
 
 
@@ -120,7 +122,6 @@ def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_b
     """The frame loop of both animators.  decode(gen, afl) -> the batch's outputs; store(pos, outputs) puts them at
     positions ``pos`` (indices into ``frames``).  ``policy`` (CONV_POLICIES):
       "fp32"  every convolution on this package's fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32): the reference's arithmetic;
-      "torch" every stage through its torch definition (F.conv2d -> MIOpen fp32): the route the kernels are validated against;
       "split" split-f16 matrix-core kernels; an activation outside their exact range raises after the clip;
       "auto"  split-f16 kernels; every decoder batch leaves an asynchronous record of the device's saturation counter
               (no host synchronisation inside the loop); after the last batch the records are read and the batches in
@@ -144,8 +145,8 @@ def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_b
             for p_ in pos:
                 on_frame(p_)
 
-    if policy in ("fp32", "torch") or not dev.type == "cuda":
-        with (nets.fp32_kernels() if policy == "fp32" else nets.torch_convolutions() if policy == "torch" else _null()):
+    if policy == "fp32" or not dev.type == "cuda":
+        with (nets.fp32_kernels() if policy == "fp32" else _null()):
             for i0, gen, afl in groups(frames):
                 pos = list(range(i0, i0 + gen.shape[0]))
                 store(pos, decode_batch(gen, afl))
@@ -282,7 +283,7 @@ class BaselineAnimator(torch.nn.Module, _ConvRung):
         """clamp_z / softmax_v1 / softmax_v2: see ClipSynthesizer; ``opts`` (the checkpoint's pickled Namespace)
         sets them the way the reference's forward_flow reads them (splat_options).  convs: arithmetic of the encoder /
         decoder convolutions, one of CONV_POLICIES (see _render): "auto" = split-f16 matrix-core kernels with an automatic
-        step up (activation scale 1, then fp32 through torch) where an activation leaves their exact range."""
+        step up (activation scale 1, then the package's fp32 matrix-core kernels) where an activation leaves their exact range."""
         super().__init__()
         assert convs in CONV_POLICIES
         self.convs, self._conv_rung = convs, 0

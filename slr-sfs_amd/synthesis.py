@@ -64,7 +64,7 @@ def bin_flow(flow, C, role):
     N, _, H, W = flow.shape
     ws = workspace(flow, role, N, C, H, W)
     with torch.cuda.device(flow.device):
-        check(lib().slr_splat_bin(ptr(flow), N, C, H, W, ptr(ws), ws.numel(), stream_of(flow)), "slr_splat_bin")
+        check(lib().slr_splat_bin(ptr(flow), N, H, W, ptr(ws), ws.numel(), stream_of(flow)), "slr_splat_bin")
     return ws
 
 
@@ -75,7 +75,7 @@ def bin_flow_pair(flow_a, flow_b, C):
     N, _, H, W = flow_a.shape
     ws_a, ws_b = workspace(flow_a, "f", N, C, H, W), workspace(flow_a, "p", N, C, H, W)
     with torch.cuda.device(flow_a.device):
-        check(lib().slr_splat_bin_pair(ptr(flow_a), ptr(flow_b), N, C, H, W, ptr(ws_a), ptr(ws_b), ws_a.numel(),
+        check(lib().slr_splat_bin_pair(ptr(flow_a), ptr(flow_b), N, H, W, ptr(ws_a), ptr(ws_b), ws_a.numel(),
                                        stream_of(flow_a)), "slr_splat_bin_pair")
     return ws_a, ws_b
 
@@ -169,7 +169,7 @@ class MotionPlan:
         return self._where[t][0]
 
     def lookup(self, t):
-        """-> (plan buffer, frames in it, index of t, (n_items, n_multi, n_whole))."""
+        """-> (plan buffer, frames in it, index of t, work items of t's plan)."""
         if t not in self._where:
             self._build([t])                               # a frame outside the announced set: its own one-frame plan
         rec, i = self._where[t]
@@ -177,7 +177,7 @@ class MotionPlan:
             rec["event"].synchronize()                     # long done unless this is the clip's very first launch
             rec["event"] = None
         row = rec["host"][i]
-        return rec["plan"], rec["n"], i, (int(row[0]), int(row[3]), int(row[4]))
+        return rec["plan"], rec["n"], i, int(row[0])
 
 
 def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, eps=1e-8, return_norm=False, timed=False,
@@ -187,7 +187,7 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
     require_device(values, wlogit, wmax)
     assert values.shape[0] == 1 and wlogit.shape[1] == 1
     _, C, H, W = values.shape
-    plan, n, i, (n_items, n_multi, n_whole) = mp.lookup(t)
+    plan, n, i, n_items = mp.lookup(t)
     disp_f, disp_p = mp.disp_f[t], mp.disp_p[mp.N - t]
     if out is None:
         out = torch.empty_like(values)
@@ -195,14 +195,12 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
         require_device(out)
         assert out.shape == values.shape and out.device == values.device
     norm = values.new_empty(1, 1, H, W) if return_norm else None
-    scratch = workspace(values, "scratch", 1, C, H, W, nbytes=int(lib().slr_splat_scratch_bytes(C, H, W)))
     with torch.cuda.device(values.device):
         if timed and kernel_timing is not None:
             _arm_timer(values)
         check(lib().slr_synth_group_clip(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0,
                                          ptr(disp_f), ptr(disp_p), float(alpha), ptr(out), ptr(norm), C, H, W,
-                                         float(eps), ptr(plan), plan.numel(), n, i, ptr(scratch), scratch.numel(),
-                                         n_items, n_multi, n_whole, stream_of(values)), "slr_synth_group_clip")
+                                         float(eps), ptr(plan), plan.numel(), n, i, n_items, stream_of(values)), "slr_synth_group_clip")
     return (out, norm) if return_norm else out
 
 
@@ -223,14 +221,13 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
     assert all(lk[0] is plan for lk in look), "frames of one launch must come from one chunk of the plan"
     nb = len(ts)
     L = lib()
-    scratch = workspace(values, "scratch", nb, C, H, W, nbytes=int(L.slr_splat_scratch_bytes_batch(C, H, W, nb)))
     PP = ctypes.c_void_p * nb
     df = PP(*[mp.disp_f[t].data_ptr() for t in ts])
     dp = PP(*[mp.disp_p[mp.N - t].data_ptr() for t in ts])
     op = PP(*[o.data_ptr() for o in outs])
     al = (ctypes.c_float * nb)(*[float(a) for a in alphas])
     fr = (ctypes.c_int * nb)(*[lk[2] for lk in look])
-    hints = (ctypes.c_int * (3 * nb))(*[v for lk in look for v in lk[3]])
+    n_items = (ctypes.c_int * nb)(*[lk[3] for lk in look])
     for o in outs:
         assert o.shape == values.shape and o.device == values.device
     with torch.cuda.device(values.device):
@@ -238,8 +235,8 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
             _arm_timer(values, nb)
         if group2 is None:
             check(L.slr_synth_group_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, df, dp, al, op,
-                                               None, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb, ptr(scratch),
-                                               scratch.numel(), hints, stream_of(values)), "slr_synth_group_clip_batch")
+                                               None, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb, n_items,
+                                               stream_of(values)), "slr_synth_group_clip_batch")
         else:
             v2, w2, outs2 = group2
             require_device(v2, w2, *outs2)
@@ -248,7 +245,7 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
             op2 = PP(*[o.data_ptr() for o in outs2])
             check(L.slr_synth_two_groups_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, ptr(v2), ptr(w2), 1,
                                                     df, dp, al, op, op2, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb,
-                                                    ptr(scratch), scratch.numel(), hints, stream_of(values)),
+                                                    n_items, stream_of(values)),
                   "slr_synth_two_groups_clip_batch")
     return outs
 

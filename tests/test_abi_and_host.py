@@ -35,9 +35,9 @@ def test_header_symbols_exported(L):
 def test_workspace_size_and_argument_errors(L):
     # (row-segment lists: 256 records of 8 bytes per tile and list, three lists + plans -- 12.7 MB at 768x1280; the per-pixel bins of
     #  rounds 1-3 took 12 bytes per source pixel + partial tiles: ~300 MB)
-    assert 3 * 1920 * 256 * 8 < L.slr_splat_workspace_bytes(1, 65, 768, 1280) < 32 << 20
-    assert L.slr_splat_workspace_bytes(0, 65, 768, 1280) == 0
-    assert L.slr_splat_workspace_bytes(1, 0, 16, 16) > 0
+    assert 3 * 1920 * 256 * 8 < L.slr_splat_workspace_bytes(1, 768, 1280) < 32 << 20
+    assert L.slr_splat_workspace_bytes(0, 768, 1280) == 0
+    assert L.slr_splat_workspace_bytes(1, 16, 16) > 0
     # argument validation happens before anything touches the device
     rc = L.slr_softsplat_forward(None, None, None, 1, 1, 8, 8, None, 0, 0, None)
     assert rc == -1 and b"null" in L.slr_last_error()
@@ -219,3 +219,57 @@ def test_splat_options_from_checkpoint_opts():
                                                         use_alpha_softmax=False))
     assert an.use_alpha0 and an.clamp_alpha == 0.25 and not an.use_fluid_alpha_only
     assert pipeline.BaselineAnimator(opts=old).splat_kw["clamp_z"] == (-20.0, 20.0)
+
+
+def test_conv_rung_retry_and_reset():
+    """convs="auto": a raised rung is not for good (pipeline._ConvRung) -- after RUNG_RETRY_CLIPS clips on it the next clip starts at
+    rung 0 again, and reset_conv_rung() goes back at once.  Host logic only."""
+    from slr_sfs_amd import pipeline
+
+    class Owner(pipeline._ConvRung):
+        pass
+    a = Owner()
+    a._clip_begins()                                       # rung 0: nothing is counted
+    assert getattr(a, "_conv_rung", 0) == 0 and getattr(a, "_rung_clips", 0) == 0
+    a._conv_rung = 2
+    for _ in range(pipeline.RUNG_RETRY_CLIPS):
+        a._clip_begins()
+        assert a._conv_rung == 2
+    a._clip_begins()                                       # the clip after RUNG_RETRY_CLIPS raised ones: back to rung 0
+    assert a._conv_rung == 0 and a._rung_clips == 0
+    a._conv_rung = 1
+    a._clip_begins()
+    assert a._rung_clips == 1
+    a.reset_conv_rung()
+    assert a._conv_rung == 0 and a._rung_clips == 0
+    saved = pipeline.RUNG_RETRY_CLIPS
+    try:
+        pipeline.RUNG_RETRY_CLIPS = 0                     # 0 = never retry
+        a._conv_rung = 2
+        for _ in range(40):
+            a._clip_begins()
+        assert a._conv_rung == 2
+    finally:
+        pipeline.RUNG_RETRY_CLIPS = saved
+
+
+def test_conv_policies_are_the_package_kernels_only():
+    """The torch / MIOpen composition of the networks is a validation aid (nets.torch_convolutions), not a selectable product route."""
+    from slr_sfs_amd import pipeline
+    assert pipeline.CONV_POLICIES == ("auto", "split", "fp32")
+    with pytest.raises(AssertionError):
+        pipeline.BaselineAnimator(convs="torch")
+
+
+def test_failed_call_drops_cached_workspaces():
+    """A hipError from a library call drops the cached workspaces (their counters may be dirty; later calls say SLR_WS_CLEAN)."""
+    from slr_sfs_amd import _lib
+    _lib._ws_cache[("fake",)] = object()
+    with pytest.raises(RuntimeError):
+        _lib.check(1, "test")
+    assert not _lib._ws_cache
+    _lib._ws_cache[("fake",)] = object()
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "test")                           # an argument error launched nothing: the cache stays
+    assert _lib._ws_cache
+    _lib.clear_workspaces()

@@ -259,3 +259,68 @@ def test_differential_fuzz_of_the_front_ends(S):
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "fuzz_frontends.py")
     r = subprocess.run([sys.executable, tool, "150", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_prebinned_plan_reused_after_deferred_pieces_with_empty_channel_groups(S, oracle):
+    """ADVICE r4 (medium): the pass-by-pass launch empties the deferred list for the plan's next use when its LAST workgroup arrives;
+    with C = 72 (8 channel groups of 16 planes: three of them empty) the workgroups without planes used to return before
+    arriving, the list stayed in place, and the next prebinned call on the same plan walked the same pieces again (ACCUM passes: wrong
+    sums).  One binning, three calls on it, a flow with deferred pieces; every call must equal the oracle."""
+    from slr_sfs_amd._lib import lib, ptr, stream_of, WS_PREBINNED
+    L = lib()
+    H, W = 64, 256
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flow = np.stack([(100.3 + (xx % 7)) - xx, (20.6 + (yy % 8)) - yy])[None].astype(np.float32)       # 16384 sources -> 7 x 8 pixels
+    dfl = dev(flow)
+    st = stream_of(dfl)
+    nbytes = int(L.slr_splat_workspace_bytes(1, H, W))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    assert L.slr_splat_bin(ptr(dfl), 1, H, W, ptr(ws), nbytes, st) == 0
+    rng = np.random.default_rng(72)
+    for C in (72, 36, 72):
+        x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+        dx, out = dev(x), torch.empty(1, C, H, W, device="cuda")
+        assert L.slr_softsplat_forward(ptr(dx), ptr(dfl), ptr(out), 1, C, H, W, ptr(ws), nbytes, WS_PREBINNED, st) == 0
+        ref = oracle.softsplat_forward(x, flow)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(host(out) - ref).max()) < 2e-4 * scale, (C, float(np.abs(host(out) - ref).max()), scale)
+
+
+def test_plane_stack_of_more_than_2_gib(S, oracle):
+    """FunctionSoftsplat on 65 x 2160 x 3840 (a 4K frame through the same model: 2.16 GB per tensor, C*H*W*4 >= 2^31).  The reference
+    indexes up to 2^31 ELEMENTS (softsplat.py:163, 408-416); here a sample's planes are addressed through 32-bit buffer offsets, so
+    the stack is rendered in plane groups (plane_group: 64 + 1 planes).  Forward (summation and softmax) and both gradients against
+    the oracle on sampled planes -- the first and last plane of each group among them."""
+    C, H, W = 65, 2160, 3840
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(1, C, H, W, device="cuda", generator=g)
+    met = torch.randn(1, 1, H, W, device="cuda", generator=g)
+    m = smooth_motion(H, W, 3, amp=6.0)
+    flow = torch.from_numpy(m).cuda() + (torch.rand(1, 2, H, W, device="cuda", generator=g) - 0.5)
+    assert x.numel() * 4 >= 2 ** 31
+    planes = [0, 31, 63, 64]
+    fl = host(flow)
+    xs = host(x[:, planes])
+    out = S.FunctionSoftsplat(x, flow, None, "summation")
+    ref = oracle.softsplat_forward(xs, fl)
+    err = float(np.abs(host(out[:, planes]) - ref).max())
+    assert err < 1e-4 * max(1.0, float(np.abs(ref).max())), err
+    del out
+    # softmax mode on the same planes: out = splat(x e^m) / splat(e^m)
+    out = S.FunctionSoftsplat(x, flow, met, "softmax")
+    ref = oracle.function_softsplat(xs, fl, host(met), "softmax")
+    err = float(np.abs(host(out[:, planes]) - ref).max())
+    assert err < 1e-4 * max(1.0, float(np.abs(ref).max())), err
+    del out
+    # backward: gradInput per plane is independent of the other planes; gradFlow sums over all of them -> a stack whose other planes
+    # have zero gradOutput reduces to the sampled ones
+    gout = torch.zeros(1, C, H, W, device="cuda")
+    gs = torch.randn(1, len(planes), H, W, device="cuda", generator=g)
+    gout[:, planes] = gs
+    xr, fr = x.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    S.softsplat._FunctionSoftsplat.apply(xr, fr).backward(gout)
+    gin_ref, gflow_ref = oracle.softsplat_backward(xs, fl, host(gs))
+    assert np.array_equal(host(xr.grad[:, planes]), gin_ref)
+    assert float(np.abs(host(xr.grad[:, [1, 62]])).max()) == 0.0
+    d = np.abs(host(fr.grad) - gflow_ref)
+    assert float(d.max()) <= 1e-5 * max(1.0, float(np.abs(gflow_ref).max())), float(d.max())

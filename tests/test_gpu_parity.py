@@ -417,7 +417,7 @@ def test_batched_launch_with_whole_tile_items(S, oracle):
     hints = [cs.plan.lookup(t)[3] for t in ts]
     # (round 4: a piece of more than a segment is found by its workgroup at run time and walked by the pass-by-pass launch behind the
     #  main one -- the plan no longer knows; frames 1 and 2 pile 4 x H x W entries and overflowing row lists into four tiles)
-    assert all(h[0] >= (H // 8) * (W // 64) for h in hints), hints
+    assert all(h >= (H // 8) * (W // 64) for h in hints), hints
     out = torch.empty(len(ts), 5, H, W, device="cuda")
     cs.features_batch(ts, out)
     for k, t in enumerate(ts):
@@ -1034,6 +1034,54 @@ def test_clip_assembler_on_rccl(S, tmp_path):
     assert r.returncode == 0 and "ASSEMBLED" in r.stdout, r.stderr[-2000:]
 
 
+def test_multi_gpu_preflight_on_rccl(S, tmp_path):
+    """Everything the N > 1 bench line runs on the communicator, on backend nccl (= RCCL) with the collectives FORCED at world size 1
+    (the first real multi-GPU run must not be the first run of this code on RCCL): communicator_report (all_gather_object
+    + device properties + RCCL version), gather_clip on fp32 frames and on the uint8 frames of frames_for_assembly
+    (all_gather_into_tensor of padded shards + the reordering view), encode_banded (row band + all-gather of the band).  The 2 / 4 /
+    8-rank logic of the same functions runs on gloo (tests/test_parallel_gloo.py)."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = tmp_path / "preflight.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import slr_sfs_amd as S\n"
+        "from slr_sfs_amd import parallel\n"
+        f"os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{port}', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "rep = parallel.communicator_report(dev, 7, 0.5)\n"
+        "assert rep['backend'] == 'nccl' and rep['world_size'] == 1 and rep['distinct_devices'] == 1, rep\n"
+        "assert rep['rccl_version'] and rep['ranks'][0]['frames'] == 7 and rep['ranks'][0]['device_name'], rep\n"
+        "torch.manual_seed(5)\n"
+        "frames = torch.rand(7, 3, 40, 72, device=dev) * 2 - 1\n"
+        "clip = parallel.gather_clip(frames, 7, 0, 1, always_collective=True)\n"
+        "assert clip.data_ptr() != frames.data_ptr() and torch.equal(clip, frames)\n"
+        "u8 = parallel.frames_for_assembly(frames, (80, 144))\n"
+        "assert u8.dtype == torch.uint8 and tuple(u8.shape) == (7, 80, 144, 3)\n"
+        "assert torch.equal(parallel.gather_clip(u8, 7, 0, 1, always_collective=True), u8)\n"
+        "an = S.pipeline.BaselineAnimator().cuda().eval()\n"
+        "img = torch.rand(1, 3, 40, 72, device=dev) * 2 - 1\n"
+        "with torch.no_grad():\n"
+        "    want = an.encoder(img)\n"
+        "    got = parallel.encode_banded(an.encoder, img, 0, 1, always_collective=True)\n"
+        "want = want if isinstance(want, tuple) else (want,)\n"
+        "got = got if isinstance(got, tuple) else (got,)\n"
+        "assert len(want) == len(got) and all(torch.equal(a, b) for a, b in zip(want, got))\n"
+        "torch.cuda.synchronize()\n"
+        "dist.destroy_process_group()\n"
+        "print('PREFLIGHT', rep['rccl_version'])\n")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PREFLIGHT" in r.stdout, r.stderr[-2000:]
+
+
 def test_c_abi_from_a_plain_host_program(S, oracle, tmp_path):
     """examples/cabi_demo.cpp: a C++ host program with hipMalloc'ed buffers and its own stream, linked against the
     library through include/slr_splat.h only (no Python, no torch in the process) -- Euler integration, summation
@@ -1079,10 +1127,10 @@ def test_c_abi_prebinned_reuse_and_errors(S, oracle):
     fl = rng.uniform(-3, 3, (N, 2, H, W)).astype(np.float32)
     xs = [rng.standard_normal((N, C, H, W)).astype(np.float32) for _ in range(2)]
     dfl = dev(fl)
-    nbytes = int(L.slr_splat_workspace_bytes(N, C, H, W))
+    nbytes = int(L.slr_splat_workspace_bytes(N, H, W))
     ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     st = stream_of(dfl)
-    assert L.slr_splat_bin(ptr(dfl), N, C, H, W, ptr(ws), nbytes, st) == 0
+    assert L.slr_splat_bin(ptr(dfl), N, H, W, ptr(ws), nbytes, st) == 0
     for x in xs:
         dx, out = dev(x), torch.empty(N, C, H, W, device="cuda")
         assert L.slr_softsplat_forward(ptr(dx), ptr(dfl), ptr(out), N, C, H, W, ptr(ws), nbytes, 1, st) == 0
@@ -1114,7 +1162,7 @@ def test_prebinned_pair_and_single_splats_share_their_bins_in_any_order(S, oracl
     Z = rng.standard_normal((1, 1, H, W)).astype(np.float32)
     dff, dfp, dx, dZ = dev(ff), dev(fp), dev(x), dev(Z)
     st = stream_of(dx)
-    nbytes = int(L.slr_splat_workspace_bytes(1, C, H, W))
+    nbytes = int(L.slr_splat_workspace_bytes(1, H, W))
     wsf, wsp = (torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2))
     zmax = dZ.max().reshape(1)
     e = np.exp(Z - Z.max())
@@ -1124,7 +1172,7 @@ def test_prebinned_pair_and_single_splats_share_their_bins_in_any_order(S, oracl
     nrm = S_f[:, -1:] + S_p[:, -1:]
     ref_pair = (S_f[:, :-1] + S_p[:, :-1]) / np.maximum(nrm, np.float32(1e-8))
     for order in (0, 1):
-        assert L.slr_splat_bin_pair(ptr(dff), ptr(dfp), 1, C, H, W, ptr(wsf), ptr(wsp), nbytes, st) == 0
+        assert L.slr_splat_bin_pair(ptr(dff), ptr(dfp), 1, H, W, ptr(wsf), ptr(wsp), nbytes, st) == 0
         outs = {}
 
         def pair():
@@ -1184,17 +1232,13 @@ def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
     tiles = ((H + 7) // 8) * ((W + 63) // 64)
     assert all(int(totals[i, 0]) >= tiles for i in range(nb))             # at least one work item per tile
     zmax = dZ.max().reshape(1).contiguous()
-    sbytes = int(L.slr_splat_scratch_bytes_batch(C, H, W, nb))
-    assert sbytes >= int(L.slr_splat_scratch_bytes(C, H, W)) and int(L.slr_splat_scratch_bytes_batch(C, H, W, 17)) == 0
-    scratch = torch.empty(sbytes, dtype=torch.uint8, device="cuda")
     refs = [oracle.synth_baseline(fs, Z, m, t, N) for t in ts]
     alphas = [1.0 - t / N for t in ts]
     for k, t in enumerate(ts):                                             # one frame per call, exact and upper-bound grids
-        for hints in ((int(totals[k, 0]), int(totals[k, 3]), int(totals[k, 4])), (-1, -1, -1)):
+        for n_items in (int(totals[k, 0]), -1):
             out = torch.empty(1, C, H, W, device="cuda")
             assert L.slr_synth_group_clip(ptr(dfs), ptr(dZ), ptr(zmax), 1, ptr(disp_f[t]), ptr(disp_p[N - t]), alphas[k],
-                                          ptr(out), None, C, H, W, 1e-8, ptr(plan), pbytes, nb, k, ptr(scratch), sbytes,
-                                          *hints, st) == 0
+                                          ptr(out), None, C, H, W, 1e-8, ptr(plan), pbytes, nb, k, n_items, st) == 0
             np.testing.assert_allclose(host(out), refs[k], rtol=2e-4, atol=2e-5)
     outs = torch.empty(nb, C, H, W, device="cuda")                        # all three frames in one launch
     PP = ctypes.c_void_p * nb
@@ -1202,18 +1246,19 @@ def test_c_abi_clip_plan_entry_points_and_errors(S, oracle):
     po = PP(*[outs[k].data_ptr() for k in range(nb)])
     al = (ctypes.c_float * nb)(*alphas)
     fr = (ctypes.c_int * nb)(*range(nb))
-    call = lambda n_, fr_, sb_: L.slr_synth_group_clip_batch(ptr(dfs), ptr(dZ), ptr(zmax), 1, df, dp, al, po, None, C, H, W, 1e-8,
-                                                             ptr(plan), pbytes, nb, fr_, n_, ptr(scratch), sb_, None, st)
-    assert call(nb, fr, sbytes) == 0
+    call = lambda n_, fr_, ni_=None: L.slr_synth_group_clip_batch(ptr(dfs), ptr(dZ), ptr(zmax), 1, df, dp, al, po, None, C, H, W, 1e-8,
+                                                                  ptr(plan), pbytes, nb, fr_, n_, ni_, st)
+    assert call(nb, fr) == 0
     for k in range(nb):
         np.testing.assert_allclose(host(outs[k:k + 1]), refs[k], rtol=2e-4, atol=2e-5)
-    assert call(17, fr, sbytes) == -1 and b"frames per launch" in L.slr_last_error()
-    assert call(nb, (ctypes.c_int * nb)(0, 1, 5), sbytes) == -1 and b"frame index" in L.slr_last_error()
-    assert call(nb, fr, 0) == 0                                            # (no scratch since the rows front end: pieces own their pixels)
+    assert call(17, fr) == -1 and b"frames per launch" in L.slr_last_error()
+    assert call(nb, (ctypes.c_int * nb)(0, 1, 5)) == -1 and b"frame index" in L.slr_last_error()
+    assert call(nb, (ctypes.c_int * nb)(0, 1, 1)) == -1 and b"twice" in L.slr_last_error()      # (a frame's deferred list is per frame)
+    assert call(nb, fr, (ctypes.c_int * nb)(*[int(totals[k, 0]) for k in range(nb)])) == 0      # exact grids from the totals
     for k in range(nb):
         np.testing.assert_allclose(host(outs[k:k + 1]), refs[k], rtol=2e-4, atol=2e-5)
     assert L.slr_synth_group_clip_batch(ptr(dfs), ptr(dZ), ptr(zmax), 1, df, dp, al, po, None, C, H, W, 1e-8, ptr(plan), pbytes // 2,
-                                        nb, fr, nb, None, 0, None, st) == -2 and b"plan needs" in L.slr_last_error()
+                                        nb, fr, nb, None, st) == -2 and b"plan needs" in L.slr_last_error()
 
 
 def test_splat_over_budget_tiles_whole_tile_path(S, oracle):

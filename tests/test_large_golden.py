@@ -127,3 +127,57 @@ def test_frames_at_native_768_vs_reference_models(golden_dir):
             errs.append(_check_envelope(g, f"v1_{k}_t{t}", outs[k][i:i + 1], 1e-4))
     print("native 768 frames: max distance to the reference's own interval", max(e[0] for e in errs),
           "| max distance to the nearer single run", max(e[1] for e in errs))
+
+
+def test_native_fixture_holds_the_fp64_arbiter(golden_dir):
+    """The single-valued arbiter: the reference's own classes run in float64 (tools/make_golden_large.py --native --fp64).
+    What the fixture says about the reference itself: its two fp32 runs sit 3e-6 ... 1.9e-4 from the fp64 frames -- on frame 30 of
+    the baseline model BOTH are further than 1e-4 from it (1.9e-4 plain, 1.2e-4 oneDNN): fp32 convolution rounding at this depth,
+    not a property of any implementation."""
+    g = np.load(f"{golden_dir}/native_frames_768.npz")
+    tags = [k[:-4] for k in g.files if k.endswith("_val")]
+    assert len(tags) == 12 and all(t + "_val_fp64" in g.files and t + "_plane_sums_fp64" in g.files for t in tags)
+    d = {t: (float(np.abs(g[t + "_val"] - g[t + "_val_fp64"]).max()), float(np.abs(g[t + "_val_onednn"] - g[t + "_val_fp64"]).max())) for t in tags}
+    assert 1.5e-4 < d["baseline_PredImg_t30"][0] < 2.5e-4 and 1.0e-4 < d["baseline_PredImg_t30"][1] < 1.5e-4, d
+    assert all(max(v) < 1e-4 for t, v in d.items() if t != "baseline_PredImg_t30"), d
+
+
+def _check_fp64(g, tag, x):
+    """-> max distance of x to the reference's fp64 frame at the sampled positions (+ the mean error per pixel of every plane)."""
+    x = np.ascontiguousarray(x.detach().cpu().numpy() if torch.is_tensor(x) else x, dtype=np.float32)
+    assert list(x.shape) == [int(v) for v in g[f"{tag}_shape"]], tag
+    pos = NF.digest_positions(tag, x.size, int(g["npos"]))
+    err = float(np.abs(x.ravel()[pos].astype(np.float64) - g[f"{tag}_val_fp64"]).max())
+    hw = x.shape[-2] * x.shape[-1]
+    sums = x.reshape(-1, hw).astype(np.float64).sum(1)
+    return err, float(np.abs(sums - g[f"{tag}_plane_sums_fp64"]).max()) / hw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("convs", ["auto", "fp32"])
+def test_frames_at_native_768_vs_the_fp64_reference(golden_dir, convs):
+    """Frames t = 1, 30, 59 of both animators at the reference's native 768 x 768, N = 60 (HIP kernels throughout) against the frames of
+    the reference's own classes run in FLOAT64 -- one value per sample, no envelope.  Both convolution rungs: the default
+    (split-f16 matrix-core kernels, convs="auto") and the fp32 matrix-core rung.  Bound: 1e-4 (north_star) on every sampled value --
+    measured on MI355X: 1.4e-5 at worst on either rung, i.e. closer to the fp64 frames than the reference's own fp32 CPU runs are
+    (1.2e-4 / 1.9e-4 on frame 30 of the baseline model; test_native_fixture_holds_the_fp64_arbiter) -- and 4e-5 asserted so that a
+    regression shows long before the contract is at risk.  The mean error per pixel of every plane stays below 5e-6."""
+    g = np.load(f"{golden_dir}/native_frames_768.npz")
+    S, N = int(g["S"]), int(g["N"])
+    img, motion, _ = NF.e2e_inputs(S, N)
+    img, motion = torch.from_numpy(img).cuda(), torch.from_numpy(motion).cuda()
+    ts = [int(t) for t in g["ts"]]
+    keys = ("PredImg", "FluidImg", "CompositeFluidAlpha")
+    base, v1 = _baseline(golden_dir).cuda(), _v1(golden_dir).cuda()
+    base.convs = v1.convs = convs
+    frames = base.synthesize(img, motion, N, frames=ts)
+    errs = {f"baseline_PredImg_t{t}": _check_fp64(g, f"baseline_PredImg_t{t}", frames[k:k + 1]) for k, t in enumerate(ts)}
+    v1_ts = [int(t) for t in g["v1_ts"]]
+    outs = v1.synthesize(img, motion, N, frames=v1_ts, keys=keys)
+    for i, t in enumerate(v1_ts):
+        for k in keys:
+            errs[f"v1_{k}_t{t}"] = _check_fp64(g, f"v1_{k}_t{t}", outs[k][i:i + 1])
+    print(f"native 768 frames vs the fp64 reference (convs={convs}):", {k: f"{v[0]:.2e}" for k, v in errs.items()})
+    for tag, (err, mean_err) in errs.items():
+        assert err <= 4e-5, (tag, err)
+        assert mean_err <= 5e-6, (tag, mean_err)

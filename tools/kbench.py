@@ -68,7 +68,7 @@ def main():
             check(L.slr_softsplat_forward(ptr(x), ptr(fl), ptr(out), 1, C, H, W, ptr(ws), ws.numel(), 0, st), "f")
 
         def binonly():
-            check(L.slr_splat_bin(ptr(fl), 1, C, H, W, ptr(ws), ws.numel(), st), "b")
+            check(L.slr_splat_bin(ptr(fl), 1, H, W, ptr(ws), ws.numel(), st), "b")
 
         def splatonly():
             check(L.slr_softsplat_forward(ptr(x), ptr(fl), ptr(out), 1, C, H, W, ptr(ws), ws.numel(), 1, st), "s")
