@@ -50,25 +50,44 @@ __global__ __launch_bounds__(256) void euler_kernel(const float *__restrict__ mo
     if (visible) visible[i] = inv ? 0.0f : 1.0f;
 }
 
+// All frames t = 0 .. nmax of one direction in one pass; a work-item carries SLR_EULER_PPT pixels (256 apart: every store of a wave is
+// 256 contiguous bytes).  The displacement maps are written once and read by later kernels only: nontemporal stores (round 5: 135 ->
+// 115-127 us per direction at 768x1280, N = 60 = 480 MB written: ~4 TB/s, store-bound).  More independent gather chains per lane do
+// not help -- 2 pixels per work-item 125-134 us, 4: 144-151 (the chain's latency is hidden already; fewer waves store less evenly).
+#ifndef SLR_EULER_PPT
+#define SLR_EULER_PPT 1
+#endif
 __global__ __launch_bounds__(256) void euler_all_kernel(const float *__restrict__ motion, int H, int W,
                                                         int nmax, float sign,
                                                         float *__restrict__ disp_all,
                                                         float *__restrict__ vis_all) {
+    constexpr int P = SLR_EULER_PPT;
     const int HW = H * W;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= HW) return;
+    const int i0 = blockIdx.x * (256 * P) + threadIdx.x;
     const float *mx = motion, *my = motion + HW;
-    const int y = i / W, x = i - y * W;
-    const float ox = (float)x, oy = (float)y;
     const float big = (float)(H > W ? H : W) + 1.0f;
-    float px = ox, py = oy;
-    bool inv = false;
+    float ox[P], oy[P], px[P], py[P];
+    bool inv[P], on[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int i = i0 + 256 * k;
+        on[k] = i < HW;
+        const int ii = on[k] ? i : 0, y = ii / W, x = ii - y * W;
+        ox[k] = px[k] = (float)x; oy[k] = py[k] = (float)y;
+        inv[k] = false;
+    }
     for (int t = 0; t <= nmax; ++t) {
-        if (t > 0 && !inv) euler_step(mx, my, H, W, sign, ox, oy, px, py, inv);
-        size_t o = (size_t)t * 2 * HW + i;
-        disp_all[o] = inv ? big : px - ox;
-        disp_all[o + HW] = inv ? big : py - oy;
-        if (vis_all) vis_all[(size_t)t * HW + i] = inv ? 0.0f : 1.0f;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+            if (t > 0 && !inv[k]) euler_step(mx, my, H, W, sign, ox[k], oy[k], px[k], py[k], inv[k]);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            if (!on[k]) continue;
+            const size_t o = (size_t)t * 2 * HW + i0 + 256 * k;
+            __builtin_nontemporal_store(inv[k] ? big : px[k] - ox[k], disp_all + o);
+            __builtin_nontemporal_store(inv[k] ? big : py[k] - oy[k], disp_all + o + HW);
+            if (vis_all) vis_all[(size_t)t * HW + i0 + 256 * k] = inv[k] ? 0.0f : 1.0f;
+        }
     }
 }
 
@@ -128,7 +147,7 @@ SLR_EXPORT int slr_euler_integrate_all(const float *motion, int H, int W, int nm
     SLR_CHECK_ARG(H > 0 && W > 0 && nmax >= 0, "sizes");
     SLR_CHECK_ARG((long long)H * W < (1LL << 30), "H*W too large");
     SLR_CHECK_ARG(sign == 1.0f || sign == -1.0f, "sign must be +1 or -1");
-    int blocks = (H * W + 255) / 256;
+    int blocks = (H * W + 256 * SLR_EULER_PPT - 1) / (256 * SLR_EULER_PPT);
     hipLaunchKernelGGL(slr::euler_all_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        motion, H, W, nmax, sign, disp_all, vis_all);
     SLR_CHECK_LAUNCH();

@@ -120,6 +120,9 @@ constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
 #ifndef SLR_GRAD_BENT
 #define SLR_GRAD_BENT 2                                // stage through LDS only where a wave's destinations spread over more rows than this
 #endif
+#ifndef SLR_GRAD_STRIPS
+#define SLR_GRAD_STRIPS 2                              // column strips of a block with a destination box each (1, 2, 4: power of two)
+#endif
 #ifndef SLR_GRAD_WAVES
 #define SLR_GRAD_WAVES 4                               // __launch_bounds__ waves per SIMD of the tiled kernel
 #endif
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
                                                                float *__restrict__ gflow, int C, int H, int W, int tiles_x) {
     constexpr int U = SLR_GRAD_TU;
     __shared__ float box[U][GT_BOX];
-    __shared__ int red[TILE_H][4];
+    __shared__ int red[TILE_H][SLR_GRAD_STRIPS][4];
+    __shared__ int bentw[TILE_H];
     const int HW = H * W;
     const int n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -158,33 +162,59 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     const float ay = (float)(c.y0 + 1) - Y, by = Y - (float)c.y0;
     const float dx[4] = {(-1.0f) * ay, (+1.0f) * ay, (-1.0f) * by, (+1.0f) * by};
     const float dy[4] = {ax * (-1.0f), bx * (-1.0f), ax * (+1.0f), bx * (+1.0f)};
-    // bounding box of the in-image corners of the block
+    // Destination boxes of the block's in-image corners, one per STRIP of GT_STRIPS column ranges of the block (64 / GT_STRIPS source
+    // columns each): where the flow bends or shears the block, the strips' boxes together are much smaller than the one box around
+    // everything (a sheared 8 x 64 block: one 100 x 45 box = 4500 cells does not fit, two 52 x 27 strips = 2800 do) -- round 5; the
+    // cells of all strips share the GT_BOX floats per channel, strip after strip.
+    constexpr int NSTR = SLR_GRAD_STRIPS, SW = TILE_W / NSTR;
+    const int strip = lane / SW;
     const bool any = k0 | k1 | k2 | k3;
     int bx0 = any ? max(c.x0, 0) : 0x7fffffff, bx1 = any ? min(c.x0 + 1, W - 1) : -1;
     int by0 = any ? max(c.y0, 0) : 0x7fffffff, by1 = any ? min(c.y0 + 1, H - 1) : -1;
+    int ry0 = by0, ry1 = by1;                                      // the whole row's rows (the "bent" test below)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
-        bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
-        by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
+        if (d < SW) {
+            bx0 = min(bx0, __shfl_xor(bx0, d)); bx1 = max(bx1, __shfl_xor(bx1, d));
+            by0 = min(by0, __shfl_xor(by0, d)); by1 = max(by1, __shfl_xor(by1, d));
+        }
+        ry0 = min(ry0, __shfl_xor(ry0, d)); ry1 = max(ry1, __shfl_xor(ry1, d));
     }
-    if (lane == 0) { red[wid][0] = bx0; red[wid][1] = bx1; red[wid][2] = by0; red[wid][3] = by1; }
+    if ((lane & (SW - 1)) == 0) { red[wid][strip][0] = bx0; red[wid][strip][1] = bx1; red[wid][strip][2] = by0; red[wid][strip][3] = by1; }
+    if (lane == 0) bentw[wid] = ry1 - ry0 + 1;
     __syncthreads();
     // rows of gradOutput ONE wave's 64 destinations spread over: 2 for a flow that keeps rows straight (the direct gathers
     // are then as coalesced as they get: identity flow 4.7 TB/s), more where the flow bends them
     int bent = 0;
+    int sx0[NSTR], sy0[NSTR], sbw[NSTR], sbase[NSTR + 1];          // per strip: box origin, width, first cell (workgroup-uniform)
+    sbase[0] = 0;
+    bool fits = true, some = false;
 #pragma unroll
-    for (int w = 0; w < TILE_H; ++w) {
-        bent = max(bent, red[w][3] - red[w][2] + 1);
-        bx0 = min(bx0, red[w][0]); bx1 = max(bx1, red[w][1]); by0 = min(by0, red[w][2]); by1 = max(by1, red[w][3]);
+    for (int w = 0; w < TILE_H; ++w) bent = max(bent, bentw[w]);
+#pragma unroll
+    for (int q = 0; q < NSTR; ++q) {
+        int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1;
+#pragma unroll
+        for (int w = 0; w < TILE_H; ++w) { x0 = min(x0, red[w][q][0]); x1 = max(x1, red[w][q][1]); y0 = min(y0, red[w][q][2]); y1 = max(y1, red[w][q][3]); }
+        const int w_ = x1 - x0 + 1, h_ = y1 - y0 + 1;              // (<= 0: nothing of this strip lands in the image)
+        const bool has = w_ > 0 && h_ > 0;
+        sx0[q] = has ? x0 : 0; sy0[q] = has ? y0 : 0; sbw[q] = has ? w_ : 1;
+        const long long cells = has ? (long long)w_ * h_ : 0;
+        fits = fits && cells <= GT_BOX;
+        sbase[q + 1] = sbase[q] + (int)(cells <= GT_BOX ? cells : 0);
+        some = some || has;
     }
-    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;              // (<= 0: nothing of this block lands in the image)
-    const bool staged = bw > 0 && bh > 0 && (long long)bw * bh <= GT_BOX && bent > SLR_GRAD_BENT;   // workgroup-uniform
+    const int nbox = sbase[NSTR];
+    const bool staged = some && fits && nbox <= GT_BOX && bent > SLR_GRAD_BENT;   // workgroup-uniform
     const int o = c.y0 * W + c.x0;
     // global offsets (direct gathers) / LDS offsets (staged); an out-of-image corner reads a valid address and its
     // PRODUCT is replaced by +0.0 (see grad_kernel)
     const int g0 = k0 ? o : i, g1 = k1 ? o + 1 : i, g2 = k2 ? o + W : i, g3 = k3 ? o + W + 1 : i;
-    const int lo = (c.y0 - by0) * bw + (c.x0 - bx0);
-    const int l0 = k0 ? lo : 0, l1 = k1 ? lo + 1 : 0, l2 = k2 ? lo + bw : 0, l3 = k3 ? lo + bw + 1 : 0;
+    int mx0 = sx0[0], my0 = sy0[0], mbw = sbw[0], mbase = sbase[0];          // this work-item's strip
+#pragma unroll
+    for (int q = 1; q < NSTR; ++q) if (strip == q) { mx0 = sx0[q]; my0 = sy0[q]; mbw = sbw[q]; mbase = sbase[q]; }
+    const int lo = mbase + (c.y0 - my0) * mbw + (c.x0 - mx0);
+    const int l0 = k0 ? lo : 0, l1 = k1 ? lo + 1 : 0, l2 = k2 ? lo + mbw : 0, l3 = k3 ? lo + mbw + 1 : 0;
     // The gradInput stores go through a buffer descriptor (plane offset in an SGPR, one 32-bit pixel offset; work-items outside the image
     // are dropped by its range check); the loads stay global loads (SLR_GRAD_BUF_LD above: the same gathers through a descriptor are slower).
     const uint32_t hw4 = (uint32_t)HW * 4u;
@@ -204,14 +234,16 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     // staged path: the box is walked as ONE linear index range (dense wave loads across row ends); the values of the NEXT
     // pass are loaded into registers while this pass is gathered from LDS, and written to LDS after the barrier
     constexpr int NS = (GT_BOX + GT_THREADS - 1) / GT_THREADS;
-    const int nbox = bw * bh;
-    uint32_t soff[NS];                                             // byte offset of this work-item's k-th box element inside a plane
-    const float inv_bw = 1.0f / (float)(bw > 0 ? bw : 1);
+    uint32_t soff[NS];                                             // byte offset of this work-item's k-th box cell inside a plane
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int idx = tid + k * GT_THREADS;
-        const int r = (int)(((float)idx + 0.5f) * inv_bw);         // idx / bw, exact for idx < 2^22
-        soff[k] = (staged && idx < nbox) ? (uint32_t)((by0 + r) * W + bx0 + (idx - r * bw)) * 4u : 0u;
+        int qx0 = sx0[0], qy0 = sy0[0], qbw = sbw[0], qb = sbase[0];           // the strip cell idx belongs to
+#pragma unroll
+        for (int q = 1; q < NSTR; ++q) if (idx >= sbase[q]) { qx0 = sx0[q]; qy0 = sy0[q]; qbw = sbw[q]; qb = sbase[q]; }
+        const int rel = idx - qb;
+        const int r = (int)(((float)rel + 0.5f) / (float)qbw);     // rel / qbw, exact for rel < 2^22
+        soff[k] = (staged && idx < nbox) ? (uint32_t)((qy0 + r) * W + qx0 + (rel - r * qbw)) * 4u : 0u;
     }
     float sv[NS][U];
     auto issue = [&](int ch) {
