@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 H, W, NFRAMES = 768, 1280, 60
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_ROUND = "r4"            # profiles/r4_traffic_<name>.json: PMC passes (tools/collect_profiles.sh -> tools/pmc_kernel_traffic.py) of one
+TRAFFIC_ROUND = "r5"            # profiles/r4_traffic_<name>.json: PMC passes (tools/collect_profiles.sh -> tools/pmc_kernel_traffic.py) of one
                                 # kernel each; every file carries the hash of the kernel sources it was taken on
 
 
@@ -65,7 +65,7 @@ def static_traffic(name, units):
     if "traffic_bytes_per_unit" not in tj:
         return None, None
     same = tj.get("source_sha16") == csrc_hash()
-    src = (f"static: PMC passes (FETCH_SIZE x2 / WRITE_SIZE) of {rel} per unit of work x the units of this launch, not measured in "
+    src = (f"static: PMC passes (FETCH_SIZE x2 -- calibrated on this access pattern, profiles/r5_fetch_calibration.txt -- / WRITE_SIZE) of {rel} per unit of work x the units of this launch, not measured in "
            "this run; " + ("taken on these kernel sources" if same else
                            "STALE: taken on other kernel sources (re-run tools/collect_profiles.sh)"))
     return round(tj["traffic_bytes_per_unit"] * units), src
@@ -165,6 +165,7 @@ def splat_roofline(kev, sev, c_splat, kernel):
     traffic, src = static_traffic("clip_c3" if c_splat == 65 else "clip_c4", fpl)
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+            "frac_traffic": None if not traffic else round(traffic / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "alg_bytes_per_launch": round(alg * fpl), "frames_per_launch": round(fpl, 2), "launch_avg_us": round(l_avg, 1),
             "alg_bytes_per_frame": alg, "min_bytes_per_frame": min_bytes,
             "frac_min_bytes": round(min_bytes / (k_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_us": round(k_avg, 1), "min_us": round(per_frame[0], 1),
@@ -570,6 +571,8 @@ def dropin_roofline(dev, motion):
         r["front_end"] = "rows"                            # 1920 tiles > the scan threshold (1024): rowbin (+ plan) -> tile kernel -> deferred pieces
         if name.startswith("euler"):
             r["traffic"], r["traffic_source"] = static_traffic("op_rows_" + name[6:], 1)
+            if r["traffic"]:                               # the tile kernel's physical share of the 8 TB/s (counter bytes / its time)
+                r["frac_traffic"] = round(r["traffic"] / r["tile_us"] / 1e3 / HBM_PEAK_GBS, 4)
         prev = L.slr_splat_set_front_end(1)
         try:
             r["scan_front_end"] = measure(lambda: S.FunctionSoftsplat(x, flow, None, "summation"), alg)
@@ -604,7 +607,21 @@ def dropin_roofline(dev, motion):
     res["c2"] = small.pop("c2")
     res["c2"]["workload"] = "C2: " + res["c2"]["workload"] + " U(-8,8)"
     res["c2"]["traffic"], res["c2"]["traffic_source"] = static_traffic("op_scan_c2", 1)
+    if res["c2"]["traffic"]:
+        res["c2"]["frac_traffic"] = round(res["c2"]["traffic"] / res["c2"]["call_us"] / 1e3 / HBM_PEAK_GBS, 4)
     res["small_grids"] = small
+    # config C2 with N = 60 as ONE call (BASELINE.json: "random 64-ch 256x480 feature + flow, N=60"): FunctionSoftsplat on
+    # [60,64,256,480] with 60 different incoherent flows -- 14400 output tiles, the rows front end, the chip full
+    nb = 60
+    fb = torch.randn(nb, 64, 256, 480, device=dev)
+    mb = torch.randn(nb, 1, 256, 480, device=dev)
+    flb = torch.rand(nb, 2, 256, 480, device=dev) * 16 - 8
+    algb = nb * (2 * 64 + 3) * 256 * 480 * 4
+    rb = measure(lambda: S.FunctionSoftsplat(fb, flb, mb, "softmax"), algb, tile=False)
+    rb.update({"workload": "C2 batched: ONE FunctionSoftsplat(softmax) call on [60,64,256,480], 60 incoherent U(-8,8) flows", "alg_bytes": algb,
+               "front_end": "rows", "per_sample_us": round(rb["call_us"] / nb, 2)})
+    res["c2_batched"] = rb
+    del fb, mb, flb
     return res
 
 

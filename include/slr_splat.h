@@ -310,6 +310,12 @@ int slr_conv_saturation_record(unsigned *host_slot, void *stream);
  * activations -- at the rate of the fp32 matrix pipe (157 TFLOP/s, 1/16 of the f16 rate).  `wsplit` must then come from
  * slr_conv3x3_f32_weights / slr_conv1x1_f32_weights (same byte counts as the split-f16 buffers), wscale = xscale = 1. */
 #define SLR_CONV_F32    8
+/* Together with SLR_CONV_F32 on the 3x3 entry points (Cout > 4): the convolution as Winograd F(2x2, 3x3) on the same fp32 matrix
+ * instructions -- 16 multiplications per (input channel, output channel, 2x2 output tile) instead of 36, the transforms are additions
+ * (csrc/conv_wino.hpp).  fp32 operands, products and accumulation as on the plain fp32 rung; the rounding error of the transform
+ * domain is within a small factor of the direct fp32 convolution's (tests/test_gpu_conv_f32.py: both against fp64).  `wsplit` must then
+ * come from slr_conv3x3_wino_weights (slr_conv3x3_wino_weight_bytes: 16 transformed values per weight instead of 9). */
+#define SLR_CONV_WINO   16
 /* Cout <= 4 (the 128 -> 3 end of the decoders): the 3x3 entry points run a kernel of their own on EITHER rung -- fp32 FMAs on the vector
  * ALUs (csrc/conv_few.hpp; the narrowest matrix-core tile would compute 32 channels for 3), i.e. the reference's arithmetic: both
  * weight-preparation calls then write plain fp32 weights into the buffer, wscale / xscale are accepted and unused, nothing saturates. */
@@ -319,6 +325,9 @@ int slr_conv3x3_split_weights(const float *w /* [Cout,Cin,3,3] */, void *wsplit,
                               float wscale, void *stream);
 int slr_conv3x3_f32_weights(const float *w /* [Cout,Cin,3,3] */, void *wfrag /* slr_conv3x3_weight_bytes */, int Cout, int Cin,
                             void *stream);
+size_t slr_conv3x3_wino_weight_bytes(int Cout, int Cin);
+int slr_conv3x3_wino_weights(const float *w /* [Cout,Cin,3,3] */, void *wfrag /* slr_conv3x3_wino_weight_bytes */, int Cout, int Cin,
+                             void *stream);
 
 /* out = conv3x3(pre(in)) + bias + residual, pre(x) = relu(x*pre_scale[c] - pre_shift[c]) when pre_scale
  * is given (eval-mode noise-BN + ReLU in front of the convolution, models/layers/blocks.py:66-74 +

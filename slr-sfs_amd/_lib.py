@@ -23,7 +23,7 @@ SYMBOLS = (
     "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
-    "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
+    "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_wino_weight_bytes", "slr_conv3x3_wino_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_f32_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
 )
@@ -71,6 +71,8 @@ def lib():
         L.slr_clip_plan_bytes.argtypes = [i, i, i]
         L.slr_conv3x3_weight_bytes.restype = sz
         L.slr_conv3x3_weight_bytes.argtypes = [i, i]
+        L.slr_conv3x3_wino_weight_bytes.restype = sz
+        L.slr_conv3x3_wino_weight_bytes.argtypes = [i, i]
         L.slr_conv1x1_weight_bytes.restype = sz
         L.slr_conv1x1_weight_bytes.argtypes = [i, i]
         sig = {
@@ -100,6 +102,7 @@ def lib():
             "slr_conv3x3_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv1x1_split_weights": [fp, vp, i, i, f, vp],
             "slr_conv3x3_f32_weights": [fp, vp, i, i, vp],
+            "slr_conv3x3_wino_weights": [fp, vp, i, i, vp],
             "slr_conv1x1_f32_weights": [fp, vp, i, i, vp],
             "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, f, i, vp],
             "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, f, fp, fp, i, vp],

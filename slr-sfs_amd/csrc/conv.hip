@@ -788,6 +788,7 @@ static int sat_counter(unsigned **p) {
 }
 
 }  // namespace slr
+#include "conv_wino.hpp"
 
 using namespace slr;
 
@@ -892,6 +893,21 @@ SLR_EXPORT int slr_conv3x3_f32_weights(const float *w, void *wfrag, int Cout, in
     return 0;
 }
 
+SLR_EXPORT size_t slr_conv3x3_wino_weight_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)wino_cout_pad(Cout) * conv_cin_pad(Cin) * 16 * sizeof(float);
+}
+
+SLR_EXPORT int slr_conv3x3_wino_weights(const float *w, void *wfrag, int Cout, int Cin, void *stream) {
+    SLR_CHECK_ARG(w && wfrag, "null pointer");
+    SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)wino_cout_pad(Cout) * conv_cin_pad(Cin) * 16 < (1LL << 30), "sizes");
+    const int CoutP = wino_cout_pad(Cout), CinP = conv_cin_pad(Cin);
+    hipLaunchKernelGGL(conv_wino_weights_kernel, dim3((CoutP * CinP + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float *)wfrag,
+                       Cout, Cin, CoutP, CinP);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
 SLR_EXPORT int slr_conv1x1_f32_weights(const float *w, void *wfrag, int Cout, int Cin, void *stream) {
     SLR_CHECK_ARG(w && wfrag, "null pointer");
     SLR_CHECK_ARG(Cout > 0 && Cin > 0 && (long long)conv1x1_cout_pad(Cout) * conv_cin_pad(Cin) < (1LL << 30), "sizes");
@@ -943,9 +959,34 @@ SLR_EXPORT int slr_conv1x1_forward(const float *in, const void *wsplit, const fl
 template <bool F32>
 static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st);
 
-static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, bool f32, hipStream_t st) {
+static int conv_wino_launch(ConvArgs &a, bool in_b8, hipStream_t st) {
+    static bool attr_set[64][4] = {};
+    int dev = 0;
+    SLR_CHECK_HIP(hipGetDevice(&dev));
+    const int which = (a.pre != PRE_NONE ? 2 : 0) + (in_b8 ? 1 : 0);
+    const void *fn = which == 3 ? (const void *)conv3x3_wino_kernel<true, true> : which == 2 ? (const void *)conv3x3_wino_kernel<true, false>
+                   : which == 1 ? (const void *)conv3x3_wino_kernel<false, true> : (const void *)conv3x3_wino_kernel<false, false>;
+    if (dev < 0 || dev >= 64 || !attr_set[dev][which]) {
+        SLR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES));
+        if (dev >= 0 && dev < 64) attr_set[dev][which] = true;
+    }
+    a.tiles_x = (a.W + CV_W - 1) / CV_W;
+    a.nchunk = conv_cin_pad(a.Cin) / 16;
+    a.xscale = 1.0f; a.unscale = 1.0f;
+    const dim3 grid(a.tiles_x * ((a.H + CV_H - 1) / CV_H), wino_cout_pad(a.Cout) / 64, a.N);
+    if (which == 3) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
+    else if (which == 2) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
+    else if (which == 1) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, bool f32, hipStream_t st, bool wino = false) {
     if (int e = check_xscale(xscale)) return e;
     SLR_CHECK_ARG(!f32 || (wscale == 1.0f && xscale == 1.0f), "the fp32 rung takes no operand scales (wscale = xscale = 1)");
+    SLR_CHECK_ARG(!wino || (f32 && a.Cout > CF_MAXCO), "SLR_CONV_WINO goes with SLR_CONV_F32 and more than 4 output channels");
+    if (wino) return conv_wino_launch(a, in_b8, st);
     if (a.Cout <= CF_MAXCO) {                           // fp32 FMAs on the vector ALUs on either rung: no operand scales, nothing saturates
         switch (a.Cout) {
             case 1: return conv_few_launch<1>(a, in_b8, st);
@@ -994,7 +1035,7 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
 
 static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
                              bool derived_mask) {
-    layout &= ~SLR_CONV_F32;
+    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO);
     SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8 | SLR_CONV_RES_B8)) == 0, "layout flags");
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8) || ((layout & SLR_CONV_OUT_B8) && residual && !((uintptr_t)residual & 15)),
                   "a channel-blocked residual goes with a channel-blocked output");
@@ -1027,7 +1068,7 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.residual = residual;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
-    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream);
+    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream, (layout & SLR_CONV_WINO) != 0);
 }
 
 SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
@@ -1053,5 +1094,5 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
-    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream);
+    return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream, (layout & SLR_CONV_WINO) != 0);
 }

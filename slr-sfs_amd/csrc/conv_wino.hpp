@@ -1,0 +1,420 @@
+// conv_wino.hpp -- the fp32 rung's 3x3 convolution as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (gfx950); included by conv.hip.
+//
+// The fp32 rung (SLR_CONV_F32: fp32 operands, fp32 products, fp32 accumulation -- the arithmetic class of the reference's decoder,
+// models/layers/partialconv2d.py:61-74) runs at 0.84 of the fp32 matrix peak (157 TFLOP/s) as a direct implicit GEMM: it can only get
+// faster by doing fewer multiplications.  F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input patch with 16 multiplications per
+// (input channel, output channel) instead of 36:  Y = A^T [ (G g G^T) .* (B^T d B) ] A, summed over the input channels BEFORE the
+// output transform -- i.e. 16 independent GEMMs (one per position xi of the 4x4 transformed tile) of [couts x cins] x [cins x tiles].
+//
+// One workgroup (256 work-items = 4 waves, ONE per CU: 156 KiB of LDS, 256 accumulator registers per wave) = the same 8 x 32 output
+// block as the direct kernel (64 tiles of 2x2) x 64 output channels:
+//   * staging: the (8+2) x (32+2) halo block of 16 input channels, through the same prologue as the direct kernel
+//     (relu(x*scale - shift)*mask, zero padding), as fp32 rows in LDS (`raw`, single buffer);
+//   * input transform: every work-item turns 4 patches (4 channels of one tile) into V[xi][cin][tile] (32 additions per patch),
+//     double-buffered in LDS -- the transform of chunk c + 1 is issued between the MFMAs of chunk c;
+//   * wave (cot, tb) owns the 32 output channels cot x the 32 tiles tb for ALL 16 positions: 16 accumulator tiles of 32x32; per chunk
+//     and position 8 MFMAs (K = 2 input channels each) whose B operand is ONE ds_read_b32 of V and whose A operand (the transformed
+//     weights U = G g G^T, prepared by slr_conv3x3_wino_weights in fragment order) comes from L2, one position ahead;
+//   * output transform in registers (the 16 positions of a (channel, tile) pair sit in one lane), then the direct kernel's epilogues
+//     (plain + bias + residual, or the partial-convolution one with its mask box sum, next-layer BN, update mask) on the 2x2 pixels.
+// 2.25x fewer MFMAs than the direct kernel per output; the transforms are additions only (exact up to fp32 rounding; the error of
+// F(2x2, 3x3) in fp32 is within a small factor of the direct fp32 convolution's -- tests/test_gpu_conv_f32.py measures both against fp64).
+#pragma once
+
+namespace slr {
+
+constexpr int WN_RAWSTR = 344;                       // floats per channel row of the staged halo block (340 used)
+constexpr int WN_TILES = 64;                         // 2x2 output tiles of the 8 x 32 block: 4 tile rows x 16 tile columns
+constexpr size_t WN_OFF_RAW = 0;
+constexpr size_t WN_OFF_V = WN_OFF_RAW + (size_t)16 * WN_RAWSTR * 4;                       // [2][16 xi][16 cin][64 tiles]
+constexpr size_t WN_OFF_MPL = WN_OFF_V + (size_t)2 * 16 * 16 * WN_TILES * 4;
+constexpr size_t WN_OFF_MPLB = WN_OFF_MPL + (size_t)CV_NPX * 4;
+constexpr size_t WN_OFF_PSS = (WN_OFF_MPLB + (size_t)2 * (CV_NPX - 256) * 4 + 15) & ~(size_t)15;
+constexpr size_t WN_LDS_BYTES = WN_OFF_PSS + (size_t)2 * CV_MAXCIN * 4;
+static_assert(WN_LDS_BYTES <= 160 * 1024, "one workgroup per CU: everything fits the 160 KiB of LDS");
+
+__host__ __device__ inline int wino_cout_pad(int Cout) { return (Cout + 63) / 64 * 64; }
+
+// w [Cout,Cin,3,3] -> U = G g G^T per (co, ci), fp32, in fragment order [co tile 32][chunk of 16 ci][xi 16][lane 64][k pair 8]:
+// lane = (co & 31) + 32 * (ci & 1), k = (ci & 15) >> 1 (the A operand of v_mfma_f32_32x32x2_f32: lanes 0-31 hold input channel 2k,
+// lanes 32-63 channel 2k + 1).  Computed in double, rounded once.
+__global__ __launch_bounds__(256) void conv_wino_weights_kernel(const float *__restrict__ w, float *__restrict__ wf, int Cout, int Cin,
+                                                                int CoutP, int CinP) {
+    const int total = CoutP * CinP, nchunk = CinP >> 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ci = i % CinP, co = i / CinP;
+        double g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[r][c] = (co < Cout && ci < Cin) ? (double)w[((size_t)co * Cin + ci) * 9 + r * 3 + c] : 0.0;
+        double t[4][3];                                  // G g
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            t[0][c] = g[0][c];
+            t[1][c] = 0.5 * (g[0][c] + g[1][c] + g[2][c]);
+            t[2][c] = 0.5 * (g[0][c] - g[1][c] + g[2][c]);
+            t[3][c] = g[2][c];
+        }
+        const int cl = ci & 15;
+        const size_t frag0 = ((size_t)(co >> 5) * nchunk + (ci >> 4)) * 16;
+        const int within = ((co & 31) + 32 * (cl & 1)) * 8 + (cl >> 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                    // (G g) G^T
+            const double u[4] = {t[r][0], 0.5 * (t[r][0] + t[r][1] + t[r][2]), 0.5 * (t[r][0] - t[r][1] + t[r][2]), t[r][2]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wf[(frag0 + r * 4 + c) * 512 + within] = (float)u[c];
+        }
+    }
+}
+
+constexpr int WN_THREADS = 512;                      // 8 waves: two per SIMD (one workgroup per CU) -- a lone wave per SIMD idles the matrix pipe at every wait
+
+template <bool PRE, bool INB8>
+__global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wn_smem[];
+    float (*raw)[WN_RAWSTR] = reinterpret_cast<float (*)[WN_RAWSTR]>(wn_smem + WN_OFF_RAW);                       // [16 cin][halo pixel]
+    float (*V)[16][16][WN_TILES] = reinterpret_cast<float (*)[16][16][WN_TILES]>(wn_smem + WN_OFF_V);            // [buf][xi][cin][tile]
+    float *mpl = reinterpret_cast<float *>(wn_smem + WN_OFF_MPL);                                                // mask plane over the halo block
+    float *pss = reinterpret_cast<float *>(wn_smem + WN_OFF_PSS);                                                // prologue scale | shift
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this wave: output channels 32 * cot .. + 31 of the workgroup's 64, tiles 32 * tb .. + 31, positions 8 * xh .. + 7
+    const int cot = wave & 1, tb = (wave >> 1) & 1, xh = wave >> 2;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int x0 = tx * CV_W, y0 = ty * CV_H;
+    const int n = blockIdx.z;
+    const int cotile = blockIdx.y * 2 + cot;             // 32-channel tile of the weight buffer
+    const int HW = a.H * a.W;
+    const int nchunk = a.nchunk;
+    const int cmax = a.Cin - 1;
+    const float *inb = a.in + (size_t)n * a.Cin * HW;
+    const int pre = a.pre;
+
+    if (PRE) {
+        for (int i = tid; i < nchunk * 16; i += WN_THREADS) {       // padded channels: scale = shift = 0 -> 0
+            pss[i] = i < a.Cin ? a.pre_scale[i] : 0.0f;
+            pss[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] : 0.0f;
+        }
+    }
+    // ---- staging of a chunk: 680 items = 340 halo pixels x 2 groups of 8 channels; item A = tid (all work-items), item B = 512 + tid
+    // (work-items < 168).  Same prologue as the direct kernel (conv.hip: stage_value).
+    const bool liveB = tid < 168;
+    const int gA = tid >= CV_NPX ? 1 : 0, pA = tid - CV_NPX * gA;      // group / halo pixel of item A
+    const int pB = 172 + tid;                                          // item B: group 1, pixels 172 .. 339
+    bool okA, okB;
+    int offA, offB;
+    {
+        const int pr = pA / CV_HW, pc = pA - pr * CV_HW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        okA = (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        offA = okA ? gy * a.W + gx : 0;
+    }
+    {
+        const int pq = liveB ? pB : 0, pr = pq / CV_HW, pc = pq - pr * CV_HW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        okB = liveB & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        offB = okB ? gy * a.W + gx : 0;
+    }
+    const float mvA = (a.mask && okA) ? a.mask[(size_t)n * HW + offA] : 0.0f;
+    const float mvB = (a.mask && okB) ? a.mask[(size_t)n * HW + offB] : 0.0f;
+    if (a.mask && tid < CV_NPX) mpl[tid] = mvA;        // (items A of group 0 cover every halo pixel)
+    const float mA = okA ? (pre == PRE_BN_MASK ? mvA : 1.0f) : 0.0f;
+    const float mB = okB ? (pre == PRE_BN_MASK ? mvB : 1.0f) : 0.0f;
+    float cntA = 0.0f, cntB = 0.0f;                    // derived mask: non-zero inputs per staging item, over all chunks
+    const bool nonzero_mask = pre == PRE_BN_NONZERO;
+    const int c8max = (a.Cin >> 3) - 1;
+    auto load_item = [&](bool isB, int c, float (&st)[8]) {
+        const int g = isB ? 1 : gA, off = isB ? offB : offA;
+        if (INB8) {
+            const int grp = min(c * 2 + g, c8max);
+            const float4 *q = reinterpret_cast<const float4 *>(inb) + ((size_t)grp * HW + (unsigned)off) * 2;
+            const float4 u = q[0], v = q[1];
+            st[0] = u.x; st[1] = u.y; st[2] = u.z; st[3] = u.w;
+            st[4] = v.x; st[5] = v.y; st[6] = v.z; st[7] = v.w;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st[j] = inb[(size_t)min(c * 16 + g * 8 + j, cmax) * HW + (unsigned)off];
+    };
+    auto store_item = [&](bool isB, int c, const float (&st)[8]) {
+        const int g = isB ? 1 : gA, px = isB ? pB : pA;
+        const int cb = c * 16 + g * 8;
+        const float mk0 = isB ? mB : mA;
+        float count = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = st[j];
+            float v;
+            if (PRE) {
+                const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : mk0;
+                v = fmaxf(x * pss[cb + j] - pss[CV_MAXCIN + cb + j], 0.0f) * mk;
+                count += (cb + j <= cmax) ? mk : 0.0f;
+            } else {
+                v = (cb + j <= cmax) ? x * mk0 : 0.0f;   // (padded channels meet zero weights; keep them finite and zero)
+            }
+            if (!isB || liveB) raw[g * 8 + j][px] = v;
+        }
+        if (isB) cntB += count; else cntA += count;
+    };
+
+    // ---- input transform: work-item -> tile tid & 63, channels 2 * (tid >> 6), + 1 of the chunk
+    const int tt = tid & 63, tcg = tid >> 6;
+    const int tpy = (tt >> 4) * 2, tpx = (tt & 15) * 2;  // the patch's first halo row / column
+    // A patch's transform in 7 slices, issued between the MFMA groups (a slice of <= 16 instructions issues in the shadow of the matrix
+    // pipe): 0 patch loads, 1-2 B^T d, 3-6 one output row each.
+    struct PatchRegs { float d[4][4], t[4][4]; };
+    auto transform_slice = [&](int slice, int vb, int k, PatchRegs &pr) {
+        const int ch = tcg * 2 + k;
+        if (slice == 0) {
+            const float *rp = &raw[ch][tpy * CV_HW + tpx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 lo = *reinterpret_cast<const float2 *>(rp + i * CV_HW), hi = *reinterpret_cast<const float2 *>(rp + i * CV_HW + 2);
+                pr.d[i][0] = lo.x; pr.d[i][1] = lo.y; pr.d[i][2] = hi.x; pr.d[i][3] = hi.y;
+            }
+        } else if (slice == 1 || slice == 2) {           // B^T d, two columns per slice
+#pragma unroll
+            for (int j = 2 * (slice - 1); j < 2 * slice; ++j) {
+                pr.t[0][j] = pr.d[0][j] - pr.d[2][j];
+                pr.t[1][j] = pr.d[1][j] + pr.d[2][j];
+                pr.t[2][j] = pr.d[2][j] - pr.d[1][j];
+                pr.t[3][j] = pr.d[1][j] - pr.d[3][j];
+            }
+        } else if (slice <= 6) {                         // (B^T d) B, one row per slice
+            const int i = slice - 3;
+            V[vb][i * 4 + 0][ch][tt] = pr.t[i][0] - pr.t[i][2];
+            V[vb][i * 4 + 1][ch][tt] = pr.t[i][1] + pr.t[i][2];
+            V[vb][i * 4 + 2][ch][tt] = pr.t[i][2] - pr.t[i][1];
+            V[vb][i * 4 + 3][ch][tt] = pr.t[i][1] - pr.t[i][3];
+        }
+    };
+
+    f16v acc[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+
+    __syncthreads();                                   // pss
+    float sA[8], sB[8];
+    load_item(false, 0, sA);
+    load_item(true, 0, sB);
+    store_item(false, 0, sA);
+    store_item(true, 0, sB);
+    __syncthreads();
+    if (nchunk > 1) {                                  // the next chunk's loads fly under the first transform
+        load_item(false, 1, sA);
+        load_item(true, 1, sB);
+    }
+    {
+        PatchRegs pr;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int sl = 0; sl < 7; ++sl) transform_slice(sl, 0, k, pr);
+    }
+    __syncthreads();
+
+    const int bcol = lane & 31, bgrp = lane >> 5;
+    typedef float f8v __attribute__((ext_vector_type(8)));
+    const float4 *wbase = reinterpret_cast<const float4 *>(a.w) + ((size_t)cotile * nchunk * 16 + 8 * xh) * 128;       // 128 float4 per (chunk, xi) fragment
+    auto load_a = [&](int g /* chunk * 16 + local xi */) -> f8v {
+        const float4 *q = wbase + (size_t)g * 128 + 2u * (unsigned)lane;
+        const float4 u = q[0], v = q[1];
+        f8v r;
+        r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w; r[4] = v.x; r[5] = v.y; r[6] = v.z; r[7] = v.w;
+        return r;
+    };
+    // A wave's 8 positions go two at a time ("pair": 8 k-pairs x 2 accumulators), the pair's two weight fragments loaded a whole pair
+    // ahead of their use: the loads are ISSUED at the top of the previous pair (scheduling barrier) -- sunk to their use by the
+    // compiler, every pair waited for an L2 round trip (2255 -> 1749 us at 128 -> 128, 768x1280).  Local pair p of chunk c: fragments
+    // c * 16 + 2p, + 1 (wbase already points at this wave's half of the positions).
+    const int nlast = (nchunk - 1) * 16 + 7;
+    auto frag = [&](int c, int j) { return min(c * 16 + j, nlast); };
+    f8v aq[2], an[2];
+    aq[0] = load_a(frag(0, 0)); aq[1] = load_a(frag(0, 1));
+    for (int c = 0; c < nchunk; ++c) {
+        const int vb = c & 1;
+        if (c + 1 < nchunk) {                          // (uniform) raw <- chunk c + 1 (its loads were issued a whole chunk ago)
+            store_item(false, c + 1, sA);
+            store_item(true, c + 1, sB);
+        }
+        __syncthreads();
+        if (c + 2 < nchunk) {
+            load_item(false, c + 2, sA);
+            load_item(true, c + 2, sB);
+        }
+        PatchRegs pr;                                  // (the last chunk transforms stale rows into the buffer nobody reads: no branch in the pairs)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // next pair's fragments: p + 1 of this chunk, or pair 0 of the next chunk
+            an[0] = load_a(p < 3 ? frag(c, 2 * p + 2) : frag(c + 1, 0));
+            an[1] = load_a(p < 3 ? frag(c, 2 * p + 3) : frag(c + 1, 1));
+            float b[2], bn[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = V[vb][8 * xh + 2 * p + i][bgrp][tb * 32 + bcol];
+            __builtin_amdgcn_sched_barrier(0);         // the next pair's weights are in flight from HERE
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) {
+                if (kp < 7) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bn[i] = V[vb][8 * xh + 2 * p + i][2 * (kp + 1) + bgrp][tb * 32 + bcol];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[2 * p + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][kp], b[i], acc[2 * p + i], 0, 0, 0);
+                const int slot = p * 8 + kp;           // 32 slots per chunk: patch 0 in slots 0-6, patch 1 in 16-22
+                if ((slot & 15) < 7) transform_slice(slot & 15, vb ^ 1, slot >> 4, pr);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) b[i] = bn[i];
+            }
+            aq[0] = an[0]; aq[1] = an[1];
+        }
+        __syncthreads();
+    }
+
+    if (pre == PRE_BN_NONZERO) {                       // mask plane = channel sum of (x != 0) over both channel groups of a pixel
+        float *c0 = &raw[0][0], *c1 = c0 + CV_NPX;     // (raw is free: the last transform has been read)
+        (gA ? c1 : c0)[pA] = cntA;
+        if (liveB) c1[pB] = cntB;
+        __syncthreads();
+        if (tid < CV_NPX) mpl[tid] = c0[tid] + c1[tid];
+    }
+    // ---- the two halves of the positions meet: a wave finishes the output channels (accumulator rows) 8 * xh .. + 7 of its tile and hands
+    // the other 8 rows of its 8 positions to its partner (same cot, tb) through the V area (16 KiB per wave, all of V)
+    float *xch = reinterpret_cast<float *>(wn_smem + WN_OFF_V);
+    {
+        float *mine = xch + (size_t)wave * 64 * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) mine[(j * 8 + rr) * 64 + lane] = acc[j][8 * (1 - xh) + rr];
+    }
+    __syncthreads();
+    const float *theirs = xch + (size_t)(wave ^ 4) * 64 * 64;
+
+    // ---- output transform + epilogue.  This lane: tile tl of the block, i.e. output pixels (2 * (tl >> 4) + dy, 2 * (tl & 15) + dx);
+    // accumulator register r: output channel 32 * cotile + (r & 3) + 8 * (r >> 2) + 4 * bgrp.
+    const bool partial = a.partial != 0, has_bias = a.bias != nullptr, has_res = a.residual != nullptr, has_next = a.next_scale != nullptr;
+    const int tl = tb * 32 + bcol;
+    const int py = (tl >> 4) * 2, px = (tl & 15) * 2;
+    const int cout1 = a.Cout - 1;
+    const float mscale = a.mask_scale, winsize = a.winsize;
+    bool ok[4];
+    size_t pix[4];
+    float um[4], ratio[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int dy = q >> 1, dx = q & 1;
+        const int oy = y0 + py + dy, ox = x0 + px + dx;
+        ok[q] = (oy < a.H) & (ox < a.W);
+        pix[q] = ok[q] ? (size_t)oy * a.W + ox : 0;
+        um[q] = 1.0f; ratio[q] = 1.0f;
+        if (partial) {
+            float box = 0.0f;                            // conv(mask, ones): 3x3 box sum, zero padded (partialconv2d.py:61)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) box += mpl[(py + dy + i) * CV_HW + px + dx + j];
+            const float u = box * mscale;
+            um[q] = fminf(fmaxf(u, 0.0f), 1.0f);
+            ratio[q] = (1.0f / (u + 1e-8f)) * winsize * um[q];
+            if (ok[q] && a.um_out && blockIdx.y == 0 && cot == 0 && xh == 0 && bgrp == 0) a.um_out[(size_t)n * HW + pix[q]] = um[q];
+        }
+    }
+    const bool pair_ok = !a.out_b8 && (a.W % 2 == 0) && !(((uintptr_t)a.out | (uintptr_t)a.residual) & 7);     // 8-byte row pairs
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {                   // four channels at a time (one 16-byte group of the channel-blocked layout)
+        const int g4 = 2 * xh + gg;
+        float o[4][4];                                 // [channel of the group][pixel q]
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = g4 * 4 + rr, rl = gg * 4 + rr;           // accumulator row; its index among this wave's 8 rows
+            float m[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float own = acc[j][r], other = theirs[(j * 8 + rl) * 64 + lane];
+                m[8 * xh + j] = own;
+                m[8 * (1 - xh) + j] = other;
+            }
+            float t0[4], t1[4];                          // A^T m
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t0[j] = m[j] + m[4 + j] + m[8 + j]; t1[j] = m[4 + j] - m[8 + j] - m[12 + j]; }
+            o[rr][0] = t0[0] + t0[1] + t0[2]; o[rr][1] = t0[1] - t0[2] - t0[3];
+            o[rr][2] = t1[0] + t1[1] + t1[2]; o[rr][3] = t1[1] - t1[2] - t1[3];
+        }
+        int co[4];
+        float eb[4], esc[4], esh[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            co[rr] = cotile * 32 + rr + 8 * g4 + 4 * bgrp;
+            const int cc = min(co[rr], cout1);
+            eb[rr] = has_bias ? a.bias[cc] : 0.0f;
+            esc[rr] = has_next ? a.next_scale[cc] : 1.0f;
+            esh[rr] = has_next ? a.next_shift[cc] : 0.0f;
+        }
+        // residual (the last operation of both epilogues), in its own layout
+        float rv[4][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rv[rr][q] = 0.0f;
+        const int c8 = cotile * 4 + g4;                // 8-channel group of the blocked layouts
+        if (has_res) {
+            if (a.res_b8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = ok[q] && c8 * 8 + 4 * bgrp < a.Cout;
+                    const size_t bidx = (((size_t)n * (a.Cout >> 3) + (live ? c8 : 0)) * HW + pix[q]) * 8 + 4 * bgrp;
+                    const float4 v = *reinterpret_cast<const float4 *>(&a.residual[bidx]);
+                    rv[0][q] = v.x; rv[1][q] = v.y; rv[2][q] = v.z; rv[3][q] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[rr][q] = a.residual[((size_t)n * a.Cout + min(co[rr], cout1)) * HW + pix[q]];
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = o[rr][q];
+                if (partial) {
+                    v = (v * ratio[q] + eb[rr]) * um[q];                                         // partialconv2d.py:72-74
+                    v += rv[rr][q];                                                              // blocks.py:248
+                    if (has_next) v = fmaxf(v * esc[rr] - esh[rr], 0.0f) * um[q];                // blocks.py:233-236
+                } else {
+                    v += eb[rr];
+                    v += rv[rr][q];
+                }
+                o[rr][q] = v;
+            }
+        if (a.out_b8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool live = ok[q] && c8 * 8 + 4 * bgrp < a.Cout;
+                const size_t bidx = (((size_t)n * (a.Cout >> 3) + (live ? c8 : 0)) * HW + pix[q]) * 8 + 4 * bgrp;
+                if (live) *reinterpret_cast<float4 *>(&a.out[bidx]) = make_float4(o[0][q], o[1][q], o[2][q], o[3][q]);
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (co[rr] > cout1) continue;
+                float *op = a.out + ((size_t)n * a.Cout + co[rr]) * HW;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    if (pair_ok && ok[2 * dy] && ok[2 * dy + 1]) *reinterpret_cast<float2 *>(op + pix[2 * dy]) = make_float2(o[rr][2 * dy], o[rr][2 * dy + 1]);
+                    else {
+                        if (ok[2 * dy]) op[pix[2 * dy]] = o[rr][2 * dy];
+                        if (ok[2 * dy + 1]) op[pix[2 * dy + 1]] = o[rr][2 * dy + 1];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace slr

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import _lib
 
 
-IN_B8, OUT_B8, RES_B8, CONV_F32 = 1, 2, 4, 8      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32
+IN_B8, OUT_B8, RES_B8, CONV_F32, CONV_WINO = 1, 2, 4, 8, 16      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32 / SLR_CONV_WINO
 
 
 class _Route(threading.local):
@@ -42,6 +42,7 @@ class _Route(threading.local):
     torch_convs = False                  # inside torch_convolutions(): every stage through its torch definition (fp32)
     act_scale = 64.0                     # pre-scale of the activations in the split-f16 kernels (include/slr_splat.h: xscale)
     f32_kernels = False                  # inside fp32_kernels(): the convolutions on the fp32 matrix instructions (the fp32 rung)
+    winograd = True                      # ... its 3x3 convolutions as Winograd F(2x2, 3x3) (csrc/conv_wino.hpp); False: direct
 
 
 _S = _Route()
@@ -77,14 +78,22 @@ class fp32_kernels:
     the arithmetic of the reference's decoder (models/layers/partialconv2d.py:61-74, models/networks/architectures.py:345-375) with
     no limit on the magnitude of the activations, at the fp32 matrix rate (157 TFLOP/s against the ~830 effective of the split-f16
     rung); prologue, epilogue, mask update, layouts and every other kernel are the ones of the split-f16 rung.  The animators enter
-    it on request (convs="fp32") or by themselves when the split-f16 kernels report a clamped activation (convs="auto")."""
+    it on request (convs="fp32") or by themselves when the split-f16 kernels report a clamped activation (convs="auto").
+    winograd (default True): the 3x3 convolutions with more than 4 output channels as Winograd F(2x2, 3x3) on the same instructions
+    (csrc/conv_wino.hpp, SLR_CONV_WINO): 16 instead of 36 multiplications per 2x2 outputs, still fp32 operands / products /
+    accumulation; False: the direct implicit GEMM."""
+
+    def __init__(self, winograd=True):
+        self.winograd = bool(winograd)
 
     def __enter__(self):
         self._prev, _S.f32_kernels = _S.f32_kernels, True
+        self._prev_w, _S.winograd = _S.winograd, self.winograd
         return self
 
     def __exit__(self, *exc):
         _S.f32_kernels = self._prev
+        _S.winograd = self._prev_w
         return False
 
 
@@ -232,15 +241,19 @@ class Conv(nn.Module):
         (inside fp32_kernels()): the fp32 values themselves, no scales."""
         w = self.weight
         f32 = _S.f32_kernels
+        wino = f32 and _S.winograd and self.k == 3 and w.shape[0] > 4
         key = (w.data_ptr(), w._version, w.device)
-        name = "_wf32" if f32 else "_wsplit"
+        name = "_wwino" if wino else "_wf32" if f32 else "_wsplit"
         c = self.__dict__.get(name)
         if c is None or c[0] != key:
             L = _lib.lib()
-            nbytes = L.slr_conv3x3_weight_bytes if self.k == 3 else L.slr_conv1x1_weight_bytes
+            nbytes = L.slr_conv3x3_wino_weight_bytes if wino else L.slr_conv3x3_weight_bytes if self.k == 3 else L.slr_conv1x1_weight_bytes
             buf = torch.empty(nbytes(w.shape[0], w.shape[1]), dtype=torch.uint8, device=w.device)
             with torch.cuda.device(w.device):
-                if f32:
+                if wino:
+                    wscale = 1.0
+                    _lib.check(L.slr_conv3x3_wino_weights(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], _lib.stream_of(w)), "slr_conv3x3_wino_weights")
+                elif f32:
                     prep = L.slr_conv3x3_f32_weights if self.k == 3 else L.slr_conv1x1_f32_weights
                     wscale = 1.0
                     _lib.check(prep(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], _lib.stream_of(w)), "slr_conv_f32_weights")
@@ -251,7 +264,7 @@ class Conv(nn.Module):
                     _lib.check(split(_lib.ptr(w), _lib.ptr(buf), w.shape[0], w.shape[1], wscale, _lib.stream_of(w)),
                                "slr_conv_split_weights")
             c = self.__dict__[name] = (key, buf, wscale)
-        return (c[1], 1.0, 1.0, CONV_F32) if f32 else (c[1], c[2], _S.act_scale, 0)
+        return (c[1], 1.0, 1.0, CONV_F32 | (CONV_WINO if wino else 0)) if f32 else (c[1], c[2], _S.act_scale, 0)
 
     def conv(self, x, bias, pre_bn=None, residual=None, layout=0):
         """conv(relu(bn(x))) + bias + residual (``pre_bn`` = (scale, shift) of the BN in front, or None).

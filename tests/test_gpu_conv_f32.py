@@ -34,7 +34,7 @@ def test_conv3x3_fp32_rung_vs_fp64(S, cin, cout, h, w, bias):
         conv.bias.data.normal_()
     x = torch.randn(2, cin, h, w, device="cuda") * 3
     sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda")
-    with torch.no_grad(), nets.fp32_kernels():
+    with torch.no_grad(), nets.fp32_kernels(winograd=False):
         y = conv(x)
         ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
         yb = conv(x, (sc, sh))
@@ -49,6 +49,41 @@ def test_conv3x3_fp32_rung_vs_fp64(S, cin, cout, h, w, bias):
     with torch.no_grad():
         ys = conv(x)
     assert (ys - y).abs().max().item() < 8e-6 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,bias", [(16, 64, 9, 33, False), (32, 128, 19, 45, True), (64, 64, 64, 96, False),
+                                               (48, 192, 8, 32, True), (16, 64, 1, 1, True), (3, 32, 17, 40, True),
+                                               (20, 70, 11, 35, False), (128, 128, 40, 64, True), (256, 256, 16, 32, False),
+                                               (65, 8, 13, 31, True)])
+def test_conv3x3_winograd_fp32_vs_fp64(S, cin, cout, h, w, bias):
+    """slr_conv3x3_forward with SLR_CONV_F32 | SLR_CONV_WINO (Winograd F(2x2, 3x3) on the fp32 matrix instructions, csrc/conv_wino.hpp)
+    vs an fp64 convolution: ragged sizes (odd widths and heights: tiles cut by the image edge), padded channel counts, bias, BN + ReLU
+    prologue, residual, batch of 2, NCHW and channel-blocked activations.  Tolerance: 2e-5 of the output range (the transform domain
+    amplifies fp32 rounding by a small factor: the direct fp32 rung meets 4e-6 on the same cases); and against the direct rung itself."""
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin + h)
+    conv = nets.Conv(cin, cout, 3, bias=bias).cuda()
+    if bias:
+        conv.bias.data.normal_()
+    x = torch.randn(2, cin, h, w, device="cuda") * 3
+    sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda")
+    with torch.no_grad(), nets.fp32_kernels():
+        y = conv(x)
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
+        yb = conv(x, (sc, sh))
+        xb = F.relu(x * sc.view(1, -1, 1, 1) - sh.view(1, -1, 1, 1))
+        refb = F.conv2d(xb.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
+        res = torch.randn_like(y)
+        yr, refr = conv(x, None, res), ref + res.double()
+    assert conv.__dict__.get("_wwino") is not None and conv.__dict__.get("_wf32") is None and conv.__dict__.get("_wsplit") is None
+    errs = []
+    for got, want in ((y, ref), (yb, refb), (yr, refr)):
+        errs.append((got - want).abs().max().item() / max(want.abs().max().item(), 1.0))
+        assert errs[-1] < 2e-5, errs
+    with torch.no_grad(), nets.fp32_kernels(winograd=False):
+        yd = conv(x)
+    assert (yd - y).abs().max().item() < 2e-5 * max(ref.abs().max().item(), 1.0)
+    print(f"winograd {cin}->{cout} {h}x{w}: max err / range vs fp64 {max(errs):.2e}")
 
 
 @pytest.mark.parametrize("cin,cout,h,w,bias", [(64, 128, 16, 40, False), (128, 256, 9, 33, True), (3, 32, 7, 19, True),
@@ -105,13 +140,13 @@ def test_fp32_rung_has_no_magnitude_limit_and_needs_unit_scales(S):
     conv = nets.Conv(64, 128, 3).cuda()
     x = torch.randn(1, 64, 24, 40, device="cuda") * 1.0e6
     nets.saturation_count(x.device)
-    with torch.no_grad(), nets.fp32_kernels():
+    with torch.no_grad(), nets.fp32_kernels(winograd=False):
         y = conv(x)
     ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
     assert nets.saturation_count(x.device) == 0
     assert (y - ref).abs().max().item() < 4e-6 * ref.abs().max().item()
     L = _lib.lib()
-    with nets.fp32_kernels():
+    with nets.fp32_kernels(winograd=False):
         buf = conv._split_weights()[0]
     out = torch.empty_like(y)
     rc = L.slr_conv3x3_forward(_lib.ptr(x), _lib.ptr(buf), None, None, _lib.ptr(out), 1, 64, 128, 24, 40, 2.0, 64.0, None, None,

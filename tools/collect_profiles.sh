@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/rN_* is made from, in one run on the GPU box (from the repo root):
-#   tools/collect_profiles.sh gpurun_out/r4final
+#   tools/collect_profiles.sh gpurun_out/r5final
 # bench lines, rocprofv3 kernel traces (per-kernel summaries via tools/trace_csv_stats.py), PMC passes (SQ / TCC counters, FETCH_SIZE and
 # WRITE_SIZE in separate runs, kernel-trace only) for the fused clip kernel (C3 and C4), the one-flow operator (rows at 768x1280, scan at
 # config C2) and the backward kernel, stand-alone kernel benches.
