@@ -79,6 +79,10 @@ struct ConvArgs {
     int out_b8;            // output in the channel-blocked layout [N, Cout/8, H, W, 8] (Cout % 8 == 0)
     int res_b8;            // ... and the residual as well (only together with out_b8)
     unsigned *sat;         // device counter: incremented by every wave that had to saturate an activation (see stage_value)
+#ifdef SLR_TRACE
+    long long *trace;      // development builds: 16 time stamps per workgroup of the Winograd kernel (tools/dev/trace_wino.py)
+#endif
+    int wino_groups;       // Winograd kernel (conv_wino.hpp): groups of 64 output channels (its grid.x carries blocks x groups)
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -788,6 +792,9 @@ static int sat_counter(unsigned **p) {
 }
 
 }  // namespace slr
+#ifdef SLR_TRACE
+namespace slr { extern long long *g_trace; }       // slr_debug_trace (splat_op.hip)
+#endif
 #include "conv_wino.hpp"
 
 using namespace slr;
@@ -970,10 +977,15 @@ static int conv_wino_launch(ConvArgs &a, bool in_b8, hipStream_t st) {
         SLR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES));
         if (dev >= 0 && dev < 64) attr_set[dev][which] = true;
     }
-    a.tiles_x = (a.W + CV_W - 1) / CV_W;
+    a.tiles_x = (a.W + WN_BW - 1) / WN_BW;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.xscale = 1.0f; a.unscale = 1.0f;
-    const dim3 grid(a.tiles_x * ((a.H + CV_H - 1) / CV_H), wino_cout_pad(a.Cout) / 64, a.N);
+    const int blocks = a.tiles_x * ((a.H + WN_BH - 1) / WN_BH), ngrp = wino_cout_pad(a.Cout) / 64;
+    const dim3 grid((blocks + 7) / 8 * 8 * ngrp, 1, a.N);
+    a.wino_groups = ngrp;
+#ifdef SLR_TRACE
+    a.trace = g_trace;
+#endif
     if (which == 3) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
     else if (which == 2) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
     else if (which == 1) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true>), grid, dim3(WN_THREADS), WN_LDS_BYTES, st, a);
@@ -986,6 +998,7 @@ static int conv_launch(ConvArgs &a, float wscale, float xscale, bool in_b8, bool
     if (int e = check_xscale(xscale)) return e;
     SLR_CHECK_ARG(!f32 || (wscale == 1.0f && xscale == 1.0f), "the fp32 rung takes no operand scales (wscale = xscale = 1)");
     SLR_CHECK_ARG(!wino || (f32 && a.Cout > CF_MAXCO), "SLR_CONV_WINO goes with SLR_CONV_F32 and more than 4 output channels");
+    SLR_CHECK_ARG(!wino || a.pre == PRE_NONE || a.Cin <= WN_MAXCIN, "SLR_CONV_WINO with a prologue supports Cin <= 256");
     if (wino) return conv_wino_launch(a, in_b8, st);
     if (a.Cout <= CF_MAXCO) {                           // fp32 FMAs on the vector ALUs on either rung: no operand scales, nothing saturates
         switch (a.Cout) {

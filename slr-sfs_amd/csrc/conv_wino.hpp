@@ -6,8 +6,8 @@
 // (input channel, output channel) instead of 36:  Y = A^T [ (G g G^T) .* (B^T d B) ] A, summed over the input channels BEFORE the
 // output transform -- i.e. 16 independent GEMMs (one per position xi of the 4x4 transformed tile) of [couts x cins] x [cins x tiles].
 //
-// One workgroup (256 work-items = 4 waves, ONE per CU: 156 KiB of LDS, 256 accumulator registers per wave) = the same 8 x 32 output
-// block as the direct kernel (64 tiles of 2x2) x 64 output channels:
+// One workgroup (256 work-items = 4 waves, TWO per CU: 79 KiB of LDS, 128 accumulator registers per wave) = an 8 x 16 output block
+// (32 tiles of 2x2) x 64 output channels:
 //   * staging: the (8+2) x (32+2) halo block of 16 input channels, through the same prologue as the direct kernel
 //     (relu(x*scale - shift)*mask, zero padding), as fp32 rows in LDS (`raw`, single buffer);
 //   * input transform: every work-item turns 4 patches (4 channels of one tile) into V[xi][cin][tile] (32 additions per patch),
@@ -20,18 +20,23 @@
 // 2.25x fewer MFMAs than the direct kernel per output; the transforms are additions only (exact up to fp32 rounding; the error of
 // F(2x2, 3x3) in fp32 is within a small factor of the direct fp32 convolution's -- tests/test_gpu_conv_f32.py measures both against fp64).
 #pragma once
+#include <type_traits>
 
 namespace slr {
 
-constexpr int WN_RAWSTR = 344;                       // floats per channel row of the staged halo block (340 used)
-constexpr int WN_TILES = 64;                         // 2x2 output tiles of the 8 x 32 block: 4 tile rows x 16 tile columns
+constexpr int WN_BW = 16, WN_BH = 8;                 // output block of a workgroup: 8 rows x 16 columns = 32 tiles of 2x2 (4 tile rows x 8 tile columns)
+constexpr int WN_HW = WN_BW + 2, WN_HH = WN_BH + 2;  // its input halo block
+constexpr int WN_NPX = WN_HW * WN_HH;                // 180 halo pixels
+constexpr int WN_RAWSTR = 184;                       // floats per channel row of the staged halo block (180 used)
+constexpr int WN_TILES = 32;
+constexpr int WN_MAXCIN = 256;                       // prologue scale / shift table (wider layers take the direct kernel)
 constexpr size_t WN_OFF_RAW = 0;
-constexpr size_t WN_OFF_V = WN_OFF_RAW + (size_t)16 * WN_RAWSTR * 4;                       // [2][16 xi][16 cin][64 tiles]
+constexpr size_t WN_OFF_V = WN_OFF_RAW + (size_t)16 * WN_RAWSTR * 4;                       // [2][16 xi][16 cin][32 tiles]
 constexpr size_t WN_OFF_MPL = WN_OFF_V + (size_t)2 * 16 * 16 * WN_TILES * 4;
-constexpr size_t WN_OFF_MPLB = WN_OFF_MPL + (size_t)CV_NPX * 4;
-constexpr size_t WN_OFF_PSS = (WN_OFF_MPLB + (size_t)2 * (CV_NPX - 256) * 4 + 15) & ~(size_t)15;
-constexpr size_t WN_LDS_BYTES = WN_OFF_PSS + (size_t)2 * CV_MAXCIN * 4;
-static_assert(WN_LDS_BYTES <= 160 * 1024, "one workgroup per CU: everything fits the 160 KiB of LDS");
+constexpr size_t WN_OFF_PSS = (WN_OFF_MPL + (size_t)WN_NPX * 4 + 15) & ~(size_t)15;
+constexpr size_t WN_OFF_EPI = WN_OFF_PSS + (size_t)2 * WN_MAXCIN * 4;                       // bias | next scale | next shift of the 64 output channels
+constexpr size_t WN_LDS_BYTES = WN_OFF_EPI + (size_t)3 * 64 * 4;
+static_assert(2 * WN_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
 __host__ __device__ inline int wino_cout_pad(int Cout) { return (Cout + 63) / 64 * 64; }
 
@@ -68,7 +73,17 @@ __global__ __launch_bounds__(256) void conv_wino_weights_kernel(const float *__r
     }
 }
 
-constexpr int WN_THREADS = 512;                      // 8 waves: two per SIMD (one workgroup per CU) -- a lone wave per SIMD idles the matrix pipe at every wait
+#ifndef WN_EXP
+#define WN_EXP 0          // deletion experiments (timing only, wrong results): 1 no transform in the loop, 2 no staging in the loop, 4 no weight loads in the
+#endif                   // loop, 8 no B reads, 16 no epilogue
+constexpr int WN_THREADS = 256;                      // 4 waves; two INDEPENDENT workgroups per CU (one wave of each per SIMD): while one stands at a
+                                                     // barrier or stores its staged block the other keeps the matrix pipe busy (8 coupled waves: 1604 us)
+
+#ifdef SLR_TRACE
+#define WN_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + (slot)] = clock64(); } while (0)
+#else
+#define WN_STAMP(slot) do { } while (0)
+#endif
 
 template <bool PRE, bool INB8>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a) {
@@ -77,14 +92,30 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     float (*V)[16][16][WN_TILES] = reinterpret_cast<float (*)[16][16][WN_TILES]>(wn_smem + WN_OFF_V);            // [buf][xi][cin][tile]
     float *mpl = reinterpret_cast<float *>(wn_smem + WN_OFF_MPL);                                                // mask plane over the halo block
     float *pss = reinterpret_cast<float *>(wn_smem + WN_OFF_PSS);                                                // prologue scale | shift
+    float *epi = reinterpret_cast<float *>(wn_smem + WN_OFF_EPI);                                                // epilogue bias | scale | shift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // this wave: output channels 32 * cot .. + 31 of the workgroup's 64, tiles 32 * tb .. + 31, positions 8 * xh .. + 7
-    const int cot = wave & 1, tb = (wave >> 1) & 1, xh = wave >> 2;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    const int x0 = tx * CV_W, y0 = ty * CV_H;
+    // this wave: output channels 32 * cot .. + 31 of the workgroup's 64, all 32 tiles, positions 8 * xh .. + 7
+    const int cot = wave & 1, xh = wave >> 1;
+    constexpr int tb = 0;
+    // grid.x = output blocks x groups of 64 output channels, the groups of one block 8 workgroups apart: dispatched together and (block b
+    // runs on XCD b % 8, observed) on the SAME XCD -- the second group's staging loads find the block's input in that L2 instead of in HBM
+    // (their latency also sits in front of every weight load issued behind them: memory returns in order)
+    const int ngrp = a.wino_groups;                      // groups of 64 output channels
+    const int bsl = blockIdx.x / (8 * ngrp), brem = blockIdx.x - bsl * 8 * ngrp;
+    const int blk = bsl * 8 + (brem & 7), cgrp = brem >> 3;
+    if (blk >= a.tiles_x * ((a.H + WN_BH - 1) / WN_BH)) return;       // (the last slice of 8 blocks may be short; whole workgroups)
+#ifdef WN_STAGGER
+    // the two workgroups of a CU start together and take equally long: without this they run their prologues, chunk loops and epilogues
+    // in lock-step and the matrix pipe idles through both epilogues
+    if (blockIdx.x >= 256 && blockIdx.x < 512 && blockIdx.z == 0)
+        for (int i = 0; i < WN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    WN_STAMP(0);
+    const int tx = blk % a.tiles_x, ty = blk / a.tiles_x;
+    const int x0 = tx * WN_BW, y0 = ty * WN_BH;
     const int n = blockIdx.z;
-    const int cotile = blockIdx.y * 2 + cot;             // 32-channel tile of the weight buffer
+    const int cotile = cgrp * 2 + cot;                   // 32-channel tile of the weight buffer
     const int HW = a.H * a.W;
     const int nchunk = a.nchunk;
     const int cmax = a.Cin - 1;
@@ -94,31 +125,39 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     if (PRE) {
         for (int i = tid; i < nchunk * 16; i += WN_THREADS) {       // padded channels: scale = shift = 0 -> 0
             pss[i] = i < a.Cin ? a.pre_scale[i] : 0.0f;
-            pss[CV_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] : 0.0f;
+            pss[WN_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] : 0.0f;
         }
     }
-    // ---- staging of a chunk: 680 items = 340 halo pixels x 2 groups of 8 channels; item A = tid (all work-items), item B = 512 + tid
-    // (work-items < 168).  Same prologue as the direct kernel (conv.hip: stage_value).
-    const bool liveB = tid < 168;
-    const int gA = tid >= CV_NPX ? 1 : 0, pA = tid - CV_NPX * gA;      // group / halo pixel of item A
-    const int pB = 172 + tid;                                          // item B: group 1, pixels 172 .. 339
+    if (tid < 64) {                                    // the epilogue's per-channel constants: read from LDS there, no global round trip between
+        const int cc = min(cgrp * 64 + tid, a.Cout - 1);          // the exchange and the stores
+        epi[tid] = a.bias ? a.bias[cc] : 0.0f;
+        epi[64 + tid] = a.next_scale ? a.next_scale[cc] : 1.0f;
+        epi[128 + tid] = a.next_scale ? a.next_shift[cc] : 0.0f;
+    }
+    // ---- staging of a chunk: 360 items = 180 halo pixels x 2 groups of 8 channels; item A = tid (all work-items), item B = 256 + tid
+    // (work-items < 104).  Same prologue as the direct kernel (conv.hip: stage_value).
+    const bool liveB = tid < 2 * WN_NPX - WN_THREADS;
+    const int gA = tid >= WN_NPX ? 1 : 0, pA = tid - WN_NPX * gA;      // group / halo pixel of item A
+    const int pB = WN_THREADS - WN_NPX + tid;                          // item B: group 1, pixels 76 .. 179
     bool okA, okB;
     int offA, offB;
     {
-        const int pr = pA / CV_HW, pc = pA - pr * CV_HW;
+        const int pr = pA / WN_HW, pc = pA - pr * WN_HW;
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         okA = (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
         offA = okA ? gy * a.W + gx : 0;
+        if (WN_EXP & 128) offA = okA ? (pr + 1) * a.W + pc + 1 : 0;
     }
     {
-        const int pq = liveB ? pB : 0, pr = pq / CV_HW, pc = pq - pr * CV_HW;
+        const int pq = liveB ? pB : 0, pr = pq / WN_HW, pc = pq - pr * WN_HW;
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         okB = liveB & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
         offB = okB ? gy * a.W + gx : 0;
+        if (WN_EXP & 128) offB = okB ? (pr + 1) * a.W + pc + 1 : 0;
     }
     const float mvA = (a.mask && okA) ? a.mask[(size_t)n * HW + offA] : 0.0f;
     const float mvB = (a.mask && okB) ? a.mask[(size_t)n * HW + offB] : 0.0f;
-    if (a.mask && tid < CV_NPX) mpl[tid] = mvA;        // (items A of group 0 cover every halo pixel)
+    if (a.mask && tid < WN_NPX) mpl[tid] = mvA;        // (items A of group 0 cover every halo pixel)
     const float mA = okA ? (pre == PRE_BN_MASK ? mvA : 1.0f) : 0.0f;
     const float mB = okB ? (pre == PRE_BN_MASK ? mvB : 1.0f) : 0.0f;
     float cntA = 0.0f, cntB = 0.0f;                    // derived mask: non-zero inputs per staging item, over all chunks
@@ -137,40 +176,43 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) st[j] = inb[(size_t)min(c * 16 + g * 8 + j, cmax) * HW + (unsigned)off];
     };
-    auto store_item = [&](bool isB, int c, const float (&st)[8]) {
-        const int g = isB ? 1 : gA, px = isB ? pB : pA;
+    // (no branch around a piece: dead work-items of item B write the row's 4 padding floats, pieces past the last chunk re-stage the last
+    // chunk from stale registers into the buffer nobody reads -- 16 branches per chunk between the MFMAs cost 0.5 us of its 4.6)
+    const int pBst = liveB ? pB : WN_NPX + (tid & 3);
+    auto store_piece = [&](bool isB, int c, const float (&st)[8], int j, float counted = 1.0f) {       // channel j of the item's 8
+        const int g = isB ? 1 : gA, px = isB ? pBst : pA;
         const int cb = c * 16 + g * 8;
         const float mk0 = isB ? mB : mA;
-        float count = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = st[j];
-            float v;
-            if (PRE) {
-                const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : mk0;
-                v = fmaxf(x * pss[cb + j] - pss[CV_MAXCIN + cb + j], 0.0f) * mk;
-                count += (cb + j <= cmax) ? mk : 0.0f;
-            } else {
-                v = (cb + j <= cmax) ? x * mk0 : 0.0f;   // (padded channels meet zero weights; keep them finite and zero)
-            }
-            if (!isB || liveB) raw[g * 8 + j][px] = v;
+        const float x = st[j];
+        float v;
+        if (PRE) {
+            const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : mk0;
+            v = fmaxf(x * pss[cb + j] - pss[WN_MAXCIN + cb + j], 0.0f) * mk;
+            const float count = (cb + j <= cmax) ? mk * counted : 0.0f;
+            if (isB) cntB += count; else cntA += count;
+        } else {
+            v = (cb + j <= cmax) ? x * mk0 : 0.0f;       // (padded channels meet zero weights; keep them finite and zero)
         }
-        if (isB) cntB += count; else cntA += count;
+        raw[g * 8 + j][px] = v;
+    };
+    auto store_item = [&](bool isB, int c, const float (&st)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) store_piece(isB, c, st, j);
     };
 
-    // ---- input transform: work-item -> tile tid & 63, channels 2 * (tid >> 6), + 1 of the chunk
-    const int tt = tid & 63, tcg = tid >> 6;
-    const int tpy = (tt >> 4) * 2, tpx = (tt & 15) * 2;  // the patch's first halo row / column
+    // ---- input transform: work-item -> tile tid & 31, channels 2 * (tid >> 5), + 1 of the chunk
+    const int tt = tid & 31, tcg = tid >> 5;
+    const int tpy = (tt >> 3) * 2, tpx = (tt & 7) * 2;   // the patch's first halo row / column
     // A patch's transform in 7 slices, issued between the MFMA groups (a slice of <= 16 instructions issues in the shadow of the matrix
     // pipe): 0 patch loads, 1-2 B^T d, 3-6 one output row each.
     struct PatchRegs { float d[4][4], t[4][4]; };
     auto transform_slice = [&](int slice, int vb, int k, PatchRegs &pr) {
         const int ch = tcg * 2 + k;
         if (slice == 0) {
-            const float *rp = &raw[ch][tpy * CV_HW + tpx];
+            const float *rp = &raw[ch][tpy * WN_HW + tpx];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float2 lo = *reinterpret_cast<const float2 *>(rp + i * CV_HW), hi = *reinterpret_cast<const float2 *>(rp + i * CV_HW + 2);
+                const float2 lo = *reinterpret_cast<const float2 *>(rp + i * WN_HW), hi = *reinterpret_cast<const float2 *>(rp + i * WN_HW + 2);
                 pr.d[i][0] = lo.x; pr.d[i][1] = lo.y; pr.d[i][2] = hi.x; pr.d[i][3] = hi.y;
             }
         } else if (slice == 1 || slice == 2) {           // B^T d, two columns per slice
@@ -214,7 +256,17 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
 #pragma unroll
             for (int sl = 0; sl < 7; ++sl) transform_slice(sl, 0, k, pr);
     }
+    __syncthreads();                                   // V[0] complete, raw read
+    if (nchunk > 1) {                                  // raw <- chunk 1: the loop's invariant (raw holds chunk c + 1 when chunk c begins)
+        store_item(false, 1, sA);
+        store_item(true, 1, sB);
+    }
+    if (nchunk > 2) {
+        load_item(false, 2, sA);
+        load_item(true, 2, sB);
+    }
     __syncthreads();
+    WN_STAMP(1);
 
     const int bcol = lane & 31, bgrp = lane >> 5;
     typedef float f8v __attribute__((ext_vector_type(8)));
@@ -234,37 +286,52 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     auto frag = [&](int c, int j) { return min(c * 16 + j, nlast); };
     f8v aq[2], an[2];
     aq[0] = load_a(frag(0, 0)); aq[1] = load_a(frag(0, 1));
+    // A chunk's 32 slots (pair p, k-pair kp: slot 8p + kp), two MFMAs each.  In their shadow:
+    //   slots 0-6   patch 0 of chunk c + 1: raw -> V[other buffer]      slots 8-14  patch 1 (raw is read in slots 0 and 8 only)
+    //   slot 9      barrier: raw is free
+    //   slots 15-22 raw <- chunk c + 2 (prologue applied), one of the 8 channels of both staging items per slot
+    //   slot 24     the loads of chunk c + 3 are issued, BEHIND pair 3's weight loads: memory returns in order, so they have until the end of
+    //               the next chunk's pair 0 (two pairs), and nothing waits for them before
+    // No phase in which the matrix pipe waits for the staging (stores between two barriers at the top of the chunk: 1543 us -> see DESIGN).
     for (int c = 0; c < nchunk; ++c) {
         const int vb = c & 1;
-        if (c + 1 < nchunk) {                          // (uniform) raw <- chunk c + 1 (its loads were issued a whole chunk ago)
-            store_item(false, c + 1, sA);
-            store_item(true, c + 1, sB);
-        }
-        __syncthreads();
-        if (c + 2 < nchunk) {
-            load_item(false, c + 2, sA);
-            load_item(true, c + 2, sB);
-        }
+        const bool stage_ld = c + 3 < nchunk && !(WN_EXP & (2 | 32));          // (uniform)
+        const int cst = min(c + 2, nchunk - 1);
+        const float fst = c + 2 < nchunk ? 1.0f : 0.0f;                      // (the derived mask counts a chunk once)
+        // (64: the loads are issued and waited for, nothing is stored; 128: every workgroup loads the first block's pixels -- L2 hits)
         PatchRegs pr;                                  // (the last chunk transforms stale rows into the buffer nobody reads: no branch in the pairs)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             // next pair's fragments: p + 1 of this chunk, or pair 0 of the next chunk
+            if (WN_EXP & 4) { an[0] = aq[0]; an[1] = aq[1]; }
+            else {
             an[0] = load_a(p < 3 ? frag(c, 2 * p + 2) : frag(c + 1, 0));
             an[1] = load_a(p < 3 ? frag(c, 2 * p + 3) : frag(c + 1, 1));
+            }
+            if (p == 3 && stage_ld) {
+                load_item(false, c + 3, sA);
+                load_item(true, c + 3, sB);
+            }
             float b[2], bn[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) b[i] = V[vb][8 * xh + 2 * p + i][bgrp][tb * 32 + bcol];
+            for (int i = 0; i < 2; ++i) b[i] = (WN_EXP & 8) ? (float)(lane + i) : V[vb][8 * xh + 2 * p + i][bgrp][tb * 32 + bcol];
             __builtin_amdgcn_sched_barrier(0);         // the next pair's weights are in flight from HERE
 #pragma unroll
             for (int kp = 0; kp < 8; ++kp) {
+                const int slot = p * 8 + kp;
+                if (slot == 9) __syncthreads();
                 if (kp < 7) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bn[i] = V[vb][8 * xh + 2 * p + i][2 * (kp + 1) + bgrp][tb * 32 + bcol];
+                    for (int i = 0; i < 2; ++i) bn[i] = (WN_EXP & 8) ? b[i] + 1.0f : V[vb][8 * xh + 2 * p + i][2 * (kp + 1) + bgrp][tb * 32 + bcol];
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[2 * p + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][kp], b[i], acc[2 * p + i], 0, 0, 0);
-                const int slot = p * 8 + kp;           // 32 slots per chunk: patch 0 in slots 0-6, patch 1 in 16-22
-                if ((slot & 15) < 7) transform_slice(slot & 15, vb ^ 1, slot >> 4, pr);
+                if (slot < 15 && (slot & 7) < 7 && !(WN_EXP & 1)) transform_slice(slot & 7, vb ^ 1, slot >> 3, pr);
+                if ((WN_EXP & 64) && slot >= 15 && slot < 23 && c + 2 < nchunk) asm volatile("" :: "v"(sA[slot - 15]), "v"(sB[slot - 15]));
+                if (slot >= 15 && slot < 23 && !(WN_EXP & (2 | 64))) {
+                    store_piece(false, cst, sA, slot - 15, fst);
+                    store_piece(true, cst, sB, slot - 15, fst);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) b[i] = bn[i];
@@ -272,33 +339,26 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
             aq[0] = an[0]; aq[1] = an[1];
         }
         __syncthreads();
+        if (c < 8) WN_STAMP(2 + c);
     }
 
     if (pre == PRE_BN_NONZERO) {                       // mask plane = channel sum of (x != 0) over both channel groups of a pixel
-        float *c0 = &raw[0][0], *c1 = c0 + CV_NPX;     // (raw is free: the last transform has been read)
+        float *c0 = &raw[0][0], *c1 = c0 + WN_NPX;     // (raw is free: the last transform has been read)
         (gA ? c1 : c0)[pA] = cntA;
         if (liveB) c1[pB] = cntB;
         __syncthreads();
-        if (tid < CV_NPX) mpl[tid] = c0[tid] + c1[tid];
+        if (tid < WN_NPX) mpl[tid] = c0[tid] + c1[tid];
+        __syncthreads();
     }
-    // ---- the two halves of the positions meet: a wave finishes the output channels (accumulator rows) 8 * xh .. + 7 of its tile and hands
-    // the other 8 rows of its 8 positions to its partner (same cot, tb) through the V area (16 KiB per wave, all of V)
-    float *xch = reinterpret_cast<float *>(wn_smem + WN_OFF_V);
-    {
-        float *mine = xch + (size_t)wave * 64 * 64;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) mine[(j * 8 + rr) * 64 + lane] = acc[j][8 * (1 - xh) + rr];
-    }
-    __syncthreads();
-    const float *theirs = xch + (size_t)(wave ^ 4) * 64 * 64;
+    if ((WN_EXP & 16) && a.H > 0) { if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4] + acc[5][5] + acc[6][6] + acc[7][7] == 1.2345f) a.out[0] = 0.0f; return; }
 
-    // ---- output transform + epilogue.  This lane: tile tl of the block, i.e. output pixels (2 * (tl >> 4) + dy, 2 * (tl & 15) + dx);
-    // accumulator register r: output channel 32 * cotile + (r & 3) + 8 * (r >> 2) + 4 * bgrp.
-    const bool partial = a.partial != 0, has_bias = a.bias != nullptr, has_res = a.residual != nullptr, has_next = a.next_scale != nullptr;
+    // ---- epilogue.  This lane: tile tl of the block, i.e. output pixels (2 * (tl >> 3) + dy, 2 * (tl & 7) + dx); accumulator register r:
+    // output channel 32 * cotile + (r & 3) + 8 * (r >> 2) + 4 * bgrp.  Everything that needs global memory (the residual) is requested
+    // BEFORE the exchange, the per-channel constants come from LDS: between the exchange and the stores there is arithmetic only
+    // (bias / residual loads inside the channel loop: two L2 round trips per workgroup, 6.6 us of its 46 -> DESIGN).
+    const bool partial = a.partial != 0, has_res = a.residual != nullptr, has_next = a.next_scale != nullptr;
     const int tl = tb * 32 + bcol;
-    const int py = (tl >> 4) * 2, px = (tl & 15) * 2;
+    const int py = (tl >> 3) * 2, px = (tl & 7) * 2;
     const int cout1 = a.Cout - 1;
     const float mscale = a.mask_scale, winsize = a.winsize;
     bool ok[4];
@@ -316,17 +376,66 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) box += mpl[(py + dy + i) * CV_HW + px + dx + j];
+                for (int j = 0; j < 3; ++j) box += mpl[(py + dy + i) * WN_HW + px + dx + j];
             const float u = box * mscale;
             um[q] = fminf(fmaxf(u, 0.0f), 1.0f);
             ratio[q] = (1.0f / (u + 1e-8f)) * winsize * um[q];
-            if (ok[q] && a.um_out && blockIdx.y == 0 && cot == 0 && xh == 0 && bgrp == 0) a.um_out[(size_t)n * HW + pix[q]] = um[q];
+            if (ok[q] && a.um_out && cgrp == 0 && cot == 0 && xh == 0 && bgrp == 0) a.um_out[(size_t)n * HW + pix[q]] = um[q];
         }
     }
+    // residual (the last operation of both epilogues), in its own layout: [channel group gg][channel of the group][pixel q]
+    float rv[2][4][4];
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+        const int g4 = 2 * xh + gg, c8 = cotile * 4 + g4;           // 8-channel group of the blocked layouts
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rv[gg][rr][q] = 0.0f;
+        if (has_res) {
+            if (a.res_b8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = ok[q] && c8 * 8 + 4 * bgrp < a.Cout;
+                    const size_t bidx = (((size_t)n * (a.Cout >> 3) + (live ? c8 : 0)) * HW + pix[q]) * 8 + 4 * bgrp;
+                    const float4 v = *reinterpret_cast<const float4 *>(&a.residual[bidx]);
+                    rv[gg][0][q] = v.x; rv[gg][1][q] = v.y; rv[gg][2][q] = v.z; rv[gg][3][q] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rv[gg][rr][q] = a.residual[((size_t)n * a.Cout + min(cotile * 32 + rr + 8 * g4 + 4 * bgrp, cout1)) * HW + pix[q]];
+            }
+        }
+    }
+
+    // ---- the two halves of the positions meet: a wave finishes the output channels (accumulator rows) 8 * xh .. + 7 of its tile and hands
+    // the other 8 rows of its 8 positions to its partner (same cot) through the V area (16 KiB per wave, all of V)
+    float *xch = reinterpret_cast<float *>(wn_smem + WN_OFF_V);
+    // (xh is a run-time value: accumulator rows indexed with it go through the GPR index mode, one element per s_set_gpr_idx_on / v_mov /
+    // _off -- 192 of them, 6 us per workgroup.  Both halves are instantiated with xh as a constant and the wave branches once.)
+    auto hand_over = [&](auto half) {
+        constexpr int XH = decltype(half)::value;
+        float *mine = xch + (size_t)wave * 64 * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) mine[(j * 8 + rr) * 64 + lane] = acc[j][8 * (1 - XH) + rr];
+        if (XH) asm volatile("; hand_over, upper half"); else asm volatile("; hand_over, lower half");       // (keeps the two instantiations apart: merged, the
+    };                                                                                                     // row index is a select again)
+    if (xh == 0) hand_over(std::integral_constant<int, 0>()); else hand_over(std::integral_constant<int, 1>());
+    __syncthreads();
+    WN_STAMP(10);
+    const float *theirs = xch + (size_t)(wave ^ 2) * 64 * 64;
+
     const bool pair_ok = !a.out_b8 && (a.W % 2 == 0) && !(((uintptr_t)a.out | (uintptr_t)a.residual) & 7);     // 8-byte row pairs
+    auto finish = [&](auto half) {
+    constexpr int XH = decltype(half)::value;
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {                   // four channels at a time (one 16-byte group of the channel-blocked layout)
-        const int g4 = 2 * xh + gg;
+        const int g4 = 2 * XH + gg;
         float o[4][4];                                 // [channel of the group][pixel q]
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -335,8 +444,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float own = acc[j][r], other = theirs[(j * 8 + rl) * 64 + lane];
-                m[8 * xh + j] = own;
-                m[8 * (1 - xh) + j] = other;
+                m[8 * XH + j] = own;
+                m[8 * (1 - XH) + j] = other;
             }
             float t0[4], t1[4];                          // A^T m
 #pragma unroll
@@ -348,35 +457,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
         float eb[4], esc[4], esh[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            co[rr] = cotile * 32 + rr + 8 * g4 + 4 * bgrp;
-            const int cc = min(co[rr], cout1);
-            eb[rr] = has_bias ? a.bias[cc] : 0.0f;
-            esc[rr] = has_next ? a.next_scale[cc] : 1.0f;
-            esh[rr] = has_next ? a.next_shift[cc] : 0.0f;
+            const int cl = cot * 32 + rr + 8 * g4 + 4 * bgrp;      // channel among the workgroup's 64
+            co[rr] = cgrp * 64 + cl;
+            eb[rr] = epi[cl]; esc[rr] = epi[64 + cl]; esh[rr] = epi[128 + cl];
         }
-        // residual (the last operation of both epilogues), in its own layout
-        float rv[4][4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rv[rr][q] = 0.0f;
         const int c8 = cotile * 4 + g4;                // 8-channel group of the blocked layouts
-        if (has_res) {
-            if (a.res_b8) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool live = ok[q] && c8 * 8 + 4 * bgrp < a.Cout;
-                    const size_t bidx = (((size_t)n * (a.Cout >> 3) + (live ? c8 : 0)) * HW + pix[q]) * 8 + 4 * bgrp;
-                    const float4 v = *reinterpret_cast<const float4 *>(&a.residual[bidx]);
-                    rv[0][q] = v.x; rv[1][q] = v.y; rv[2][q] = v.z; rv[3][q] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rv[rr][q] = a.residual[((size_t)n * a.Cout + min(co[rr], cout1)) * HW + pix[q]];
-            }
-        }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -384,14 +469,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
                 float v = o[rr][q];
                 if (partial) {
                     v = (v * ratio[q] + eb[rr]) * um[q];                                         // partialconv2d.py:72-74
-                    v += rv[rr][q];                                                              // blocks.py:248
+                    v += rv[gg][rr][q];                                                          // blocks.py:248
                     if (has_next) v = fmaxf(v * esc[rr] - esh[rr], 0.0f) * um[q];                // blocks.py:233-236
                 } else {
                     v += eb[rr];
-                    v += rv[rr][q];
+                    v += rv[gg][rr][q];
                 }
                 o[rr][q] = v;
             }
+        if (gg == 0) WN_STAMP(14); else WN_STAMP(15);
         if (a.out_b8) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -415,6 +501,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
             }
         }
     }
+    };
+    if (xh == 0) finish(std::integral_constant<int, 0>()); else finish(std::integral_constant<int, 1>());
+    WN_STAMP(11);
+#ifdef SLR_TRACE
+    if (a.trace && threadIdx.x == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 12] = hw | ((long long)xcc << 32); }
+#endif
 }
 
 }  // namespace slr

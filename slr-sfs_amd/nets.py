@@ -241,7 +241,7 @@ class Conv(nn.Module):
         (inside fp32_kernels()): the fp32 values themselves, no scales."""
         w = self.weight
         f32 = _S.f32_kernels
-        wino = f32 and _S.winograd and self.k == 3 and w.shape[0] > 4
+        wino = f32 and _S.winograd and self.k == 3 and w.shape[0] > 4 and w.shape[1] <= 256     # (its prologue table holds 256 channels)
         key = (w.data_ptr(), w._version, w.device)
         name = "_wwino" if wino else "_wf32" if f32 else "_wsplit"
         c = self.__dict__.get(name)
