@@ -465,6 +465,14 @@ def context_measurements(workload, image, motion, dev):
         c32 = m3.synthesize(image, motion, NFRAMES)
         torch.cuda.synchronize()
         dt32 = time.perf_counter() - t1
+        m3.convs = "fp32-winograd"                                                 # the same rung with Winograd 3x3 layers
+        m3.synthesize(image, motion, NFRAMES)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cw = m3.synthesize(image, motion, NFRAMES)
+        torch.cuda.synchronize()
+        dt32w = time.perf_counter() - t1
+        dw = (cw - c32).abs()
         from slr_sfs_amd import nets as _nets
         m3.convs = "split"                                                         # (inside torch_convolutions() no kernel of ours runs: nothing to clamp)
         with _nets.torch_convolutions():                                           # the validation route, timed beside the product's fp32 rung
@@ -477,12 +485,19 @@ def context_measurements(workload, image, motion, dev):
         out["fps_fp32_convs"] = {"value": round(NFRAMES / dt32, 2), "unit": "frames/s",
                                  "what": "the same C3 clip (all 60 frames, one warm-up clip) with BaselineAnimator(convs='fp32'): every 3x3 / "
                                          "1x1 convolution of the encoder / decoder on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 products, "
-                                         "fp32 accumulation: the reference's arithmetic; csrc/conv.hip, SLR_CONV_F32), every other stage "
-                                         "and the splat path unchanged",
+                                         "fp32 accumulation, direct implicit GEMM: the reference's arithmetic; csrc/conv.hip, SLR_CONV_F32), "
+                                         "every other stage and the splat path unchanged",
+                                 "winograd": {"value": round(NFRAMES / dt32w, 2), "unit": "frames/s",
+                                              "what": "convs='fp32-winograd': the rung's 3x3 layers as Winograd F(2x2,3x3) on the same instructions "
+                                                      "(csrc/conv_wino.hpp): 16/36 of the products, fp32 throughout, 2-4x the direct kernel's rounding "
+                                                      "error per layer",
+                                              "frames_vs_direct_rung": {"mean_abs": float(dw.mean()), "max_abs": float(dw.max()),
+                                                                        "values_beyond_1e-4": int((dw > 1e-4).sum()), "values": dw.numel()}},
                                  "through_torch_miopen": {"value": round(20 / dtt, 2), "unit": "frames/s",
                                                           "what": "inside nets.torch_convolutions() (validation route; 20 of the 60 frames): F.conv2d -> MIOpen fp32, elementwise "
                                                                   "stages as torch ops"},
                                  "frames_fp32_kernels_vs_torch_max_abs": float((c32[::3] - ct).abs().max())}
+        del cw, dw
         del m3
     return out
 
@@ -671,14 +686,25 @@ def conv_roofline(dev, fp32=False):
     lay = nets.IN_B8 | nets.OUT_B8
     flops = 2.0 * 9 * cin * cout * H * W
     if fp32:                                             # the fp32 rung: same call, same layouts, products on v_mfma_f32_32x32x2_f32
-        with torch.no_grad(), nets.fp32_kernels():
+        with torch.no_grad(), nets.fp32_kernels(winograd=False):
+            avg_d, mn_d = _time_calls(lambda: pc(x, mask, next_bn=nb, pre_bn=(sc, sh), layout=lay), 15, warm=3)
+        with torch.no_grad(), nets.fp32_kernels(winograd=True):       # convs='fp32-winograd': 16 instead of 36 products per 2x2 outputs
             avg, mn = _time_calls(lambda: pc(x, mask, next_bn=nb, pre_bn=(sc, sh), layout=lay), 15, warm=3)
-        ach = flops / (avg * 1e-6) / 1e12
+        issued = flops * 16.0 / 36.0                     # what the matrix pipe executes in the Winograd kernel
+        ach_w = issued / (avg * 1e-6) / 1e12
+        ach_d = flops / (avg_d * 1e-6) / 1e12
         return {"bound": "mfma", "kernel": "slr::conv3x3_split_kernel<1,4,true,true,F32> (128->128, 768x1280, channel-blocked in/out, BN+mask "
-                                           "prologue, partial-conv epilogue + next BN) on v_mfma_f32_32x32x2_f32",
-                "achieved": round(ach, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-                "avg_us": round(avg, 1), "min_us": round(mn, 1), "launches": 15,
-                "precision": "fp32 operands, fp32 products, fp32 accumulation (one MFMA per product): the reference's arithmetic"}
+                                           "prologue, partial-conv epilogue + next BN) on v_mfma_f32_32x32x2_f32: the strict rung (convs='fp32')",
+                "achieved": round(ach_d, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach_d / 157.3, 4),
+                "avg_us": round(avg_d, 1), "min_us": round(mn_d, 1), "launches": 15,
+                "precision": "fp32 operands, fp32 products, fp32 accumulation (one MFMA per product): the reference's arithmetic",
+                "winograd": {"kernel": "slr::conv3x3_wino_kernel<true,true> (same layer; Winograd F(2x2,3x3) on the same instructions, "
+                                       "csrc/conv_wino.hpp: convs='fp32-winograd')",
+                             "achieved": round(ach_w, 1), "frac": round(ach_w / 157.3, 4),
+                             "achieved_is": "the flops the kernel ISSUES to the matrix pipe (16/36 of 2*9*Cin*Cout*H*W) per second",
+                             "direct_equivalent": round(flops / (avg * 1e-6) / 1e12, 1), "avg_us": round(avg, 1), "min_us": round(mn, 1),
+                             "precision": "fp32 operands, products, accumulation; transforms are fp32 additions; error per layer vs fp64 <= 1.1e-6 "
+                                          "of the output range (direct: 3e-7), tests/test_gpu_conv_f32.py"}}
     with torch.no_grad():
         avg, mn = _time_calls(lambda: pc(x, mask, next_bn=nb, pre_bn=(sc, sh), layout=lay), 30, warm=5)
     ach = flops / (avg * 1e-6) / 1e12

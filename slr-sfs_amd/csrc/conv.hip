@@ -981,7 +981,7 @@ static int conv_wino_launch(ConvArgs &a, bool in_b8, hipStream_t st) {
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.xscale = 1.0f; a.unscale = 1.0f;
     const int blocks = a.tiles_x * ((a.H + WN_BH - 1) / WN_BH), ngrp = wino_cout_pad(a.Cout) / 64;
-    const dim3 grid((blocks + 7) / 8 * 8 * ngrp, 1, a.N);
+    const dim3 grid((blocks + WN_SLICE - 1) / WN_SLICE * WN_SLICE * ngrp, 1, a.N);
     a.wino_groups = ngrp;
 #ifdef SLR_TRACE
     a.trace = g_trace;

@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void conv_wino_weights_kernel(const float *__r
 #ifndef WN_EXP
 #define WN_EXP 0          // deletion experiments (timing only, wrong results): 1 no transform in the loop, 2 no staging in the loop, 4 no weight loads in the
 #endif                   // loop, 8 no B reads, 16 no epilogue
+#ifndef WN_BDEPTH
+#define WN_BDEPTH 1      // slots the B operand reads run ahead of their MFMAs (2, 3: no change, 1269 - 1275 us at 128 -> 128)
+#endif
+#ifndef WN_SLICE
+#define WN_SLICE 8       // blocks per dispatch slice: the workgroups of a block's output-channel groups are WN_SLICE apart in dispatch order (32 .. 256: no change)
+#endif
 constexpr int WN_THREADS = 256;                      // 4 waves; two INDEPENDENT workgroups per CU (one wave of each per SIMD): while one stands at a
                                                      // barrier or stores its staged block the other keeps the matrix pipe busy (8 coupled waves: 1604 us)
 
@@ -102,8 +108,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     // runs on XCD b % 8, observed) on the SAME XCD -- the second group's staging loads find the block's input in that L2 instead of in HBM
     // (their latency also sits in front of every weight load issued behind them: memory returns in order)
     const int ngrp = a.wino_groups;                      // groups of 64 output channels
-    const int bsl = blockIdx.x / (8 * ngrp), brem = blockIdx.x - bsl * 8 * ngrp;
-    const int blk = bsl * 8 + (brem & 7), cgrp = brem >> 3;
+    const int bsl = blockIdx.x / (WN_SLICE * ngrp), brem = blockIdx.x - bsl * WN_SLICE * ngrp;
+    const int blk = bsl * WN_SLICE + (brem % WN_SLICE), cgrp = brem / WN_SLICE;
     if (blk >= a.tiles_x * ((a.H + WN_BH - 1) / WN_BH)) return;       // (the last slice of 8 blocks may be short; whole workgroups)
 #ifdef WN_STAGGER
     // the two workgroups of a CU start together and take equally long: without this they run their prologues, chunk loops and epilogues
@@ -122,18 +128,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     const float *inb = a.in + (size_t)n * a.Cin * HW;
     const int pre = a.pre;
 
-    if (PRE) {
-        for (int i = tid; i < nchunk * 16; i += WN_THREADS) {       // padded channels: scale = shift = 0 -> 0
-            pss[i] = i < a.Cin ? a.pre_scale[i] : 0.0f;
-            pss[WN_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] : 0.0f;
-        }
-    }
-    if (tid < 64) {                                    // the epilogue's per-channel constants: read from LDS there, no global round trip between
-        const int cc = min(cgrp * 64 + tid, a.Cout - 1);          // the exchange and the stores
-        epi[tid] = a.bias ? a.bias[cc] : 0.0f;
-        epi[64 + tid] = a.next_scale ? a.next_scale[cc] : 1.0f;
-        epi[128 + tid] = a.next_scale ? a.next_shift[cc] : 0.0f;
-    }
     // ---- staging of a chunk: 360 items = 180 halo pixels x 2 groups of 8 channels; item A = tid (all work-items), item B = 256 + tid
     // (work-items < 104).  Same prologue as the direct kernel (conv.hip: stage_value).
     const bool liveB = tid < 2 * WN_NPX - WN_THREADS;
@@ -157,7 +151,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     }
     const float mvA = (a.mask && okA) ? a.mask[(size_t)n * HW + offA] : 0.0f;
     const float mvB = (a.mask && okB) ? a.mask[(size_t)n * HW + offB] : 0.0f;
-    if (a.mask && tid < WN_NPX) mpl[tid] = mvA;        // (items A of group 0 cover every halo pixel)
     const float mA = okA ? (pre == PRE_BN_MASK ? mvA : 1.0f) : 0.0f;
     const float mB = okB ? (pre == PRE_BN_MASK ? mvB : 1.0f) : 0.0f;
     float cntA = 0.0f, cntB = 0.0f;                    // derived mask: non-zero inputs per staging item, over all chunks
@@ -238,36 +231,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
 
-    __syncthreads();                                   // pss
-    float sA[8], sB[8];
-    load_item(false, 0, sA);
-    load_item(true, 0, sB);
-    store_item(false, 0, sA);
-    store_item(true, 0, sB);
-    __syncthreads();
-    if (nchunk > 1) {                                  // the next chunk's loads fly under the first transform
-        load_item(false, 1, sA);
-        load_item(true, 1, sB);
-    }
-    {
-        PatchRegs pr;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int sl = 0; sl < 7; ++sl) transform_slice(sl, 0, k, pr);
-    }
-    __syncthreads();                                   // V[0] complete, raw read
-    if (nchunk > 1) {                                  // raw <- chunk 1: the loop's invariant (raw holds chunk c + 1 when chunk c begins)
-        store_item(false, 1, sA);
-        store_item(true, 1, sB);
-    }
-    if (nchunk > 2) {
-        load_item(false, 2, sA);
-        load_item(true, 2, sB);
-    }
-    __syncthreads();
-    WN_STAMP(1);
-
     const int bcol = lane & 31, bgrp = lane >> 5;
     typedef float f8v __attribute__((ext_vector_type(8)));
     const float4 *wbase = reinterpret_cast<const float4 *>(a.w) + ((size_t)cotile * nchunk * 16 + 8 * xh) * 128;       // 128 float4 per (chunk, xi) fragment
@@ -286,6 +249,54 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     auto frag = [&](int c, int j) { return min(c * 16 + j, nlast); };
     f8v aq[2], an[2];
     aq[0] = load_a(frag(0, 0)); aq[1] = load_a(frag(0, 1));
+
+    // ---- prologue.  Everything the first chunks need from global memory is requested before anything is waited for: chunks 0 and 1, the
+    // first weight fragments, then the per-channel tables (one memory round trip in front of the first MFMA instead of three).
+    float s0A[8], s0B[8], sA[8], sB[8];
+    load_item(false, 0, s0A);
+    load_item(true, 0, s0B);
+    if (nchunk > 1) {
+        load_item(false, 1, sA);
+        load_item(true, 1, sB);
+    }
+    if (a.mask && tid < WN_NPX) mpl[tid] = mvA;        // (items A of group 0 cover every halo pixel)
+    if (PRE) {
+        for (int i = tid; i < nchunk * 16; i += WN_THREADS) {       // padded channels: scale = shift = 0 -> 0
+            pss[i] = i < a.Cin ? a.pre_scale[i] : 0.0f;
+            pss[WN_MAXCIN + i] = i < a.Cin ? a.pre_shift[i] : 0.0f;
+        }
+    }
+    if (tid < 64) {                                    // the epilogue's per-channel constants: read from LDS there, no global round trip between
+        const int cc = min(cgrp * 64 + tid, a.Cout - 1);          // the exchange and the stores
+        epi[tid] = a.bias ? a.bias[cc] : 0.0f;
+        epi[64 + tid] = a.next_scale ? a.next_scale[cc] : 1.0f;
+        epi[128 + tid] = a.next_scale ? a.next_shift[cc] : 0.0f;
+    }
+    __syncthreads();                                   // tables
+    store_item(false, 0, s0A);
+    store_item(true, 0, s0B);
+    __syncthreads();
+    if (nchunk > 2) {                                  // chunk 2 flies under the first transform
+        load_item(false, 2, s0A);
+        load_item(true, 2, s0B);
+    }
+    {
+        PatchRegs pr;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int sl = 0; sl < 7; ++sl) transform_slice(sl, 0, k, pr);
+    }
+    __syncthreads();                                   // V[0] complete, raw read
+    if (nchunk > 1) {                                  // raw <- chunk 1: the loop's invariant (raw holds chunk c + 1 when chunk c begins)
+        store_item(false, 1, sA);
+        store_item(true, 1, sB);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sA[j] = s0A[j]; sB[j] = s0B[j]; }        // (the loop's staging registers hold chunk c + 2)
+    __syncthreads();
+    WN_STAMP(1);
+
     // A chunk's 32 slots (pair p, k-pair kp: slot 8p + kp), two MFMAs each.  In their shadow:
     //   slots 0-6   patch 0 of chunk c + 1: raw -> V[other buffer]      slots 8-14  patch 1 (raw is read in slots 0 and 8 only)
     //   slot 9      barrier: raw is free
@@ -293,6 +304,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     //   slot 24     the loads of chunk c + 3 are issued, BEHIND pair 3's weight loads: memory returns in order, so they have until the end of
     //               the next chunk's pair 0 (two pairs), and nothing waits for them before
     // No phase in which the matrix pipe waits for the staging (stores between two barriers at the top of the chunk: 1543 us -> see DESIGN).
+    auto read_b = [&](int vb, int slot, int i) -> float {       // B operand of slot 8p + kp, accumulator i of its pair
+        if (WN_EXP & 8) return (float)(lane + slot);
+        return V[vb][8 * xh + 2 * (slot >> 3) + i][2 * (slot & 7) + bgrp][tb * 32 + bcol];
+    };
+    float bq[WN_BDEPTH][2];
     for (int c = 0; c < nchunk; ++c) {
         const int vb = c & 1;
         const bool stage_ld = c + 3 < nchunk && !(WN_EXP & (2 | 32));          // (uniform)
@@ -312,17 +328,23 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
                 load_item(false, c + 3, sA);
                 load_item(true, c + 3, sB);
             }
-            float b[2], bn[2];
+            if (p == 0) {                              // (the B operands run WN_BDEPTH slots ahead, across the pairs of a chunk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) b[i] = (WN_EXP & 8) ? (float)(lane + i) : V[vb][8 * xh + 2 * p + i][bgrp][tb * 32 + bcol];
+                for (int d = 0; d < WN_BDEPTH; ++d)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bq[d][i] = read_b(vb, d, i);
+            }
             __builtin_amdgcn_sched_barrier(0);         // the next pair's weights are in flight from HERE
 #pragma unroll
             for (int kp = 0; kp < 8; ++kp) {
                 const int slot = p * 8 + kp;
                 if (slot == 9) __syncthreads();
-                if (kp < 7) {
+                float b[2] = {bq[0][0], bq[0][1]};
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bn[i] = (WN_EXP & 8) ? b[i] + 1.0f : V[vb][8 * xh + 2 * p + i][2 * (kp + 1) + bgrp][tb * 32 + bcol];
+                for (int d = 0; d + 1 < WN_BDEPTH; ++d) { bq[d][0] = bq[d + 1][0]; bq[d][1] = bq[d + 1][1]; }
+                if (slot + WN_BDEPTH < 32) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bq[WN_BDEPTH - 1][i] = read_b(vb, slot + WN_BDEPTH, i);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[2 * p + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][kp], b[i], acc[2 * p + i], 0, 0, 0);
@@ -333,8 +355,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
                     store_piece(true, cst, sB, slot - 15, fst);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) b[i] = bn[i];
             }
             aq[0] = an[0]; aq[1] = an[1];
         }

@@ -57,7 +57,7 @@ def _b8(x, channels):
 
 
 class torch_convolutions:
-    """VALIDATION AID, not a product route: no animator policy selects it (pipeline.CONV_POLICIES = auto | split | fp32, all on this
+    """VALIDATION AID, not a product route: no animator policy selects it (pipeline.CONV_POLICIES = auto | split | fp32 | fp32-winograd, all on this
     package's kernels).  Inside it every stage runs the torch composition that DEFINES it (nets.py: F.conv2d -> MIOpen fp32 on ROCm,
     elementwise stages as torch ops) -- the arithmetic the reference's decoder uses (models/layers/partialconv2d.py:61-74,
     models/networks/architectures.py:345-375).  The GPU tests compare the HIP stages with it, and bench.py times it beside the fp32
@@ -72,6 +72,9 @@ class torch_convolutions:
         return False
 
 
+FP32_WINOGRAD = False                    # what fp32_kernels() without an argument selects (the strict rung: direct 3x3 kernels)
+
+
 class fp32_kernels:
     """Context manager: the FULL-RANGE fp32 rung of these networks on this package's own kernels.  Inside it every 3x3 / 1x1
     convolution runs on v_mfma_f32_32x32x2_f32 (csrc/conv.hip, SLR_CONV_F32): fp32 operands, fp32 products, fp32 accumulation --
@@ -79,12 +82,16 @@ class fp32_kernels:
     no limit on the magnitude of the activations, at the fp32 matrix rate (157 TFLOP/s against the ~830 effective of the split-f16
     rung); prologue, epilogue, mask update, layouts and every other kernel are the ones of the split-f16 rung.  The animators enter
     it on request (convs="fp32") or by themselves when the split-f16 kernels report a clamped activation (convs="auto").
-    winograd (default True): the 3x3 convolutions with more than 4 output channels as Winograd F(2x2, 3x3) on the same instructions
-    (csrc/conv_wino.hpp, SLR_CONV_WINO): 16 instead of 36 multiplications per 2x2 outputs, still fp32 operands / products /
-    accumulation; False: the direct implicit GEMM."""
+    winograd=True (the animators' convs="fp32-winograd"): the 3x3 convolutions with more than 4 output channels as Winograd F(2x2, 3x3) on
+    the same instructions (csrc/conv_wino.hpp, SLR_CONV_WINO) -- 16 instead of 36 multiplications per 2x2 outputs, still fp32 operands /
+    products / accumulation, 1.5x the direct kernel's speed.  Accuracy, measured: per layer its error is 2 - 4x the direct kernel's
+    (<= 1.1e-6 of the output range against <= 3e-7); the seeded random-weight networks of the native fixture amplify a perturbation of a
+    layer about 400x at a few ill-conditioned pixels (the reference's own two fp32 runs differ by 2e-4 there), so whole frames come out
+    9e-7 from the direct rung's on average and up to 3.9e-4 at ~50 pixels -- 2.6e-4 from the fp64 frames at worst, where the direct
+    rung (the default, winograd=False / nets.FP32_WINOGRAD) stays within 1.4e-5 (tests/test_large_golden.py).  Fast fp32, not the anchor."""
 
-    def __init__(self, winograd=True):
-        self.winograd = bool(winograd)
+    def __init__(self, winograd=None):
+        self.winograd = FP32_WINOGRAD if winograd is None else bool(winograd)
 
     def __enter__(self):
         self._prev, _S.f32_kernels = _S.f32_kernels, True
@@ -582,12 +589,12 @@ class SaturationLog:
 
 def guarded(fn, device, policy, what, owner=None):
     """Run ``fn()`` (networks on split-f16 kernels) under the saturation policy of the animators:
-    "split": as is, raise if an activation was clamped; "fp32": inside fp32_kernels();
+    "split": as is, raise if an activation was clamped; "fp32" / "fp32-winograd": inside fp32_kernels() (direct / Winograd 3x3);
     "auto": split-f16 at the default activation scale; clamped -> again at scale 1 (exact up to 65472); clamped again ->
     inside fp32_kernels() (the fp32 matrix instructions: no limit).  ``owner`` (an animator) remembers the rung that worked, so later clips start there.
     Synchronises with the device once per call (per rung tried)."""
-    if policy == "fp32":
-        with fp32_kernels():
+    if policy in ("fp32", "fp32-winograd"):
+        with fp32_kernels(winograd=policy == "fp32-winograd"):
             return fn()
     if policy == "split":
         out = fn()
@@ -608,7 +615,7 @@ def guarded(fn, device, policy, what, owner=None):
                       f"activation scale {scale:g}; rendering again " + ("at scale 1" if r == 0 else "on the fp32 rung"))
         if owner is not None:
             owner._conv_rung = r + 1
-    with fp32_kernels():
+    with fp32_kernels(winograd=False):                         # (the safety net is the strict rung)
         return fn()
 
 

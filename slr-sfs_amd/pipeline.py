@@ -108,20 +108,22 @@ def _encode(encoder, image, shard, policy="split", owner=None, what="encoder"):
     return parallel.encode_banded(encoder, image, shard[0], shard[1], shard[2] if len(shard) > 2 else None, guard=guard)
 
 
-CONV_POLICIES = ("auto", "split", "fp32")
+CONV_POLICIES = ("auto", "split", "fp32", "fp32-winograd")
 _RUNG_SCALE = (64.0, 1.0)
 
 
 def _rung_context(rung):
     """Arithmetic of the decoder convolutions by rung of the ladder: 0 split-f16 at activation scale 2^6 (exact for
     |x| < 1023), 1 split-f16 at scale 1 (|x| < 65472), 2 the fp32 matrix instructions (nets.fp32_kernels: no limit)."""
-    return nets.fp32_kernels() if rung >= 2 else nets.activation_scale(_RUNG_SCALE[rung])
+    return nets.fp32_kernels(winograd=False) if rung >= 2 else nets.activation_scale(_RUNG_SCALE[rung])
 
 
 def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_by_one=False):
     """The frame loop of both animators.  decode(gen, afl) -> the batch's outputs; store(pos, outputs) puts them at
     positions ``pos`` (indices into ``frames``).  ``policy`` (CONV_POLICIES):
       "fp32"  every convolution on this package's fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32): the reference's arithmetic;
+      "fp32-winograd"  the same rung with its 3x3 layers as Winograd F(2x2, 3x3): 1.4x the clip rate of "fp32", 2 - 4x its rounding error
+              per layer (nets.fp32_kernels: what that means for whole frames);
       "split" split-f16 matrix-core kernels; an activation outside their exact range raises after the clip;
       "auto"  split-f16 kernels; every decoder batch leaves an asynchronous record of the device's saturation counter
               (no host synchronisation inside the loop); after the last batch the records are read and the batches in
@@ -145,8 +147,8 @@ def _render(owner, clip, frames, batch, overlap, decode, policy, on_frame, one_b
             for p_ in pos:
                 on_frame(p_)
 
-    if policy == "fp32" or not dev.type == "cuda":
-        with (nets.fp32_kernels() if policy == "fp32" else _null()):
+    if policy in ("fp32", "fp32-winograd") or not dev.type == "cuda":
+        with (nets.fp32_kernels(winograd=policy == "fp32-winograd") if policy in ("fp32", "fp32-winograd") else _null()):
             for i0, gen, afl in groups(frames):
                 pos = list(range(i0, i0 + gen.shape[0]))
                 store(pos, decode_batch(gen, afl))

@@ -256,7 +256,7 @@ def test_conv_rung_retry_and_reset():
 def test_conv_policies_are_the_package_kernels_only():
     """The torch / MIOpen composition of the networks is a validation aid (nets.torch_convolutions), not a selectable product route."""
     from slr_sfs_amd import pipeline
-    assert pipeline.CONV_POLICIES == ("auto", "split", "fp32")
+    assert pipeline.CONV_POLICIES == ("auto", "split", "fp32", "fp32-winograd")
     with pytest.raises(AssertionError):
         pipeline.BaselineAnimator(convs="torch")
 

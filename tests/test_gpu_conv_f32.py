@@ -67,7 +67,7 @@ def test_conv3x3_winograd_fp32_vs_fp64(S, cin, cout, h, w, bias):
         conv.bias.data.normal_()
     x = torch.randn(2, cin, h, w, device="cuda") * 3
     sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda")
-    with torch.no_grad(), nets.fp32_kernels():
+    with torch.no_grad(), nets.fp32_kernels(winograd=True):
         y = conv(x)
         ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None, padding=1)
         yb = conv(x, (sc, sh))
@@ -102,9 +102,10 @@ def test_conv1x1_fp32_rung_vs_fp64(S, cin, cout, h, w, bias):
     assert (y - ref).abs().max().item() < 4e-6 * max(ref.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("wino", [False, True])
 @pytest.mark.parametrize("cin,cout,h,w,mode", [(64, 64, 24, 70, "derived"), (65, 128, 12, 40, "derived"), (64, 128, 16, 64, "plane"),
                                                (128, 3, 9, 40, "plane"), (32, 32, 20, 33, "chain")])
-def test_pconv3x3_fp32_rung_fused_equals_staged(S, cin, cout, h, w, mode):
+def test_pconv3x3_fp32_rung_fused_equals_staged(S, cin, cout, h, w, mode, wino):
     """The one-kernel partial convolution on the fp32 rung against the staged path on the same rung (slr_bn_relu_mask ->
     slr_conv3x3_forward -> slr_pconv_epilogue): same operations in the same order on the same accumulators -- bit-exact, update
     mask included, with residual and with next-BN fusion."""
@@ -119,7 +120,7 @@ def test_pconv3x3_fp32_rung_fused_equals_staged(S, cin, cout, h, w, mode):
     res = torch.randn(2, cout, h, w, device="cuda")
     mask = None if mode == "derived" else (torch.rand(2, 1, h, w, device="cuda") > 0.3).float()
     pre = None if mode == "chain" else (sc, sh)
-    with torch.no_grad(), nets.fp32_kernels():
+    with torch.no_grad(), nets.fp32_kernels(winograd=wino):      # (both 3x3 kernels of the rung: direct, Winograd)
         for kw in ({"residual": res}, {"next_bn": (nsc, nsh)}, {}):
             out, um = pc(x, mask, pre_bn=pre, **kw)
             xin = nets.bn_relu_mask(x, sc, sh, mask) if pre is not None else x
@@ -176,9 +177,10 @@ def test_decoder_on_the_fp32_rung_vs_fp64(S):
     assert e_hip < 3e-5 and e_hip < 6 * e_f32 + 1e-6, (e_hip, e_f32)
 
 
-def test_animator_policy_fp32_uses_own_kernels(S):
-    """convs="fp32" renders a clip on the fp32 rung without entering torch's convolutions: F.conv2d is never called, the
-    frames agree with the split-f16 policy to the split's accuracy."""
+@pytest.mark.parametrize("policy", ["fp32", "fp32-winograd"])
+def test_animator_policy_fp32_uses_own_kernels(S, policy):
+    """convs="fp32" / "fp32-winograd" render a clip on the fp32 rung without entering torch's convolutions: F.conv2d is never called,
+    the frames agree with the split-f16 policy to the split's accuracy."""
     from slr_sfs_amd import pipeline
     torch.manual_seed(0)
     H, W, N = 64, 96, 6
@@ -190,7 +192,7 @@ def test_animator_policy_fp32_uses_own_kernels(S):
     orig = F.conv2d
     F.conv2d = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     try:
-        f32 = an.synthesize(img, motion, N, convs="fp32")
+        f32 = an.synthesize(img, motion, N, convs=policy)
     finally:
         F.conv2d = orig
     assert not calls

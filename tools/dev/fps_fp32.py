@@ -10,7 +10,7 @@ image = torch.rand(1, 3, H, W, device=dev) * 2 - 1
 motion = torch.from_numpy(smooth_motion(H, W)).to(dev)
 m = pipeline.BaselineAnimator(convs="fp32").to(dev).eval()
 for wino in ((True,) if "--wino" in sys.argv else (True, False)):
-    nets.fp32_kernels.__init__.__defaults__ = (wino,)         # the animator enters fp32_kernels() itself
+    m.convs = "fp32-winograd" if wino else "fp32"
     m.synthesize(image, motion, NFRAMES)
     torch.cuda.synchronize()
     t = time.perf_counter()
