@@ -164,12 +164,6 @@
 #ifndef SLR_SKIP
 #define SLR_SKIP 0              // deletion experiments on the chunk pipeline (WRONG results; timing only): 1 no plane loads, 2 no staging stores,
 #endif                          // 4 no register-record reads, 8 no list loop, 16 no output stores (first chunk excepted), 32 no barriers
-#ifndef SLR_SKIP
-#define SLR_SKIP 0              // deletion experiments on the chunk pipeline (WRONG results; timing only): 1 no plane loads, 2 no staging stores,
-#endif                          // 4 no register-record reads, 8 no list loop, 16 no output stores (first chunk excepted), 32 no barriers
-#ifndef SLR_NO_INPLACE
-#define SLR_NO_INPLACE 0        // 1: the persistent kernels skip pieces of more than a segment (timing experiments only: wrong results on such pieces)
-#endif
 #ifndef SLR_DBG
 #define SLR_DBG 0               // 1 drain vmcnt before staging, 4 verify staged values against global memory
 #endif
