@@ -78,16 +78,25 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
     RowRec *list_m = r.rowlist + (size_t)m * r.nt * ROW_CAP;
     int my_tile = -1, my_y = 0;
     uint32_t my_cnt = 0;
-    unsigned long long my_lo = 0, my_hi = 0;       // hits per column octant of the tile, 16 bits each (octants 0-3 | 4-7)
+    uint32_t my_a = 0, my_b = 0;                   // hits per column octant of the tile, one BYTE each (octants 0-3 | 4-7; <= 64 hits per append)
     int k = 0;
+    // Round 5: the kernel is bound by its SCALAR instructions (PMC: 590 SALU + 474 VALU per wave, one scalar unit per CU -> 1.0 ms of its
+    // 1.25): the per-append histogram is kept byte-packed in two dwords while it is built and parked, and widened to the 16-bit fields
+    // of the count words -- together with the octant mask of the list record -- by the 64 lanes of the flush at once.
     auto flush = [&]() {
         if (my_tile >= 0) {
             unsigned long long *w = cnt_m + 4 * (size_t)my_tile;
             const unsigned long long old = atomicAdd(w, 1ull | ((unsigned long long)my_cnt << 32));
-            if (my_lo) atomicAdd(w + 1, my_lo);                  // (no return value: fire and forget)
-            if (my_hi) atomicAdd(w + 2, my_hi);
+            const unsigned long long lo = (unsigned long long)__builtin_amdgcn_perm(0u, my_a, 0x0c010c00u) | ((unsigned long long)__builtin_amdgcn_perm(0u, my_a, 0x0c030c02u) << 32);
+            const unsigned long long hi = (unsigned long long)__builtin_amdgcn_perm(0u, my_b, 0x0c010c00u) | ((unsigned long long)__builtin_amdgcn_perm(0u, my_b, 0x0c030c02u) << 32);
+            if (my_a) atomicAdd(w + 1, lo);                      // (no return value: fire and forget)
+            if (my_b) atomicAdd(w + 2, hi);
+            // octants with at least one hit: non-zero bytes (<= 64 each: + 0x7f sets bit 7 without a carry) -> bits 0-3 | 4-7
+            const uint32_t na = (((my_a + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0x01020408u >> 24;
+            const uint32_t nb = (((my_b + 0x7f7f7f7fu) & 0x80808080u) >> 7) * 0x01020408u >> 24;
+            const uint32_t rm = (na & 0xfu) | ((nb & 0xfu) << 4);
             const uint32_t slot = (uint32_t)old;
-            if (slot < (uint32_t)ROW_CAP) list_m[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)my_y, ((uint32_t)stx << 8) | my_cnt};
+            if (slot < (uint32_t)ROW_CAP) list_m[(size_t)my_tile * ROW_CAP + slot] = RowRec{(uint32_t)my_y | (rm << 24), ((uint32_t)stx << 8) | my_cnt};
         }
         my_tile = -1;
         k = 0;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
             if (q.vxb) cm_b = 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3);
         }
         for (;;) {
-            const int cand = t0 >= 0 ? t0 : t1 >= 0 ? t1 : t2 >= 0 ? t2 : t3;
+            const int cand = (int)min(min((uint32_t)t0, (uint32_t)t1), min((uint32_t)t2, (uint32_t)t3));      // (any pending tile will do; -1 = none)
             const unsigned long long pend = __ballot(cand >= 0);
             if (!pend) break;
             const int leader = __ffsll((long long)pend) - 1;
@@ -119,31 +128,29 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
             const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
             const uint32_t c = (uint32_t)__popcll(__ballot(h));
             const uint32_t lm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
-            // exact hits per column octant: 8 ballots for a full append; the one-column overlaps into a neighbouring tile (fewer than 8
-            // hits: half of all appends) walk their <= 7 lanes with scalar operations instead (the kernel is VALU-bound)
-            uint32_t rm = 0;
-            unsigned long long lo = 0, hi = 0;
+            // exact hits per column octant, byte-packed: 8 ballots for a full append; the one-column overlaps into a neighbouring tile
+            // (fewer than 8 hits: half of all appends) walk their <= 7 lanes with scalar operations instead
+            uint32_t ha = 0, hb = 0;
             if (c >= 8u) {                                   // (wave-uniform)
 #pragma unroll
                 for (int o = 0; o < 8; ++o) {
-                    const unsigned long long co = (unsigned long long)__popcll(__ballot((lm >> o) & 1u));
-                    rm |= co ? 1u << o : 0u;
-                    if (o < 4) lo |= co << (16 * o); else hi |= co << (16 * (o - 4));
+                    const uint32_t co = (uint32_t)__popcll(__ballot((lm >> o) & 1u));
+                    if (o < 4) ha |= co << (8 * o); else hb |= co << (8 * (o - 4));
                 }
             } else {
                 for (unsigned long long mk = __ballot(h); mk; mk &= mk - 1ull) {
                     const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lm, __ffsll((long long)mk) - 1);
-                    rm |= l;
-                    // bit o of l -> +1 in the 16-bit field of octant o
-                    lo += (unsigned long long)(l & 1u) | ((unsigned long long)(l & 2u) << 15) | ((unsigned long long)(l & 4u) << 30) | ((unsigned long long)(l & 8u) << 45);
-                    hi += (unsigned long long)((l >> 4) & 1u) | ((unsigned long long)((l >> 4) & 2u) << 15) | ((unsigned long long)((l >> 4) & 4u) << 30) | ((unsigned long long)((l >> 4) & 8u) << 45);
+                    // bit o of l -> + 1 in the byte of octant o: bit i of a nibble times (1 + 2^7 + 2^14 + 2^21) lands on bit 8 i (and on
+                    // bits that are masked away; no two products share a position)
+                    ha += ((l & 0xfu) * 0x00204081u) & 0x01010101u;
+                    hb += ((l >> 4) * 0x00204081u) & 0x01010101u;
                 }
             }
             if (t0 == T) t0 = -1;
             if (t1 == T) t1 = -1;
             if (t2 == T) t2 = -1;
             if (t3 == T) t3 = -1;
-            if (lane == k) { my_tile = T; my_cnt = c; my_y = y | (int)(rm << 24); my_lo = lo; my_hi = hi; }
+            if (lane == k) { my_tile = T; my_cnt = c; my_y = y; my_a = ha; my_b = hb; }
             if (++k == 64) flush();
         }
     }
