@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void zero_u64_kernel(unsigned long long *__res
 // first lane with something left names a tile, a ballot counts the lanes that touch it); round k's append is parked in lane k and all
 // appends of the wave go out as one set of atomic instructions.
 __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int W, int tiles_x, int tiles_y) {
-    constexpr int R = 2;
+    constexpr int R = SLR_ROWBIN_CLIP_R;
     const uint32_t m = blockIdx.y, d = m >= r.nframes ? 1u : 0u, fi = m - d * r.nframes;
     const float *fl = r.disp[d] + (size_t)r.idx[d][fi] * 2 * H * W;
     const int bl = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stx = bl % tiles_x, y_base = (bl / tiles_x) * R * TILE_H + wid, x = stx * TILE_W + lane;
     float fx[R], fy[R];
 #pragma unroll
@@ -108,16 +108,8 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
         int t0 = -1, t1 = -1, t2 = -1, t3 = -1;                  // the <= 4 tiles this pixel's footprint touches
         uint32_t cm_a = 0, cm_b = 0;                             // column octants (bits) it touches in the left / right of them
         if (x < W) {
-            const Corners c = make_corners(fx[rr], fy[rr], x, y);
-            const TileSet q = footprint_tiles(c, H, W);
-            if (q.vxa & q.vya) t0 = q.tya * tiles_x + q.txa;
-            if (q.vxb & q.vya) t1 = q.tya * tiles_x + q.txb;
-            if (q.vxa & q.vyb) t2 = q.tyb * tiles_x + q.txa;
-            if (q.vxb & q.vyb) t3 = q.tyb * tiles_x + q.txb;
-            const bool x0in = c.ok & (c.x0 >= 0) & (c.x0 < W), x1in = c.ok & (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
-            if (q.vxa) cm_a = (x0in ? 1u << ((c.x0 & (TILE_W - 1)) >> 3) : 0u) |
-                              ((x1in && (c.x0 + 1) / TILE_W == q.txa) ? 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3) : 0u);
-            if (q.vxb) cm_b = 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3);
+            const BinFoot f = bin_footprint(fx[rr], fy[rr], x, y, H, W, tiles_x);
+            t0 = f.t0; t1 = f.t1; t2 = f.t2; t3 = f.t3; cm_a = f.cm_a; cm_b = f.cm_b;
         }
         for (;;) {
             const int cand = (int)min(min((uint32_t)t0, (uint32_t)t1), min((uint32_t)t2, (uint32_t)t3));      // (any pending tile will do; -1 = none)
@@ -125,9 +117,10 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
             if (!pend) break;
             const int leader = __ffsll((long long)pend) - 1;
             const int T = __builtin_amdgcn_readlane(cand, leader);
-            const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
-            const uint32_t c = (uint32_t)__popcll(__ballot(h));
-            const uint32_t lm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
+            const bool e0 = t0 == T, e1 = t1 == T, e2 = t2 == T, e3 = t3 == T;
+            const unsigned long long hmask = __ballot(e0) | __ballot(e1) | __ballot(e2) | __ballot(e3);        // (scalar ORs of the four compare masks)
+            const uint32_t c = (uint32_t)__popcll(hmask);
+            const uint32_t lm = ((e0 | e2) ? cm_a : 0u) | ((e1 | e3) ? cm_b : 0u);   // column octants of T this lane touches
             // exact hits per column octant, byte-packed: 8 ballots for a full append; the one-column overlaps into a neighbouring tile
             // (fewer than 8 hits: half of all appends) walk their <= 7 lanes with scalar operations instead
             uint32_t ha = 0, hb = 0;
@@ -138,7 +131,7 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
                     if (o < 4) ha |= co << (8 * o); else hb |= co << (8 * (o - 4));
                 }
             } else {
-                for (unsigned long long mk = __ballot(h); mk; mk &= mk - 1ull) {
+                for (unsigned long long mk = hmask; mk; mk &= mk - 1ull) {
                     const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lm, __ffsll((long long)mk) - 1);
                     // bit o of l -> + 1 in the byte of octant o: bit i of a nibble times (1 + 2^7 + 2^14 + 2^21) lands on bit 8 i (and on
                     // bits that are masked away; no two products share a position)
@@ -146,11 +139,16 @@ __global__ __launch_bounds__(CT) void rowbin_clip_kernel(ClipRows r, int H, int 
                     hb += ((l >> 4) * 0x00204081u) & 0x01010101u;
                 }
             }
-            if (t0 == T) t0 = -1;
-            if (t1 == T) t1 = -1;
-            if (t2 == T) t2 = -1;
-            if (t3 == T) t3 = -1;
-            if (lane == k) { my_tile = T; my_cnt = c; my_y = y; my_a = ha; my_b = hb; }
+            t0 = e0 ? -1 : t0;
+            t1 = e1 ? -1 : t1;
+            t2 = e2 ? -1 : t2;
+            t3 = e3 ? -1 : t3;
+            // round k's append is parked in lane k (all five values are wave-uniform: one v_writelane each, splat_types.hpp)
+            {
+                int v_cnt = (int)my_cnt, v_a = (int)my_a, v_b = (int)my_b;
+                write_lane5(k, my_tile, T, v_cnt, (int)c, my_y, y, v_a, (int)ha, v_b, (int)hb);
+                my_cnt = (uint32_t)v_cnt; my_a = (uint32_t)v_a; my_b = (uint32_t)v_b;
+            }
             if (++k == 64) flush();
         }
     }
@@ -467,7 +465,7 @@ SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const 
     p.items_cap = L.items_cap;
     const size_t nwords = (size_t)L.nmaps * L.nt * 4;
     hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, r.rowcnt, nwords);
-    const dim3 grid((unsigned)(L.tiles_x * ((L.tiles_y + 1) / 2)), L.nmaps);      // (blockIdx.y carries the map: <= 32768 maps, see clip_check)
+    const dim3 grid((unsigned)(L.tiles_x * ((L.tiles_y + SLR_ROWBIN_CLIP_R - 1) / SLR_ROWBIN_CLIP_R)), L.nmaps);      // (blockIdx.y carries the map: <= 32768 maps, see clip_check)
     hipLaunchKernelGGL(rowbin_clip_kernel, grid, dim3(CT), 0, st, r, H, W, L.tiles_x, L.tiles_y);
     hipLaunchKernelGGL(rows_sort_kernel, dim3((L.nt + CT / 64 - 1) / (CT / 64), L.nmaps), dim3(CT), 0, st, (const unsigned long long *)r.rowcnt,
                        (size_t)L.nt * 4, 4u, (const RowRec *)r.rowlist, r.rowlist, L.nt);

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
                                                           ItemDesc *__restrict__ items, uint32_t *__restrict__ totals) {
     const int tiles = tiles_x * tiles_y, by_n = (tiles_y + ROWBIN_R - 1) / ROWBIN_R, per_n = tiles_x * by_n;
     const int b = blockIdx.x, n = b / per_n, bl = b - n * per_n;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef SLR_PLAN_STAMPS
     const unsigned long long k_entry = wall_clock64();
     if (b == 0 && tid == 0) ((unsigned long long *)totals)[15] = k_entry;
@@ -257,28 +257,21 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
         int t0 = -1, t1 = -1, t2 = -1, t3 = -1;             // the <= 4 tiles this pixel's footprint touches
         uint32_t cm_a = 0, cm_b = 0;                        // column octants (bits) it touches in the left / right of them
         if (x < W) {
-            const Corners c = make_corners(fx[r], fy[r], x, y);
-            const TileSet q = footprint_tiles(c, H, W);
-            if (q.vxa & q.vya) t0 = q.tya * tiles_x + q.txa;
-            if (q.vxb & q.vya) t1 = q.tya * tiles_x + q.txb;
-            if (q.vxa & q.vyb) t2 = q.tyb * tiles_x + q.txa;
-            if (q.vxb & q.vyb) t3 = q.tyb * tiles_x + q.txb;
             // tile column a holds corner column x0 (if in the image) and x0 + 1 when it lies in the same tile column; tile column b
             // (valid only when distinct) holds x0 + 1.  Octant = 8 output columns (the finest piece of a heavy tile).
-            const bool x0in = c.ok & (c.x0 >= 0) & (c.x0 < W), x1in = c.ok & (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
-            if (q.vxa) cm_a = (x0in ? 1u << ((c.x0 & (TILE_W - 1)) >> 3) : 0u) |
-                              ((x1in && (c.x0 + 1) / TILE_W == q.txa) ? 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3) : 0u);
-            if (q.vxb) cm_b = 1u << (((c.x0 + 1) & (TILE_W - 1)) >> 3);
+            const BinFoot f = bin_footprint(fx[r], fy[r], x, y, H, W, tiles_x);
+            t0 = f.t0; t1 = f.t1; t2 = f.t2; t3 = f.t3; cm_a = f.cm_a; cm_b = f.cm_b;
         }
         for (;;) {
-            const int cand = t0 >= 0 ? t0 : t1 >= 0 ? t1 : t2 >= 0 ? t2 : t3;
+            const int cand = (int)min(min((uint32_t)t0, (uint32_t)t1), min((uint32_t)t2, (uint32_t)t3));      // (any pending tile will do; -1 = none)
             const unsigned long long pend = __ballot(cand >= 0);
             if (!pend) break;
             const int leader = __ffsll((long long)pend) - 1;
             const int T = __builtin_amdgcn_readlane(cand, leader);
-            const bool h = (t0 == T) | (t1 == T) | (t2 == T) | (t3 == T);
-            const uint32_t c = (uint32_t)__popcll(__ballot(h));
-            const uint32_t lm = (((t0 == T) | (t2 == T)) ? cm_a : 0u) | (((t1 == T) | (t3 == T)) ? cm_b : 0u);   // column octants of T this lane touches
+            const bool e0 = t0 == T, e1 = t1 == T, e2 = t2 == T, e3 = t3 == T;
+            const unsigned long long hmask = __ballot(e0) | __ballot(e1) | __ballot(e2) | __ballot(e3);        // (scalar ORs of the four compare masks)
+            const uint32_t c = (uint32_t)__popcll(hmask);
+            const uint32_t lm = ((e0 | e2) ? cm_a : 0u) | ((e1 | e3) ? cm_b : 0u);   // column octants of T this lane touches
             // Column-octant histogram of the tile (what the plan cuts heavy tiles by): ONE more atomic per append, 8 bits per octant
             // in units of 16 entries with a pseudo-random rounding offset (unbiased: a tile's sum over its ~50 appends is what
             // matters; two 16-bit-per-octant words cost +7 us per call at 46 k appends).  Appends of fewer than 8 hits -- the
@@ -296,14 +289,18 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
                     hist |= (unsigned long long)((co + ((rnd >> o) & 15u)) >> 4) << (8 * o);
                 }
             } else {
-                for (unsigned long long m = __ballot(h); m; m &= m - 1ull)
+                for (unsigned long long m = hmask; m; m &= m - 1ull)
                     rm |= (uint32_t)__builtin_amdgcn_readlane((int)lm, __ffsll((long long)m) - 1);
             }
-            if (t0 == T) t0 = -1;
-            if (t1 == T) t1 = -1;
-            if (t2 == T) t2 = -1;
-            if (t3 == T) t3 = -1;
-            if (lane == k) { my_tile = T; my_cnt = c; my_y = y | (int)(rm << 24); my_hist = hist; }
+            t0 = e0 ? -1 : t0;
+            t1 = e1 ? -1 : t1;
+            t2 = e2 ? -1 : t2;
+            t3 = e3 ? -1 : t3;
+            {                                                // round k's append is parked in lane k (wave-uniform values: v_writelane, splat_types.hpp)
+                int v_cnt = (int)my_cnt, v_lo = (int)(uint32_t)my_hist, v_hi = (int)(uint32_t)(my_hist >> 32);
+                write_lane5(k, my_tile, T, v_cnt, (int)c, my_y, y | (int)(rm << 24), v_lo, (int)(uint32_t)hist, v_hi, (int)(uint32_t)(hist >> 32));
+                my_cnt = (uint32_t)v_cnt; my_hist = (unsigned long long)(uint32_t)v_lo | ((unsigned long long)(uint32_t)v_hi << 32);
+            }
             if (++k == 64) flush();
         }
     }

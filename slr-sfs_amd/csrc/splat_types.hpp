@@ -23,6 +23,44 @@ __device__ __forceinline__ TileSet footprint_tiles(const Corners &c, int H, int 
     return s;
 }
 
+// Lane `lane` (wave-uniform) of five vectors replaced by five wave-uniform values: one VALU instruction per value where
+// `if (lane_id == lane) v = val` costs a compare and exec-masked moves.  (clang of this ROCm has no writelane builtin; a VOP3 instruction
+// of gfx9 reads one SGPR, so the lane select goes through M0.)
+__device__ __forceinline__ void write_lane5(int lane, int &v0, int a0, int &v1, int a1, int &v2, int a2, int &v3, int a3, int &v4, int a4) {
+    asm("s_mov_b32 m0, %10\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\t"
+        "v_writelane_b32 %3, %8, m0\n\tv_writelane_b32 %4, %9, m0"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4) : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(lane) : "m0");
+}
+
+// The same footprint for the binning kernels (rowbin_kernel, rowbin_clip_kernel), which are bound by their instruction count: the
+// <= 4 tiles of a source pixel as linear tile indices (-1: none) and the column octants (8 output columns) it touches in the left /
+// right tile column.  Same result as footprint_tiles + the octant rules written out in round 4, in half the instructions: range tests
+// as unsigned compares, tile coordinates as shifts (used only where the coordinate is >= 0).
+struct BinFoot { int t0, t1, t2, t3; uint32_t cm_a, cm_b; };
+__device__ __forceinline__ BinFoot bin_footprint(float fx, float fy, int x, int y, int H, int W, int tiles_x) {
+    static_assert(TILE_W == 64 && (TILE_H & (TILE_H - 1)) == 0, "shifts below");
+    constexpr int SH_H = TILE_H == 8 ? 3 : TILE_H == 4 ? 2 : TILE_H == 16 ? 4 : TILE_H == 2 ? 1 : 0;
+    static_assert((1 << SH_H) == TILE_H, "tile height");
+    const float X = (float)x + fx, Y = (float)y + fy;                    // softsplat.py:169-170
+    const bool ok = (fabsf(X) < 1073741824.0f) & (fabsf(Y) < 1073741824.0f);
+    const uint32_t ux0 = (uint32_t)(ok ? (int)floorf(X) : -0x40000000), uy0 = (uint32_t)(ok ? (int)floorf(Y) : -0x40000000);
+    const uint32_t ux1 = ux0 + 1u, uy1 = uy0 + 1u;
+    const bool xa = ux0 < (uint32_t)W, xb = ux1 < (uint32_t)W, ya = uy0 < (uint32_t)H, yb = uy1 < (uint32_t)H;
+    const uint32_t txa = ux0 >> 6, txb = ux1 >> 6, tya = uy0 >> SH_H, tyb = uy1 >> SH_H;
+    const bool same_x = txb == txa;
+    const bool vxb = xb & !(xa & same_x), vyb = yb & !(ya & (tyb == tya));        // the second column / row only when distinct
+    const int ra = (int)(tya * (uint32_t)tiles_x), rb = (int)(tyb * (uint32_t)tiles_x);
+    BinFoot f;
+    f.t0 = (xa & ya) ? ra + (int)txa : -1;
+    f.t1 = (vxb & ya) ? ra + (int)txb : -1;
+    f.t2 = (xa & vyb) ? rb + (int)txa : -1;
+    f.t3 = (vxb & vyb) ? rb + (int)txb : -1;
+    const uint32_t b0 = 1u << ((ux0 >> 3) & 7u), b1 = 1u << ((ux1 >> 3) & 7u);
+    f.cm_a = xa ? (b0 | ((xb & same_x) ? b1 : 0u)) : 0u;
+    f.cm_b = vxb ? b1 : 0u;
+    return f;
+}
+
 // Everything a tile workgroup needs to know about its work item, in ONE 32-byte record (one scalar
 // load instead of a chain of dependent lookups through items -> count/listoff/nseg/partoff).
 struct ItemDesc {
