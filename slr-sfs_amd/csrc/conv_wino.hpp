@@ -179,10 +179,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
         const float x = st[j];
         float v;
         if (PRE) {
-            const float mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : mk0;
+            float mk = mk0;
+            if (!INB8) {                                 // the derived mask (x != 0) comes with NCHW input only (conv.hip: conv_check_layout):
+                mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : mk0;         // the channel-blocked instantiation carries neither the test nor the count
+                const float count = (cb + j <= cmax) ? mk * counted : 0.0f;
+                if (isB) cntB += count; else cntA += count;
+            }
             v = fmaxf(x * pss[cb + j] - pss[WN_MAXCIN + cb + j], 0.0f) * mk;
-            const float count = (cb + j <= cmax) ? mk * counted : 0.0f;
-            if (isB) cntB += count; else cntA += count;
         } else {
             v = (cb + j <= cmax) ? x * mk0 : 0.0f;       // (padded channels meet zero weights; keep them finite and zero)
         }

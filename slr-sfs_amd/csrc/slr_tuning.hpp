@@ -126,6 +126,9 @@
 #ifndef SLR_CLIP_HEAVY
 #define SLR_CLIP_HEAVY 0        // clip plans: tiles with more than 7/8 of a segment's entries (and every tile cut into pieces) go first; 0 = one row-major pass (measured: 7/8 161.4-162.1 us per frame, 6/8 162.1-162.7, one pass 159.5-160.4: the spatial order is worth more than the shorter tail)
 #endif
+#ifndef SLR_WAVES_CLIP
+#define SLR_WAVES_CLIP 4         // waves per SIMD the fused clip kernel is compiled for (86 VGPRs as built; its 79 KiB of LDS allow two workgroups per CU)
+#endif
 #ifndef SLR_ROWBIN_CLIP_R
 #define SLR_ROWBIN_CLIP_R 4     // rowbin_clip_kernel: image rows per wave (their flow loads in flight together, their appends in one flush).  Stage us per frame, same box: 2: 172.0-172.8, 3: 171.7, 4: 171.4, 6: 171.1
 #endif
