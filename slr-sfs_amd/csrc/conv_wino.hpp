@@ -172,20 +172,22 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
     // (no branch around a piece: dead work-items of item B write the row's 4 padding floats, pieces past the last chunk re-stage the last
     // chunk from stale registers into the buffer nobody reads -- 16 branches per chunk between the MFMAs cost 0.5 us of its 4.6)
     const int pBst = liveB ? pB : WN_NPX + (tid & 3);
-    auto store_piece = [&](bool isB, int c, const float (&st)[8], int j, float counted = 1.0f) {       // channel j of the item's 8
+    // (have: sc / sh are the prologue's scale / shift of the channel, fetched ahead of time by the caller; otherwise read here)
+    auto store_piece = [&](bool isB, int c, const float (&st)[8], int j, float counted = 1.0f, bool have = false, float sc = 0.0f, float sh = 0.0f) {       // channel j of the item's 8
         const int g = isB ? 1 : gA, px = isB ? pBst : pA;
         const int cb = c * 16 + g * 8;
         const float mk0 = isB ? mB : mA;
         const float x = st[j];
         float v;
         if (PRE) {
+            if (!have) { sc = pss[cb + j]; sh = pss[WN_MAXCIN + cb + j]; }
             float mk = mk0;
             if (!INB8) {                                 // the derived mask (x != 0) comes with NCHW input only (conv.hip: conv_check_layout):
                 mk = (nonzero_mask & (x == 0.0f)) ? 0.0f : mk0;         // the channel-blocked instantiation carries neither the test nor the count
                 const float count = (cb + j <= cmax) ? mk * counted : 0.0f;
                 if (isB) cntB += count; else cntA += count;
             }
-            v = fmaxf(x * pss[cb + j] - pss[WN_MAXCIN + cb + j], 0.0f) * mk;
+            v = fmaxf(x * sc - sh, 0.0f) * mk;
         } else {
             v = (cb + j <= cmax) ? x * mk0 : 0.0f;       // (padded channels meet zero weights; keep them finite and zero)
         }
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
         const int cst = min(c + 2, nchunk - 1);
         const float fst = c + 2 < nchunk ? 1.0f : 0.0f;                      // (the derived mask counts a chunk once)
         // (64: the loads are issued and waited for, nothing is stored; 128: every workgroup loads the first block's pixels -- L2 hits)
+        float2 pq[2][4];                               // prologue constants in flight: [set][scale A, shift A, scale B, shift B] of two channels
         PatchRegs pr;                                  // (the last chunk transforms stale rows into the buffer nobody reads: no branch in the pairs)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -353,9 +356,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(ConvArgs a)
                 for (int i = 0; i < 2; ++i) acc[2 * p + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][kp], b[i], acc[2 * p + i], 0, 0, 0);
                 if (slot < 15 && (slot & 7) < 7 && !(WN_EXP & 1)) transform_slice(slot & 7, vb ^ 1, slot >> 3, pr);
                 if ((WN_EXP & 64) && slot >= 15 && slot < 23 && c + 2 < nchunk) asm volatile("" :: "v"(sA[slot - 15]), "v"(sB[slot - 15]));
+                if (PRE && (slot == 13 || slot == 15 || slot == 17 || slot == 19)) {       // scale / shift of the next two pieces' channels, two slots
+                    const int jj = slot - 13, set = (jj >> 1) & 1;                          // ahead of their use (read in the piece itself, every piece
+                    const int ca = cst * 16 + gA * 8 + jj, cbb = cst * 16 + 8 + jj;          // waited an LDS round trip: 1395 -> 1345 us)
+                    pq[set][0] = *reinterpret_cast<const float2 *>(&pss[ca]);
+                    pq[set][1] = *reinterpret_cast<const float2 *>(&pss[WN_MAXCIN + ca]);
+                    pq[set][2] = *reinterpret_cast<const float2 *>(&pss[cbb]);
+                    pq[set][3] = *reinterpret_cast<const float2 *>(&pss[WN_MAXCIN + cbb]);
+                }
                 if (slot >= 15 && slot < 23 && !(WN_EXP & (2 | 64))) {
-                    store_piece(false, cst, sA, slot - 15, fst);
-                    store_piece(true, cst, sB, slot - 15, fst);
+                    const int j = slot - 15, set = (j >> 1) & 1;
+                    const bool odd = j & 1;
+                    store_piece(false, cst, sA, j, fst, PRE, odd ? pq[set][0].y : pq[set][0].x, odd ? pq[set][1].y : pq[set][1].x);
+                    store_piece(true, cst, sB, j, fst, PRE, odd ? pq[set][2].y : pq[set][2].x, odd ? pq[set][3].y : pq[set][3].x);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
