@@ -186,12 +186,20 @@ __global__ __launch_bounds__(CT) void rows_sort_kernel(const unsigned long long 
     uint32_t rank[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) rank[i] = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const unsigned long long kj = ((unsigned long long)k_sy[w][j] << 24) | k_sx[w][j];
+    if (n <= 64u) {                                                      // (wave-uniform; the usual list: 20-60 segments -- one record per lane)
+        const unsigned long long k0 = ((unsigned long long)(rec[0].sy & 0xffffffu) << 24) | (rec[0].sx_cnt >> 8);
+        for (uint32_t j = 0; j < n; ++j) {
+            const unsigned long long kj = ((unsigned long long)k_sy[w][j] << 24) | k_sx[w][j];
+            rank[0] += kj < k0 ? 1u : 0u;                              // (keys are distinct: one append per (segment, tile))
+        }
+    } else {
+        for (uint32_t j = 0; j < n; ++j) {
+            const unsigned long long kj = ((unsigned long long)k_sy[w][j] << 24) | k_sx[w][j];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const unsigned long long ki = ((unsigned long long)(rec[i].sy & 0xffffffu) << 24) | (rec[i].sx_cnt >> 8);
-            rank[i] += kj < ki ? 1u : 0u;                              // (keys are distinct: one append per (segment, tile))
+            for (int i = 0; i < PER; ++i) {
+                const unsigned long long ki = ((unsigned long long)(rec[i].sy & 0xffffffu) << 24) | (rec[i].sx_cnt >> 8);
+                rank[i] += kj < ki ? 1u : 0u;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
