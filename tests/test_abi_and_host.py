@@ -140,6 +140,10 @@ def test_device_code_has_only_the_safe_packed_fp32_form(tmp_path):
                 # rows front end -- splat_tile_kernel<.., WHOLE = true, FE = 2>, normally empty -- gets a 20-byte frame reserved by
                 # the register allocator for its loop over deferred pieces, without a single instruction that touches it.)
                 assert not re.search(r"\bscratch_(?:load|store)", isa), f"scratch instructions in code object {objects} ({triple})"
+                # no register array is indexed with a run-time value: that compiles to s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off per
+                # element (round 5: 192 such sequences were 2.8 of the Winograd workgroup's 46 us -- accumulator rows indexed with the
+                # wave's half; both halves are instantiated now)
+                assert "s_set_gpr_idx_on" not in isa and "v_movrel" not in isa, f"GPR index mode in code object {objects} ({triple})"
                 notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(co)], capture_output=True, text=True, check=True).stdout
                 kernels = re.findall(r"\.name:\s*(\S+)[\s\S]*?\.private_segment_fixed_size:\s*(\d+)", notes)
                 sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)]
