@@ -120,6 +120,10 @@ constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
 #ifndef SLR_GRAD_BENT
 #define SLR_GRAD_BENT 2                                // stage through LDS only where a wave's destinations spread over more rows than this
 #endif
+#ifndef SLR_GRAD_XCD
+#define SLR_GRAD_XCD 0                                 // 1: blocks of an XCD contiguous in the image (see grad_tile_kernel).  Measured round 5, both gradients:
+                                                       // t=30 192 -> 208 us, t=59 250 -> 327 (the slow blocks of a region pile up on one XCD); identity 166 / 167
+#endif
 #ifndef SLR_GRAD_STRIPS
 #define SLR_GRAD_STRIPS 2                              // column strips of a block with a destination box each (1, 2, 4: power of two)
 #endif
@@ -149,7 +153,15 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     const int HW = H * W;
     const int n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int y = (blockIdx.x / tiles_x) * TILE_H + wid, x = (blockIdx.x % tiles_x) * TILE_W + lane;
+#if SLR_GRAD_XCD
+    // workgroup b runs on XCD b % 8 (observed): give every XCD a contiguous band of blocks, so that the destination boxes of neighbouring
+    // blocks -- they overlap by the flow's extent -- meet in ONE L2 instead of being fetched by several
+    const int per = (int)gridDim.x >> 3, bt = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (bt >= tiles_x * ((H + TILE_H - 1) / TILE_H)) return;        // (whole workgroups, before any barrier)
+#else
+    const int bt = (int)blockIdx.x;
+#endif
+    const int y = (bt / tiles_x) * TILE_H + wid, x = (bt % tiles_x) * TILE_W + lane;
     const bool live_px = (y < H) & (x < W);
     const int i = live_px ? y * W + x : 0;
     const float *f = flow + (size_t)n * 2 * HW;
@@ -383,7 +395,7 @@ SLR_EXPORT int slr_softsplat_backward(const float *in, const float *flow, const 
     const bool tiled = SLR_GRAD_TILED && (long long)C * H * W * 4 < (1LL << 31);
     if (tiled) {
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-    dim3 grid(tiles_x * tiles_y, N);
+    dim3 grid(SLR_GRAD_XCD ? (tiles_x * tiles_y + 7) / 8 * 8 : tiles_x * tiles_y, N);
     if (grad_in && grad_flow) hipLaunchKernelGGL((grad_tile_kernel<true, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
     else if (grad_in) hipLaunchKernelGGL((grad_tile_kernel<true, false>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
     else if (grad_flow) hipLaunchKernelGGL((grad_tile_kernel<false, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
