@@ -41,23 +41,25 @@ __device__ __forceinline__ BinFoot bin_footprint(float fx, float fy, int x, int 
     static_assert(TILE_W == 64 && (TILE_H & (TILE_H - 1)) == 0, "shifts below");
     constexpr int SH_H = TILE_H == 8 ? 3 : TILE_H == 4 ? 2 : TILE_H == 16 ? 4 : TILE_H == 2 ? 1 : 0;
     static_assert((1 << SH_H) == TILE_H, "tile height");
+    constexpr int NONE = -0x40000000;                                    // "no tile column / row": sums of two of them stay negative
     const float X = (float)x + fx, Y = (float)y + fy;                    // softsplat.py:169-170
     const bool ok = (fabsf(X) < 1073741824.0f) & (fabsf(Y) < 1073741824.0f);
-    const uint32_t ux0 = (uint32_t)(ok ? (int)floorf(X) : -0x40000000), uy0 = (uint32_t)(ok ? (int)floorf(Y) : -0x40000000);
+    const uint32_t ux0 = (uint32_t)(ok ? (int)floorf(X) : NONE), uy0 = (uint32_t)(ok ? (int)floorf(Y) : NONE);
     const uint32_t ux1 = ux0 + 1u, uy1 = uy0 + 1u;
-    const bool xa = ux0 < (uint32_t)W, xb = ux1 < (uint32_t)W, ya = uy0 < (uint32_t)H, yb = uy1 < (uint32_t)H;
-    const uint32_t txa = ux0 >> 6, txb = ux1 >> 6, tya = uy0 >> SH_H, tyb = uy1 >> SH_H;
-    const bool same_x = txb == txa;
-    const bool vxb = xb & !(xa & same_x), vyb = yb & !(ya & (tyb == tya));        // the second column / row only when distinct
-    const int ra = (int)(tya * (uint32_t)tiles_x), rb = (int)(tyb * (uint32_t)tiles_x);
+    // tile column of corner column x0 / x0 + 1 (NONE outside the image); the second one only when it is another column -- validity lives in
+    // the sign of the values, not in booleans (which this compiler materialises in registers and recombines: a third of the function)
+    const int ca = ux0 < (uint32_t)W ? (int)(ux0 >> 6) : NONE;
+    const int cb0 = ux1 < (uint32_t)W ? (int)(ux1 >> 6) : NONE;
+    const bool same_x = cb0 == ca;                                      // (both NONE: nothing lands anyway)
+    const int cb = same_x ? NONE : cb0;
+    const int ra = uy0 < (uint32_t)H ? (int)(uy0 >> SH_H) * tiles_x : NONE;
+    const int rb0 = uy1 < (uint32_t)H ? (int)(uy1 >> SH_H) * tiles_x : NONE;
+    const int rb = rb0 == ra ? NONE : rb0;
     BinFoot f;
-    f.t0 = (xa & ya) ? ra + (int)txa : -1;
-    f.t1 = (vxb & ya) ? ra + (int)txb : -1;
-    f.t2 = (xa & vyb) ? rb + (int)txa : -1;
-    f.t3 = (vxb & vyb) ? rb + (int)txb : -1;
+    f.t0 = max(ra + ca, -1); f.t1 = max(ra + cb, -1); f.t2 = max(rb + ca, -1); f.t3 = max(rb + cb, -1);
     const uint32_t b0 = 1u << ((ux0 >> 3) & 7u), b1 = 1u << ((ux1 >> 3) & 7u);
-    f.cm_a = xa ? (b0 | ((xb & same_x) ? b1 : 0u)) : 0u;
-    f.cm_b = vxb ? b1 : 0u;
+    f.cm_a = ca >= 0 ? (same_x ? b0 | b1 : b0) : 0u;                   // x0 + 1 in the same tile column: its octant joins column a's mask
+    f.cm_b = cb >= 0 ? b1 : 0u;
     return f;
 }
 
