@@ -1,24 +1,27 @@
 // conv_wino.hpp -- the fp32 rung's 3x3 convolution as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (gfx950); included by conv.hip.
 //
 // The fp32 rung (SLR_CONV_F32: fp32 operands, fp32 products, fp32 accumulation -- the arithmetic class of the reference's decoder,
-// models/layers/partialconv2d.py:61-74) runs at 0.84 of the fp32 matrix peak (157 TFLOP/s) as a direct implicit GEMM: it can only get
+// models/layers/partialconv2d.py:61-74) runs at 0.85 of the fp32 matrix peak (157 TFLOP/s) as a direct implicit GEMM: it can only get
 // faster by doing fewer multiplications.  F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input patch with 16 multiplications per
 // (input channel, output channel) instead of 36:  Y = A^T [ (G g G^T) .* (B^T d B) ] A, summed over the input channels BEFORE the
 // output transform -- i.e. 16 independent GEMMs (one per position xi of the 4x4 transformed tile) of [couts x cins] x [cins x tiles].
 //
-// One workgroup (256 work-items = 4 waves, TWO per CU: 79 KiB of LDS, 128 accumulator registers per wave) = an 8 x 16 output block
-// (32 tiles of 2x2) x 64 output channels:
-//   * staging: the (8+2) x (32+2) halo block of 16 input channels, through the same prologue as the direct kernel
-//     (relu(x*scale - shift)*mask, zero padding), as fp32 rows in LDS (`raw`, single buffer);
-//   * input transform: every work-item turns 4 patches (4 channels of one tile) into V[xi][cin][tile] (32 additions per patch),
-//     double-buffered in LDS -- the transform of chunk c + 1 is issued between the MFMAs of chunk c;
-//   * wave (cot, tb) owns the 32 output channels cot x the 32 tiles tb for ALL 16 positions: 16 accumulator tiles of 32x32; per chunk
-//     and position 8 MFMAs (K = 2 input channels each) whose B operand is ONE ds_read_b32 of V and whose A operand (the transformed
-//     weights U = G g G^T, prepared by slr_conv3x3_wino_weights in fragment order) comes from L2, one position ahead;
-//   * output transform in registers (the 16 positions of a (channel, tile) pair sit in one lane), then the direct kernel's epilogues
-//     (plain + bias + residual, or the partial-convolution one with its mask box sum, next-layer BN, update mask) on the 2x2 pixels.
-// 2.25x fewer MFMAs than the direct kernel per output; the transforms are additions only (exact up to fp32 rounding; the error of
-// F(2x2, 3x3) in fp32 is within a small factor of the direct fp32 convolution's -- tests/test_gpu_conv_f32.py measures both against fp64).
+// One workgroup (256 work-items = 4 waves, TWO workgroups per CU: 80 KB of LDS each, 128 accumulator registers per wave) = an 8 x 16
+// output block (32 tiles of 2x2) x 64 output channels:
+//   * staging: the (8+2) x (16+2) halo block of 16 input channels through the same prologue as the direct kernel
+//     (relu(x*scale - shift)*mask, zero padding) as fp32 rows in LDS (`raw`, single buffer): the global loads of chunk c + 3 are issued
+//     behind the weight loads of chunk c's last pair, chunk c + 2 is stored piece by piece in slots 15-22 of chunk c (branch-free);
+//   * input transform: every work-item turns 2 patches (2 channels of one tile) into V[xi][cin][tile] (32 additions per patch),
+//     double-buffered in LDS -- the transform of chunk c + 1 runs in 7 slices between the MFMAs of chunk c (slots 0-6 and 8-14);
+//   * wave (cot, xh) owns 32 output channels x the 32 tiles x 8 of the 16 positions: 8 accumulator tiles of 32x32; per chunk and
+//     position 8 MFMAs (K = 2 input channels each) whose B operand is ONE ds_read_b32 of V and whose A operand (the transformed
+//     weights U = G g G^T, prepared by slr_conv3x3_wino_weights in fragment order) comes from L2, a pair of positions ahead;
+//   * after the last chunk the two halves of the positions meet through LDS; output transform in registers, then the direct kernel's
+//     epilogues (plain + bias + residual, or the partial-convolution one with its mask box sum, next-layer BN, update mask) on the
+//     2x2 pixels, per-channel constants from an LDS table, the residual requested before the exchange.
+// 2.25x fewer MFMAs than the direct kernel per output; the transforms are additions only.  Accuracy: per layer 2 - 4x the direct fp32
+// kernel's error against fp64 (tests/test_gpu_conv_f32.py measures both); what that does to whole frames of an ill-conditioned network
+// is in DESIGN.md 3.4 -- the reason this is a rung of its own (convs="fp32-winograd"), not the strict fp32 rung.
 #pragma once
 #include <type_traits>
 
