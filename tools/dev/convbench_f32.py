@@ -25,7 +25,7 @@ for cin, cout, h, w in ((128, 128, 768, 1280), (256, 256, 384, 640), (64, 128, 7
         t_split = timeit(lambda: conv(x, layout=LAY))
         with nets.fp32_kernels(winograd=False):
             t_f32 = timeit(lambda: conv(x, layout=LAY))
-        with nets.fp32_kernels():
+        with nets.fp32_kernels(winograd=True):
             t_w = timeit(lambda: conv(x, layout=LAY))
         t_mi = timeit(lambda: F.conv2d(x, conv.weight, conv.bias, padding=1), 5)
     print(f"{cin:4d}->{cout:4d} {h}x{w}: split-f16 {t_split:8.1f} us ({fl / t_split / 1e6:6.1f} TF) | fp32 rung {t_f32:8.1f} us ({fl / t_f32 / 1e6:6.1f} TF = {fl / t_f32 / 1e6 / 157.3:.2f} of 157.3) | Winograd fp32 {t_w:8.1f} us ({fl / t_w / 1e6:6.1f} TF direct-equivalent) | MIOpen fp32 {t_mi:8.1f} us ({fl / t_mi / 1e6:6.1f} TF)")

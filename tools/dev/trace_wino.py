@@ -15,7 +15,7 @@ x = torch.randn(1, cin, h, w, device="cuda")
 nb = 1 << 16
 LAY = 0 if '--nchw' in sys.argv else nets.IN_B8 | nets.OUT_B8        # the networks' activations are channel-blocked
 buf = torch.zeros(nb * 16, dtype=torch.int64, device="cuda")
-with torch.no_grad(), nets.fp32_kernels():
+with torch.no_grad(), nets.fp32_kernels(winograd=True):
     for _ in range(3):
         y = conv(x, layout=LAY)
     torch.cuda.synchronize()
