@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 7
+#define SLR_ABI_VERSION 8
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -192,6 +192,12 @@ int slr_clip_plan_build(const float *disp_f, const int *idx_f, const float *disp
  * side on one XCD and shares its L2.  Per frame of work at 768x1280: 239 us with 1 frame per launch, 158 with 8, 151 with 16.
  * Arrays of nb entries: disp_f / disp_p / out / norm_out (device pointers per frame; norm_out may be NULL), alpha,
  * frame (index into the plan, every frame at most once); n_items = nb work-item counts (slr_clip_plan_totals) or NULL (all unknown). */
+/* (ABI 8) exp_weights of the three clip calls below is a set of flags: bit 0 = exp weights (as before), SLR_SYNTH_VALUES_B4 = `values` is
+ * plane-blocked by 4 in memory, [C/4][H][W][4] (C % 4 == 0, the stack below 2 GiB), as slr_pack_planes4 writes it: the 4 planes of a chunk
+ * are then ONE 16-byte load per source pixel instead of four 4-byte loads.  The outputs stay [C,H,W]; same arithmetic in the same order. */
+#define SLR_SYNTH_VALUES_B4 2
+/* in [N,C,H,W] -> out [N,C/4,H,W,4] (C % 4 == 0; out 16-byte aligned, not in place): once per clip for its feature planes. */
+int slr_pack_planes4(const float *in, float *out, int N, int C, int H, int W, void *stream);
 int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,
                                const float *const *disp_f, const float *const *disp_p, const float *alpha,
                                float *const *out, float *const *norm_out, int C, int H, int W, float eps,

@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 7
+ABI_VERSION = 8
 WS_PREBINNED, WS_CLEAN = 1, 2       # include/slr_splat.h: flags of the `prebinned` argument
 
 # every symbol include/slr_splat.h declares
@@ -20,7 +20,7 @@ SYMBOLS = (
     "slr_softsplat_forward", "slr_softsplat_mode_forward", "slr_splat_normalize",
     "slr_synth_group", "slr_global_max",
     "slr_clip_plan_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
-    "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch",
+    "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch", "slr_pack_planes4",
     "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_wino_weight_bytes", "slr_conv3x3_wino_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
@@ -91,6 +91,7 @@ def lib():
             "slr_clip_plan_build": [fp, vp, fp, vp, i, i, i, vp, sz, vp],
             "slr_synth_group_clip": [fp, fp, fp, i, fp, fp, f, fp, fp, i, i, i, f, vp, sz, i, i, i, vp],
             "slr_synth_group_clip_batch": [fp, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, vp],
+            "slr_pack_planes4": [fp, fp, i, i, i, i, vp],
             "slr_synth_two_groups_clip_batch": [fp, fp, fp, i, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, vp],
             "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],

@@ -26,6 +26,8 @@ namespace slr {
 
 using ClipCfg = TileCfg<2, SLR_EPT_TWO, false, SLR_KREG_TWO>;      // two flows: 1536 entries per workgroup, 8-byte records, 79 KiB of LDS
 using ClipPassCfg = TileCfg<2, SLR_EPT_DEFER, false, SLR_KREG_TWO>; // the pass-by-pass launch: passes of 2048 entries, 103 KiB
+using ClipCfgB4 = TileCfg<2, SLR_EPT_TWO, false, SLR_KREG_TWO, true>;         // ... with the value planes plane-blocked by 4 (slr_pack_planes4)
+using ClipPassCfgB4 = TileCfg<2, SLR_EPT_DEFER, false, SLR_KREG_TWO, true>;
 constexpr int CT = TT;                             // work-items per workgroup = output pixels of a tile
 constexpr int C_SEG = ClipCfg::SEG;                // entries a workgroup stages at once
 constexpr int C_MAXB = SLR_CLIP_MAXB;              // frames per launch
@@ -339,9 +341,9 @@ __global__ __launch_bounds__(CT) void rows_plan_pair_kernel(const unsigned long 
 //  between two workgroups of ~75 us.  The loop keeps the by-value kernel arguments live around the whole body: 80 spilled SGPRs, and the
 //  kernel went from 152 to 190 us per frame of work even with one round per workgroup, 202 us with 512 persistent ones.  It needs the
 //  per-frame arguments in memory, read per item, first.)
-template <bool G2, bool PASSES>
+template <bool G2, bool PASSES, bool B4 = false>
 SLR_TILE_KERNEL __global__ __launch_bounds__(CT, PASSES ? 1 : SLR_WAVES_CLIP) void clip_tile_kernel(ClipBatch b) {
-    using Cfg = std::conditional_t<PASSES, ClipPassCfg, ClipCfg>;
+    using Cfg = std::conditional_t<PASSES, std::conditional_t<B4, ClipPassCfgB4, ClipPassCfg>, std::conditional_t<B4, ClipCfgB4, ClipCfg>>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
     const TileShared &s = b.s;
@@ -415,18 +417,23 @@ static int clip_check(int nframes, int C, int H, int W, const char *who) {
     return 0;
 }
 
-template <bool G2, bool PASSES>
+template <bool G2, bool PASSES, bool B4 = false>
 static int launch_clip_kernel(const ClipBatch &b, uint32_t grid, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device
     static bool attr_set[64] = {};
     int dev = 0;
     SLR_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)clip_tile_kernel<G2, PASSES>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)clip_tile_kernel<G2, PASSES, B4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((clip_tile_kernel<G2, PASSES>), dim3(grid), dim3(CT), PASSES ? ClipPassCfg::LDS_BYTES : ClipCfg::LDS_BYTES, st, b);
+    hipLaunchKernelGGL((clip_tile_kernel<G2, PASSES, B4>), dim3(grid), dim3(CT), PASSES ? ClipPassCfg::LDS_BYTES : ClipCfg::LDS_BYTES, st, b);
     return 0;
+}
+template <bool PASSES>
+static int launch_clip_kernel(const ClipBatch &b, uint32_t grid, bool g2, bool b4, hipStream_t st) {
+    if (g2) return b4 ? launch_clip_kernel<true, PASSES, true>(b, grid, st) : launch_clip_kernel<true, PASSES, false>(b, grid, st);
+    return b4 ? launch_clip_kernel<false, PASSES, true>(b, grid, st) : launch_clip_kernel<false, PASSES, false>(b, grid, st);
 }
 
 extern thread_local void *g_ev_start, *g_ev_stop;          // slr_splat_time_next (splat.hip)
@@ -485,8 +492,9 @@ SLR_EXPORT int slr_clip_plan_build(const float *disp_f, const int *idx_f, const 
 
 // The fused kernel (+ the pass-by-pass launch) over the frames of `b`, once per plane group (plane_group, splat_op.hip: one group unless
 // the plane stack reaches 2 GiB).  Groups after the first take the kernel without the second weight group and write no normaliser.
-static int launch_clip_groups(ClipBatch &b, uint32_t grid, bool g2, hipStream_t st) {
+static int launch_clip_groups(ClipBatch &b, uint32_t grid, bool g2, hipStream_t st, bool b4 = false) {
     const int C = b.s.C, gp = plane_group(C, b.s.H, b.s.W);
+    SLR_CHECK_ARG(!b4 || (C % 4 == 0 && gp >= C), "plane-blocked values: C % 4 == 0 and the whole stack below 2 GiB");
     const size_t hw = (size_t)b.s.H * b.s.W;
     const float *values = b.s.in;
     float *outs[C_MAXB];
@@ -502,14 +510,12 @@ static int launch_clip_groups(ClipBatch &b, uint32_t grid, bool g2, hipStream_t 
         const bool two = g2 && pb == 0;
         if (pb == 0 && g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));        // slr_splat_time_next: the dominant kernel only
         if (grid) {
-            if (two) { if (int e = launch_clip_kernel<true, false>(b, grid, st)) return e; }
-            else if (int e = launch_clip_kernel<false, false>(b, grid, st)) return e;
+            if (int e = launch_clip_kernel<false>(b, grid, two, b4, st)) return e;
         }
         if (pb == 0 && g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
         if (pb == 0) g_ev_start = g_ev_stop = nullptr;
         // pieces of more than SEG entries (none for ordinary flows): pass by pass
-        if (two) { if (int e = launch_clip_kernel<true, true>(b, b.nb * C_DEFER_WG, st)) return e; }
-        else if (int e = launch_clip_kernel<false, true>(b, b.nb * C_DEFER_WG, st)) return e;
+        if (int e = launch_clip_kernel<true>(b, b.nb * C_DEFER_WG, two, b4, st)) return e;
     }
     SLR_CHECK_LAUNCH();
     return 0;
@@ -536,7 +542,8 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
     ClipBatch b = {};
     b.s.in = values; b.s.mul = wlogit; b.s.mulmax = wmax; b.s.in2 = values2; b.s.mul2 = wlogit2;
     b.s.N = 1; b.s.C = C; b.s.H = H; b.s.W = W; b.s.tiles_x = L.tiles_x; b.s.tiles = L.tiles;
-    b.s.mulmode = wmax ? MUL_EXP_SHIFT : (exp_weights ? MUL_EXP : MUL_PLANE);
+    const bool b4 = (exp_weights & SLR_SYNTH_VALUES_B4) != 0;
+    b.s.mulmode = wmax ? MUL_EXP_SHIFT : ((exp_weights & 1) ? MUL_EXP : MUL_PLANE);
     b.s.mulmode2 = exp_weights2 ? MUL_EXP : MUL_PLANE;
     b.s.norm_mode = SLR_NORM_CLAMP_EPS;
     b.s.eps = eps;
@@ -573,7 +580,7 @@ static int synth_clip_batch(const float *values, const float *wlogit, const floa
     // of frame k.  With the groups of 8 * C_XCD blocks dealt round-robin over the frames they run side by side on the same XCD and
     // share its L2 (frames with fewer groups leave a few empty blocks).
     const uint32_t grid = b.interleave ? gmax * b.nb : gsum;
-    return launch_clip_groups(b, grid, values2 != nullptr, st);
+    return launch_clip_groups(b, grid, values2 != nullptr, st, b4);
 }
 
 // slr_synth_group: one frame from two workspaces that slr_splat_bin / slr_splat_bin_pair filled (no clip plan).  Their row lists are
@@ -617,6 +624,25 @@ SLR_EXPORT int slr_synth_group(const float *values, const float *wlogit, const f
     f.scale[0] = alpha; f.scale[1] = 1.0f - alpha;
     f.grid = ((wf.L.items2_cap + 8 * C_XCD - 1) / (8 * C_XCD)) * 8 * C_XCD;
     return launch_clip_groups(b, f.grid, false, st);
+}
+
+// [N,C,H,W] -> [N,C/4,H,W,4]: what SLR_SYNTH_VALUES_B4 reads (a clip's feature planes, once per clip)
+__global__ __launch_bounds__(256) void pack_planes4_kernel(const float *__restrict__ in, float4 *__restrict__ out, size_t hw, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t q = i / hw, p = i - q * hw;                   // q = sample * C/4 + chunk
+        const float *src = in + q * 4 * hw + p;
+        out[i] = make_float4(src[0], src[hw], src[2 * hw], src[3 * hw]);
+    }
+}
+
+SLR_EXPORT int slr_pack_planes4(const float *in, float *out, int N, int C, int H, int W, void *stream) {
+    SLR_CHECK_ARG(in && out && in != out, "null pointer / in place");
+    SLR_CHECK_ARG(N > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0 && !((uintptr_t)out & 15), "N, C % 4 == 0, H, W; 16-byte aligned output");
+    const size_t hw = (size_t)H * W, total = (size_t)N * (C / 4) * hw;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536u * 16u ? (total + 255) / 256 : 65536u * 16u);
+    hipLaunchKernelGGL(pack_planes4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (float4 *)out, hw, total);
+    SLR_CHECK_LAUNCH();
+    return 0;
 }
 
 SLR_EXPORT int slr_synth_group_clip_batch(const float *values, const float *wlogit, const float *wmax, int exp_weights,

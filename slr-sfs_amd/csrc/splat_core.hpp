@@ -34,6 +34,16 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
 __device__ __forceinline__ float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// 16 bytes at a 16-byte aligned offset.  (The whole vector is bit-cast before its elements are taken: with the elements of the builtin's
+// integer vector bit-cast one by one, this compiler narrows the load to ONE dword and splats it -- tests/test_abi_and_host.py counts the
+// buffer_load_dwordx4 of the clip kernels.)
+typedef unsigned int buf_u32x4 __attribute__((vector_size(16)));
+typedef float buf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const buf_f32x4 f = __builtin_bit_cast(buf_f32x4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
 __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, SLR_STORE_AUX);
 }

@@ -31,10 +31,13 @@ enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
 // records of an output pixel kept in registers across the chunks.  LDS: counts | scan words | misc | offsets | records | staged
 // values (+ the all-zero slot).  One flow: EPT 2, REC6 -> 46 KiB, three workgroups per CU; two flows: EPT 3, 8-byte records
 // (their lists are twice as long: one ds_read_b64 per record beats two reads) -> 79 KiB, two per CU.
-template <int NDIR_, int EPT_, bool REC6_, int KREG_>
+// B4: the value planes are plane-blocked by 4 in memory ([C/4][H][W][4], slr_pack_planes4: the clip path packs its feature planes once per
+// clip): a chunk's 4 planes of an entry are ONE 16-byte load that arrives as the staged float4 -- a quarter of the load instructions.
+template <int NDIR_, int EPT_, bool REC6_, int KREG_, bool B4_ = false>
 struct TileCfg {
     static constexpr int NDIR = NDIR_, EPT = EPT_, KREG = KREG_, CHUNK = 4;
-    static constexpr bool REC6 = REC6_;
+    static constexpr bool REC6 = REC6_, B4 = B4_;
+    static_assert(!B4_ || EPT_ <= 4, "one 16-byte load per gather stop");
     static constexpr int SEG = EPT * TT;
     static constexpr int RECCAP = 4 * SEG + TT;    // <= 4 records per entry + one pad per pixel (odd list lengths: bank spreading)
     static constexpr uint32_t NULL_E = SEG;        // staged-entry index of the all-zero slot
@@ -149,6 +152,15 @@ struct EntryRegs {
 
 template <class Cfg>
 __device__ __forceinline__ void prefetch_planes(rsrc_t rin, const EntryRegs<Cfg> &e, float (&pre)[Cfg::EPT][4], int c0, int cmax, uint32_t hw4) {
+    if constexpr (Cfg::B4) {                           // (C % 4 == 0, chunks start at multiples of 4: past the last chunk re-read it)
+        const uint32_t soff = (uint32_t)(min(c0, cmax - 3) >> 2) * (hw4 * 4u);
+#pragma unroll
+        for (int j = 0; j < Cfg::EPT; ++j) {
+            const float4 v = buf_ld4(rin, e.off[j] * 4u, soff);
+            pre[j][0] = v.x; pre[j][1] = v.y; pre[j][2] = v.z; pre[j][3] = v.w;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t soff = (uint32_t)min(c0 + u, cmax) * hw4;           // (planes past the last re-read it)
@@ -494,6 +506,15 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
                 return;
             }
             if (SLR_SKIP & 1) return;
+            if constexpr (Cfg::B4) {                              // one entry's 16 bytes per stop
+                if (u < EPT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float4 v = buf_ld4(rin, e.off[u] * 4u, (uint32_t)(min(c0 + 8, cmax - 3) >> 2) * (hw4 * 4u));
+                    pre[u][0] = v.x; pre[u][1] = v.y; pre[u][2] = v.z; pre[u][3] = v.w;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t soff = (uint32_t)min(c0 + 8 + u, cmax) * hw4;
 #pragma unroll

@@ -109,6 +109,8 @@ def synth_group(values, wlogit, disp_f, disp_p, alpha, ws_f, ws_p, wmax=None, ex
     return (out, norm) if return_norm else out
 
 
+VALUES_B4 = 2         # include/slr_splat.h: SLR_SYNTH_VALUES_B4
+USE_B4 = os.environ.get("SLR_SFS_AMD_VALUES_B4", "1") != "0"
 PLAN_CHUNK = 64      # frames per clip plan (bounds the plan buffer: ~16 MB of bin lists per map at 768x1280, worst case)
 
 
@@ -181,7 +183,7 @@ class MotionPlan:
 
 
 def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, eps=1e-8, return_norm=False, timed=False,
-                     out=None):
+                     out=None, values_b4=None):
     """synth_group for frame t of a MotionPlan (bins and work plan prepared per clip).
     out: optional [1,C,H,W] destination (e.g. one sample of a batch buffer the decoder will read)."""
     require_device(values, wlogit, wmax)
@@ -198,7 +200,8 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
     with torch.cuda.device(values.device):
         if timed and kernel_timing is not None:
             _arm_timer(values)
-        check(lib().slr_synth_group_clip(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0,
+        flags = (1 if exp_weights else 0) | (VALUES_B4 if values_b4 is not None else 0)
+        check(lib().slr_synth_group_clip(ptr(values if values_b4 is None else values_b4), ptr(wlogit), ptr(wmax), flags,
                                          ptr(disp_f), ptr(disp_p), float(alpha), ptr(out), ptr(norm), C, H, W,
                                          float(eps), ptr(plan), plan.numel(), n, i, n_items, stream_of(values)), "slr_synth_group_clip")
     return (out, norm) if return_norm else out
@@ -207,12 +210,27 @@ def synth_group_clip(values, wlogit, mp, t, alpha, wmax=None, exp_weights=True, 
 MAX_BATCH = min(16, max(1, int(os.environ.get("SLR_SFS_AMD_SPLAT_BATCH", "16"))))   # frames per launch of slr_synth_group_clip_batch (csrc: SLR_CLIP_MAXB = 16; 8 / 12 / 16: 158 / 153 / 151-153 us per frame of work)
 
 
+
+
+def pack_planes4(values):
+    """[N,C,H,W] -> the same planes blocked by 4 in memory ([N,C/4,H,W,4], carried in a tensor of the logical shape [N,C,H,W]): what the
+    clip kernels read with one 16-byte load per chunk and source pixel (slr_pack_planes4; once per clip)."""
+    require_device(values)
+    assert values.is_contiguous() and values.shape[1] % 4 == 0
+    out = torch.empty_like(values)
+    N, C, H, W = values.shape
+    with torch.cuda.device(values.device):
+        check(lib().slr_pack_planes4(ptr(values), ptr(out), N, C, H, W, stream_of(values)), "slr_pack_planes4")
+    return out
+
+
 def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_weights=True, eps=1e-8, timed=False,
-                           group2=None):
+                           group2=None, values_b4=None):
     """synth_group_clip for up to MAX_BATCH frames `ts` of ONE chunk of a MotionPlan in one launch of the tile kernel:
     outs[k] ([1,C,H,W], e.g. the samples of a decoder batch) receives frame ts[k].
     group2 = (values2 [1,1,H,W], wlogit2 [1,1,H,W], outs2): a second weight group (exp weights) splatted by the same launch
-    with the same records -- the 2-layer model's alpha plane (slr_synth_two_groups_clip_batch)."""
+    with the same records -- the 2-layer model's alpha plane (slr_synth_two_groups_clip_batch).
+    values_b4: pack_planes4(values) -- the kernel then reads that copy (same results, a quarter of the plane loads)."""
     require_device(values, wlogit, wmax, *outs)
     assert values.shape[0] == 1 and wlogit.shape[1] == 1 and 1 <= len(ts) <= MAX_BATCH and len(outs) == len(ts)
     _, C, H, W = values.shape
@@ -230,11 +248,14 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
     n_items = (ctypes.c_int * nb)(*[lk[3] for lk in look])
     for o in outs:
         assert o.shape == values.shape and o.device == values.device
+    flags = (1 if exp_weights else 0) | (VALUES_B4 if values_b4 is not None else 0)
+    vsrc = values if values_b4 is None else values_b4
+    assert vsrc.shape == values.shape and vsrc.device == values.device
     with torch.cuda.device(values.device):
         if timed and kernel_timing is not None:
             _arm_timer(values, nb)
         if group2 is None:
-            check(L.slr_synth_group_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, df, dp, al, op,
+            check(L.slr_synth_group_clip_batch(ptr(vsrc), ptr(wlogit), ptr(wmax), flags, df, dp, al, op,
                                                None, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb, n_items,
                                                stream_of(values)), "slr_synth_group_clip_batch")
         else:
@@ -243,7 +264,7 @@ def synth_group_clip_batch(values, wlogit, mp, ts, alphas, outs, wmax=None, exp_
             assert v2.shape == (1, 1, H, W) and w2.shape == (1, 1, H, W) and len(outs2) == nb
             assert all(o.shape == (1, 1, H, W) and o.is_contiguous() for o in outs2)
             op2 = PP(*[o.data_ptr() for o in outs2])
-            check(L.slr_synth_two_groups_clip_batch(ptr(values), ptr(wlogit), ptr(wmax), 1 if exp_weights else 0, ptr(v2), ptr(w2), 1,
+            check(L.slr_synth_two_groups_clip_batch(ptr(vsrc), ptr(wlogit), ptr(wmax), flags, ptr(v2), ptr(w2), 1,
                                                     df, dp, al, op, op2, C, H, W, float(eps), ptr(plan), plan.numel(), n, fr, nb,
                                                     n_items, stream_of(values)),
                   "slr_synth_two_groups_clip_batch")
@@ -296,6 +317,9 @@ class ClipSynthesizer:
             else:                                                      # :974-976: same weights as the features
                 self.fs = torch.cat([self.fs, af], 1).contiguous()
                 self.C += 1
+        # the feature planes once more, blocked by 4 in memory: the clip kernels read a chunk's 4 planes of a source pixel with ONE 16-byte
+        # load (251 MB and 0.1 ms per clip at 768x1280; env SLR_SFS_AMD_VALUES_B4=0: the planar tensor as in round 4)
+        self.fs4 = pack_planes4(self.fs) if (USE_B4 and self.C % 4 == 0 and self.fs.numel() * 4 < 2 ** 31) else None
 
     def alpha(self, t):
         a = torch.tensor(1.0, dtype=torch.float32) - torch.tensor(float(t), dtype=torch.float32) / \
@@ -337,7 +361,7 @@ class ClipSynthesizer:
             with _stage("frame", self.fs.device, frames=len(grp)):
                 # (2-layer model: the alpha plane, weighted by alpha0, rides in the same launch as a second weight group)
                 synth_group_clip_batch(self.fs, self.Z, self.plan, grp, al, [out[k:k + 1] for k in range(k0, k1)],
-                                       wmax=self.zmax, timed=True,
+                                       wmax=self.zmax, timed=True, values_b4=self.fs4,
                                        group2=(self.af, self.A0, [out_alpha[k:k + 1] for k in range(k0, k1)]) if self.v1 else None)
             k0 = k1
 
@@ -352,9 +376,10 @@ class ClipSynthesizer:
         if self.v1 and self.use_alpha0 and not return_norm:      # both weight groups in one launch
             gen = out if out is not None else torch.empty_like(self.fs)
             afl = out_alpha if out_alpha is not None else self.fs.new_empty(1, 1, *self.fs.shape[2:])
-            synth_group_clip_batch(self.fs, Zt, self.plan, [t], [a], [gen], wmax=self.zmax, timed=True, group2=(self.af, self.A0, [afl]))
+            synth_group_clip_batch(self.fs, Zt, self.plan, [t], [a], [gen], wmax=self.zmax, timed=True, group2=(self.af, self.A0, [afl]),
+                                   values_b4=self.fs4)
             return gen, afl
-        res = synth_group_clip(self.fs, Zt, self.plan, t, a, wmax=self.zmax, return_norm=return_norm, timed=True, out=out)
+        res = synth_group_clip(self.fs, Zt, self.plan, t, a, wmax=self.zmax, return_norm=return_norm, timed=True, out=out, values_b4=self.fs4)
         gen, norm = res if return_norm else (res, None)
         if not self.v1:
             return (gen, norm) if return_norm else gen

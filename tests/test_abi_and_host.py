@@ -144,6 +144,11 @@ def test_device_code_has_only_the_safe_packed_fp32_form(tmp_path):
                 # element (round 5: 192 such sequences were 2.8 of the Winograd workgroup's 46 us -- accumulator rows indexed with the
                 # wave's half; both halves are instantiated now)
                 assert "s_set_gpr_idx_on" not in isa and "v_movrel" not in isa, f"GPR index mode in code object {objects} ({triple})"
+                # the clip kernels on plane-blocked values load 16 bytes per entry and chunk: this compiler narrows
+                # __builtin_amdgcn_raw_buffer_load_b128 to ONE dword (and splats it) when the elements of its integer result are bit-cast one
+                # by one (csrc/splat_core.hpp: buf_ld4) -- 12 such loads in each of the four blocked instantiations
+                if "clip_tile_kernel" in isa:
+                    assert isa.count("buffer_load_dwordx4") >= 48, isa.count("buffer_load_dwordx4")
                 notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(co)], capture_output=True, text=True, check=True).stdout
                 kernels = re.findall(r"\.name:\s*(\S+)[\s\S]*?\.private_segment_fixed_size:\s*(\d+)", notes)
                 sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)]

@@ -1895,3 +1895,40 @@ def test_channel_blocked_resample_and_skip_kernels(S):
         ref = conv(x, None, res)
         assert torch.equal(conv(x, None, res, layout=nets.OUT_B8), to_b8(ref))                                  # NCHW residual
         assert torch.equal(conv(xb, None, to_b8(res), layout=nets.IN_B8 | nets.OUT_B8 | nets.RES_B8), to_b8(ref))   # blocked residual
+
+
+@pytest.mark.gpu
+def test_clip_kernels_on_plane_blocked_values(S):
+    """SLR_SYNTH_VALUES_B4 (ABI 8): slr_pack_planes4 writes [C/4][H][W][4]; the clip kernels then read a chunk's 4 planes of a source pixel
+    with one 16-byte load.  Same arithmetic as on the planar tensor: the two agree to the run-to-run noise of the summation order
+    (pieces whose entry slots come from atomics), and with the oracle; a ragged grid, both models' packings, one frame and a batch."""
+    from slr_sfs_amd import synthesis
+    torch.manual_seed(5)
+    H, W, N = 88, 200, 9
+    fs = torch.randn(1, 64, H, W, device="cuda")
+    Z = torch.randn(1, 1, H, W, device="cuda")
+    motion = torch.from_numpy(smooth_motion(H, W, 3, amp=2.0)).cuda()
+    p4 = synthesis.pack_planes4(fs)
+    assert torch.equal(p4.view(1, 16, H, W, 4), fs.view(1, 16, 4, H, W).permute(0, 1, 3, 4, 2))
+    af, abg = torch.randn(1, 1, H, W, device="cuda"), torch.rand(1, 1, H, W, device="cuda")
+    for kw in ({}, {"alpha_fluid_logit": af, "alpha_bg": abg}):
+        res = {}
+        for b4 in (True, False):
+            old = synthesis.USE_B4
+            synthesis.USE_B4 = b4
+            try:
+                cs = synthesis.ClipSynthesizer(fs, Z, motion, N, **kw)
+            finally:
+                synthesis.USE_B4 = old
+            assert (cs.fs4 is not None) == b4
+            ts = [1, 4, 5, 8]
+            out = torch.empty(len(ts), 64, H, W, device="cuda")
+            oa = torch.empty(len(ts), 1, H, W, device="cuda") if kw else None
+            cs.features_batch(ts, out, oa)
+            one = cs.features(4)
+            res[b4] = (out, oa, one[0] if isinstance(one, tuple) else one)
+        for a, b in zip(res[True], res[False]):
+            if a is not None:
+                assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+        assert float((res[True][0][1] - res[True][2][0]).abs().max()) < 2e-5 * max(1.0, float(res[True][0].abs().max()))     # batch == single call
+
