@@ -19,7 +19,7 @@ A step  : ONE 60-frame clip, everything included (both all-frames Euler passes, 
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     : the fused clip kernel (slr::clip_tile_kernel<G2,false>, csrc/splat_clip.hip: the kernel that does
+  roofline     : the fused clip kernel (slr::clip_tile_kernel<G2,false,B4 = true>, csrc/splat_clip.hip; its feature planes plane-blocked by 4: the kernel that does
                  the exp-weighted two-direction splat + normalisation of one frame), timed
                  with HIP events on its launch stream inside the timed steps.
                  algorithmic bytes per launch = 2 * (2*65+2)*H*W*4 = 1038.1 MB at C3
@@ -158,7 +158,8 @@ def splat_roofline(kev, sev, c_splat, kernel):
     alg = splat_alg_bytes(c_splat)
     ach = alg / (k_avg * 1e-6) / 1e9
     frames = [(e0.elapsed_time(e1) * 1e3, nf) for k, e0, e1, nf in sev if k == "frame"]
-    prep = [e0.elapsed_time(e1) * 1e3 for k, e0, e1, nf in sev if k == "prep"]
+    prep = [e0.elapsed_time(e1) * 1e3 for k, e0, e1, nf in sev if k in ("prep", "prep+")]
+    nclips = sum(1 for k, *_ in sev if k == "prep")
     stage_us = (sum(us for us, _ in frames) + sum(prep)) / max(1, sum(nf for _, nf in frames))
     # the fused operator's own minimum traffic: 64 feature planes + Z + 2 x 2 displacement planes in, 64 planes out
     min_bytes = (c_splat - 1 + 1 + 4 + c_splat - 1) * H * W * 4
@@ -172,9 +173,9 @@ def splat_roofline(kev, sev, c_splat, kernel):
             "max_us": round(per_frame[-1], 1), "launches": len(launches),
             "note": "avg/min/max_us = launch duration / frames in the launch; achieved = alg_bytes_per_launch / launch_avg_us",
             "stage_us": round(stage_us, 1), "stage_frac": round(alg / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-            "stage_prep_us_per_clip": round(sum(prep) / max(1, len(prep)), 1),
+            "stage_prep_us_per_clip": round(sum(prep) / max(1, nclips), 1),
             "stage": "per frame: fused tile kernel + the (normally empty) pass-by-pass launch; per clip / frames: both "
-                     "all-frames Euler passes + row lists and plan of all displacement maps"}
+                     "all-frames Euler passes + row lists and plan of all displacement maps + the feature planes packed by 4"}
 
 
 def main():
@@ -229,7 +230,7 @@ def main():
     assert clip.shape == ((NFRAMES, H, W, 3) if u8 else (NFRAMES, 3, H, W)) and (u8 or bool(torch.isfinite(clip).all()))
 
     c_splat = 65 if a.workload == "c3" else 67              # planes per reference splat call (v1: 67)
-    roofline = splat_roofline(kev, sev, c_splat, "slr::clip_tile_kernel<false,false>" if a.workload == "c3" else "slr::clip_tile_kernel<true,false>")
+    roofline = splat_roofline(kev, sev, c_splat, "slr::clip_tile_kernel<false,false,true>" if a.workload == "c3" else "slr::clip_tile_kernel<true,false,true>")
 
     extra, cpu, parity = {}, None, None
     if world > 1 and (a.assembly, a.encoder) == ("final", "redundant"):
@@ -450,7 +451,7 @@ def context_measurements(workload, image, motion, dev):
                   "parity_err": parity_check(m2, image, motion, other, dev),
                   "workload": ("C4 SLR-v1 2-layer pipeline (fluid + background + alpha), " if other == "c4" else
                                "C3 baseline pipeline, ") + "768x1280, N=60",
-                  "roofline": splat_roofline(kev, sev, c2, "slr::clip_tile_kernel<G2,false> (" +
+                  "roofline": splat_roofline(kev, sev, c2, "slr::clip_tile_kernel<G2,false,true> (" +
                                              ("64 features + the alpha group" if other == "c4" else "64 features") + ")")}
     del m2
     # ---- the all-fp32 context: the same C3 clip with every convolution in the reference's arithmetic (fp32 operands, products and

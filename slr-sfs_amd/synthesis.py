@@ -24,8 +24,8 @@ from .euler_integration_manipulator import euler_integration_all
 # bench.py sets this to a list to collect (start, stop) torch events around the tile kernel of
 # every synth_group call with timed=True (through slr_splat_time_next); None = no timing.
 kernel_timing = None
-# bench.py sets this to a list to collect ("prep" | "frame", start, stop, frames) torch events around the WHOLE splat
-# stage: "prep" = the per-clip motion work (Euler passes, binning, planning), "frame" = one features(t) call or one
+# bench.py sets this to a list to collect ("prep" | "prep+" | "frame", start, stop, frames) torch events around the WHOLE splat
+# stage: "prep" = the per-clip motion work (Euler passes, binning, planning), "prep+" = the clip's feature planes packed by 4, "frame" = one features(t) call or one
 # features_batch group (`frames` of them in one launch).
 stage_timing = None
 
@@ -319,7 +319,10 @@ class ClipSynthesizer:
                 self.C += 1
         # the feature planes once more, blocked by 4 in memory: the clip kernels read a chunk's 4 planes of a source pixel with ONE 16-byte
         # load (251 MB and 0.1 ms per clip at 768x1280; env SLR_SFS_AMD_VALUES_B4=0: the planar tensor as in round 4)
-        self.fs4 = pack_planes4(self.fs) if (USE_B4 and self.C % 4 == 0 and self.fs.numel() * 4 < 2 ** 31) else None
+        self.fs4 = None
+        if USE_B4 and self.C % 4 == 0 and self.fs.numel() * 4 < 2 ** 31:
+            with _stage("prep+", self.fs.device):           # (more per-clip work of the splat stage: counted in bench.py's stage_us)
+                self.fs4 = pack_planes4(self.fs)
 
     def alpha(self, t):
         a = torch.tensor(1.0, dtype=torch.float32) - torch.tensor(float(t), dtype=torch.float32) / \

@@ -32,8 +32,8 @@ pmc() {     # name, kernel pattern, units of work per dispatch, command...
     python tools/pmc_kernel_traffic.py $out/pmc_$name "$pat" $out/traffic_$name.json $units
     find $out/pmc_$name -name "*.csv" -delete; find $out/pmc_$name -name "*.log" -delete
 }
-pmc clip_c3 "clip_tile_kernel<false, false>" 15 python tools/splat_stage.py
-pmc clip_c4 "clip_tile_kernel<true, false>" 15 python tools/splat_stage.py v1
+pmc clip_c3 "clip_tile_kernel<false, false, true>" 15 python tools/splat_stage.py
+pmc clip_c4 "clip_tile_kernel<true, false, true>" 15 python tools/splat_stage.py v1
 pmc op_rows_t30 "op_rows_kernel<false, false, false>" 1 python tools/dev/fe_one.py 2 t30
 pmc op_rows_t59 "op_rows_kernel<false, false, false>" 1 python tools/dev/fe_one.py 2 t59
 pmc op_scan_c2 "op_scan_kernel<true, false, false>" 1 python tools/dev/fe_one.py 1 c2
