@@ -167,6 +167,10 @@
 #endif
 
 // ---- development aids
+#ifndef SLR_OUT_B8_EXP
+#define SLR_OUT_B8_EXP 0          // experiment: the clip kernels on blocked planes also WRITE channel-blocked by 8 (tools/dev/b4_check.py --out-b8): correct,
+                                 // and 209 against 135 us per frame -- a chunk's 16-byte store fills HALF of a pixel's 32 bytes, the other half comes a chunk later
+#endif
 #ifndef SLR_SKIP
 #define SLR_SKIP 0              // deletion experiments on the chunk pipeline (WRONG results; timing only): 1 no plane loads, 2 no staging stores,
 #endif                          // 4 no register-record reads, 8 no list loop, 16 no output stores (first chunk excepted), 32 no barriers

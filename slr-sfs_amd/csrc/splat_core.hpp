@@ -44,6 +44,10 @@ __device__ __forceinline__ float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff
     const buf_f32x4 f = __builtin_bit_cast(buf_f32x4, v);
     return make_float4(f.x, f.y, f.z, f.w);
 }
+__device__ __forceinline__ void buf_st4(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {     // 16 bytes at a 16-byte aligned offset
+    const buf_f32x4 f = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_u32x4, f), r, voff, soff, SLR_STORE_AUX);
+}
 __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, SLR_STORE_AUX);
 }

@@ -524,6 +524,14 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
         if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));
         if (!(SLR_SKIP & 32)) __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up)
         if (c0 - cb < 32) T_STAMP(s, 13 + 6 * ((c0 - cb) / 4));
+#if SLR_OUT_B8_EXP
+        if constexpr (Cfg::B4 && !ACCUM) {            // experiment: the output channel-blocked by 8 ([C/8][H][W][8]): one 16-byte store per chunk
+            float4 r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (NORM) { r4.x *= inv; r4.y *= inv; r4.z *= inv; r4.w *= inv; }
+            buf_st4(rout, inside ? opix * 32u + (uint32_t)(c0 & 4) * 4u : BUF_OOB, (uint32_t)(c0 >> 3) * (hw4 * 8u), r4);
+            return;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (FULL || c0 + u < ce) {                // (scalar: only the last chunk of a plane count that is not a multiple of 4)

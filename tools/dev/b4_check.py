@@ -18,6 +18,9 @@ for b4 in (True, False, 'again'):
     cs.features_batch(ts, out)
     outs[b4] = out
 torch.cuda.synchronize()
+if "--out-b8" in sys.argv:                         # experiment build (-DSLR_OUT_B8_EXP=1): the B4 kernels write [C/8][H][W][8]
+    o = outs[True]
+    outs[True] = o.view(o.shape[0], 8, H, W, 8).permute(0, 1, 4, 2, 3).reshape(o.shape)
 print("B4 vs planar: equal", torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max()), "| planar vs planar again: equal", torch.equal(outs[False], outs["again"]), float((outs[False] - outs["again"]).abs().max()))
 p = synthesis.pack_planes4(fs)
 ref = fs.view(1, 16, 4, H, W).permute(0, 1, 3, 4, 2).contiguous().view_as(fs)
