@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 8
+#define SLR_ABI_VERSION 9
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -82,6 +82,20 @@ int slr_euler_integrate_all(const float *motion, int H, int W, int nmax, float s
  *   grad_disp [2,H,W] in;  grad_motion [2,H,W] out (zeroed here, then accumulated with fp32 atomics) */
 int slr_euler_backward(const float *motion, int H, int W, int nsteps, float sign, const float *grad_disp,
                        float *grad_motion, void *stream);
+
+/* EulerIntegration(opt).forward(motion, destination_frame) -- the batch form the training step calls
+ * (models/projection/euler_integration_manipulator.py:58-71, used at animating_softmax_splating.py:579-580): every sample
+ * b integrated for its own steps[b] in ONE launch; the step counts stay on the device (the reference loops over b in
+ * Python and reads destination_frame[b] on the host).
+ *   motion [B,2,H,W];  steps [B] int64 ON THE DEVICE (what `index.long()` arithmetic yields; <= 0: no step, :36)
+ *   disp [B,2,H,W] out;  visible [B,H,W] out, may be NULL.  Per sample bit-exact with slr_euler_integrate. */
+int slr_euler_integrate_batch(const float *motion, const long long *steps, int B, int H, int W, float sign,
+                              float *disp, float *visible, void *stream);
+
+/* Gradient of slr_euler_integrate_batch w.r.t. the motion fields (per sample: slr_euler_backward).
+ *   grad_disp [B,2,H,W] in;  grad_motion [B,2,H,W] out (zeroed here) */
+int slr_euler_backward_batch(const float *motion, const long long *steps, int B, int H, int W, float sign,
+                             const float *grad_disp, float *grad_motion, void *stream);
 
 /* ------------------------------------------------------------------ splat: workspace, binning, front ends */
 

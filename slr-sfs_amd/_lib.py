@@ -7,13 +7,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 8
+ABI_VERSION = 9
 WS_PREBINNED, WS_CLEAN = 1, 2       # include/slr_splat.h: flags of the `prebinned` argument
 
 # every symbol include/slr_splat.h declares
 SYMBOLS = (
     "slr_abi_version", "slr_last_error", "slr_splat_time_next",
-    "slr_euler_integrate", "slr_euler_integrate_all", "slr_euler_backward",
+    "slr_euler_integrate", "slr_euler_integrate_all", "slr_euler_backward", "slr_euler_integrate_batch", "slr_euler_backward_batch",
     "slr_splat_workspace_bytes", "slr_splat_workspace_init", "slr_splat_bin", "slr_splat_bin_pair", "slr_splat_set_scan_max_tiles",
     "slr_splat_set_front_end",
     "slr_splat_set_scan_shape",
@@ -79,6 +79,8 @@ def lib():
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_backward": [fp, i, i, i, f, fp, fp, vp],
+            "slr_euler_integrate_batch": [fp, vp, i, i, i, f, fp, fp, vp],
+            "slr_euler_backward_batch": [fp, vp, i, i, i, f, fp, fp, vp],
             "slr_splat_workspace_init": [vp, sz, i, i, i, vp],
             "slr_splat_bin": [fp, i, i, i, vp, sz, vp],
             "slr_splat_bin_pair": [fp, fp, i, i, i, vp, vp, sz, vp],

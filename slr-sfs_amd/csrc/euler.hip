@@ -29,12 +29,18 @@ __device__ __forceinline__ void euler_step(const float *__restrict__ mx, const f
     py = inv ? oy : ny;
 }
 
+// grid.y = sample of a batch; steps (device, one count per sample) overrides nsteps when given: the batch form of
+// EulerIntegration.forward (euler_integration_manipulator.py:58-71) is ONE launch with no step count read back by the host.
 __global__ __launch_bounds__(256) void euler_kernel(const float *__restrict__ motion, int H, int W,
-                                                    int nsteps, float sign,
+                                                    int nsteps, const long long *__restrict__ steps, float sign,
                                                     float *__restrict__ disp, float *__restrict__ visible) {
     const int HW = H * W;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
+    const size_t b = blockIdx.y;
+    motion += b * 2 * HW; disp += b * 2 * HW;
+    if (visible) visible += b * HW;
+    if (steps) nsteps = (int)min(max(steps[b], 0ll), (long long)0x7fffffff);      // (range(1, n + 1): no step for n <= 0)
     const float *mx = motion, *my = motion + HW;
     const int y = i / W, x = i - y * W;
     const float ox = (float)x, oy = (float)y;
@@ -99,11 +105,15 @@ __global__ __launch_bounds__(256) void euler_all_kernel(const float *__restrict_
 // atomics: many paths cross the same cell; training-only path, HBM-atomic-bound, order as unspecified as torch's own
 // index_put_(accumulate=True) backward).
 __global__ __launch_bounds__(256) void euler_backward_kernel(const float *__restrict__ motion, int H, int W, int nsteps,
+                                                             const long long *__restrict__ steps,
                                                              float sign, const float *__restrict__ gdisp,
                                                              float *__restrict__ gmotion) {
     const int HW = H * W;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
+    const size_t b = blockIdx.y;                          // sample of a batch (see euler_kernel)
+    motion += b * 2 * HW; gdisp += b * 2 * HW; gmotion += b * 2 * HW;
+    if (steps) nsteps = (int)min(max(steps[b], 0ll), (long long)0x7fffffff);
     const float *mx = motion, *my = motion + HW;
     const int y = i / W, x = i - y * W;
     const float ox = (float)x, oy = (float)y;
@@ -136,7 +146,19 @@ SLR_EXPORT int slr_euler_integrate(const float *motion, int H, int W, int nsteps
     SLR_CHECK_ARG(sign == 1.0f || sign == -1.0f, "sign must be +1 or -1");
     int blocks = (H * W + 255) / 256;
     hipLaunchKernelGGL(slr::euler_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       motion, H, W, nsteps, sign, disp, visible);
+                       motion, H, W, nsteps, (const long long *)nullptr, sign, disp, visible);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_euler_integrate_batch(const float *motion, const long long *steps, int B, int H, int W, float sign,
+                                         float *disp, float *visible, void *stream) {
+    SLR_CHECK_ARG(motion && steps && disp, "null pointer");
+    SLR_CHECK_ARG(B > 0 && B < 65536 && H > 0 && W > 0, "sizes");
+    SLR_CHECK_ARG((long long)H * W < (1LL << 30), "H*W too large");
+    SLR_CHECK_ARG(sign == 1.0f || sign == -1.0f, "sign must be +1 or -1");
+    hipLaunchKernelGGL(slr::euler_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       motion, H, W, 0, steps, sign, disp, visible);
     SLR_CHECK_LAUNCH();
     return 0;
 }
@@ -164,7 +186,22 @@ SLR_EXPORT int slr_euler_backward(const float *motion, int H, int W, int nsteps,
     hipLaunchKernelGGL(slr::zero_f32_kernel, dim3(2 * blocks), dim3(256), 0, (hipStream_t)stream, grad_motion,
                        (size_t)2 * H * W);
     hipLaunchKernelGGL(slr::euler_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, motion, H, W, nsteps,
-                       sign, grad_disp, grad_motion);
+                       (const long long *)nullptr, sign, grad_disp, grad_motion);
+    SLR_CHECK_LAUNCH();
+    return 0;
+}
+
+SLR_EXPORT int slr_euler_backward_batch(const float *motion, const long long *steps, int B, int H, int W, float sign,
+                                        const float *grad_disp, float *grad_motion, void *stream) {
+    SLR_CHECK_ARG(motion && steps && grad_disp && grad_motion, "null pointer");
+    SLR_CHECK_ARG(B > 0 && B < 65536 && H > 0 && W > 0, "sizes");
+    SLR_CHECK_ARG((long long)H * W < (1LL << 30) && (long long)B * H * W < (1LL << 40), "sizes too large");
+    SLR_CHECK_ARG(sign == 1.0f || sign == -1.0f, "sign must be +1 or -1");
+    const int blocks = (H * W + 255) / 256;
+    const size_t n = (size_t)B * 2 * H * W;
+    hipLaunchKernelGGL(slr::zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_motion, n);
+    hipLaunchKernelGGL(slr::euler_backward_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, motion, H, W, 0,
+                       steps, sign, grad_disp, grad_motion);
     SLR_CHECK_LAUNCH();
     return 0;
 }

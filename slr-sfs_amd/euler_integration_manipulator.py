@@ -98,18 +98,72 @@ def euler_integration_all(motion, nmax, sign=1.0, want_visible=True):
     return disp, vis
 
 
+def _steps_on_device(destination_frame, batch, device):
+    """Per-sample step counts as an int64 tensor on `device` without reading anything back: the training step hands over
+    `middle_index.long() - start_index.long()` (animating_softmax_splating.py:579-580), already on the device."""
+    if torch.is_tensor(destination_frame):
+        steps = destination_frame.reshape(-1)
+    else:
+        steps = torch.as_tensor([int(v) for v in destination_frame], dtype=torch.int64)
+    assert steps.numel() >= batch, f'{steps.numel()} step counts for a batch of {batch}'
+    return steps[:batch].to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
+
+
+def _integrate_batch(motion, steps):
+    b, _, height, width = motion.shape
+    disp = torch.empty_like(motion)
+    vis = motion.new_empty(b, 1, height, width)
+    with torch.cuda.device(motion.device):
+        check(lib().slr_euler_integrate_batch(ptr(motion), ptr(steps), b, height, width, 1.0, ptr(disp), ptr(vis),
+                                              stream_of(motion)), "slr_euler_integrate_batch")
+    return disp, vis
+
+
+class _EulerIntegrateBatch(torch.autograd.Function):
+    """The batch of _EulerIntegrate: one launch forward, one backward, step counts never leave the device."""
+
+    @staticmethod
+    def forward(ctx, motion, steps):
+        ctx.save_for_backward(motion, steps)
+        disp, vis = _integrate_batch(motion, steps)
+        ctx.mark_non_differentiable(vis)
+        return disp, vis
+
+    @staticmethod
+    def backward(ctx, grad_disp, _grad_vis):
+        motion, steps = ctx.saved_tensors
+        grad_disp = grad_disp.contiguous()
+        require_device(grad_disp)
+        b, _, height, width = motion.shape
+        grad_motion = torch.empty_like(motion)
+        with torch.cuda.device(motion.device):
+            check(lib().slr_euler_backward_batch(ptr(motion), ptr(steps), b, height, width, 1.0, ptr(grad_disp),
+                                                 ptr(grad_motion), stream_of(motion)), "slr_euler_backward_batch")
+        return grad_motion, None
+
+
 class EulerIntegration(nn.Module):
-    """euler_integration_manipulator.py:58-71 (batch wrapper, per-sample step counts)."""
+    """euler_integration_manipulator.py:58-71 (batch wrapper, per-sample step counts).  The reference loops over the
+    samples in Python and reads every step count on the host; here the whole batch is ONE launch (`slr_euler_integrate_batch`)
+    and `destination_frame` stays where it is -- no `.item()`, no per-sample slice copies."""
 
     def __init__(self, opt=None):
         super().__init__()
         self.opt = opt
 
     def forward(self, motion, destination_frame, return_all_frames=False, show_visible_pixels=False):
-        displacements = torch.empty_like(motion)
-        visible_pixels = motion.new_empty(motion.shape[0], 1, motion.shape[2], motion.shape[3])
-        for b in range(motion.shape[0]):
-            displacements[b:b + 1], visible_pixels[b:b + 1] = euler_integration(motion[b:b + 1], destination_frame[b])
+        assert (motion.dim() == 4)
+        assert (motion.shape[1] == 2), f'Input motion field should be Bx2xHxW. Given tensor is: {motion.shape}'
+        if motion.shape[0] == 0:
+            displacements, visible_pixels = torch.empty_like(motion), motion.new_empty(0, 1, motion.shape[2], motion.shape[3])
+        else:
+            motion = motion.contiguous()
+            require_device(motion)
+            steps = _steps_on_device(destination_frame, motion.shape[0], motion.device)
+            if torch.is_grad_enabled() and motion.requires_grad:
+                displacements, visible_pixels = _EulerIntegrateBatch.apply(motion, steps)
+            else:
+                displacements, visible_pixels = _integrate_batch(motion, steps)
         if show_visible_pixels:
             return displacements, visible_pixels
         else:

@@ -78,6 +78,43 @@ def test_euler_tensor_step_count_and_module(S, golden_dir):
     assert np.array_equal(host(d1), g["module_disp"])
 
 
+def test_euler_batch_is_one_launch_without_host_sync(S, golden_dir):
+    """EulerIntegration.forward on a batch (euler_integration_manipulator.py:58-71; the training step's call,
+    animating_softmax_splating.py:579-580): 16 samples with their own step counts, bit-exact with the reference module's
+    output, gradient w.r.t. the motion fields vs torch autograd through the reference -- and with the step counts on the device the
+    call never synchronises the host (torch's sync debug mode raises on any .item() / blocking copy)."""
+    g = load(golden_dir, "euler_batch")
+    mod = S.EulerIntegration()
+    for tag in ("a", "b"):
+        m = dev(g[f"{tag}_motion"])
+        steps = torch.from_numpy(g[f"{tag}_steps"]).cuda()
+        gout = dev(g[f"{tag}_gout"])
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            d, v = mod(m, steps, show_visible_pixels=True)
+            mg_ = m.clone().requires_grad_(True)
+            dg = mod(mg_, steps)
+            (gm,) = torch.autograd.grad(dg, mg_, gout)
+            d_neg = mod(-m, steps + 1 - steps)              # (device arithmetic on the counts, as the model does)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert np.array_equal(host(d), g[f"{tag}_disp"]), tag
+        assert np.array_equal(host(v), g[f"{tag}_vis"]), tag
+        assert np.array_equal(host(dg), g[f"{tag}_disp"]), tag
+        np.testing.assert_allclose(host(gm), g[f"{tag}_gmotion"], rtol=1e-5, atol=1e-5, err_msg=tag)
+        for b in (0, 5, 15):                                 # one step of the negated field, per sample = the one-sample call
+            d1, _ = S.euler_integration(-m[b:b + 1], 1)
+            assert np.array_equal(host(d_neg[b:b + 1]), host(d1))
+        # step counts as a host tensor / a list / int32: same result
+        assert np.array_equal(host(mod(m, torch.from_numpy(g[f"{tag}_steps"]))), g[f"{tag}_disp"])
+        assert np.array_equal(host(mod(m, [int(x) for x in g[f"{tag}_steps"]])), g[f"{tag}_disp"])
+        assert np.array_equal(host(mod(m, steps.to(torch.int32))), g[f"{tag}_disp"])
+    assert mod(torch.zeros(0, 2, 4, 4).cuda(), torch.zeros(0, dtype=torch.long)).shape == (0, 2, 4, 4)
+    with pytest.raises(NotImplementedError):
+        mod(torch.zeros(2, 2, 4, 4), torch.tensor([1, 1]))
+
+
 def test_euler_all_frames_vs_oracle(S, oracle):
     for (H, W, seed) in [(48, 80, 0), (37, 53, 1)]:
         m = smooth_motion(H, W, seed, amp=2.5)

@@ -42,6 +42,18 @@ def test_euler_module_batch(oracle, golden_dir):
         assert np.array_equal(v[0], g["module_vis"][b])
 
 
+def test_euler_batch_of_16(oracle, golden_dir):
+    """The reference's EulerIntegration module on 16 samples with their own step counts (tools/make_golden_euler_batch.py)."""
+    g = _load(golden_dir, "euler_batch")
+    for tag in ("a", "b"):
+        m, steps = g[f"{tag}_motion"], g[f"{tag}_steps"]
+        assert m.shape[0] == 16
+        for b in range(m.shape[0]):
+            d, v = oracle.euler_integration(m[b:b + 1], int(steps[b]))
+            assert np.array_equal(d[0], g[f"{tag}_disp"][b]), (tag, b)
+            assert np.array_equal(v[0], g[f"{tag}_vis"][b]), (tag, b)
+
+
 def test_splat_summation_forward_backward(oracle, golden_dir):
     g = _load(golden_dir, "splat_sum")
     for i in range(int(g["count"])):
