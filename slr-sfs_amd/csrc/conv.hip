@@ -967,16 +967,11 @@ template <bool F32>
 static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st);
 
 static int conv_wino_launch(ConvArgs &a, bool in_b8, hipStream_t st) {
-    static bool attr_set[64][4] = {};
-    int dev = 0;
-    SLR_CHECK_HIP(hipGetDevice(&dev));
+    static LdsOptIn attr[4];
     const int which = (a.pre != PRE_NONE ? 2 : 0) + (in_b8 ? 1 : 0);
     const void *fn = which == 3 ? (const void *)conv3x3_wino_kernel<true, true> : which == 2 ? (const void *)conv3x3_wino_kernel<true, false>
                    : which == 1 ? (const void *)conv3x3_wino_kernel<false, true> : (const void *)conv3x3_wino_kernel<false, false>;
-    if (dev < 0 || dev >= 64 || !attr_set[dev][which]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES));
-        if (dev >= 0 && dev < 64) attr_set[dev][which] = true;
-    }
+    if (int e = lds_opt_in(fn, (int)WN_LDS_BYTES, attr[which])) return e;
     a.tiles_x = (a.W + WN_BW - 1) / WN_BW;
     a.nchunk = conv_cin_pad(a.Cin) / 16;
     a.xscale = 1.0f; a.unscale = 1.0f;

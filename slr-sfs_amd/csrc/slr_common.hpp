@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 
 #include "../../include/slr_splat.h"
 #include "slr_tuning.hpp"
@@ -22,6 +23,19 @@ void set_error(const char *fmt, ...);
          if (e_ != hipSuccess) { slr::set_error("%s: %s", __func__, hipGetErrorString(e_)); return (int)e_; } } while (0)
 
 #define SLR_CHECK_LAUNCH() SLR_CHECK_HIP(hipGetLastError())
+
+// More than 64 KiB of dynamic LDS needs an explicit opt-in per kernel and device: set once per (kernel, device), safe to call from
+// several host threads (the flags are atomics; the attribute call itself is idempotent, a lost race only repeats it).
+struct LdsOptIn { std::atomic<bool> done[64] = {}; };
+inline int lds_opt_in(const void *kernel, int bytes, LdsOptIn &st) {
+    int dev = 0;
+    SLR_CHECK_HIP(hipGetDevice(&dev));                  // (a process may drive several GPUs)
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && st.done[dev].load(std::memory_order_acquire)) return 0;
+    SLR_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (tracked) st.done[dev].store(true, std::memory_order_release);
+    return 0;
+}
 
 // ---- geometry of the output tiling ------------------------------------------------------
 // One workgroup owns a TILE_H x TILE_W block of OUTPUT pixels of one sample ("tile"); its bin

@@ -420,13 +420,8 @@ static int clip_check(int nframes, int C, int H, int W, const char *who) {
 template <bool G2, bool PASSES, bool B4 = false>
 static int launch_clip_kernel(const ClipBatch &b, uint32_t grid, hipStream_t st) {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device
-    static bool attr_set[64] = {};
-    int dev = 0;
-    SLR_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)clip_tile_kernel<G2, PASSES, B4>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static LdsOptIn attr;
+    if (int e = lds_opt_in((const void *)clip_tile_kernel<G2, PASSES, B4>, 159 * 1024, attr)) return e;
     hipLaunchKernelGGL((clip_tile_kernel<G2, PASSES, B4>), dim3(grid), dim3(CT), PASSES ? ClipPassCfg::LDS_BYTES : ClipCfg::LDS_BYTES, st, b);
     return 0;
 }

@@ -712,17 +712,6 @@ static void scan_shape(uint32_t nt, int C, uint32_t &pieces, uint32_t &groups) {
     groups = groups < byc ? groups : byc;
 }
 
-template <typename K>
-static int set_lds_attr(K kernel, bool (&done)[64]) {
-    int dev = 0;
-    SLR_CHECK_HIP(hipGetDevice(&dev));                  // (a process may drive several GPUs)
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-        SLR_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        if (dev >= 0 && dev < 64) done[dev] = true;
-    }
-    return 0;
-}
-
 // rowbin + plan of one flow into its workspace (the binning of slr_splat_bin and of every self-contained rows call).
 static int do_rowbin(const float *flow, OpWs &w, int N, int H, int W, bool clean, hipStream_t st) {
     const uint32_t nt = w.L.nt;
@@ -736,9 +725,9 @@ static int do_rowbin(const float *flow, OpWs &w, int N, int H, int W, bool clean
 
 template <bool NORM, bool MAXOP>
 static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
-    static bool attr_main[64] = {}, attr_pass[64] = {};
-    if (int e = set_lds_attr(op_rows_kernel<NORM, MAXOP, false>, attr_main)) return e;
-    if (int e = set_lds_attr(op_rows_kernel<NORM, MAXOP, true>, attr_pass)) return e;
+    static LdsOptIn attr_main, attr_pass;
+    if (int e = lds_opt_in((const void *)op_rows_kernel<NORM, MAXOP, false>, 159 * 1024, attr_main)) return e;
+    if (int e = lds_opt_in((const void *)op_rows_kernel<NORM, MAXOP, true>, 159 * 1024, attr_pass)) return e;
     a.f.rowlist[0] = w.rowlist; a.f.items = w.items; a.f.totals = w.totals; a.f.defer = w.defer; a.f.items_cap = w.L.items_cap;
     // (the grid covers the bound on the plan's items; workgroups past totals[0] exit at once: measured free)
     const uint32_t grid = ((w.L.items_cap + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
@@ -757,9 +746,9 @@ static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
 
 template <bool NORM, bool MAXOP>
 static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
-    static bool attr[64] = {}, attr_d[64] = {};
-    if (int e = set_lds_attr(op_scan_kernel<NORM, MAXOP, false>, attr)) return e;
-    if (int e = set_lds_attr(op_scan_kernel<NORM, MAXOP, true>, attr_d)) return e;
+    static LdsOptIn attr, attr_d;
+    if (int e = lds_opt_in((const void *)op_scan_kernel<NORM, MAXOP, false>, 159 * 1024, attr)) return e;
+    if (int e = lds_opt_in((const void *)op_scan_kernel<NORM, MAXOP, true>, 159 * 1024, attr_d)) return e;
     a.f.box = (const SrcBox *)w.box; a.f.totals = w.totals; a.f.defer = w.defer;
     hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
     const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;

@@ -42,7 +42,7 @@ class _Route(threading.local):
     torch_convs = False                  # inside torch_convolutions(): every stage through its torch definition (fp32)
     act_scale = 64.0                     # pre-scale of the activations in the split-f16 kernels (include/slr_splat.h: xscale)
     f32_kernels = False                  # inside fp32_kernels(): the convolutions on the fp32 matrix instructions (the fp32 rung)
-    winograd = True                      # ... its 3x3 convolutions as Winograd F(2x2, 3x3) (csrc/conv_wino.hpp); False: direct
+    winograd = False                     # ... its 3x3 convolutions as Winograd F(2x2, 3x3) (csrc/conv_wino.hpp); False (= FP32_WINOGRAD): direct
 
 
 _S = _Route()

@@ -279,10 +279,14 @@ class ClipSynthesizer:
                                use_alpha0=True, clamp_alpha=True).features(t)   -> gen_fs, alpha_fluid
     ``plan``: a MotionPlan built earlier for the same motion / N (the animators build it before the encoder);
     ``frames``: the frames that will be asked for (default all; a rank of a sharded job passes its share).
+    ``blocked_planes``: keep a second copy of the feature planes blocked by 4 ([C/4][H][W][4]) for the clip kernels -- one 16-byte load
+    per chunk and source pixel, 150 -> 134 us per frame -- at the cost of the planes' size once more for the life of the clip (+251 MB
+    at 64 x 768 x 1280; the planar tensor stays: the single-frame / normaliser paths and callers read it).  None: on, unless the
+    environment says SLR_SFS_AMD_VALUES_B4=0; False for many live clips on a tight memory budget.
     """
 
     def __init__(self, fs, Z, motion, N, alpha_fluid_logit=None, alpha_bg=None, use_alpha0=True,
-                 clamp_alpha=None, softmax_v1=False, softmax_v2=False, clamp_z=None, plan=None, frames=None):
+                 clamp_alpha=None, softmax_v1=False, softmax_v2=False, clamp_z=None, plan=None, frames=None, blocked_planes=None):
         require_device(fs, Z, motion)
         assert fs.shape[0] == 1 and Z.shape[1] == 1 and motion.shape[1] == 2
         self.N = int(N)
@@ -320,7 +324,7 @@ class ClipSynthesizer:
         # the feature planes once more, blocked by 4 in memory: the clip kernels read a chunk's 4 planes of a source pixel with ONE 16-byte
         # load (251 MB and 0.1 ms per clip at 768x1280; env SLR_SFS_AMD_VALUES_B4=0: the planar tensor as in round 4)
         self.fs4 = None
-        if USE_B4 and self.C % 4 == 0 and self.fs.numel() * 4 < 2 ** 31:
+        if (USE_B4 if blocked_planes is None else blocked_planes) and self.C % 4 == 0 and self.fs.numel() * 4 < 2 ** 31:
             with _stage("prep+", self.fs.device):           # (more per-clip work of the splat stage: counted in bench.py's stage_us)
                 self.fs4 = pack_planes4(self.fs)
 
@@ -357,7 +361,10 @@ class ClipSynthesizer:
         while k0 < len(ts):
             chunk = self.plan.chunk_of(ts[k0])
             k1 = k0 + 1
-            while k1 < len(ts) and k1 - k0 < MAX_BATCH and self.plan.chunk_of(ts[k1]) is chunk:
+            # (a launch renders each of its frames once -- slr_synth_group_clip_batch rejects a repeated frame index -- so a frame list
+            #  with repeats, e.g. a ping-pong loop [.., N-2, N-1, N-1, N-2, ..], closes the group at the repeat: the reference's frame
+            #  loop takes any index list, test_*_4eval_rawsize.py:234-245)
+            while k1 < len(ts) and k1 - k0 < MAX_BATCH and self.plan.chunk_of(ts[k1]) is chunk and ts[k1] not in ts[k0:k1]:
                 k1 += 1
             grp = ts[k0:k1]
             al = [self.alpha(t) for t in grp]

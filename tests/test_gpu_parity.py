@@ -951,6 +951,24 @@ def test_banded_encoder_is_exact(S):
         assert (a - b).abs().max().item() < 1e-4
 
 
+def test_repeated_frames_in_one_batch(S):
+    """A frame list with repeats inside one 16-frame splat batch (a ping-pong loop; frames=[3, 3]): the reference's frame loop takes
+    any index list (test_baseline_4eval_rawsize.py:234-245).  The tile launch renders each of its frames once, so the grouping closes
+    a launch at a repeat: every output slot equals the frame rendered on its own, for both models."""
+    torch.manual_seed(5)
+    img = torch.rand(1, 3, 72, 136, device="cuda") * 2 - 1
+    m = torch.randn(1, 2, 72, 136, device="cuda")
+    N = 6
+    with torch.no_grad():
+        for an in (S.pipeline.BaselineAnimator().cuda().eval(), S.pipeline.SLRv1Animator().cuda().eval()):
+            single = {t: an.synthesize(img, m, N, frames=[t]) for t in range(N)}
+            for frames in ([0, 1, 1, 0], [3, 3], [0, 1, 2, 3, 4, 5, 5, 4, 3, 2, 1, 0], [2, 2, 2, 5]):
+                got = an.synthesize(img, m, N, frames=frames)
+                assert got.shape[0] == len(frames)
+                for k, t in enumerate(frames):
+                    assert torch.allclose(got[k], single[t][0], rtol=0, atol=2e-6, equal_nan=True), (frames, k)
+
+
 def _run_two_ranks(backend):
     import socket
     import subprocess
