@@ -71,6 +71,44 @@ def static_traffic(name, units):
     return round(tj["traffic_bytes_per_unit"] * units), src
 
 
+def measured_traffic(workload):
+    """HBM-side bytes of the dominant kernel (the fused clip kernel) per frame of work, MEASURED IN THIS RUN: after the timed steps, two child
+    processes run the splat stage of the same workload (tools/splat_stage.py: same sizes, same kernels, synthetic feature planes) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, kernel-trace only, as MI355X_MICROARCH.md
+    prescribes); FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64; calibrated on this access pattern, profiles/r5_fetch_calibration.txt),
+    WRITE_SIZE exact, both in KiB, mean over the kernel's dispatches / the 15 frames a dispatch of that command renders on average.
+    -> (bytes per frame, description) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not on this box"
+    pat = "clip_tile_kernel<false, false, true>" if workload == "c3" else "clip_tile_kernel<true, false, true>"
+    tmp = tempfile.mkdtemp(prefix="slr_pmc_", dir="/tmp")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "splat_stage.py")] + (["v1"] if workload != "c3" else [])
+            try:
+                subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), timeout=170, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except Exception as e:
+                return None, f"rocprofv3 pass {counter} failed: {type(e).__name__}"
+            vals = []
+            for f in glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if pat in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 pass {counter}: no dispatch of {pat} in the counter file"
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per_dispatch = got["FETCH_SIZE"][0] * 1024 * 2.0 + got["WRITE_SIZE"][0] * 1024
+    return per_dispatch / 15.0, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE, separate passes over tools/splat_stage.py after the "
+                                 f"timed steps, {got['FETCH_SIZE'][1]} + {got['WRITE_SIZE'][1]} dispatches of {pat}; read "
+                                 f"{got['FETCH_SIZE'][0] * 2048 / 15e6:.1f} MB + written {got['WRITE_SIZE'][0] * 1024 / 15e6:.1f} MB per frame")
+
+
 def csrc_hash():
     """sha256 (first 16 hex digits) over the sources of the splat kernels (the files the fused tile kernel is built from)."""
     import hashlib
@@ -146,7 +184,7 @@ def timed_clips(step, steps, warmup, world, dev):
     return dt, clip, kev, sev
 
 
-def splat_roofline(kev, sev, c_splat, kernel):
+def splat_roofline(kev, sev, c_splat, kernel, measured=None):
     """Tile kernel (HIP events recorded by the library around that launch) and the whole stage per frame."""
     # one launch of the tile kernel does the work of `nf` frames (pipeline.DECODE_BATCH of them share a launch)
     launches = [(e0.elapsed_time(e1) * 1e3, nf) for e0, e1, nf in kev]
@@ -164,6 +202,10 @@ def splat_roofline(kev, sev, c_splat, kernel):
     # the fused operator's own minimum traffic: 64 feature planes + Z + 2 x 2 displacement planes in, 64 planes out
     min_bytes = (c_splat - 1 + 1 + 4 + c_splat - 1) * H * W * 4
     traffic, src = static_traffic("clip_c3" if c_splat == 65 else "clip_c4", fpl)
+    if measured is not None and measured[0]:              # bytes per frame of work from this run's own counter passes
+        traffic, src = round(measured[0] * fpl), measured[1]
+    elif measured is not None and src:
+        src += f" (in-run counter passes unavailable: {measured[1]})"
     return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
             "frac_traffic": None if not traffic else round(traffic / (l_avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -186,6 +228,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the context measurements after the timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE of the clip kernel) after the timed steps")
+    ap.add_argument("--full-line", action="store_true", help="also put the context objects into the last line (rounds 1-5 format, > 10 KB)")
     ap.add_argument("--assembly", default="final", choices=["rounds", "final"],
                     help="N>1: ONE all-gather of the finished clip (default, the north_star form) | all-gather per round of frames "
                          "under the next round")
@@ -230,8 +274,6 @@ def main():
     assert clip.shape == ((NFRAMES, H, W, 3) if u8 else (NFRAMES, 3, H, W)) and (u8 or bool(torch.isfinite(clip).all()))
 
     c_splat = 65 if a.workload == "c3" else 67              # planes per reference splat call (v1: 67)
-    roofline = splat_roofline(kev, sev, c_splat, "slr::clip_tile_kernel<false,false,true>" if a.workload == "c3" else "slr::clip_tile_kernel<true,false,true>")
-
     extra, cpu, parity = {}, None, None
     if world > 1 and (a.assembly, a.encoder) == ("final", "redundant"):
         # context beside the contract form: per-round hidden all-gathers + banded encoder (every rank takes part)
@@ -254,6 +296,14 @@ def main():
             extra["context_error"] = f"{type(e).__name__}: {e}"[:500]
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(motion.cpu().numpy())
+    # HBM bytes of the dominant kernel from counter passes taken NOW, on this box (child processes; the static file is the fallback)
+    meas = None
+    if rank == 0 and world == 1 and not a.no_pmc and not a.no_extras:
+        try:
+            meas = measured_traffic(a.workload)
+        except Exception as e:
+            meas = (None, f"{type(e).__name__}: {e}"[:200])
+    roofline = splat_roofline(kev, sev, c_splat, "slr::clip_tile_kernel<false,false,true>" if a.workload == "c3" else "slr::clip_tile_kernel<true,false,true>", meas)
 
     if rank == 0:
         frame_bytes = 3 * H * W * 4
@@ -295,11 +345,92 @@ def main():
                        "frames_rank0": mine, "collective_bytes_received_per_rank_per_clip": moved},
             "roofline": roofline, "parity_err": parity, "cpu_baseline": cpu,
         }
-        line.update(extra)
-        print(json.dumps(line), flush=True)
+        emit(line, extra, a.full_line)
     if world > 1:
         dist.barrier()                               # rank 0's extra measurements are done: leave together
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ output
+
+def _pick(d, *keys):
+    return None if not d else {k: d[k] for k in keys if k in d}
+
+
+def emit(line, extra, full=False):
+    """Context first, contract last.  Every context object goes out on a line of its own, prefixed `#ctx <name> ` (not a JSON line: a reader
+    that takes the first or the last JSON line of stdout finds the contract line either way); the LAST line is the contract of the task
+    statement, compact (about 2 KB) so that a record keeping the tail of stdout holds it whole: metric, value, config, dtype, roofline,
+    cpu_baseline, parity_err and the headline figure of every context leg -- the strict-fp32 clip rate (`fps_fp32_convs`), the other
+    pipeline (`c4_fps` / `c3_fps`), the drop-in operator, the training shape, the backward."""
+    ctx = {"roofline_full": line["roofline"], "parity_err_full": line["parity_err"], "cpu_baseline_full": line["cpu_baseline"]}
+    ctx.update(extra)
+    for k, v in ctx.items():
+        if v is not None:
+            print(f"#ctx {k} " + json.dumps(v), flush=True)
+    if full:
+        big = dict(line)
+        big.update(extra)
+        print("#ctx full_line " + json.dumps(big), flush=True)
+    c = dict(line)
+    c["dtype"] = "f32 (splat path fp32; convs: fp32 in/out/accumulate, operands as 2 x f16 splits = 22 bits; all-fp32 rate = fps_fp32_convs)"
+    c["config"] = {k: v for k, v in line["config"].items() if v is not None and k not in ("H", "W", "frames_per_step")}
+    r = line["roofline"]
+    c["roofline"] = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "alg_bytes_per_launch",
+                          "frames_per_launch", "launch_avg_us", "frac_min_bytes", "avg_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
+    src = r.get("traffic_source") or ""
+    c["roofline"]["traffic_source"] = "measured in this run" if src.startswith("measured in this run") else ("static (profiles/), not this run" if src else None)
+    pe = line["parity_err"]
+    if pe:
+        c["parity_err"] = {"ok": pe.get("ok"), "tolerance": pe.get("tolerance"),
+                           "decoder_input_vs_oracle": pe.get("timed_clip_decoder_input_vs_oracle_max_abs"),
+                           "vs_reference_forward_flow_digest": pe.get("reference_forward_flow_digest_max_abs"),
+                           "frames_vs_reference_models": pe.get("frames_vs_reference_models_max_abs"),
+                           "frames_256_vs_reference_models": pe.get("frames_256_vs_reference_models_digest_max_abs"),
+                           "holes": pe.get("holes"), "reference_holes": pe.get("reference_holes")}
+    cb = line["cpu_baseline"]
+    if cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s (splat stage)", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                             "one_thread": cb["one_thread"]["value"], "with_decoder": cb["with_decoder"]["value"]}
+    f32 = extra.get("fps_fp32_convs")
+    if f32:
+        c["fps_fp32_convs"] = f32["value"]                       # the same clip with every convolution in plain fp32 (direct kernels)
+        c["fps_fp32_winograd"] = f32["winograd"]["value"]
+    for other in ("c3", "c4"):
+        if other in extra:
+            c[f"{other}_fps"] = extra[other]["value"]
+            c[f"{other}_roofline_frac"] = extra[other]["roofline"]["frac"]
+            c[f"{other}_parity_ok"] = (extra[other].get("parity_err") or {}).get("ok")
+    d = extra.get("roofline_dropin")
+    if d:
+        fl = d["flows"]
+        c["dropin"] = {"what": "one-flow operator, whole call (all launches, HIP graph): us, fraction of 8 TB/s on B_sum",
+                       "frac": d.get("frac"), "frac_is": d.get("frac_is")}
+        for k in ("euler_t30", "euler_t59", "identity", "incoherent"):
+            if k in fl:
+                c["dropin"][k] = [fl[k]["call_us"], fl[k]["call_frac"]]
+        c["dropin"]["c2"] = [d["c2"]["call_us"], d["c2"]["call_frac"]]
+        for k, v in d.get("small_grids", {}).items():
+            c["dropin"][k] = [v["call_us"], v["call_frac"]]
+        if "c2_batched" in d:
+            c["dropin"]["c2_batched_per_sample"] = [d["c2_batched"]["per_sample_us"], d["c2_batched"]["call_frac"]]
+        if "train_shape" in d:
+            c["train_shape"] = {k: [v["fwd_us"], v["bwd_us"], v["frac"]] for k, v in d["train_shape"]["flows"].items()}
+            c["train_shape"]["what"] = "_FunctionSoftsplat [2,65,256,256]: forward us, backward us, fraction of 8 TB/s (fwd + bwd bytes / time)"
+    b = extra.get("roofline_backward")
+    if b:
+        c["backward"] = {k: [v["avg_us"], v["frac"]] for k, v in b["flows"].items()}
+    for k in ("splat_stage_fps_1gpu", "context_error"):
+        if k in extra:
+            c[k] = extra[k]
+    if "value_rounds_banded" in extra:
+        c["value_rounds_banded"] = _pick(extra["value_rounds_banded"], "value", "unit")
+    if "communicator" in extra:                                 # the proof of which ranks / devices took part stays in the contract line
+        cm = extra["communicator"]
+        c["communicator"] = _pick(cm, "backend", "rccl_version", "world_size", "distinct_devices")
+        c["communicator"]["ranks"] = [_pick(r, "rank", "device_index", "device_name", "pci_bus_id", "frames", "fps_this_rank") for r in cm["ranks"]]
+    c["context"] = "full objects: the '#ctx <name> {...}' lines above this one"
+    print(json.dumps(c), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ parity
@@ -580,6 +711,7 @@ def dropin_roofline(dev, motion):
         return r
 
     worst = None
+    res["train_shape"] = train_shape_roofline(dev)
     flows = [("euler_t30", S.euler_integration(motion, 30)[0]), ("euler_t59", S.euler_integration(motion, 59)[0]),
              ("identity", torch.zeros(1, 2, H, W, device=dev)), ("incoherent", torch.rand(1, 2, H, W, device=dev) * 16 - 8)]
     for name, flow in flows:
@@ -595,9 +727,12 @@ def dropin_roofline(dev, motion):
         finally:
             L.slr_splat_set_front_end(prev)
         res["flows"][name] = r
-        if name.startswith("euler") and (worst is None or r["tile_frac"] < worst["tile_frac"]):
+        if name.startswith("euler") and (worst is None or r["call_frac"] < worst["call_frac"]):
             worst = r
-    res["achieved"], res["frac"], res["avg_us"] = worst["tile_gbs"], worst["tile_frac"], worst["tile_us"]
+    # the object's own figure is the CALL a user makes (all launches of the slower Euler flow), not the tile kernel alone
+    res["achieved"], res["frac"], res["avg_us"] = round(alg / worst["call_us"] / 1e3, 1), worst["call_frac"], worst["call_us"]
+    res["frac_is"] = "call_frac of the slower Euler flow (whole call, all launches); tile_frac / tile_us beside it per flow"
+    res["tile_frac"], res["tile_us"] = worst["tile_frac"], worst["tile_us"]
     # config C2 of BASELINE.json: random 64-channel 256x480 features + flow, softmax mode, one call
     small = {}
     for tag, (c2, h2, w2) in (("c2", (64, 256, 480)), ("128x240", (64, 128, 240)), ("384x640", (65, 384, 640))):
@@ -638,6 +773,42 @@ def dropin_roofline(dev, motion):
                "front_end": "rows", "per_sample_us": round(rb["call_us"] / nb, 2)})
     res["c2_batched"] = rb
     del fb, mb, flb
+    return res
+
+
+def train_shape_roofline(dev):
+    """The shape the reference TRAINS the operator at: W = 256, batch 2 per GPU (train_animating_scripts/train_baseline2_pconv.sh:14,
+    options/train_options.py:271) -- _FunctionSoftsplat forward + backward (both gradients) on [2,65,256,256] with Euler-integrated
+    smooth flows, t = 30 and t = 59 (models/animating_softmax_splating.py:579-595: 64 features + the weight plane through
+    ModuleSoftsplat('summation'), softsplat.py:390-479).  fwd_us / bwd_us: GPU time of everything the forward call / the backward call
+    launches (20 calls in a HIP graph); bytes: forward B_sum = (2C+2) N H W 4, backward (3C+4) N H W 4."""
+    import slr_sfs_amd as S
+    from slr_sfs_amd._lib import check, lib, ptr, stream_of
+    L = lib()
+    N, C, h, w = 2, 65, 256, 256
+    x, go = torch.randn(N, C, h, w, device=dev), torch.randn(N, C, h, w, device=dev)
+    gi, gf = torch.empty_like(x), torch.empty(N, 2, h, w, device=dev)
+    mo = torch.from_numpy(np.concatenate([smooth_motion(h, w, seed=0), smooth_motion(h, w, seed=1)], 0)).to(dev)
+    alg_f, alg_b = (2 * C + 2) * N * h * w * 4, (3 * C + 4) * N * h * w * 4
+    res = {"bound": "hbm", "shape": [N, C, h, w], "peak": HBM_PEAK_GBS, "unit": "GB/s", "alg_bytes_forward": alg_f, "alg_bytes_backward": alg_b,
+           "what": "_FunctionSoftsplat forward + backward (gradInput + gradFlow) at the reference's training shape, Euler flows of two smooth fields",
+           "flows": {}}
+    for t in (30, 59):
+        fl = S.EulerIntegration()(mo, torch.tensor([t, t], device=dev)).contiguous()
+        with torch.no_grad():
+            fwd = _graph_call_us(lambda: S.softsplat._FunctionSoftsplat.apply(x, fl))
+            bwd = _graph_call_us(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), N, C, h, w, stream_of(x)), "backward"))
+        # the autograd route end to end (eager, host launch pace included): what a training step pays
+        xg, fg = x.clone().requires_grad_(True), fl.clone().requires_grad_(True)
+
+        def step():
+            with torch.enable_grad():
+                out = S.softsplat._FunctionSoftsplat.apply(xg, fg)
+                torch.autograd.grad(out, (xg, fg), go)
+        eager, _ = _time_calls(step, 20)
+        res["flows"][f"euler_t{t}"] = {"fwd_us": round(fwd, 1), "bwd_us": round(bwd, 1), "fwd_frac": round(alg_f / fwd / 1e3 / HBM_PEAK_GBS, 4),
+                                       "bwd_frac": round(alg_b / bwd / 1e3 / HBM_PEAK_GBS, 4),
+                                       "frac": round((alg_f + alg_b) / (fwd + bwd) / 1e3 / HBM_PEAK_GBS, 4), "autograd_eager_us": round(eager, 1)}
     return res
 
 

@@ -39,7 +39,7 @@
 #define SLR_WAVES_ONE 5         // __launch_bounds__ waves per SIMD, one-flow: <= 96 VGPRs.  4 / 5 / 6 measure the same (118.7 / 119.2 / 118.2 us identity);
 #endif                          // 6 leaves the normalising variant two registers short
 #ifndef SLR_WAVES_SCAN
-#define SLR_WAVES_SCAN 4        // SCAN instantiation (work loop + pass loop): <= 128 VGPRs = two workgroups per CU, no scratch.  5 / 6: spills (+10..70 %)
+#define SLR_WAVES_SCAN 5        // scan tile kernel: 83 VGPRs, two workgroups per CU, no scratch (6: 80 VGPRs + 12 bytes of scratch, three per CU -- the same time on every small grid)
 #endif
 #ifndef SLR_KREG_ONE
 #define SLR_KREG_ONE 4          // records of an output pixel kept in registers across the chunks (one flow; 8 / 10: < 1 % gain)
@@ -84,11 +84,23 @@
 #ifndef SLR_CSPLIT_SLOTS
 #define SLR_CSPLIT_SLOTS 512    // workgroup slots of the chip the groups may fill (256 CUs x 2).  1024 / 8 groups: config C2 39 -> 54 us
 #endif
-#ifndef SLR_SCAN_DEFER_WG
-#define SLR_SCAN_DEFER_WG 32     // pass-by-pass launch of the scan front end: workgroups along the deferred list x SLR_SCAN_DEFER_GROUPS channel groups x 8 column
-#endif                          // sub-pieces.  Round 4 (empty workgroups end after one scalar load; before, each added to an arrival counter and 2048 of them cost 25 us):
-#ifndef SLR_SCAN_DEFER_GROUPS   // config C2 incoherent / smooth t=30 and 384x640 incoherent / t=30, call us: 16 x 2: 35.7 / 176 and 60.7 / 178; 32 x 2: 35.5 / 134 and
-#define SLR_SCAN_DEFER_GROUPS 4 // 61.0 / 157; 32 x 4: 35.0 / 135 and 61.2 / 146; 64 x 4: 35.0 / 140 and 61.5 / 145; 64 x 8: 35.8 / 195 and 62.6 / 152
+#ifndef SLR_SINK_PIECES
+#define SLR_SINK_PIECES 33      // sink launch of the scan front end (splat_op.hip: op_sink_kernel): deferred pieces rendered at once (more: the list is looped) ...
+#endif
+#ifndef SLR_SINK_TASKS
+#define SLR_SINK_TASKS 16       // ... x task slots per piece (a task = 2 candidate source tiles = 16 row segments <= 1024 entries) ...
+#endif
+#ifndef SLR_SINK_ORDER
+#define SLR_SINK_ORDER 0        // grid of the sink launch: 0 = pieces x groups x task slots (with an ODD number of piece slots a piece's workgroups land on different XCDs), 1 = task slots x groups x pieces
+#endif
+#ifndef SLR_SINK_POOL_MB
+#define SLR_SINK_POOL_MB 64     // ... bytes of slabs in the workspace (a slab = the partial sums of one task slot: (planes of its channel group + 1) x 2 KiB)
+#endif
+#ifndef SLR_SINK_ENT_MB
+#define SLR_SINK_ENT_MB 16      // ... bytes of entries (16 each) the deferred pieces of a call may write out; pieces beyond that are cut by candidate pairs
+#endif
+#ifndef SLR_SINK_GROUPS
+#define SLR_SINK_GROUPS 8       // ... x channel groups
 #endif
 #ifndef SLR_SCAN_MAX_TILES
 #define SLR_SCAN_MAX_TILES 1024 // default of slr_splat_set_scan_max_tiles: one-flow calls on grids of at most this many tiles take the scan front end,

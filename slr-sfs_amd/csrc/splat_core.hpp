@@ -48,8 +48,15 @@ __device__ __forceinline__ void buf_st4(rsrc_t r, uint32_t voff, uint32_t soff, 
     const buf_f32x4 f = {v.x, v.y, v.z, v.w};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_u32x4, f), r, voff, soff, SLR_STORE_AUX);
 }
+template <int AUX = SLR_STORE_AUX>
 __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, SLR_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, AUX);
+}
+// agent scope (sc1): a store that is written through to memory / a load that does not take another workgroup's data from this XCD's L2
+// -- what workgroups on different XCDs exchange through (their L2s are not coherent with each other)
+constexpr int BUF_SC1 = 16;
+__device__ __forceinline__ float buf_ld_sc1(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, BUF_SC1));
 }
 
 // ---- scans --------------------------------------------------------------------------------------------------------------------

@@ -396,7 +396,14 @@ __device__ __forceinline__ bool channel_group(int C, int &cb, int &ce) {
     return cb < C;
 }
 
-struct OpArgs { TileShared s; TileFrame f; };
+struct OpArgs {
+    TileShared s; TileFrame f;
+    uint32_t *sink_cnt;            // scan front end: [items_cap][16] per deferred piece: arrivals of the sink launch per channel group [0..7], its tasks [8]
+    float *sink_pool;              // ... slabs: [sink_qcap][sink_t][rows][TILE_PIX], then the emergency slabs [SINK_P][rows][TILE_PIX]
+    uint32_t sink_qcap, sink_t;    // ... deferred pieces the pool holds slabs for; task slots per piece (rows = planes + channel groups of the sink launch)
+    float4 *sink_ent;              // ... [sink_ent_cap] the entries of the deferred pieces
+    uint32_t sink_ent_cap;
+};
 
 // rows front end.  grid.x: a multiple of 8 * SLR_XCD_GROUP blocks covering the plan's items (surplus workgroups exit at once).
 // PASSES = false: one piece per workgroup, no loop over work (80 VGPRs: three workgroups per CU); a piece of more than SEG entries is
@@ -451,148 +458,334 @@ SLR_TILE_KERNEL __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) vo
 // rows of the candidates are listed in LDS 32 candidates at a time (wave w = row w of each: coalesced 256-byte loads) and walked by
 // rows_walk.  Optimistic first: one LDS atomic per wave and row hands out the entry slots; a tile that turns out to hold more than SEG
 // entries is walked again in passes of SEG entries with reproducible ordinals (a count walk, then one emitting walk per pass).
-template <class Cfg, int MODE, bool EMIT>
-__device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, Piece &p, int tid,
-                                                 uint32_t wave_base, uint32_t lo, uint32_t hi) {
+// The candidate source tiles of a piece among source tiles [base, base + 2048): their boxes tested against the piece's columns, the hits
+// as an ordered list in LDS (clist, in the record area).  Returns their number; ends with a barrier.
+template <class Cfg>
+__device__ __forceinline__ uint32_t scan_candidates(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, const Piece &p, int tid, int base) {
     uint32_t *cmask = reinterpret_cast<uint32_t *>(L.off);         // [64] candidate bits of a block of 2048 source tiles (off[] is free until phase 1b)
     uint32_t *clist = L.rl + 4 * ROW_CAP;                           // [2048] candidate source tiles of the block, in index order
     const SrcBox *boxes = f.box + (size_t)p.n * s.tiles;
+    SrcBox bx4[2048 / TT];
+#pragma unroll
+    for (int q = 0; q < 2048 / TT; ++q) {                           // the box loads do not depend on LDS: issue them first
+        const int st = base + tid + q * TT;
+        bx4[q] = boxes[st < s.tiles ? st : 0];
+    }
+    if (tid < 64) cmask[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2048 / TT; ++q) {
+        const int st = base + tid + q * TT;
+        const SrcBox b = bx4[q];
+        // (against the piece's own columns: where a flow contracts -- the pile-ups that get cut into pieces -- source boxes are narrow)
+        if (st < s.tiles && b.x1 >= p.tx0 + p.pca - 1 && b.x0 <= p.tx0 + p.pcb - 1 && b.y1 >= p.ty0 - 1 && b.y0 <= p.ty0 + TILE_H - 1)
+            atomicOr(&cmask[(st - base) >> 5], 1u << (st & 31));
+    }
+    __syncthreads();
+    // the bit mask -> the ordered candidate list (lane l of wave 0 owns word l; a wave scan places its bits)
+    const int lane = tid & 63;
+    const uint32_t word = cmask[lane];
+    const uint32_t pc = (uint32_t)__popc(word);
+    const uint32_t inc = wave_incl_scan(pc, lane);
+    const uint32_t nc = (uint32_t)__shfl(inc, 63);
+    if (tid < 64) {
+        uint32_t w = word, at = inc - pc;
+        while (w) {
+            const int bit = __ffs((int)w) - 1;
+            w &= w - 1;
+            clist[at++] = (uint32_t)(base + lane * 32 + bit);
+        }
+    }
+    __syncthreads();
+    return nc;
+}
+
+// rows [r0, r0 + n) of the flattened (candidate, row) space -> the row-segment list in LDS (index 8 * candidate + row: wave w walks row w of each)
+__device__ __forceinline__ void scan_row_words(const TileShared &s, uint32_t st, int row, uint32_t &w0, uint32_t &w1) {
+    const uint32_t sty = st / (uint32_t)s.tiles_x, stx = st - sty * (uint32_t)s.tiles_x;
+    const uint32_t sy = sty * TILE_H + (uint32_t)row;
+    w0 = sy < (uint32_t)s.H ? sy | 0xff000000u : 0u;               // (no octants: a row past the image is skipped)
+    w1 = stx << ROWW_STX;
+}
+
+// scan front end: one workgroup per output tile (x channel groups).  The boxes of all source tiles are tested 2048 at a time, the
+// rows of the candidates are listed in LDS 32 candidates at a time (wave w = row w of each: coalesced 256-byte loads) and walked by
+// rows_walk: one LDS atomic per wave and row hands out the entry slots (the total is exact even when it exceeds SEG).
+// MODE 1: one LDS atomic per wave and row hands out the entry slots (the total, L.misc[0], is exact even when it exceeds SEG; entries past
+// SEG are dropped); MODE 2 + GLB: the second walk of a piece that turned out to be a sink -- reproducible ordinals (wave_base from the
+// first walk's per-wave hits), every entry written to `gent`.  Returns this wave's hits; ntask: the candidate-pair tasks of the piece.
+template <class Cfg, int MODE, bool GLB>
+__device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, Piece &p, int tid,
+                                                 uint32_t wave_base, float4 *gent, uint32_t &ntask) {
+    const uint32_t *clist = L.rl + 4 * ROW_CAP;
     uint32_t wcount = 0;
+    ntask = 0;
     for (int base = 0; base < s.tiles; base += 2048) {
-        SrcBox bx4[2048 / TT];
-#pragma unroll
-        for (int q = 0; q < 2048 / TT; ++q) {                       // the box loads do not depend on LDS: issue them first
-            const int st = base + tid + q * TT;
-            bx4[q] = boxes[st < s.tiles ? st : 0];
-        }
-        if (tid < 64) cmask[tid] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2048 / TT; ++q) {
-            const int st = base + tid + q * TT;
-            const SrcBox b = bx4[q];
-            // (against the piece's own columns: where a flow contracts -- the pile-ups that get cut into pieces -- source boxes are narrow)
-            if (st < s.tiles && b.x1 >= p.tx0 + p.pca - 1 && b.x0 <= p.tx0 + p.pcb - 1 && b.y1 >= p.ty0 - 1 && b.y0 <= p.ty0 + TILE_H - 1)
-                atomicOr(&cmask[(st - base) >> 5], 1u << (st & 31));
-        }
-        __syncthreads();
-        // the bit mask -> the ordered candidate list (lane l of wave 0 owns word l; a wave scan places its bits)
-        uint32_t nc = 0;
-        {
-            const int lane = tid & 63;
-            const uint32_t word = cmask[lane];
-            const uint32_t pc = (uint32_t)__popc(word);
-            const uint32_t inc = wave_incl_scan(pc, lane);
-            nc = (uint32_t)__shfl(inc, 63);
-            if (tid < 64) {
-                uint32_t w = word, at = inc - pc;
-                while (w) {
-                    const int bit = __ffs((int)w) - 1;
-                    w &= w - 1;
-                    clist[at++] = (uint32_t)(base + lane * 32 + bit);
-                }
-            }
-        }
-        __syncthreads();
-        if (base == 0) { T_STAMP(s, 1); T_NOTE(s, 61, nc); }
-        // 32 candidates at a time: their 8 rows each as a row-segment list in LDS (index 8 * candidate + row: wave w walks row w of each)
+        const uint32_t nc = scan_candidates<Cfg>(s, f, L, p, tid, base);
+        ntask += (nc + 1u) / 2u;
+        if (base == 0 && MODE == 1) { T_STAMP(s, 1); T_NOTE(s, 61, nc); }
         for (uint32_t c0 = 0; c0 < nc; c0 += ROW_CAP / TILE_H) {
             const uint32_t n = min(nc - c0, (uint32_t)(ROW_CAP / TILE_H));
-            if ((uint32_t)tid < n * TILE_H) {
-                const uint32_t st = clist[c0 + (uint32_t)tid / TILE_H];
-                const uint32_t sty = st / (uint32_t)s.tiles_x, stx = st - sty * (uint32_t)s.tiles_x;
-                const uint32_t sy = sty * TILE_H + (uint32_t)tid % TILE_H;
-                L.rl[tid] = sy < (uint32_t)s.H ? sy | 0xff000000u : 0u;          // (no octants: a row past the image is skipped)
-                L.rl[ROW_CAP + tid] = stx << ROWW_STX;
-            }
+            if ((uint32_t)tid < n * TILE_H) scan_row_words(s, clist[c0 + (uint32_t)tid / TILE_H], tid % TILE_H, L.rl[tid], L.rl[ROW_CAP + tid]);
             __syncthreads();
             p.len0 = p.n0 = n * TILE_H;
-            wcount += rows_walk<Cfg, MODE, EMIT, false>(s, f, L, p, tid, wave_base + wcount, lo, hi);
+            wcount += rows_walk<Cfg, MODE, true, false, GLB>(s, f, L, p, tid, wave_base + wcount, 0u, GLB ? 0xffffffffu : (uint32_t)Cfg::SEG, gent);
             __syncthreads();
         }
     }
     return wcount;
 }
 
-// DEFER = false: one workgroup per output tile, or per column piece of it (grid.z).  A piece that turns out to hold more than SEG entries
-// is not walked pass by pass by its own workgroup (on a small grid the rest of the chip would idle behind it): it is appended to the
-// deferred list with the number of sub-pieces it should be cut into (2, 4 or 8 equal column ranges: ~1.25 x its entries / SEG).
-// DEFER = true (grid: SCAN_DEFER_WG x channel groups x 8): the second, normally empty launch -- every deferred tile's pieces (x channel
-// groups) in parallel, every piece re-scanning the tile's candidates for its own columns; a piece that still holds more than SEG
-// entries is walked in passes with reproducible ordinals (a count walk, then one emitting walk per pass).
-// (Measured and rejected: the deferred pieces as TAIL blocks of the same launch, waiting on an arrival counter of the tile blocks --
-//  no second launch, but the sleeping tail blocks and the larger kernel cost more than the 5.6 us of an empty launch: config C2
-//  37 -> 49.5 us, and with few tail slots a smooth flow's heavy tiles queue up behind each other: 177 -> 883 us.)
-constexpr uint32_t SCAN_DEFER_WG = SLR_SCAN_DEFER_WG;
-template <bool NORM, bool MAXOP, bool DEFER>
-SLR_TILE_KERNEL __global__ __launch_bounds__(TT, DEFER ? 2 : SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
+// One workgroup per output tile, or per column piece of it (grid.z), x channel groups.  A piece that turns out to hold more than SEG
+// entries -- a pile-up of a contracting flow -- is not rendered here: it is appended to the deferred list, and the SINK launch that
+// follows (normally empty) renders it with many workgroups at once.
+// (Measured and rejected in rounds 4 / 5: the deferred pieces as TAIL blocks of the same launch behind an arrival counter -- config C2
+//  37 -> 49.5 us, 512 arrival atomics on one word ~ 20 us; column pieces in the first launch: every piece repeats the candidate walk.)
+template <bool NORM, bool MAXOP>
+SLR_TILE_KERNEL __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     using Cfg = OpCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
-    const uint32_t ndef = DEFER ? f.totals[4] : 1u;
-    if (DEFER && ndef == 0u) return;                       // the normal case: an empty launch whose workgroups do one scalar load
     int cb, ce;
     if (!channel_group(s.C, cb, ce)) return;
     const TileScalars k = tile_scalars(s, f);
-    for (uint32_t q = DEFER ? blockIdx.x : 0u; q < ndef; q += gridDim.x) {
-        ItemDesc it = {};
-        if (DEFER) {
-            // a deferred piece (tile | first octant << 20 | log2 octants << 23) and the number of sub-pieces it is cut into (<< 28)
-            const uint32_t w = f.defer[q], np = w >> 28, noct = 1u << ((w >> 23) & 3u);
-            if (blockIdx.z >= np) continue;
-            it.tile = w & 0xfffffu; it.nseg = noct / np; it.seg = ((w >> 20) & 7u) + blockIdx.z * it.nseg;
-        } else {
-            // grid.z column pieces per tile (1, 2, 4 or 8: on a grid smaller than the chip the spare workgroup slots go to column ranges
-            // first -- every piece builds and streams only its own records -- and to channel groups after that)
-            it.tile = xcd_item(blockIdx.x); it.nseg = 8u / gridDim.z; it.seg = blockIdx.z * it.nseg;
-            if (it.tile >= (uint32_t)s.N * (uint32_t)s.tiles) return;
-        }
-        Piece p = make_piece<Cfg>(s, it);
-        T_STAMP(s, 0);
-        __syncthreads();
-        L.cnt[tid] = 0;
-        if (tid == 0) L.misc[0] = 0;
-        __syncthreads();
-        scan_collect<Cfg, 1, true>(s, f, L, p, tid, 0u, 0u, (uint32_t)Cfg::SEG);
-        const uint32_t total = L.misc[0];
-        T_STAMP(s, 2);
-        T_NOTE(s, 60, total);
+    // grid.z column pieces per tile (1, 2, 4 or 8: slr_splat_set_scan_shape; 1 by default -- every piece repeats the candidate walk)
+    ItemDesc it = {};
+    it.tile = xcd_item(blockIdx.x); it.nseg = 8u / gridDim.z; it.seg = blockIdx.z * it.nseg;
+    if (it.tile >= (uint32_t)s.N * (uint32_t)s.tiles) return;
+    Piece p = make_piece<Cfg>(s, it);
+    T_STAMP(s, 0);
+    L.cnt[tid] = 0;
+    if (tid == 0) L.misc[0] = 0;
+    __syncthreads();
+    uint32_t ntask;
+    const uint32_t whits = scan_collect<Cfg, 1, false>(s, f, L, p, tid, 0u, nullptr, ntask);
+    const uint32_t total = L.misc[0];
+    T_STAMP(s, 2);
+    T_NOTE(s, 60, total);
+    if (total <= (uint32_t)Cfg::SEG) {
         const rsrc_t rin = sample_planes(s, p, k.hw4);
         PixelSums sums = {0.0f, 0.0f, 0.0f};
-        if (total <= (uint32_t)Cfg::SEG) {
+        EntryRegs<Cfg> e;
+        float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
+        build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+        T_STAMP(s, 6);
+        stream_planes<Cfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
+        T_STAMP(s, 59);
+        return;
+    }
+    // a sink.  Its first channel group appends it to the deferred list (tile | first octant << 20 | log2 octants << 23; arrival words at
+    // zero), takes room for its entries in the call's entry array and walks the candidates once more, writing EVERY entry out at its
+    // reproducible ordinal: the sink launch then cuts the piece into tasks of exactly SEG entries without walking anything.  No room left
+    // (a flow with hundreds of sinks): the sink launch cuts it by candidate pairs instead.
+    if (blockIdx.y != 0) return;
+    uint32_t wb;
+    const uint32_t all = wave_bases<Cfg>(L, tid, whits, wb);      // (== total)
+    if (tid == 0) {
+        const uint32_t q = atomicAdd(f.totals + 4, 1u), off = atomicAdd(f.totals + 7, all);
+        const bool room = off <= a.sink_ent_cap && all <= a.sink_ent_cap - off;
+        f.defer[q] = it.tile | (it.seg << 20) | ((uint32_t)(31 - __clz((int)it.nseg)) << 23);
+        uint32_t *hd = a.sink_cnt + (size_t)q * 16u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hd[i] = 0u;
+        hd[8] = ntask; hd[9] = all; hd[10] = room ? off : 0xffffffffu;
+        L.misc[10] = room ? off : 0xffffffffu;
+    }
+    __syncthreads();
+    const uint32_t off = L.misc[10];
+    if (off != 0xffffffffu) scan_collect<Cfg, 2, true>(s, f, L, p, tid, wb, a.sink_ent + off, ntask);
+}
+
+// The SINK launch (grid: SINK_T task slots x channel groups x SINK_P pieces -- the slots of a piece on different XCDs; normally the deferred list is empty and every workgroup ends
+// after one scalar load).  A deferred piece holds thousands of entries -- Euler-integrated flows pile hundreds of source pixels onto a few
+// output pixels; on a 256 x 256 training crop at t = 59 two tiles receive 12 000 entries each and one pixel 4 000 -- and walking them pass by
+// pass in ONE workgroup (rounds 1-5) left the chip idle behind it: 116 us for a C2-sized call whose other tiles take 29, 670 us at the
+// training shape.  Here the piece is cut by SOURCE: task k = candidate source tiles 2k, 2k + 1 of the piece's ordered candidate list
+// (16 row segments: at most 1024 entries, one segment of LDS, no count pass), tasks dealt round-robin to the piece's task slots; a
+// slot's workgroup renders its tasks one after the other into a SLAB of its own (un-normalised sums of its channel group's planes + the
+// normaliser, accumulated through its own earlier stores: stream_planes<SLAB>), and the last workgroup of a (piece, channel group) to
+// arrive adds the slabs up in slot order -- reproducible, no float atomics -- normalises and writes the piece's pixels.
+// (First built with agent-scope fp32 atomicAdds into the output instead of slabs: correct, and 375 us for the C2-sized smooth case --
+//  8 M memory-side atomics at ~22 G/s.)
+// Slabs: the pool holds sink_t slabs for the first sink_qcap deferred pieces; a piece beyond them is rendered by ONE workgroup per channel
+// group (task slot 0) out of that workgroup's emergency slab -- correct for any flow, slow only for flows with hundreds of sinks.
+constexpr uint32_t SINK_P = SLR_SINK_PIECES, SINK_T = SLR_SINK_TASKS, SINK_MINE = 2048 / 2;
+#ifdef SLR_TRACE      // per-workgroup wall-clock stamps of the sink launch (tools/dev/trace_sink.py): 16 words per workgroup behind the tile kernels' area
+#define SINK_STAMP(slot, v) do { if (s.trace && threadIdx.x == 0) s.trace[(size_t)16384 * 64 + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (slot)] = (long long)(v); } while (0)
+#else
+#define SINK_STAMP(slot, v) do { } while (0)
+#endif
+static_assert(SINK_T <= 16, "slab bits of the arrival word");
+template <bool NORM, bool MAXOP>
+SLR_TILE_KERNEL __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
+    using Cfg = OpCfg;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t mine[2 * SINK_MINE];              // this workgroup's tasks of a candidate block (build_records overwrites the list)
+    __shared__ uint32_t arrived;
+    const TileLds<Cfg> L(smem);
+    const TileShared &s = a.s;
+    const TileFrame &f = a.f;
+    const int tid = threadIdx.x;
+#if SLR_SINK_ORDER
+    const uint32_t bslot = blockIdx.x, bpiece = blockIdx.z, npiece = gridDim.z;
+#else
+    const uint32_t bslot = blockIdx.z, bpiece = blockIdx.x, npiece = gridDim.x;
+#endif
+    const uint32_t ndef = f.totals[4];
+    if (ndef == 0u) return;                                // the normal case: an empty launch whose workgroups do one scalar load
+    int cb, ce;
+    if (!channel_group(s.C, cb, ce)) return;              // (arrivals are counted per channel group)
+    SINK_STAMP(0, wall_clock64());
+    const TileScalars k = tile_scalars(s, f);
+    const uint32_t *clist = L.rl + 4 * ROW_CAP;
+    const size_t hw = (size_t)s.H * s.W;
+    const uint32_t rows = (uint32_t)s.C + gridDim.y;      // slab rows of one task slot over all channel groups; this group's start at cb + its index
+    const size_t slot_floats = (size_t)rows * TILE_PIX, my_rows = (size_t)(cb + (int)blockIdx.y) * TILE_PIX;
+    for (uint32_t q = bpiece; q < ndef; q += npiece) {
+        const bool pooled = q < a.sink_qcap;
+        const uint32_t *hd = a.sink_cnt + (size_t)q * 16u;
+        const uint32_t all = hd[9], eoff = hd[10];
+        const bool listed = eoff != 0xffffffffu;           // the piece's entries were written out: tasks of exactly SEG entries, nothing to walk
+        const uint32_t ntask_q = listed ? (all + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : hd[8];
+        const uint32_t nslot = pooled ? min(a.sink_t, max(ntask_q, 1u)) : 1u;       // (no more slots than tasks)
+        if (bslot >= nslot) continue;
+        float *slab0 = pooled ? a.sink_pool + (size_t)q * a.sink_t * slot_floats + my_rows
+                              : a.sink_pool + ((size_t)a.sink_qcap * a.sink_t + bpiece) * slot_floats + my_rows;
+        float *slab = slab0 + (size_t)bslot * slot_floats;
+        const uint32_t w = f.defer[q];
+        ItemDesc it = {};
+        it.tile = w & 0xfffffu; it.nseg = 1u << ((w >> 23) & 3u); it.seg = (w >> 20) & 7u;
+        Piece p = make_piece<Cfg>(s, it);
+        const rsrc_t rin = sample_planes(s, p, k.hw4);
+        PixelSums sums = {0.0f, 0.0f, 0.0f};
+        bool wrote = false;
+        if (listed) { SINK_STAMP(1, wall_clock64()); SINK_STAMP(8, all); SINK_STAMP(9, (ntask_q - bslot + nslot - 1u) / nslot); }
+        for (uint32_t k_ = bslot; listed && k_ < ntask_q; k_ += nslot) {
+            const uint32_t lo = k_ * (uint32_t)Cfg::SEG, total = min((uint32_t)Cfg::SEG, all - lo);
+            const float4 *src = a.sink_ent + eoff + lo;
+            L.cnt[tid] = 0;
+#pragma unroll
+            for (int j = 0; j < Cfg::EPT; ++j)
+                if ((uint32_t)tid + (uint32_t)j * TT < total) L.ent4[tid + j * TT] = src[tid + j * TT];
+            __syncthreads();
             EntryRegs<Cfg> e;
             float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
             build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
-            T_STAMP(s, 6);
-            stream_planes<Cfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
-            T_STAMP(s, 59);
-            continue;
+            stream_planes<Cfg, NORM, MAXOP, false, true, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, !wrote, false, slab);
+            wrote = true;
+            __syncthreads();
         }
-        if constexpr (!DEFER) {
-            if (tid == 0 && blockIdx.y == 0) {             // (one entry per piece: every channel group gets here)
-                const uint32_t want = (total + total / 4u + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG;
-                const uint32_t np = min(want <= 2u ? 2u : want <= 4u ? 4u : 8u, it.nseg);
-                f.defer[atomicAdd(f.totals + 4, 1u)] = it.tile | (it.seg << 20) | ((uint32_t)(31 - __clz((int)it.nseg)) << 23) | (np << 28);
+        uint32_t tk0 = 0;                                  // tasks of the candidate blocks before this one
+        for (int base = 0; !listed && base < s.tiles; base += 2048) {
+            __syncthreads();
+            const uint32_t nc = scan_candidates<Cfg>(s, f, L, p, tid, base);
+            const uint32_t ntask = (nc + 1u) / 2u;
+            const uint32_t t0 = (bslot + nslot - tk0 % nslot) % nslot;         // my first task of this block
+            const uint32_t n_mine = t0 < ntask ? (ntask - t0 + nslot - 1u) / nslot : 0u;
+            for (uint32_t i = (uint32_t)tid; i < 2u * n_mine; i += TT) {
+                const uint32_t c = 2u * (t0 + (i >> 1) * nslot) + (i & 1u);
+                mine[i] = c < nc ? clist[c] : 0xffffffffu;
             }
-            return;
-        } else {
-            uint32_t wb;
-            const uint32_t all = wave_bases<Cfg>(L, tid, scan_collect<Cfg, 2, false>(s, f, L, p, tid, 0u, 0u, 0u), wb);
-            const uint32_t npass = (all + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG;
-            for (uint32_t si = 0; si < npass; ++si) {
-                __syncthreads();
+            tk0 += ntask;
+            __syncthreads();
+            if (base == 0) { SINK_STAMP(1, wall_clock64()); SINK_STAMP(8, nc); SINK_STAMP(9, n_mine); }
+            for (uint32_t j = 0; j < n_mine; ++j) {
                 L.cnt[tid] = 0;
-                const uint32_t lo = si * (uint32_t)Cfg::SEG;
-                scan_collect<Cfg, 2, true>(s, f, L, p, tid, wb, lo, lo + (uint32_t)Cfg::SEG);
-                EntryRegs<Cfg> e;
-                float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
-                build_records<Cfg, NORM, false>(s, L, p, tid, min((uint32_t)Cfg::SEG, all - lo), rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
-                stream_planes<Cfg, NORM, MAXOP, false, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, si == 0, si + 1 == npass);
+                if (tid == 0) L.misc[0] = 0;
+                if (tid < 2 * TILE_H) {
+                    const uint32_t st = mine[2u * j + (uint32_t)tid / TILE_H];
+                    uint32_t w0 = 0u, w1 = 0u;
+                    if (st != 0xffffffffu) scan_row_words(s, st, tid % TILE_H, w0, w1);
+                    L.rl[tid] = w0; L.rl[ROW_CAP + tid] = w1;
+                }
+                __syncthreads();
+                p.len0 = p.n0 = 2 * TILE_H;
+                rows_walk<Cfg, 1, true, false>(s, f, L, p, tid, 0u, 0u, (uint32_t)Cfg::SEG);
+                __syncthreads();
+                const uint32_t total = L.misc[0];          // <= 16 row segments x 64 pixels = SEG
+                if (total != 0u) {
+                    EntryRegs<Cfg> e;
+                    float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
+                    build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+                    stream_planes<Cfg, NORM, MAXOP, false, true, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, !wrote, false, slab);
+                    wrote = true;
+                }
+                __syncthreads();
             }
         }
+        // arrive: this workgroup's slab stores (sc1: written through) have been performed; the last workgroup of the (piece, channel
+        // group) adds the slabs up with agent-scope loads.  (No fences: an agent-scope fence writes back and invalidates the whole L2 of
+        // the XCD -- with 2048 workgroups doing that the sink launch took 440 us.)
+        SINK_STAMP(2, wall_clock64());
+        __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0)
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t mineb = wrote ? 1u << (8u + bslot) : 0u;
+            arrived = atomicAdd(a.sink_cnt + (size_t)q * 16u + blockIdx.y, 1u | mineb) | mineb;
+        }
+        __syncthreads();
+        const uint32_t aw = arrived;
+        SINK_STAMP(3, wall_clock64()); SINK_STAMP(10, (aw & 0xffu) == nslot - 1u); SINK_STAMP(11, q);
+        if ((aw & 0xffu) == nslot - 1u) {
+            const uint32_t have = aw >> 8;
+            const int ly = tid / TILE_W, lx = p.pca + (tid - ly * TILE_W);
+            const int oy = p.ty0 + ly, ox = p.tx0 + lx;
+            const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb);
+            const uint32_t nrow = (uint32_t)(ce - cb), voff = inside ? (uint32_t)(ly * TILE_W + lx) * 4u : BUF_OOB;
+            const rsrc_t rs = make_rsrc(slab0, (uint32_t)((nslot - 1u) * slot_floats + (size_t)(nrow + 1u) * TILE_PIX) * 4u);
+            float inv = 1.0f;
+            // the slabs' values of RC rows in flight together, NS slabs at a time (a load chain per slab and row group is a memory round trip
+            // each: 14 slabs x 3 row groups took 13-23 us; sc1 loads come from memory: ~2.5 us a trip)
+            auto soff_of = [&](uint32_t z, uint32_t row) { return (uint32_t)(z * slot_floats + (size_t)row * TILE_PIX) * 4u; };
+            if (NORM) {
+                float tn[SINK_T];
+#pragma unroll
+                for (uint32_t z = 0; z < SINK_T; ++z) tn[z] = buf_ld_sc1(rs, ((have >> z) & 1u) ? voff : BUF_OOB, soff_of(z, nrow));
+                float nrm = 0.0f;
+#pragma unroll
+                for (uint32_t z = 0; z < SINK_T; ++z) nrm += ((have >> z) & 1u) ? tn[z] : 0.0f;
+                inv = 1.0f / norm_divisor(nrm, s.norm_mode, s.eps);
+            }
+            float *o = f.out + ((size_t)p.n * s.Cs + cb) * hw + (size_t)oy * s.W + ox;
+            auto add_up = [&](auto ns_tag, auto rc_tag) {
+                constexpr uint32_t NS = decltype(ns_tag)::value, RC = decltype(rc_tag)::value;
+                for (uint32_t c = 0; c < nrow; c += RC) {
+                    float v[RC];
+#pragma unroll
+                    for (uint32_t u = 0; u < RC; ++u) v[u] = MAXOP ? s.init : 0.0f;
+                    for (uint32_t hv = have; hv;) {                       // NS slabs (in slot order) per trip
+                        float t[NS][RC];
+                        uint32_t hq = hv;
+#pragma unroll
+                        for (uint32_t k = 0; k < NS; ++k) {
+                            const bool on = hq != 0u;
+                            const uint32_t z = on ? (uint32_t)__ffs((int)hq) - 1u : 0u;
+                            hq &= hq - 1u;
+#pragma unroll
+                            for (uint32_t u = 0; u < RC; ++u) t[k][u] = buf_ld_sc1(rs, on ? voff : BUF_OOB, soff_of(z, min(c + u, nrow - 1u)));
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < NS; ++k) {
+                            const bool on = hv != 0u;
+                            hv &= hv - 1u;
+#pragma unroll
+                            for (uint32_t u = 0; u < RC; ++u)
+                                if (on) v[u] = MAXOP ? fmaxf(v[u], t[k][u]) : v[u] + t[k][u];
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < RC; ++u)
+                        if (inside && c + u < nrow) __builtin_nontemporal_store(v[u] * inv, o + (size_t)(c + u) * hw);
+                }
+            };
+            if (__popc(have) <= 4) add_up(std::integral_constant<uint32_t, 4>{}, std::integral_constant<uint32_t, 16>{});
+            else add_up(std::integral_constant<uint32_t, 8>{}, std::integral_constant<uint32_t, 8>{});
+        }
+        __syncthreads();
+        SINK_STAMP(4, wall_clock64());
     }
     // (the deferred list is emptied by the next call's scan_box_kernel: the scan front end has no prebinned form)
 }
@@ -656,6 +849,9 @@ int op_ws_open(OpWs &w, int N, int H, int W, void *ws, size_t bytes, const char 
     w.defer2 = (uint32_t *)(b + w.L.off_defer2);
     w.ctl = (uint32_t *)(b + w.L.off_ctl);
     w.arrive = (uint32_t *)(b + w.L.off_arrive);
+    w.sink_cnt = (uint32_t *)(b + w.L.off_sink_cnt);
+    w.sink_pool = (float *)(b + w.L.off_sink_pool);
+    w.sink_ent = (float4 *)(b + w.L.off_sink_ent);
     w.box = b + w.L.off_box;
     return 0;
 }
@@ -746,25 +942,38 @@ static int launch_rows(OpArgs &a, OpWs &w, hipStream_t st) {
 
 template <bool NORM, bool MAXOP>
 static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
-    static LdsOptIn attr, attr_d;
-    if (int e = lds_opt_in((const void *)op_scan_kernel<NORM, MAXOP, false>, 159 * 1024, attr)) return e;
-    if (int e = lds_opt_in((const void *)op_scan_kernel<NORM, MAXOP, true>, 159 * 1024, attr_d)) return e;
+    static LdsOptIn attr, attr_s;
+    if (int e = lds_opt_in((const void *)op_scan_kernel<NORM, MAXOP>, 159 * 1024, attr)) return e;
+    if (int e = lds_opt_in((const void *)op_sink_kernel<NORM, MAXOP>, (int)OpCfg::LDS_BYTES, attr_s)) return e;
     a.f.box = (const SrcBox *)w.box; a.f.totals = w.totals; a.f.defer = w.defer;
+    a.sink_cnt = w.sink_cnt; a.sink_pool = w.sink_pool; a.sink_ent = w.sink_ent; a.sink_ent_cap = w.L.sink_ent_cap;
     hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
     const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
     uint32_t pieces, groups;
     scan_shape(w.L.nt, a.s.C, pieces, groups);
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, false>), dim3(grid, groups, pieces), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, groups, pieces), dim3(TT), OpCfg::LDS_BYTES, st, a);
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
-    // pieces of more than SEG entries (appended by their workgroups): 2 - 8 column sub-pieces each x channel groups, pass by pass where needed
-    // (an empty launch: every workgroup does one scalar load and ends -- 256 or 4096 of them cost the same 2 - 3 us)
+    // pieces of more than SEG entries (appended by their workgroups): the sink launch -- every piece by up to SINK_T x channel groups
+    // workgroups at once (an empty launch: every workgroup does one scalar load and ends -- 256 or 4096 of them cost the same 2 - 3 us)
     const int dwg = g_scan_defer_wg.load(), dgr = g_scan_defer_groups.load();
-    const uint32_t gmax = dgr > 0 ? (uint32_t)dgr : (uint32_t)SLR_SCAN_DEFER_GROUPS;
+    const uint32_t gmax = dgr > 0 ? (uint32_t)dgr : (uint32_t)SLR_SINK_GROUPS;
     const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > gmax ? gmax : (uint32_t)a.s.C / 8u;
-    const uint32_t dw = dwg > 0 ? (uint32_t)dwg : SCAN_DEFER_WG;
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP, true>), dim3(w.L.nt * pieces < dw ? w.L.nt * pieces : dw, wgroups, 8), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    const uint32_t dw = dwg > 0 ? (uint32_t)dwg : SINK_P;
+    uint32_t sink_x = w.L.nt * pieces < dw ? w.L.nt * pieces : dw;
+    // slabs: rows x 2 KiB per task slot; the emergency slabs of the sink_x piece slots come first out of the pool's budget
+    const size_t slot_bytes = (size_t)((uint32_t)a.s.C + wgroups) * TILE_PIX * 4, avail = w.L.sink_pool_bytes / slot_bytes;
+    SLR_CHECK_ARG(avail >= 1, "plane count too large for the scan front end (use the rows front end: slr_splat_set_front_end(2))");
+    if (avail < sink_x) sink_x = (uint32_t)avail;
+    a.sink_t = (uint32_t)((avail - sink_x) / sink_x < SINK_T ? (avail - sink_x) / sink_x : SINK_T);      // (at least every piece slot's own pieces get full slots)
+    a.sink_qcap = a.sink_t ? (uint32_t)((avail - sink_x) / a.sink_t) : 0u;
+    if (a.sink_qcap > w.L.items_cap) a.sink_qcap = w.L.items_cap;
+    #if SLR_SINK_ORDER
+    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(SINK_T, wgroups, sink_x), dim3(TT), OpCfg::LDS_BYTES, st, a);
+#else
+    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_x, wgroups, SINK_T), dim3(TT), OpCfg::LDS_BYTES, st, a);
+#endif
     SLR_CHECK_LAUNCH();
     return 0;
 }

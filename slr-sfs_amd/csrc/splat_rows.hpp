@@ -86,9 +86,12 @@ __device__ __forceinline__ void rows_setup_unsorted(const TileFrame &f, const Ti
 // EMIT: write the entries (source pixel | direction << 31, target X, Y, weight logit [+ second group's logit and value]) with slots
 // in [lo, hi) to the entry array.  The weight logits of a row segment are loaded with its flow: coalesced, and the dependent gather
 // round trip they used to be, after the entries were known, is gone from phase 1.
-template <class Cfg, int MODE, bool EMIT, bool G2>
+// GLB: the entries go to the global array `gent` (at their slot) instead of the entry array in LDS -- a piece of more than a segment
+// written out once for the sink launch of the scan front end (splat_op.hip).
+template <class Cfg, int MODE, bool EMIT, bool G2, bool GLB = false>
 __device__ __forceinline__ uint32_t rows_walk(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, const Piece &p, int tid,
-                                              uint32_t wave_base, uint32_t lo, uint32_t hi) {
+                                              uint32_t wave_base, uint32_t lo, uint32_t hi, float4 *gent = nullptr) {
+    static_assert(!GLB || !G2, "one weight group");
     constexpr int CB = Cfg::NDIR > 1 ? SLR_ROW_CB_CLIP : SLR_ROW_CB;
     const int lane = tid & 63;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,7 +164,8 @@ __device__ __forceinline__ uint32_t rows_walk(const TileShared &s, const TileFra
             if (EMIT) {
                 const uint32_t slot = b0 + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
                 if (hit && slot >= lo && slot < hi) {
-                    L.ent4[slot - lo] = make_float4(__uint_as_float((uint32_t)(sy * s.W + sx) | (g.d[i] << 31)), X, Y, g.z[i]);
+                    const float4 en = make_float4(__uint_as_float((uint32_t)(sy * s.W + sx) | (g.d[i] << 31)), X, Y, g.z[i]);
+                    if constexpr (GLB) gent[slot - lo] = en; else L.ent4[slot - lo] = en;
                     if (G2) L.ent2[slot - lo] = make_float2(g.l2[i], g.v2[i]);
                 }
             }

@@ -284,7 +284,7 @@ __device__ __forceinline__ int lane_group_log(const Piece &p) {
 }
 
 template <class Cfg>
-__device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int tid, int g_log) {
+__device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int tid, int g_log, int heavy_max = SLR_HEAVY_MAX) {
     PixelList<Cfg> g;
     g.g_log = g_log;
     g.pid = (tid & ~63) | ((tid & 63) >> g_log);
@@ -301,7 +301,25 @@ __device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int 
     g.rl = (g.r1 - first >= own + (uint32_t)SLR_HEAVY_SLACK) ? first + own : g.r1;
     g.heavy = __ballot(g.r1 > g.rl);
     // (the cooperative passes run one after the other; with many long lists in one wave -- or lane groups -- every lane walks its own)
-    if (__popcll(g.heavy) > SLR_HEAVY_MAX || g_log) { g.rl = g.r1; g.heavy = 0ull; }
+    if (heavy_max >= 64 && !g_log) {
+        // sink tasks (whole tiles whose entries pile onto some pixels, splat_op.hip): how long a list a lane walks alone is chosen per wave --
+        // a lane's record costs ~32 cycles of its wave, a cooperative pass ~512 (cross-lane reductions of 4 planes) + its share; of the
+        // thresholds 16 .. 256 and "everybody alone" the cheapest by that model.  (The fixed rule -- twice the wave's average, as many
+        // cooperative passes as it takes -- made tasks with ~40 long lists in a wave take 12 us per chunk.)
+        const uint32_t len = g.r1 - first;
+        uint32_t mx = len;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+        uint32_t best_t = mx, best_c = mx * 32u;
+#pragma unroll
+        for (uint32_t t = 16; t <= 256; t <<= 1) {
+            const uint32_t nh = (uint32_t)__popcll(__ballot(len >= t + (uint32_t)SLR_HEAVY_SLACK));
+            const uint32_t c = t * 32u + nh * 512u;
+            if (c < best_c) { best_c = c; best_t = t; }
+        }
+        g.rl = len >= best_t + (uint32_t)SLR_HEAVY_SLACK ? first + best_t : g.r1;
+        g.heavy = __ballot(g.r1 > g.rl);
+    } else if (__popcll(g.heavy) > heavy_max || g_log) { g.rl = g.r1; g.heavy = 0ull; }
 #pragma unroll
     for (int k = 0; k < Cfg::KREG; ++k) {
         const uint32_t r = g.r0 + ((uint32_t)k << g_log);
@@ -371,7 +389,8 @@ __device__ __forceinline__ void accum4(Acc4 &a, const float4 &v, const WRec &r, 
 // between(k), k = 0..3: called at four points of the gather -- the chunk pipeline issues the plane loads of a later chunk there, a
 // few at a time: the waves of a workgroup run in step, and a burst of loads per wave waits for the texture addresser (0.28 us per
 // chunk, measured) while the LDS pipe idles, then the LDS reads of the gather queue up while the addresser idles.
-template <class Cfg, bool MAXOP, typename F>
+// COOP4 (sink tasks: lists of ~1000 records on a pixel): the cooperative walks read 4 records per lane and trip.
+template <class Cfg, bool MAXOP, bool COOP4 = false, typename F>
 __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane, float init, float (&acc)[4], F &&between) {
     constexpr int RB = 4, KREG = Cfg::KREG;
     constexpr uint32_t NULL_B = Cfg::NULL_E * 16u;
@@ -401,7 +420,20 @@ __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelL
         const int src = __ffsll((long long)hv) - 1;
         const uint32_t hb = __shfl(g.rl, src), he = __shfl(g.r1, src);
         Acc4 part = acc4_init<MAXOP>(-INFINITY);
-        for (uint32_t r = hb + (uint32_t)lane; r < he; r += 64) {
+        uint32_t r = hb + (uint32_t)lane;
+        if constexpr (COOP4) {
+            for (; r + 192u < he; r += 256) {               // (all four inside the list)
+                WRec q[4];
+                float4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = L.rec_get(r + 64u * (uint32_t)k);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = L.staged(q[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) accum4<MAXOP>(part, v[k], q[k], true);
+            }
+        }
+        for (; r < he; r += 64) {
             const WRec q = L.rec_get(r);
             accum4<MAXOP>(part, L.staged(q), q, true);
         }
@@ -448,34 +480,47 @@ struct PixelSums { float nrm, g2_sum, g2_nrm; };
 // Phase 2 for one pass over the planes [cb, ce) (the whole stack, or a channel group's share on small grids): [special chunk] ->
 // chunk pipeline.  first / last: the pass is the piece's first / last one (ACCUM kernels: a piece of several passes accumulates
 // through its own earlier stores and normalises in the last pass).
-template <class Cfg, bool NORM, bool MAXOP, bool G2, bool ACCUM>
+// SLAB (the sink launch of the scan front end, splat_op.hip; with ACCUM): this workgroup holds only SOME of the piece's entries, batch after
+// batch -- other workgroups the rest -- so it accumulates its un-normalised sums in a slab of its own ([planes of its channel group + a
+// normaliser row][8 x 64 pixels of the tile], through its own earlier stores) and the piece's last workgroup adds the slabs up.
+template <class Cfg, bool NORM, bool MAXOP, bool G2, bool ACCUM, bool SLAB = false>
 __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, const Piece &p, int tid,
                                               rsrc_t rin, uint32_t hw4, int cb, int ce, const EntryRegs<Cfg> &e,
-                                              float (&preA)[Cfg::EPT][4], float (&preB)[Cfg::EPT][4], PixelSums &sums, bool first, bool last) {
+                                              float (&preA)[Cfg::EPT][4], float (&preB)[Cfg::EPT][4], PixelSums &sums, bool first, bool last,
+                                              float *slab = nullptr) {
+    static_assert(!SLAB || (!G2 && ACCUM), "sink tasks: one weight group, accumulated batch after batch");
     constexpr int EPT = Cfg::EPT;
     const int lane = tid & 63;
-    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid, lane_group_log(p));
+    // (a sink task: whole tiles whose entries pile onto a few pixels -- every list far above the wave's average is walked by the whole wave;
+    //  left to their own lanes, lists of ~1000 records made single tasks take 250 us)
+    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid, lane_group_log(p), SLAB ? 64 : SLR_HEAVY_MAX);
     const int ly = g.pid / TILE_W, lx = p.pca + g.pid - ly * TILE_W;
     const int oy = p.ty0 + ly, ox = p.tx0 + lx;
     const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb) & ((tid & ((1 << g.g_log) - 1)) == 0);      // (the first lane of a pixel's group stores)
     const uint32_t opix = (uint32_t)(oy * s.W + ox);
-    const uint32_t voff = inside ? opix * 4u : BUF_OOB;                   // (work-items outside the image / the piece: stores dropped)
+    const uint32_t voff = inside ? (SLAB ? (uint32_t)(ly * TILE_W + lx) : opix) * 4u : BUF_OOB;   // (work-items outside the image / the piece: stores dropped)
     const size_t hw = (size_t)s.H * s.W;
-    const rsrc_t rout = make_rsrc(f.out + (size_t)p.n * s.Cs * hw, (uint32_t)s.C * hw4);
+    const uint32_t obytes = SLAB ? (uint32_t)TILE_PIX * 4u : hw4;         // bytes of an output plane; a slab's planes start at cb
+    const int cbase = SLAB ? cb : 0;
+    const rsrc_t rout = SLAB ? make_rsrc(slab, (uint32_t)(ce - cb + 1) * obytes) : make_rsrc(f.out + (size_t)p.n * s.Cs * hw, (uint32_t)s.C * hw4);
     float inv = 1.0f;
     if (NORM) {
         if (G2) {
             // the special chunk (m | in2 * m2 | m2 per entry, staged in phase 1a): both normalisers and the second group's sum
             float a2[4];
-            gather_chunk<Cfg, false>(L, g, lane, 0.0f, a2, [](int) {});
+            gather_chunk<Cfg, false, false>(L, g, lane, 0.0f, a2, [](int) {});
             sums.nrm += a2[0]; sums.g2_sum += a2[1]; sums.g2_nrm += a2[2];
             if (last && inside && cb == 0) f.out2[(size_t)p.n * hw + opix] = sums.g2_sum / norm_divisor(sums.g2_nrm, s.norm_mode, s.eps);
             __syncthreads();                          // val4 is overwritten by the first value chunk
         } else {
             sums.nrm += weight_sum<Cfg>(L, g, lane);
         }
-        if (last && inside && f.norm_out && cb == 0) f.norm_out[(size_t)p.n * hw + opix] = norm_divisor(sums.nrm, s.norm_mode, s.eps);
-        inv = 1.0f / norm_divisor(sums.nrm, s.norm_mode, s.eps);           // ONE division per output pixel
+        if constexpr (SLAB) {
+            buf_st<BUF_SC1>(rout, voff, (uint32_t)(ce - cb) * obytes, sums.nrm);    // the normaliser so far: the slab's last row
+        } else {
+            if (last && inside && f.norm_out && cb == 0) f.norm_out[(size_t)p.n * hw + opix] = norm_divisor(sums.nrm, s.norm_mode, s.eps);
+            inv = 1.0f / norm_divisor(sums.nrm, s.norm_mode, s.eps);       // ONE division per output pixel
+        }
     }
     T_STAMP(s, 7);
     T_NOTE(s, 63, g.r1 - g.r0);
@@ -496,7 +541,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
         if (c0 - cb < 32) T_STAMP(s, 9 + 6 * ((c0 - cb) / 4));
         float acc[4];
         // the plane loads of the chunk after next (two chunks ahead), one plane at each of the gather's four stops
-        gather_chunk<Cfg, MAXOP>(L, g, lane, s.init, acc, [&](int u) {
+        gather_chunk<Cfg, MAXOP, SLAB>(L, g, lane, s.init, acc, [&](int u) {
             if (SLR_PREFETCH_BURST_ONE && Cfg::NDIR == 1) {      // one flow: all planes' loads at the first stop (its chunks are short: every load
                 if (u == 0) {                                     // as early as possible)
                     __builtin_amdgcn_sched_barrier(0);
@@ -535,11 +580,11 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (FULL || c0 + u < ce) {                // (scalar: only the last chunk of a plane count that is not a multiple of 4)
-                const uint32_t soff = (uint32_t)(c0 + u) * hw4;
+                const uint32_t soff = (uint32_t)(c0 + u - cbase) * obytes;
                 float r = acc[u];
                 if (ACCUM && !first) { const float o = buf_ld(rout, voff, soff); r = MAXOP ? fmaxf(r, o) : r + o; }   // earlier passes of this piece
-                if (NORM && (!ACCUM || last)) r *= inv;
-                if (!(SLR_SKIP & 16) || c0 == cb) buf_st(rout, voff, soff, r);
+                if (NORM && !SLAB && (!ACCUM || last)) r *= inv;
+                if (!(SLR_SKIP & 16) || c0 == cb) buf_st<SLAB ? BUF_SC1 : SLR_STORE_AUX>(rout, voff, soff, r);      // (a slab is read by another workgroup)
             }
         }
     };

@@ -19,6 +19,11 @@ struct OpLayout {
     size_t off_box;       // SrcBox[nt]  scan front end: destination box of every source tile
     size_t off_ctl;       // uint32[64]  arrival counter (second level) of rowbin_kernel
     size_t off_arrive;    // uint32[ceil(nt / 64)][32]  first-level arrival counters, one per 128-byte line
+    size_t off_sink_cnt;  // uint32[items_cap][16]  scan front end, per deferred piece: [0..7] arrivals (| slabs written << 8) of the sink launch's workgroups per channel group, [8] its candidate-pair tasks, [9] its entries, [10] where they start in sink_ent (0xffffffff: not written out)
+    size_t off_sink_pool; // float[sink_pool_bytes / 4]  scan front end: slabs of the sink launch (partial sums of a deferred piece per task slot)
+    size_t sink_pool_bytes;
+    size_t off_sink_ent;  // float4[sink_ent_cap]  scan front end: the entries of the deferred pieces, written out by their workgroups
+    uint32_t sink_ent_cap;
     size_t off_rowlist2;  // RowRec[2][nt][ROW_CAP]  slr_synth_group: sorted copies of this and the other workspace's lists
     size_t off_items2;    // ItemDesc[items2_cap]  slr_synth_group's two-flow plan
     size_t off_defer2;    // uint32[items2_cap]
@@ -44,8 +49,15 @@ inline OpLayout op_layout(int N, int H, int W) {
     L.off_defer = o;    o += al256((size_t)L.items_cap * 4);
     L.off_items2 = o;   o += al256((size_t)L.items2_cap * sizeof(ItemDesc));
     L.off_defer2 = o;   o += al256((size_t)L.items2_cap * 4);
+    L.off_sink_cnt = o; o += al256((size_t)L.items_cap * 16 * 4);
     L.off_rowlist = o;  o += al256((size_t)L.nt * ROW_CAP * sizeof(RowRec));
     L.off_rowlist2 = o; o += al256((size_t)2 * L.nt * ROW_CAP * sizeof(RowRec));
+    // (only grids the scan front end takes by default -- up to SLR_SCAN_MAX_TILES tiles -- get the full pool; a larger grid forced onto the scan
+    //  front end renders its sinks out of the emergency slabs: one workgroup per piece and channel group, as rounds 1-5 did)
+    L.sink_pool_bytes = (size_t)(L.nt <= (uint32_t)SLR_SCAN_MAX_TILES ? SLR_SINK_POOL_MB : 8) << 20;
+    L.off_sink_pool = o; o += al256(L.sink_pool_bytes);
+    L.sink_ent_cap = (uint32_t)(((size_t)(L.nt <= (uint32_t)SLR_SCAN_MAX_TILES ? SLR_SINK_ENT_MB : 1) << 20) / 16);
+    L.off_sink_ent = o; o += al256((size_t)L.sink_ent_cap * 16);
     L.total = o;
     return L;
 }
@@ -56,7 +68,9 @@ struct OpWs {
     unsigned long long *rowcnt, *rowinfo;
     RowRec *rowlist, *rowlist2;
     ItemDesc *items, *items2;
-    uint32_t *totals, *defer, *defer2, *ctl, *arrive;
+    uint32_t *totals, *defer, *defer2, *ctl, *arrive, *sink_cnt;
+    float *sink_pool;
+    float4 *sink_ent;
     void *box;
 };
 
