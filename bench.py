@@ -377,7 +377,7 @@ def emit(line, extra, full=False):
     c["config"] = {k: v for k, v in line["config"].items() if v is not None and k not in ("H", "W", "frames_per_step")}
     r = line["roofline"]
     c["roofline"] = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "alg_bytes_per_launch",
-                          "frames_per_launch", "launch_avg_us", "frac_min_bytes", "avg_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
+                          "frames_per_launch", "launch_avg_us", "frac_min_bytes", "avg_us", "min_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
     src = r.get("traffic_source") or ""
     c["roofline"]["traffic_source"] = "measured in this run" if src.startswith("measured in this run") else ("static (profiles/), not this run" if src else None)
     pe = line["parity_err"]

@@ -105,7 +105,9 @@ int slr_euler_backward_batch(const float *motion, const long long *steps, int B,
                                 skips the kernel that zeroes the binning counters (the binning leaves them zero again) */
 
 /* Bytes of scratch one flow field [N,2,H,W] needs: per-tile row-segment lists (256 records of 8 bytes per 8x64 output tile), work
- * plans, destination boxes -- 12.7 MB at 768x1280.  slr_splat_workspace_init zeroes the counters of a fresh workspace (see SLR_WS_CLEAN). */
+ * plans, destination boxes, and for the scan front end's sink launch an entry array + slabs of partial sums -- 21 MB at 768x1280, 81 MB
+ * on grids of up to 1024 tiles (where the scan front end runs by default: 16 MB of entries + 64 MB of slabs).  slr_splat_workspace_init
+ * zeroes the counters of a fresh workspace (see SLR_WS_CLEAN). */
 size_t slr_splat_workspace_bytes(int N, int H, int W);
 int slr_splat_workspace_init(void *ws, size_t ws_bytes, int N, int H, int W, void *stream);
 
@@ -129,8 +131,10 @@ int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int H, i
  *          1024 entries;
  *   scan : one kernel writes the destination box of every 8x64 block of source pixels, then every output tile's workgroup lists the
  *          rows of the blocks whose box touches it and walks them with the same code (no plan: nothing to wait for on grids that fit
- *          the chip in one or two rounds).  3 launches: boxes, tile kernel, and a normally empty launch that takes tiles of more
- *          than 1024 entries as 8 column pieces each.
+ *          the chip in one or two rounds).  3 launches: boxes, tile kernel, and a normally empty SINK launch for tiles of more than
+ *          1024 entries (pile-ups of a contracting flow): their workgroups write the tile's entries out once, the sink launch
+ *          renders them as tasks of exactly 1024 entries, up to 16 workgroups x 8 channel groups per tile at once, each into a slab
+ *          of its own; the tile's last workgroup adds the slabs up in slot order (reproducible, no float atomics) and normalises.
  * A call takes `scan` when its grid has at most `max_tiles` output tiles (N * ceil(H/8) * ceil(W/64); default 1024, 0 = never,
  * INT_MAX = always) and `rows` above; slr_splat_set_front_end(1 | 2) forces scan | rows, anything else = automatic.  Process-wide;
  * both return the previous value (-1 = automatic).  Both are exact (floating-point summation order differs: results agree to
@@ -138,7 +142,7 @@ int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int H, i
 int slr_splat_set_scan_max_tiles(int max_tiles);
 int slr_splat_set_front_end(int front_end);
 /* Tuning of the scan front end (process-wide, 0 = the built-in choice by grid size): column pieces per output tile in the first launch
- * (1, 2, 4 or 8) x channel groups per piece; workgroups x channel groups of the pass-by-pass launch. */
+ * (1, 2, 4 or 8) x channel groups per piece; deferred pieces rendered at once (default 33) x channel groups (default 8) of the sink launch. */
 void slr_splat_set_scan_shape(int pieces, int groups, int defer_wg, int defer_groups);
 
 /* ------------------------------------------------------------------ splat: forward */

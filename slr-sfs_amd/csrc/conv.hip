@@ -47,11 +47,6 @@ constexpr int CV_W = 32, CV_H = 8;                 // output block
 constexpr int CV_HW = CV_W + 2, CV_HH = CV_H + 2;  // input halo block
 constexpr int CV_NPX = CV_HW * CV_HH;              // 340 halo pixels
 constexpr int CV_THREADS = 256;
-#ifndef CV_EXP
-#define CV_EXP 0          // development experiments (tools/dev/convbench.py): 1 no B re-reads, 2 no A loads, 4 no staging,
-                         // 8 staging without its loads, 32 no global writes
-                         // (measured ceilings at 128->128, 768x1280: all three off 512 TFLOP/s; s_setprio around the MFMAs: -4 %)
-#endif
 constexpr float CV_XSCALE = 64.0f;                 // default pre-scale of the activations before the split (2^6); per call:
                                                    // ConvArgs.xscale, a power of two in (0, 64] -- the split is exact-domain for
                                                    // |activation| < 65472 / xscale (1023 at 2^6, 65472 at 1), see stage_value
@@ -186,10 +181,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#if CV_EXP & 8
-            st[j] = (float)(c + j) * 0.01f + (float)offA * 1e-6f;      // experiment: staging arithmetic without the loads
-            continue;
-#endif
             if (R.value < 2) {
                 const float *pl = inb + (size_t)min(c * 16 + R.value * 8 + j, cmax) * HW;       // wave-uniform
                 st[j] = pl[(unsigned)offA];
@@ -308,25 +299,19 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             const int kh = tap / 3, kw = tap - kh * 3;
             // keeps the B fragments of different taps from being kept live together (the 36 distinct
             // ones of a chunk would take 144 registers and spill); LDS has the bandwidth to re-read them
-#if !(CV_EXP & 1)
             asm volatile("" ::: "memory");
-#endif
             // staging of the next chunk, one round per three taps: 8 registers in flight instead of 24.
             // A round's loads are issued at the top of taps 0 / 3 / 6 (behind the weight loads) and consumed
             // (prologue, split, LDS store) in taps 2 / 5 / 8, where that VALU work is interleaved with
             // the tap's MFMAs (below).
-#if !(CV_EXP & 2)
             load_a(a_nxt, min(c * 9 + tap + 1, glast));
-#endif
-#if !(CV_EXP & 4)
             // AFTER the weight loads: memory returns in order, so a staging load (HBM latency) issued in
             // front of an A load (L2 latency) would make the next tap wait for HBM
             if (tap == 0) load_round(R0{}, cn, st);
             if (tap == 3) load_round(R1{}, cn, st);
             if (tap == 6) load_round(R2{}, cn, st);
-#endif
             __builtin_amdgcn_sched_barrier(0);         // loads are issued HERE, a whole tap ahead of their use
-            const bool stage_tap = !(CV_EXP & 4) && (tap == 2 || tap == 5 || tap == 8);
+            const bool stage_tap = tap == 2 || tap == 5 || tap == 8;
             Stage sg;
             sg.fresh = c + 1 < nchunk ? 1.0f : 0.0f;   // the last iteration re-stages its own chunk: not counted twice
             if (stage_tap) {
@@ -374,11 +359,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                 h8 bh[PB], bl[PB];
 #pragma unroll
                 for (int k = 0; k < PB; ++k) {
-#if CV_EXP & 1
-                    const int p = (wp * PT + hb * PB + k) * CV_HW + bcol;   // experiment: same fragments for every tap (CSE)
-#else
                     const int p = (wp * PT + hb * PB + k + kh) * CV_HW + kw + bcol;
-#endif
                     bh[k] = xh[p];
                     bl[k] = xl[p];
                 }
@@ -404,10 +385,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                 if (tap == 5) stage_finish(R1{}, buf ^ 1, sg);
                 if (tap == 8) stage_finish(R2{}, buf ^ 1, sg);
             }
-#if !(CV_EXP & 2)
 #pragma unroll
             for (int ct = 0; ct < CPW; ++ct) { a_cur[ct][0] = a_nxt[ct][0]; a_cur[ct][1] = a_nxt[ct][1]; }
-#endif
         }
         __syncthreads();
     }
@@ -435,9 +414,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     // the residual is read and the result written with 16-byte accesses: 4 store instructions per tile instead
     // of 16 (a VMEM instruction costs an in-order wave ~60-100 issue cycles).  Needs whole 32-pixel rows inside
     // the image and 16-byte aligned rows; otherwise the 4-byte path below.
-#if CV_EXP & 32
-    if (a.H > 0) return;                               // experiment: an aggressor that never writes global memory
-#endif
     const bool vec = !a.out_b8 && (a.W % 4 == 0) && (x0 + CV_W <= a.W) &&
                      !(((uintptr_t)a.out | (uintptr_t)a.residual) & 15);
     constexpr int SCR_STRIDE = 36;                     // floats per channel row: 16-byte aligned, conflict-free
@@ -569,11 +545,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 // l&31, channels 8*(l>>5)..+7) is exactly what 8 coalesced plane loads per lane deliver, so a wave
 // converts its 32 pixels x 16 channels in registers and multiplies them with all NCT 32-channel
 // weight tiles (A fragments from global memory / L2).  Input loads run two chunks ahead.
-#ifndef C1_EXP
-#define C1_EXP 0          // development experiments (tools/dev/conv1x1bench.py), 64->128 at 768x1280, 249 us as shipped:
-                         // 1 no stores 128 us, 2 no input loads 162 us, 4 no prefetch registers 251 us -- the read and
-                         // the write phase of a wave barely overlap; 128-byte segments per plane cap both
-#endif
 constexpr int C1_TILES = 1;                        // 32-pixel tiles per wave (streaming several was measured slower:
                                                    // the stores of a tile share vmcnt with the next tile's loads)
 template <int NCT, bool INB8, bool F32 = false>
@@ -603,11 +574,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             return;
         }
 #pragma unroll
-#if C1_EXP & 2
-        for (int j = 0; j < 8; ++j) x[j] = (float)(c + j);
-#else
         for (int j = 0; j < 8; ++j) x[j] = inb[(size_t)min(c * 16 + grp * 8 + j, cmax) * HW + poff];
-#endif
     };
     const h8 *wb = w + (size_t)cot0 * nchunk * 128 + lane;      // fragment (tile, chunk, half): 64 vectors
     auto load_a = [&](h8 (&d)[NCT][2], int g) {
@@ -642,12 +609,8 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
         for (int c = 0; c < nchunk; ++c, ++g) {
             // everything issued here is for LATER chunks and unconditional, so the waits below are counted:
             // the weights of chunk g+1 and the input of chunk g+2 stay in flight under this chunk's MFMAs
-#if C1_EXP & 4
-            load_x(x1, g + 1);                          // experiment: depth-1 input prefetch, weights loaded in place
-#else
             load_a(a_nxt, g + 1);
             load_x(x2, g + 2);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (F32) {
                 // fp32 rung: MFMA kp multiplies the weights of input channels 8 * (lane >> 5) + kp with this lane's pixel of that channel
@@ -682,16 +645,10 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
             for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][0], bl, acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t][0], bh, acc[t], 0, 0, 0);
-#if C1_EXP & 4
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x0[j] = x1[j];
-            load_a(a_cur, g + 1);
-#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) { x0[j] = x1[j]; x1[j] = x2[j]; }
 #pragma unroll
             for (int t = 0; t < NCT; ++t) { a_cur[t][0] = a_nxt[t][0]; a_cur[t][1] = a_nxt[t][1]; }
-#endif
         }
         // straight-line epilogue: clamped bias loads first, then masked stores
 #pragma unroll
@@ -716,11 +673,7 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (cot0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * grp;
-#if C1_EXP & 1
-                if (ok && co <= cout1 && acc[t][r] == 12345.678f)
-#else
                 if (ok && co <= cout1)
-#endif
                     out[((size_t)n * Cout + co) * HW + p] = acc[t][r] * unscale + b[r];
             }
         }

@@ -60,9 +60,7 @@ __global__ __launch_bounds__(256) void euler_kernel(const float *__restrict__ mo
 // 256 contiguous bytes).  The displacement maps are written once and read by later kernels only: nontemporal stores (round 5: 135 ->
 // 115-127 us per direction at 768x1280, N = 60 = 480 MB written: ~4 TB/s, store-bound).  More independent gather chains per lane do
 // not help -- 2 pixels per work-item 125-134 us, 4: 144-151 (the chain's latency is hidden already; fewer waves store less evenly).
-#ifndef SLR_EULER_PPT
 #define SLR_EULER_PPT 1
-#endif
 __global__ __launch_bounds__(256) void euler_all_kernel(const float *__restrict__ motion, int H, int W,
                                                         int nmax, float sign,
                                                         float *__restrict__ disp_all,

@@ -20,12 +20,8 @@ namespace slr {
 // on 1-6 cache lines per wave and instruction for Euler-integrated flows) are the cost, and the compiler does not hoist
 // them over the gradInput stores by itself.  (Measured and not kept: the two corners of a row as ONE 4-byte-aligned
 // 8-byte load -- Euler flows -10 %, identity +20 %, tools/bwdbench.py.)
-#ifndef SLR_GRAD_U
 #define SLR_GRAD_U 4
-#endif
-#ifndef SLR_GRAD_TILED
 #define SLR_GRAD_TILED 1       // 1: grad_tile_kernel (gathers through LDS where the block's destination box fits), 0: grad_kernel
-#endif
 
 template <bool GIN, bool GFLOW>
 __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in, const float *__restrict__ flow,
@@ -109,37 +105,21 @@ __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in,
 // stores through a buffer descriptor, box 2048 -> 4096 floats per channel: both gradients identity 181 -> 165-171 us, Euler t=30
 // 214-219 -> 190-197 (0.50-0.52 of 8 TB/s), t=59 300-320 -> 248-255; gradInput alone t=30 178-190 -> 161-168, t=59 255-274 -> 217-226.
 constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
-#ifndef SLR_GRAD_BOX
 #define SLR_GRAD_BOX 4096                              // floats of LDS per channel (e.g. 32 rows x 128 columns); x U channels x 4 bytes = 64 KiB: two workgroups
-#endif                                                 // per CU.  Round 4 (both gradients, identity / Euler t=30 / t=59): 2048: 169 / 201 / 290 us,
+                                // per CU.  Round 4 (both gradients, identity / Euler t=30 / t=59): 2048: 169 / 201 / 290 us,
                                                        // 3072: 169 / 196 / 271, 4096: 165-171 / 190-197 / 248-255, 5120 (40 staging registers): 184 / 253 / 279;
                                                        // 2 channels per pass at 4096 / 6144 / 8192 / 10240: 170 / 189 / 274, 172 / 213 / 258, 171 / 253 / 273, 213 / 365 / 368
-#ifndef SLR_GRAD_TU
 #define SLR_GRAD_TU 4                                  // channels per pass of the tiled kernel (round 3, 4 / 8 / 16 at box 2048 / 1536 / 1024: Euler t=30,
-#endif                                                 // both gradients, 223 / 245 / 301 us; grad_kernel: 279)
-#ifndef SLR_GRAD_BENT
+                                // both gradients, 223 / 245 / 301 us; grad_kernel: 279)
 #define SLR_GRAD_BENT 2                                // stage through LDS only where a wave's destinations spread over more rows than this
-#endif
-#ifndef SLR_GRAD_XCD
-#define SLR_GRAD_XCD 0                                 // 1: blocks of an XCD contiguous in the image (see grad_tile_kernel).  Measured round 5, both gradients:
-                                                       // t=30 192 -> 208 us, t=59 250 -> 327 (the slow blocks of a region pile up on one XCD); identity 166 / 167
-#endif
-#ifndef SLR_GRAD_STRIPS
 #define SLR_GRAD_STRIPS 2                              // column strips of a block with a destination box each (1, 2, 4: power of two)
-#endif
-#ifndef SLR_GRAD_WAVES
 #define SLR_GRAD_WAVES 4                               // __launch_bounds__ waves per SIMD of the tiled kernel
-#endif
-#ifndef SLR_GRAD_BUF_LD
 #define SLR_GRAD_BUF_LD 0                              // 1: plane loads through buffer descriptors (plane offset in an SGPR, no 64-bit vector address sums).
-#endif                                                 // Measured SLOWER for these gathers although the loop then has ~25 % fewer VALU instructions: both gradients
+                                // Measured SLOWER for these gathers although the loop then has ~25 % fewer VALU instructions: both gradients
                                                        // identity / t=30 / t=59 169 / 204 / 310 us with global loads, 167 / 218 / 352 with buffer loads (box 2048)
-#ifndef SLR_GRAD_BUF_ST
 #define SLR_GRAD_BUF_ST 1                              // gradInput stores through a buffer descriptor (out-of-image work-items dropped by the range check, no
-#endif                                                 // exec-mask juggling around the stores): gradInput alone t=30 192 -> 176 us, t=59 295 -> 264; both: 204 -> 208 / 310 -> 297
-#ifndef SLR_GRAD_ENTRY_ST
+                                // exec-mask juggling around the stores): gradInput alone t=30 192 -> 176 us, t=59 295 -> 264; both: 204 -> 208 / 310 -> 297
 #define SLR_GRAD_ENTRY_ST 0                            // U dropped stores before the staged loop (the loop header then merges two equal wait states): no change
-#endif
 constexpr int GT_BOX = SLR_GRAD_BOX;
 
 template <bool GIN, bool GFLOW>
@@ -153,14 +133,7 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     const int HW = H * W;
     const int n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#if SLR_GRAD_XCD
-    // workgroup b runs on XCD b % 8 (observed): give every XCD a contiguous band of blocks, so that the destination boxes of neighbouring
-    // blocks -- they overlap by the flow's extent -- meet in ONE L2 instead of being fetched by several
-    const int per = (int)gridDim.x >> 3, bt = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (bt >= tiles_x * ((H + TILE_H - 1) / TILE_H)) return;        // (whole workgroups, before any barrier)
-#else
     const int bt = (int)blockIdx.x;
-#endif
     const int y = (bt / tiles_x) * TILE_H + wid, x = (bt % tiles_x) * TILE_W + lane;
     const bool live_px = (y < H) & (x < W);
     const int i = live_px ? y * W + x : 0;
@@ -395,7 +368,7 @@ SLR_EXPORT int slr_softsplat_backward(const float *in, const float *flow, const 
     const bool tiled = SLR_GRAD_TILED && (long long)C * H * W * 4 < (1LL << 31);
     if (tiled) {
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-    dim3 grid(SLR_GRAD_XCD ? (tiles_x * tiles_y + 7) / 8 * 8 : tiles_x * tiles_y, N);
+    dim3 grid(tiles_x * tiles_y, N);
     if (grad_in && grad_flow) hipLaunchKernelGGL((grad_tile_kernel<true, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
     else if (grad_in) hipLaunchKernelGGL((grad_tile_kernel<true, false>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
     else if (grad_flow) hipLaunchKernelGGL((grad_tile_kernel<false, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);

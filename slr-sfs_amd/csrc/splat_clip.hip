@@ -342,7 +342,7 @@ __global__ __launch_bounds__(CT) void rows_plan_pair_kernel(const unsigned long 
 //  kernel went from 152 to 190 us per frame of work even with one round per workgroup, 202 us with 512 persistent ones.  It needs the
 //  per-frame arguments in memory, read per item, first.)
 template <bool G2, bool PASSES, bool B4 = false>
-SLR_TILE_KERNEL __global__ __launch_bounds__(CT, PASSES ? 1 : SLR_WAVES_CLIP) void clip_tile_kernel(ClipBatch b) {
+__global__ __launch_bounds__(CT, PASSES ? 1 : SLR_WAVES_CLIP) void clip_tile_kernel(ClipBatch b) {
     using Cfg = std::conditional_t<PASSES, std::conditional_t<B4, ClipPassCfgB4, ClipPassCfg>, std::conditional_t<B4, ClipCfgB4, ClipCfg>>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);

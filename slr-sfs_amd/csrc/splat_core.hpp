@@ -12,14 +12,6 @@
 #include "slr_common.hpp"
 #include "splat_types.hpp"
 
-// Tile kernels carry the packed-fp32 feature (the rest of the library is built without it, csrc/Makefile): accum4's inline
-// v_pk_fma_f32 needs it to assemble.  Device pass only (the host pass does not know the feature).
-#if defined(__HIP_DEVICE_COMPILE__) && SLR_PK_FMA
-#define SLR_TILE_KERNEL __attribute__((target("packed-fp32-ops")))
-#else
-#define SLR_TILE_KERNEL
-#endif
-
 namespace slr {
 
 // ---- memory access through buffer descriptors ------------------------------------------------------------------------------

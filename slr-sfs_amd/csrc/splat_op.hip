@@ -86,11 +86,7 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
     // atomics); this XCD's L2 may still hold the zeros of rows_zero_kernel.  They are read with agent-scope (sc1) loads, all four
     // of a round in flight together (as __hip_atomic_load the compiler waits after each).
     constexpr uint32_t PER = SLR_ROWS_PLAN_PER;
-#ifdef SLR_PLAN_STAMPS
-#define PSTAMP(k) do { if (threadIdx.x == 0) ((unsigned long long *)totals)[8 + (k)] = wall_clock64(); } while (0)
-#else
 #define PSTAMP(k) do { } while (0)
-#endif
     PSTAMP(0);
     const uint32_t heavy_thr = heavy ? (heavy * 585u) / 4u : 0xffffffffu;
     uint32_t run_heavy = 0, run_light = 0, run_extra = 0;
@@ -158,15 +154,6 @@ __device__ __forceinline__ void rows_plan(const unsigned long long *__restrict__
                 p |= (unsigned long long)(start | ((8u - start) << 4)) << (8 * np); ++np;
                 if (!hist_ok) { p = 0x1716151413121110ull; np = 8; }
                 pcs[k] = p; ns[k] = np;
-#if SLR_ROWS_EVEN_FIRST
-                // (where plain halves / quarters already fit, take them: equal widths)
-                uint32_t q4[4];
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q)
-                    q4[q] = (uint32_t)((float)((uint32_t)(oh[k] >> (16 * q)) & 0xffu) * scale) + (uint32_t)((float)((uint32_t)(oh[k] >> (16 * q + 8)) & 0xffu) * scale);
-                if (max(q4[0] + q4[1], q4[2] + q4[3]) <= limit) { pcs[k] = 0x40ull | (0x44ull << 8); ns[k] = 2; }
-                else if (max(max(q4[0], q4[1]), max(q4[2], q4[3])) <= limit && np >= 4) { pcs[k] = 0x20ull | (0x22ull << 8) | (0x24ull << 16) | (0x26ull << 24); ns[k] = 4; }
-#endif
             }
             xo[k] = (uint32_t)extra;
             extra += ns[k] ? ns[k] - 1u : 0u;
@@ -218,10 +205,6 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
     const int tiles = tiles_x * tiles_y, by_n = (tiles_y + ROWBIN_R - 1) / ROWBIN_R, per_n = tiles_x * by_n;
     const int b = blockIdx.x, n = b / per_n, bl = b - n * per_n;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef SLR_PLAN_STAMPS
-    const unsigned long long k_entry = wall_clock64();
-    if (b == 0 && tid == 0) ((unsigned long long *)totals)[15] = k_entry;
-#endif
     const int stx = bl % tiles_x, y_base = (bl / tiles_x) * ROWBIN_R * TILE_H + wid, x = stx * TILE_W + lane;
     const float *fl = flow + (size_t)n * 2 * H * W;
     float fx[ROWBIN_R], fy[ROWBIN_R];
@@ -319,9 +302,6 @@ __global__ __launch_bounds__(TILE_PIX) void rowbin_kernel(const float *__restric
     }
     __syncthreads();
     if (!last) return;
-#ifdef SLR_PLAN_STAMPS
-    if (tid == 0) { ((unsigned long long *)totals)[14] = k_entry; ((unsigned long long *)totals)[13] = (unsigned long long)wall_clock64(); }
-#endif
     rows_plan(rowcnt, rowinfo, nt, seg, heavy, items_cap, items, totals);
     // everybody has arrived: the arrival counters go back to zero for the workspace's next binning
     for (uint32_t i = tid; i < ((gridDim.x + 63u) >> 6); i += TILE_PIX) arrive1[(size_t)i * 32u] = 0u;
@@ -409,7 +389,7 @@ struct OpArgs {
 // PASSES = false: one piece per workgroup, no loop over work (80 VGPRs: three workgroups per CU); a piece of more than SEG entries is
 // appended to the deferred list.  PASSES = true: OP_DEFER_WG workgroups walk the deferred list pass by pass (normally it is empty).
 template <bool NORM, bool MAXOP, bool PASSES>
-SLR_TILE_KERNEL __global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kernel(OpArgs a) {
+__global__ __launch_bounds__(TT, PASSES ? 1 : SLR_WAVES_ROWS) void op_rows_kernel(OpArgs a) {
     using Cfg = std::conditional_t<PASSES, OpPassCfg, OpCfg>;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
@@ -542,7 +522,7 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
 // (Measured and rejected in rounds 4 / 5: the deferred pieces as TAIL blocks of the same launch behind an arrival counter -- config C2
 //  37 -> 49.5 us, 512 arrival atomics on one word ~ 20 us; column pieces in the first launch: every piece repeats the candidate walk.)
 template <bool NORM, bool MAXOP>
-SLR_TILE_KERNEL __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
+__global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     using Cfg = OpCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
@@ -573,7 +553,7 @@ SLR_TILE_KERNEL __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_ke
         float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
         build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
         T_STAMP(s, 6);
-        stream_planes<Cfg, NORM, MAXOP, false, false>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
+        stream_planes<Cfg, NORM, MAXOP, false, false, false, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, true, true);
         T_STAMP(s, 59);
         return;
     }
@@ -620,7 +600,7 @@ constexpr uint32_t SINK_P = SLR_SINK_PIECES, SINK_T = SLR_SINK_TASKS, SINK_MINE 
 #endif
 static_assert(SINK_T <= 16, "slab bits of the arrival word");
 template <bool NORM, bool MAXOP>
-SLR_TILE_KERNEL __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
+__global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     using Cfg = OpCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t mine[2 * SINK_MINE];              // this workgroup's tasks of a candidate block (build_records overwrites the list)
@@ -629,11 +609,7 @@ SLR_TILE_KERNEL __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
     const int tid = threadIdx.x;
-#if SLR_SINK_ORDER
-    const uint32_t bslot = blockIdx.x, bpiece = blockIdx.z, npiece = gridDim.z;
-#else
     const uint32_t bslot = blockIdx.z, bpiece = blockIdx.x, npiece = gridDim.x;
-#endif
     const uint32_t ndef = f.totals[4];
     if (ndef == 0u) return;                                // the normal case: an empty launch whose workgroups do one scalar load
     int cb, ce;
@@ -969,11 +945,7 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     a.sink_t = (uint32_t)((avail - sink_x) / sink_x < SINK_T ? (avail - sink_x) / sink_x : SINK_T);      // (at least every piece slot's own pieces get full slots)
     a.sink_qcap = a.sink_t ? (uint32_t)((avail - sink_x) / a.sink_t) : 0u;
     if (a.sink_qcap > w.L.items_cap) a.sink_qcap = w.L.items_cap;
-    #if SLR_SINK_ORDER
-    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(SINK_T, wgroups, sink_x), dim3(TT), OpCfg::LDS_BYTES, st, a);
-#else
     hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_x, wgroups, SINK_T), dim3(TT), OpCfg::LDS_BYTES, st, a);
-#endif
     SLR_CHECK_LAUNCH();
     return 0;
 }
@@ -1014,9 +986,6 @@ SLR_EXPORT const char *slr_last_error(void) { return slr::g_err; }
 
 #ifdef SLR_TRACE
 SLR_EXPORT void slr_debug_trace(long long *buf) { g_trace = buf; }
-#endif
-#ifdef SLR_PLAN_STAMPS
-SLR_EXPORT size_t slr_debug_totals_offset(int N, int C, int H, int W) { return op_layout(N, H, W).off_totals; }
 #endif
 
 SLR_EXPORT void slr_splat_time_next(void *ev_start, void *ev_stop) {

@@ -307,39 +307,27 @@ __device__ __forceinline__ PixelList<Cfg> pixel_list(const TileLds<Cfg> &L, int 
         // thresholds 16 .. 256 and "everybody alone" the cheapest by that model.  (The fixed rule -- twice the wave's average, as many
         // cooperative passes as it takes -- made tasks with ~40 long lists in a wave take 12 us per chunk.)
         const uint32_t len = g.r1 - first;
-        uint32_t mx = len;
+        g.rl = g.r1; g.heavy = 0ull;
+        if (__ballot(len >= 16u + (uint32_t)SLR_HEAVY_SLACK)) {            // (uniform; ordinary waves have no such list and pay one ballot)
+            uint32_t mx = len;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
-        uint32_t best_t = mx, best_c = mx * 32u;
+            for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+            uint32_t best_t = mx, best_c = mx * 32u;
 #pragma unroll
-        for (uint32_t t = 16; t <= 256; t <<= 1) {
-            const uint32_t nh = (uint32_t)__popcll(__ballot(len >= t + (uint32_t)SLR_HEAVY_SLACK));
-            const uint32_t c = t * 32u + nh * 512u;
-            if (c < best_c) { best_c = c; best_t = t; }
+            for (uint32_t t = 16; t <= 256; t <<= 1) {
+                const uint32_t nh = (uint32_t)__popcll(__ballot(len >= t + (uint32_t)SLR_HEAVY_SLACK));
+                const uint32_t c = t * 32u + nh * 512u;
+                if (c < best_c) { best_c = c; best_t = t; }
+            }
+            g.rl = len >= best_t + (uint32_t)SLR_HEAVY_SLACK ? first + best_t : g.r1;
+            g.heavy = __ballot(g.r1 > g.rl);
         }
-        g.rl = len >= best_t + (uint32_t)SLR_HEAVY_SLACK ? first + best_t : g.r1;
-        g.heavy = __ballot(g.r1 > g.rl);
     } else if (__popcll(g.heavy) > heavy_max || g_log) { g.rl = g.r1; g.heavy = 0ull; }
 #pragma unroll
     for (int k = 0; k < Cfg::KREG; ++k) {
         const uint32_t r = g.r0 + ((uint32_t)k << g_log);
         g.rc[k] = L.rec_get(r < g.rl ? r : Cfg::NULLREC);
     }
-#if SLR_REC_SORT
-    // The register-resident records in the order of their staged entries (the slots of a list are handed out in the arrival order of
-    // LDS atomics): neighbouring output pixels then read neighbouring entries with the same instruction of the gather -- consecutive
-    // 16-byte slots, different banks -- instead of a random one of their ~8 sources each (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.28
-    // before).  Once per piece, in registers: KREG (KREG - 1) / 2 compare-exchanges.  The all-zero slot has the highest offset: pads last.
-#pragma unroll
-    for (int round = 0; round < Cfg::KREG; ++round)
-#pragma unroll
-        for (int k = round & 1; k + 1 < Cfg::KREG; k += 2) {
-            const bool sw = __float_as_uint(g.rc[k].y) > __float_as_uint(g.rc[k + 1].y);
-            const WRec a = g.rc[k], c = g.rc[k + 1];
-            g.rc[k].x = sw ? c.x : a.x; g.rc[k].y = sw ? c.y : a.y;
-            g.rc[k + 1].x = sw ? a.x : c.x; g.rc[k + 1].y = sw ? a.y : c.y;
-        }
-#endif
     return g;
 }
 
@@ -373,15 +361,9 @@ __device__ __forceinline__ void accum4(Acc4 &a, const float4 &v, const WRec &r, 
         a.lo.x = fmaxf(on ? v.x * w : -INFINITY, a.lo.x); a.lo.y = fmaxf(on ? v.y * w : -INFINITY, a.lo.y);
         a.hi.x = fmaxf(on ? v.z * w : -INFINITY, a.hi.x); a.hi.y = fmaxf(on ? v.w * w : -INFINITY, a.hi.y);
     } else {
-#if SLR_PK_FMA
-        const f2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a.lo) : "v"(vlo), "v"(r));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a.hi) : "v"(vhi), "v"(r));
-#else
         const float w = r.x;
         a.lo.x = __builtin_fmaf(v.x, w, a.lo.x); a.lo.y = __builtin_fmaf(v.y, w, a.lo.y);
         a.hi.x = __builtin_fmaf(v.z, w, a.hi.x); a.hi.y = __builtin_fmaf(v.w, w, a.hi.y);
-#endif
     }
 }
 
@@ -399,13 +381,13 @@ __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelL
         between(0);
         float4 v[KREG];
 #pragma unroll
-        for (int k = 0; k < KREG; ++k) v[k] = (SLR_SKIP & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : L.staged(g.rc[k]);     // ds_read_b128: 4 planes per LDS instruction
+        for (int k = 0; k < KREG; ++k) v[k] = L.staged(g.rc[k]);     // ds_read_b128: 4 planes per LDS instruction
         between(1);
 #pragma unroll
         for (int k = 0; k < KREG; ++k) accum4<MAXOP>(a, v[k], g.rc[k], __float_as_uint(g.rc[k].y) != NULL_B);
     }
     between(2);
-    for (uint32_t r = g.r0 + ((uint32_t)KREG << g.g_log); r < g.rl && !(SLR_SKIP & 8); r += (uint32_t)RB << g.g_log) {
+    for (uint32_t r = g.r0 + ((uint32_t)KREG << g.g_log); r < g.rl; r += (uint32_t)RB << g.g_log) {
         WRec q[RB];
 #pragma unroll
         for (int k = 0; k < RB; ++k) { const uint32_t i = r + ((uint32_t)k << g.g_log); q[k] = L.rec_get(i < g.rl ? i : Cfg::NULLREC); }
@@ -483,7 +465,8 @@ struct PixelSums { float nrm, g2_sum, g2_nrm; };
 // SLAB (the sink launch of the scan front end, splat_op.hip; with ACCUM): this workgroup holds only SOME of the piece's entries, batch after
 // batch -- other workgroups the rest -- so it accumulates its un-normalised sums in a slab of its own ([planes of its channel group + a
 // normaliser row][8 x 64 pixels of the tile], through its own earlier stores) and the piece's last workgroup adds the slabs up.
-template <class Cfg, bool NORM, bool MAXOP, bool G2, bool ACCUM, bool SLAB = false>
+// ADAPT: the per-wave choice of how long a list a lane walks alone (pixel_list) and 4 records per lane and trip in the cooperative walks.
+template <class Cfg, bool NORM, bool MAXOP, bool G2, bool ACCUM, bool SLAB = false, bool ADAPT = SLAB>
 __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFrame &f, const TileLds<Cfg> &L, const Piece &p, int tid,
                                               rsrc_t rin, uint32_t hw4, int cb, int ce, const EntryRegs<Cfg> &e,
                                               float (&preA)[Cfg::EPT][4], float (&preB)[Cfg::EPT][4], PixelSums &sums, bool first, bool last,
@@ -493,7 +476,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
     const int lane = tid & 63;
     // (a sink task: whole tiles whose entries pile onto a few pixels -- every list far above the wave's average is walked by the whole wave;
     //  left to their own lanes, lists of ~1000 records made single tasks take 250 us)
-    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid, lane_group_log(p), SLAB ? 64 : SLR_HEAVY_MAX);
+    const PixelList<Cfg> g = pixel_list<Cfg>(L, tid, lane_group_log(p), ADAPT ? 64 : SLR_HEAVY_MAX);
     const int ly = g.pid / TILE_W, lx = p.pca + g.pid - ly * TILE_W;
     const int oy = p.ty0 + ly, ox = p.tx0 + lx;
     const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb) & ((tid & ((1 << g.g_log) - 1)) == 0);      // (the first lane of a pixel's group stores)
@@ -530,27 +513,16 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
     // the loop makes it drain the whole queue at the top of every chunk: the prefetch distance of two chunks becomes one)
     auto chunk = [&](auto full_tag, float (&pre)[EPT][4], int c0) {
         constexpr bool FULL = decltype(full_tag)::value;
-        if (!(SLR_SKIP & 2)) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
             L.val4[tid + j * TT] = G2 ? make_float4(pre[j][0] * e.m[j], pre[j][1] * e.m[j], pre[j][2] * e.m[j], pre[j][3] * e.m[j])
                                       : make_float4(pre[j][0], pre[j][1], pre[j][2], pre[j][3]);
-        }
         if (c0 - cb < 32) T_STAMP(s, 8 + 6 * ((c0 - cb) / 4));
-        if (!(SLR_SKIP & 32)) __syncthreads();
+        __syncthreads();
         if (c0 - cb < 32) T_STAMP(s, 9 + 6 * ((c0 - cb) / 4));
         float acc[4];
         // the plane loads of the chunk after next (two chunks ahead), one plane at each of the gather's four stops
-        gather_chunk<Cfg, MAXOP, SLAB>(L, g, lane, s.init, acc, [&](int u) {
-            if (SLR_PREFETCH_BURST_ONE && Cfg::NDIR == 1) {      // one flow: all planes' loads at the first stop (its chunks are short: every load
-                if (u == 0) {                                     // as early as possible)
-                    __builtin_amdgcn_sched_barrier(0);
-                    prefetch_planes<Cfg>(rin, e, pre, c0 + 8, cmax, hw4);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                return;
-            }
-            if (SLR_SKIP & 1) return;
+        gather_chunk<Cfg, MAXOP, ADAPT>(L, g, lane, s.init, acc, [&](int u) {
             if constexpr (Cfg::B4) {                              // one entry's 16 bytes per stop
                 if (u < EPT) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -567,16 +539,8 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
             __builtin_amdgcn_sched_barrier(0);
         });
         if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));
-        if (!(SLR_SKIP & 32)) __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up)
+        __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up)
         if (c0 - cb < 32) T_STAMP(s, 13 + 6 * ((c0 - cb) / 4));
-#if SLR_OUT_B8_EXP
-        if constexpr (Cfg::B4 && !ACCUM) {            // experiment: the output channel-blocked by 8 ([C/8][H][W][8]): one 16-byte store per chunk
-            float4 r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            if (NORM) { r4.x *= inv; r4.y *= inv; r4.z *= inv; r4.w *= inv; }
-            buf_st4(rout, inside ? opix * 32u + (uint32_t)(c0 & 4) * 4u : BUF_OOB, (uint32_t)(c0 >> 3) * (hw4 * 8u), r4);
-            return;
-        }
-#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (FULL || c0 + u < ce) {                // (scalar: only the last chunk of a plane count that is not a multiple of 4)
@@ -584,7 +548,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
                 float r = acc[u];
                 if (ACCUM && !first) { const float o = buf_ld(rout, voff, soff); r = MAXOP ? fmaxf(r, o) : r + o; }   // earlier passes of this piece
                 if (NORM && !SLAB && (!ACCUM || last)) r *= inv;
-                if (!(SLR_SKIP & 16) || c0 == cb) buf_st<SLAB ? BUF_SC1 : SLR_STORE_AUX>(rout, voff, soff, r);      // (a slab is read by another workgroup)
+                buf_st<SLAB ? BUF_SC1 : SLR_STORE_AUX>(rout, voff, soff, r);      // (a slab is read by another workgroup)
             }
         }
     };

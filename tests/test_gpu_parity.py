@@ -102,7 +102,8 @@ def test_euler_batch_is_one_launch_without_host_sync(S, golden_dir):
         assert np.array_equal(host(d), g[f"{tag}_disp"]), tag
         assert np.array_equal(host(v), g[f"{tag}_vis"]), tag
         assert np.array_equal(host(dg), g[f"{tag}_disp"]), tag
-        np.testing.assert_allclose(host(gm), g[f"{tag}_gmotion"], rtol=1e-5, atol=1e-5, err_msg=tag)
+        # (fp32 atomics in any order against torch's index_put order: cells that hundreds of paths cross hold sums of ~3)
+        np.testing.assert_allclose(host(gm), g[f"{tag}_gmotion"], rtol=1e-4, atol=1e-4, err_msg=tag)
         for b in (0, 5, 15):                                 # one step of the negated field, per sample = the one-sample call
             d1, _ = S.euler_integration(-m[b:b + 1], 1)
             assert np.array_equal(host(d_neg[b:b + 1]), host(d1))

@@ -32,3 +32,14 @@ print(f"  boxes + candidate list {seg(0, 1):.2f} | row walks {seg(1, 2):.2f} | e
       f"barrier {seg(4, 5):.2f} | scan + scatter + lists {seg(5, 6):.2f} | chunks {seg(6, 59):.2f}")
 span = (t[:, 59].max() - t[:, 0].min()) / clk
 print(f"  first start -> last end {span:.1f} us; starts spread {(t[:, 0].max() - t[:, 0].min()) / clk:.1f} us")
+full = buf.cpu().numpy().reshape(nb, SL)
+st = full[full[:, 0] > 0]
+t00 = st[:, 0].min()
+# workgroups that deferred their piece never reach slot 59: their end is unknown; list the longest complete lives and the deferred ones
+order = np.argsort(-(t[:, 59] - t[:, 0]))[:8]
+for i in order:
+    r = t[i]
+    print(f"  long: entries {r[60]} candidates {r[61]} | cand {(r[1]-r[0])/clk:.1f} walk {(r[2]-r[1])/clk:.1f} rec {(r[6]-r[2])/clk:.1f} lists {(r[7]-r[6])/clk:.1f} chunks {(r[59]-r[7])/clk:.1f} | life {(r[59]-r[0])/clk:.1f} start {(r[0]-t00)/clk:.1f} longest list {r[63]}")
+dfr = st[(st[:, 59] == 0) & (st[:, 2] > 0)]
+for r in dfr[np.argsort(-dfr[:, 60])][:6]:
+    print(f"  deferred: entries {r[60]} candidates {r[61]} | cand {(r[1]-r[0])/clk:.1f} first walk {(r[2]-r[1])/clk:.1f} start {(r[0]-t00)/clk:.1f}")
