@@ -21,6 +21,7 @@
 #define SLR_LMAX 16             // records a work-item walks alone before the wave helps (8 / 16 / 32: within 1 %)
 #define SLR_HEAVY_SLACK 24      // a list this much longer than the wave's share is walked by the whole wave (8: t=59 +55 %; 64: +10 %)
 #define SLR_HEAVY_MAX 4         // at most this many cooperative (whole-wave) list walks per wave and chunk; more long lists: every lane walks its own
+#define SLR_BAL_SLACK 24        // scan kernels: a tile whose longest record list exceeds its positions per work-item by more than this takes the balanced gather (splat_tile.hpp)
 #define SLR_XCD_GROUP 4         // neighbouring tiles kept on one XCD (column halo from its L2: -12 % HBM fetch).  1 / 2 / 4 / 8: 183.9 / 182.9 / 185.5 / 182.3 us per frame
 #define SLR_BATCH_INTERLEAVE 1  // block groups of the frames of a launch dealt round-robin: same tile of consecutive frames shares an L2 (fetch 770 -> 482 MB per frame)
 

@@ -37,6 +37,7 @@ void set_error(const char *fmt, ...) {
 using OpCfg = TileCfg<1, SLR_EPT_ONE, true, SLR_KREG_ROWS>;       // one flow: 1024 entries per workgroup, 6-byte records, 46 KiB of LDS
 using OpPassCfg = TileCfg<1, SLR_EPT_DEFER, true, SLR_KREG_ROWS>; // the pass-by-pass launches: passes of 2048 entries, 86 KiB (most deferred pieces
                                                                   // are just over a segment and finish in one pass; these run on a near-empty chip)
+using ScanCfg = TileCfg<1, SLR_EPT_ONE, true, SLR_KREG_ROWS, false, true>;     // the scan front end's kernels: + the balanced gather's sums (splat_tile.hpp: BalLane), 63 KiB (two workgroups per CU by their registers anyway)
 constexpr int OP_SEG = OpCfg::SEG;
 constexpr uint32_t OP_DEFER_WG = 64;               // workgroups of the pass-by-pass launch (x channel groups)
 static_assert(4 * ROW_CAP * 4 + 2048 * 4 <= OpCfg::REC_BYTES, "row lists and the scan's candidate list live in the record area");
@@ -523,7 +524,7 @@ __device__ __forceinline__ uint32_t scan_collect(const TileShared &s, const Tile
 //  37 -> 49.5 us, 512 arrival atomics on one word ~ 20 us; column pieces in the first launch: every piece repeats the candidate walk.)
 template <bool NORM, bool MAXOP>
 __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
-    using Cfg = OpCfg;
+    using Cfg = ScanCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const TileLds<Cfg> L(smem);
     const TileShared &s = a.s;
@@ -601,7 +602,7 @@ constexpr uint32_t SINK_P = SLR_SINK_PIECES, SINK_T = SLR_SINK_TASKS, SINK_MINE 
 static_assert(SINK_T <= 16, "slab bits of the arrival word");
 template <bool NORM, bool MAXOP>
 __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
-    using Cfg = OpCfg;
+    using Cfg = ScanCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t mine[2 * SINK_MINE];              // this workgroup's tasks of a candidate block (build_records overwrites the list)
     __shared__ uint32_t arrived;
@@ -638,37 +639,40 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
         const rsrc_t rin = sample_planes(s, p, k.hw4);
         PixelSums sums = {0.0f, 0.0f, 0.0f};
         bool wrote = false;
+        // One task loop for both kinds of piece (one copy of the record / gather code): listed -- task k_ = entries [k_ * SEG, ...) of the
+        // piece's entry array, loaded as they are; not listed -- task = the next pair of candidate source tiles dealt to this slot, walked.
         if (listed) { SINK_STAMP(1, wall_clock64()); SINK_STAMP(8, all); SINK_STAMP(9, (ntask_q - bslot + nslot - 1u) / nslot); }
-        for (uint32_t k_ = bslot; listed && k_ < ntask_q; k_ += nslot) {
-            const uint32_t lo = k_ * (uint32_t)Cfg::SEG, total = min((uint32_t)Cfg::SEG, all - lo);
-            const float4 *src = a.sink_ent + eoff + lo;
-            L.cnt[tid] = 0;
+        uint32_t k_ = bslot;
+        int base = 0;
+        uint32_t j = 0, n_mine = 0, tk0 = 0;              // pairs: my tasks of the current candidate block; tasks of the blocks before it
+        for (;;) {
+            uint32_t total;
+            if (listed) {
+                if (k_ >= ntask_q) break;
+                const uint32_t lo = k_ * (uint32_t)Cfg::SEG;
+                total = min((uint32_t)Cfg::SEG, all - lo);
+                const float4 *src = a.sink_ent + eoff + lo;
+                L.cnt[tid] = 0;
 #pragma unroll
-            for (int j = 0; j < Cfg::EPT; ++j)
-                if ((uint32_t)tid + (uint32_t)j * TT < total) L.ent4[tid + j * TT] = src[tid + j * TT];
-            __syncthreads();
-            EntryRegs<Cfg> e;
-            float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
-            build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
-            stream_planes<Cfg, NORM, MAXOP, false, true, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, !wrote, false, slab);
-            wrote = true;
-            __syncthreads();
-        }
-        uint32_t tk0 = 0;                                  // tasks of the candidate blocks before this one
-        for (int base = 0; !listed && base < s.tiles; base += 2048) {
-            __syncthreads();
-            const uint32_t nc = scan_candidates<Cfg>(s, f, L, p, tid, base);
-            const uint32_t ntask = (nc + 1u) / 2u;
-            const uint32_t t0 = (bslot + nslot - tk0 % nslot) % nslot;         // my first task of this block
-            const uint32_t n_mine = t0 < ntask ? (ntask - t0 + nslot - 1u) / nslot : 0u;
-            for (uint32_t i = (uint32_t)tid; i < 2u * n_mine; i += TT) {
-                const uint32_t c = 2u * (t0 + (i >> 1) * nslot) + (i & 1u);
-                mine[i] = c < nc ? clist[c] : 0xffffffffu;
-            }
-            tk0 += ntask;
-            __syncthreads();
-            if (base == 0) { SINK_STAMP(1, wall_clock64()); SINK_STAMP(8, nc); SINK_STAMP(9, n_mine); }
-            for (uint32_t j = 0; j < n_mine; ++j) {
+                for (int i = 0; i < Cfg::EPT; ++i)
+                    if ((uint32_t)tid + (uint32_t)i * TT < total) L.ent4[tid + i * TT] = src[tid + i * TT];
+                k_ += nslot;
+                __syncthreads();
+            } else {
+                while (j >= n_mine && base < s.tiles) {    // the next block of 2048 source tiles: its candidates, my pairs of them
+                    __syncthreads();
+                    const uint32_t nc = scan_candidates<Cfg>(s, f, L, p, tid, base);
+                    const uint32_t ntask = (nc + 1u) / 2u;
+                    const uint32_t t0 = (bslot + nslot - tk0 % nslot) % nslot;
+                    n_mine = t0 < ntask ? (ntask - t0 + nslot - 1u) / nslot : 0u;
+                    for (uint32_t i = (uint32_t)tid; i < 2u * n_mine; i += TT) {
+                        const uint32_t c = 2u * (t0 + (i >> 1) * nslot) + (i & 1u);
+                        mine[i] = c < nc ? clist[c] : 0xffffffffu;
+                    }
+                    tk0 += ntask; j = 0; base += 2048;
+                    __syncthreads();
+                }
+                if (j >= n_mine) break;
                 L.cnt[tid] = 0;
                 if (tid == 0) L.misc[0] = 0;
                 if (tid < 2 * TILE_H) {
@@ -677,20 +681,21 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
                     if (st != 0xffffffffu) scan_row_words(s, st, tid % TILE_H, w0, w1);
                     L.rl[tid] = w0; L.rl[ROW_CAP + tid] = w1;
                 }
+                ++j;
                 __syncthreads();
                 p.len0 = p.n0 = 2 * TILE_H;
                 rows_walk<Cfg, 1, true, false>(s, f, L, p, tid, 0u, 0u, (uint32_t)Cfg::SEG);
                 __syncthreads();
-                const uint32_t total = L.misc[0];          // <= 16 row segments x 64 pixels = SEG
-                if (total != 0u) {
-                    EntryRegs<Cfg> e;
-                    float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
-                    build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
-                    stream_planes<Cfg, NORM, MAXOP, false, true, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, !wrote, false, slab);
-                    wrote = true;
-                }
-                __syncthreads();
+                total = L.misc[0];                         // <= 16 row segments x 64 pixels = SEG
             }
+            if (total != 0u) {
+                EntryRegs<Cfg> e;
+                float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
+                build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+                stream_planes<Cfg, NORM, MAXOP, false, true, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, !wrote, false, slab);
+                wrote = true;
+            }
+            __syncthreads();
         }
         // arrive: this workgroup's slab stores (sc1: written through) have been performed; the last workgroup of the (piece, channel
         // group) adds the slabs up with agent-scope loads.  (No fences: an agent-scope fence writes back and invalidates the whole L2 of
@@ -920,7 +925,7 @@ template <bool NORM, bool MAXOP>
 static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     static LdsOptIn attr, attr_s;
     if (int e = lds_opt_in((const void *)op_scan_kernel<NORM, MAXOP>, 159 * 1024, attr)) return e;
-    if (int e = lds_opt_in((const void *)op_sink_kernel<NORM, MAXOP>, (int)OpCfg::LDS_BYTES, attr_s)) return e;
+    if (int e = lds_opt_in((const void *)op_sink_kernel<NORM, MAXOP>, (int)ScanCfg::LDS_BYTES, attr_s)) return e;
     a.f.box = (const SrcBox *)w.box; a.f.totals = w.totals; a.f.defer = w.defer;
     a.sink_cnt = w.sink_cnt; a.sink_pool = w.sink_pool; a.sink_ent = w.sink_ent; a.sink_ent_cap = w.L.sink_ent_cap;
     hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
@@ -928,7 +933,7 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
     uint32_t pieces, groups;
     scan_shape(w.L.nt, a.s.C, pieces, groups);
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, groups, pieces), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, groups, pieces), dim3(TT), ScanCfg::LDS_BYTES, st, a);
     if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
     g_ev_start = g_ev_stop = nullptr;
     // pieces of more than SEG entries (appended by their workgroups): the sink launch -- every piece by up to SINK_T x channel groups
@@ -945,7 +950,7 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     a.sink_t = (uint32_t)((avail - sink_x) / sink_x < SINK_T ? (avail - sink_x) / sink_x : SINK_T);      // (at least every piece slot's own pieces get full slots)
     a.sink_qcap = a.sink_t ? (uint32_t)((avail - sink_x) / a.sink_t) : 0u;
     if (a.sink_qcap > w.L.items_cap) a.sink_qcap = w.L.items_cap;
-    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_x, wgroups, SINK_T), dim3(TT), OpCfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_x, wgroups, SINK_T), dim3(TT), ScanCfg::LDS_BYTES, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }

@@ -33,17 +33,19 @@ enum { MUL_ONE = 0, MUL_PLANE = 1, MUL_EXP = 2, MUL_EXP_SHIFT = 3 };
 // (their lists are twice as long: one ds_read_b64 per record beats two reads) -> 79 KiB, two per CU.
 // B4: the value planes are plane-blocked by 4 in memory ([C/4][H][W][4], slr_pack_planes4: the clip path packs its feature planes once per
 // clip): a chunk's 4 planes of an entry are ONE 16-byte load that arrives as the staged float4 -- a quarter of the load instructions.
-template <int NDIR_, int EPT_, bool REC6_, int KREG_, bool B4_ = false>
+// BAL: 17 KiB more of LDS (a float4 per work-item, a float4 per output pixel, a byte per work-item) for the BALANCED gather of tiles whose
+// records pile onto a few pixels (BalLane below; the scan front end's kernels).
+template <int NDIR_, int EPT_, bool REC6_, int KREG_, bool B4_ = false, bool BAL_ = false>
 struct TileCfg {
     static constexpr int NDIR = NDIR_, EPT = EPT_, KREG = KREG_, CHUNK = 4;
-    static constexpr bool REC6 = REC6_, B4 = B4_;
+    static constexpr bool REC6 = REC6_, B4 = B4_, BAL = BAL_;
     static_assert(!B4_ || EPT_ <= 4, "one 16-byte load per gather stop");
     static constexpr int SEG = EPT * TT;
     static constexpr int RECCAP = 4 * SEG + TT;    // <= 4 records per entry + one pad per pixel (odd list lengths: bank spreading)
     static constexpr uint32_t NULL_E = SEG;        // staged-entry index of the all-zero slot
     static_assert(!REC6_ || (EPT_ * TILE_PIX + 1) * 16 <= 65536, "byte offsets of staged entries travel in 16 bits (6-byte records)");
     static constexpr uint32_t NULLREC = RECCAP - 1;   // a record (all-zero slot, weight 0) that no list owns (the last pixel's pad)
-    static constexpr size_t HEAD = (size_t)(TT + 16 + 16 + TT / 2) * 4;
+    static constexpr size_t HEAD = (size_t)(TT + 16 + 16 + TT / 2) * 4 + (BAL_ ? (size_t)TT * 32 + (size_t)TT * 2 : 0);
     static constexpr size_t REC_BYTES = ((size_t)RECCAP * (REC6 ? 6 : 8) + 15) & ~(size_t)15;
     static constexpr size_t LDS_BYTES = HEAD + REC_BYTES + (size_t)(SEG + 1) * 16;
     static_assert(HEAD % 16 == 0, "records and staged values are 16-byte aligned");
@@ -89,6 +91,8 @@ template <class Cfg>
 struct TileLds {
     uint32_t *cnt, *wsum, *misc;   // [TT] records per output pixel; [16] scan words; [16] counters
     uint16_t *off;                 // [TT] exclusive prefix of the (padded) counts
+    float4 *bcarry, *bsum;         // BAL: [TT] the open sum a work-item's positions end with; [TT] the sums of 4 planes per output pixel
+    uint16_t *bflag;               // ... [TT] per work-item: 1 = a pixel's region starts or ends among its positions
     uint2 *rec8;                   // !REC6: [RECCAP] (entry, weight bits)
     float *rec_w;                  // REC6: [RECCAP] weights ...
     uint16_t *rec_e;               // ... and [RECCAP] entry indices
@@ -102,6 +106,9 @@ struct TileLds {
         wsum = smem + TT;
         misc = smem + TT + 16;
         off = reinterpret_cast<uint16_t *>(smem + TT + 32);
+        bcarry = reinterpret_cast<float4 *>(smem + TT + 32 + TT / 2);
+        bsum = bcarry + TT;
+        bflag = reinterpret_cast<uint16_t *>(bsum + TT);
         char *r = reinterpret_cast<char *>(smem) + Cfg::HEAD;
         rec8 = reinterpret_cast<uint2 *>(r);
         rec_w = reinterpret_cast<float *>(r);
@@ -439,6 +446,101 @@ __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelL
     }
 }
 
+// ---- the BALANCED gather ------------------------------------------------------------------------------------------------------------
+// Euler-integrated flows pile records onto a few output pixels and rows: a tile of 885 entries whose 3500 records sit in ONE tile row keeps
+// that row's wave busy for 5-6 us per chunk (~55 records per lane, two dependent LDS reads each) while seven waves idle -- such tiles made
+// the scan tile kernel take 55-73 us on smooth flows against 29 on incoherent ones.  The record lists of a tile are contiguous in pixel
+// order, so the work is dealt by POSITION: work-item t takes positions [t * S, (t + 1) * S) of the record area (S = positions / 512 <= 9,
+// list pads included).  A pixel whose region lies inside one work-item's positions is summed and stored by it (bsum[pixel]); a region cut
+// by position ranges is put together without atomics: every work-item leaves the open sum its range ends with in bcarry[t], and after the
+// chunk's second barrier the work-item holding the region's END adds its own head, the carries of the ranges in between and the tail of
+// the range the region starts in -- in a fixed order: reproducible -- then a third barrier, and every work-item reads its own pixel's sum.
+// Chosen per tile, when its longest list exceeds S by SLR_BAL_SLACK records (ordinary tiles keep the register path).
+// (Tried first: LDS float atomics into the pixel's sum -- 152 us for the C2-sized smooth case against 91: a pile-up pixel's ~100 flushes
+//  hit one address; without the flushes, timing only, 75.  Then the long lists dealt to the tile's waves as cooperative walks: 96.)
+struct BalLane {
+    uint32_t q0, p0;               // first position of this work-item; the output pixel of that position
+    uint32_t valid, endm;          // bit k: position q0 + k holds a record; ... is the last position of its pixel's region
+    uint32_t ua;                   // for a work-item that ends a region begun before its range: the work-item whose range the region starts in
+    bool cont_in;                  // the first position continues a region begun before this range
+};
+
+template <class Cfg>
+__device__ __forceinline__ BalLane bal_setup(const TileLds<Cfg> &L, int tid, uint32_t S, uint32_t ntot) {
+    static_assert(TT == 512, "nine halvings");
+    BalLane b;
+    b.q0 = (uint32_t)tid * S;
+    uint32_t lo = 0, hi = TT - 1;                        // the last pixel whose region starts at or before q0
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        const bool le = (uint32_t)L.off[mid] <= b.q0;
+        lo = le ? mid : lo; hi = le ? hi : mid - 1u;
+    }
+    b.p0 = lo;
+    uint32_t p = lo, roff = L.off[p], rcnt = L.cnt[p];
+    b.valid = 0u; b.endm = 0u;
+    b.cont_in = b.q0 < ntot && roff != b.q0;
+    for (uint32_t k = 0; k < S; ++k) {
+        const uint32_t q = b.q0 + k;
+        if (q >= ntot) break;
+        if (q >= roff + (rcnt | 1u)) { ++p; roff = L.off[p]; rcnt = L.cnt[p]; }      // (every region holds a position: one step at most)
+        b.valid |= (q < roff + rcnt ? 1u : 0u) << k;
+        b.endm |= (q + 1u == roff + (rcnt | 1u) ? 1u : 0u) << k;
+    }
+    L.bflag[tid] = (b.endm != 0u || !b.cont_in) ? 1u : 0u;
+    __syncthreads();
+    b.ua = (uint32_t)tid;
+    if (b.cont_in && b.endm) {                           // walk back to the range the region starts in (pass-through ranges in between)
+        uint32_t u = (uint32_t)tid - 1u;                  // (cont_in: tid > 0)
+        while (!L.bflag[u]) --u;                          // (range 0 never continues a region: the walk ends)
+        b.ua = u;
+    }
+    return b;
+}
+
+// one chunk (WEIGHTS: the record weights instead of weight x staged value, in .x): complete regions -> bsum, the open tail -> bcarry
+template <class Cfg, bool WEIGHTS, typename F>
+__device__ __forceinline__ Acc4 bal_walk(const TileLds<Cfg> &L, const BalLane &b, int tid, uint32_t S, F &&between) {
+    Acc4 a = acc4_init<false>(0.0f), head = acc4_init<false>(0.0f);
+    uint32_t p = b.p0;
+    bool first = b.cont_in;
+    for (uint32_t k = 0; k < S; ++k) {
+        if (k < 4u) between((int)k);
+        if ((b.valid >> k) & 1u) {
+            if (WEIGHTS) a.lo.x += L.rec_weight(b.q0 + k);
+            else { const WRec r = L.rec_get(b.q0 + k); accum4<false>(a, L.staged(r), r, true); }
+        }
+        if ((b.endm >> k) & 1u) {
+            if (first) head = a; else L.bsum[p] = make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y);
+            first = false;
+            a = acc4_init<false>(0.0f);
+            ++p;
+        }
+    }
+    for (uint32_t k = S; k < 4u; ++k) between((int)k);
+    L.bcarry[tid] = make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y);
+    return head;
+}
+
+// after the barrier: the regions cut by position ranges, by the work-item that holds their end
+template <class Cfg>
+__device__ __forceinline__ void bal_join(const TileLds<Cfg> &L, const BalLane &b, int tid, const Acc4 &head) {
+    if (b.cont_in && b.endm) {
+        float4 t = make_float4(head.lo.x, head.lo.y, head.hi.x, head.hi.y);
+        // (8 carries in flight: a pile-up pixel's region spans ~100 ranges; one LDS round trip per carry was 6 us per chunk)
+        for (int u = tid - 1; u >= (int)b.ua; u -= 8) {
+            float4 c[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = L.bcarry[max(u - i, 0)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (u - i >= (int)b.ua) { t.x += c[i].x; t.y += c[i].y; t.z += c[i].z; t.w += c[i].w; }
+        }
+        L.bsum[b.p0] = t;
+    }
+}
+
 // sum of the pixel's record weights (the normaliser when the weights carry m)
 template <class Cfg>
 __device__ __forceinline__ float weight_sum(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane) {
@@ -477,6 +579,21 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
     // (a sink task: whole tiles whose entries pile onto a few pixels -- every list far above the wave's average is walked by the whole wave;
     //  left to their own lanes, lists of ~1000 records made single tasks take 250 us)
     const PixelList<Cfg> g = pixel_list<Cfg>(L, tid, lane_group_log(p), ADAPT ? 64 : SLR_HEAVY_MAX);
+    // balanced gather (BAL configurations, one weight group, sums; not the sink tasks, whose pile-ups sit on single pixels: cooperative walks
+    // serve those better): by the tile's longest list against the positions per work-item.  Every wave leaves its longest list in LDS now;
+    // the decision is taken behind the first chunk's barrier (a barrier of its own cost ordinary tiles ~1 us per call).
+    int bal = 0;                                       // 0 undecided, 1 balanced, 2 register path
+    uint32_t bal_s = 0;
+    BalLane bl = {0u, 0u, 0u, 0u, 0u, false};
+    constexpr bool CAN_BAL = Cfg::BAL && !MAXOP && !G2 && !SLAB;
+    if constexpr (CAN_BAL) {
+        if (g.g_log == 0) {                            // (uniform; pieces with lane groups keep their own rule)
+            uint32_t mx = g.r1 - (uint32_t)L.off[g.pid];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+            if (lane == 0) L.wsum[8 + (tid >> 6)] = mx;
+        } else bal = 2;
+    }
     const int ly = g.pid / TILE_W, lx = p.pca + g.pid - ly * TILE_W;
     const int oy = p.ty0 + ly, ox = p.tx0 + lx;
     const bool inside = (oy < s.H) & (ox < s.W) & (lx < p.pcb) & ((tid & ((1 << g.g_log) - 1)) == 0);      // (the first lane of a pixel's group stores)
@@ -522,7 +639,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
         if (c0 - cb < 32) T_STAMP(s, 9 + 6 * ((c0 - cb) / 4));
         float acc[4];
         // the plane loads of the chunk after next (two chunks ahead), one plane at each of the gather's four stops
-        gather_chunk<Cfg, MAXOP, ADAPT>(L, g, lane, s.init, acc, [&](int u) {
+        auto later_loads = [&](int u) {
             if constexpr (Cfg::B4) {                              // one entry's 16 bytes per stop
                 if (u < EPT) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -537,9 +654,31 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
 #pragma unroll
             for (int j = 0; j < EPT; ++j) pre[j][u] = buf_ld(rin, e.off[j], soff);
             __builtin_amdgcn_sched_barrier(0);
-        });
+        };
+        Acc4 head = acc4_init<false>(0.0f);
+        if constexpr (CAN_BAL) {
+            if (bal == 0) {                               // (first chunk, uniform: the waves' longest lists are in LDS behind this chunk's barrier)
+                uint32_t mx = 0;
+#pragma unroll
+                for (int w_ = 0; w_ < TT / 64; ++w_) mx = max(mx, L.wsum[8 + w_]);
+                const uint32_t ntot = (uint32_t)L.off[TT - 1] + (L.cnt[TT - 1] | 1u);
+                bal_s = (ntot + TT - 1u) / TT;
+                bal = mx > bal_s + (uint32_t)SLR_BAL_SLACK ? 1 : 2;
+                if (bal == 1) bl = bal_setup<Cfg>(L, tid, bal_s, ntot);
+            }
+            if (bal == 1) head = bal_walk<Cfg, false>(L, bl, tid, bal_s, later_loads);
+        }
+        if (!CAN_BAL || bal != 1) gather_chunk<Cfg, MAXOP, ADAPT>(L, g, lane, s.init, acc, later_loads);
         if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));
-        __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up)
+        __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up); balanced: every carry is in
+        if constexpr (CAN_BAL) {
+            if (bal == 1) {
+                bal_join<Cfg>(L, bl, tid, head);
+                __syncthreads();
+                const float4 r4 = L.bsum[tid];            // (written again after the next chunk's first barrier)
+                acc[0] = r4.x; acc[1] = r4.y; acc[2] = r4.z; acc[3] = r4.w;
+            }
+        }
         if (c0 - cb < 32) T_STAMP(s, 13 + 6 * ((c0 - cb) / 4));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
