@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 H, W, NFRAMES = 768, 1280, 60
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_ROUND = "r5"            # profiles/r4_traffic_<name>.json: PMC passes (tools/collect_profiles.sh -> tools/pmc_kernel_traffic.py) of one
+TRAFFIC_ROUND = "r6"            # profiles/<round>_traffic_<name>.json: PMC passes (tools/collect_profiles.sh -> tools/pmc_kernel_traffic.py) of one
                                 # kernel each; every file carries the hash of the kernel sources it was taken on
 
 
@@ -373,11 +373,13 @@ def emit(line, extra, full=False):
         big.update(extra)
         print("#ctx full_line " + json.dumps(big), flush=True)
     c = dict(line)
-    c["dtype"] = "f32 (splat path fp32; convs: fp32 in/out/accumulate, operands as 2 x f16 splits = 22 bits; all-fp32 rate = fps_fp32_convs)"
+    c["dtype"] = "f32 (convs: fp32 in/out/accumulate, operands 2 x f16 splits = 22 bits; all-fp32: fps_fp32_convs)"
     c["config"] = {k: v for k, v in line["config"].items() if v is not None and k not in ("H", "W", "frames_per_step")}
+    c["config"]["workload"] = c["config"]["workload"].replace(", random-init weights of the reference architecture", ", random-init weights").replace(
+        " encoder->Euler->softmax-splat->pconv2 decoder", "")
     r = line["roofline"]
     c["roofline"] = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "alg_bytes_per_launch",
-                          "frames_per_launch", "launch_avg_us", "frac_min_bytes", "avg_us", "min_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
+                          "launch_avg_us", "frac_min_bytes", "avg_us", "min_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
     src = r.get("traffic_source") or ""
     c["roofline"]["traffic_source"] = "measured in this run" if src.startswith("measured in this run") else ("static (profiles/), not this run" if src else None)
     pe = line["parity_err"]
@@ -388,6 +390,7 @@ def emit(line, extra, full=False):
                            "frames_vs_reference_models": pe.get("frames_vs_reference_models_max_abs"),
                            "frames_256_vs_reference_models": pe.get("frames_256_vs_reference_models_digest_max_abs"),
                            "holes": pe.get("holes"), "reference_holes": pe.get("reference_holes")}
+        c["parity_err"] = {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in c["parity_err"].items()}
     cb = line["cpu_baseline"]
     if cb:
         c["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s (splat stage)", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
@@ -404,8 +407,7 @@ def emit(line, extra, full=False):
     d = extra.get("roofline_dropin")
     if d:
         fl = d["flows"]
-        c["dropin"] = {"what": "one-flow operator, whole call (all launches, HIP graph): us, fraction of 8 TB/s on B_sum",
-                       "frac": d.get("frac"), "frac_is": d.get("frac_is")}
+        c["dropin"] = {"is": "one-flow operator, whole call: [us, frac of 8 TB/s]; frac = slower Euler flow", "frac": d.get("frac")}
         for k in ("euler_t30", "euler_t59", "identity", "incoherent"):
             if k in fl:
                 c["dropin"][k] = [fl[k]["call_us"], fl[k]["call_frac"]]
@@ -416,7 +418,7 @@ def emit(line, extra, full=False):
             c["dropin"]["c2_batched_per_sample"] = [d["c2_batched"]["per_sample_us"], d["c2_batched"]["call_frac"]]
         if "train_shape" in d:
             c["train_shape"] = {k: [v["fwd_us"], v["bwd_us"], v["frac"]] for k, v in d["train_shape"]["flows"].items()}
-            c["train_shape"]["what"] = "_FunctionSoftsplat [2,65,256,256]: forward us, backward us, fraction of 8 TB/s (fwd + bwd bytes / time)"
+            c["train_shape"]["is"] = "_FunctionSoftsplat [2,65,256,256]: [fwd us, bwd us, frac]"
     b = extra.get("roofline_backward")
     if b:
         c["backward"] = {k: [v["avg_us"], v["frac"]] for k, v in b["flows"].items()}
@@ -429,7 +431,8 @@ def emit(line, extra, full=False):
         cm = extra["communicator"]
         c["communicator"] = _pick(cm, "backend", "rccl_version", "world_size", "distinct_devices")
         c["communicator"]["ranks"] = [_pick(r, "rank", "device_index", "device_name", "pci_bus_id", "frames", "fps_this_rank") for r in cm["ranks"]]
-    c["context"] = "full objects: the '#ctx <name> {...}' lines above this one"
+    c = {k: v for k, v in c.items() if v is not None or k in ("vs_baseline", "cpu_baseline", "parity_err")}      # (contract keys stay, null or not)
+    c["context"] = "#ctx lines above"
     print(json.dumps(c), flush=True)
 
 
@@ -682,7 +685,7 @@ def dropin_roofline(dev, motion):
     x = torch.randn(1, C, H, W, device=dev)
     alg = (2 * C + 2) * H * W * 4
     res = {"bound": "hbm", "kernel": "slr::op_rows_kernel<false,false,false> (rows front end, the default at 1920 tiles); scan_front_end: "
-                                     "slr::op_scan_kernel<false,false,false>", "peak": HBM_PEAK_GBS,
+                                     "slr::op_scan_kernel<false,false>", "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "alg_bytes_per_call": alg, "flows": {},
            "call": "call_us = call_graph_us = GPU time of all launches of one call (HIP graph of 20 calls replayed; since round 3 -- rounds 1 and 2 "
                    "printed the eager figure under call_us); call_eager_us: Python call, event pair per call"}
@@ -740,12 +743,14 @@ def dropin_roofline(dev, motion):
         met = torch.randn(1, 1, h2, w2, device=dev)
         alg2 = (2 * c2 + 3) * h2 * w2 * 4
         cases = {"incoherent": torch.rand(1, 2, h2, w2, device=dev) * 16 - 8}
-        if tag == "c2":
+        if tag in ("c2", "128x240"):                 # Euler-integrated smooth fields: the flows the reference produces (pile-ups -> the sink launch)
             cases["smooth_t30"] = S.euler_integration(torch.from_numpy(smooth_motion(h2, w2)).to(dev), 30)[0]
+        if tag == "c2":
+            cases["smooth_t59"] = S.euler_integration(torch.from_numpy(smooth_motion(h2, w2)).to(dev), 59)[0]
         for fname, fl2 in cases.items():
             r = measure(lambda: S.FunctionSoftsplat(f2, fl2, met, "softmax"), alg2, tile=False)
             r.update({"workload": f"FunctionSoftsplat softmax, {c2} ch, {h2}x{w2}, {fname} flow", "alg_bytes": alg2,
-                      "front_end": "scan (box kernel + tile kernel + the pass-by-pass launch)"})
+                      "front_end": "scan (box kernel + tile kernel + the sink launch)"})
             prev = L.slr_splat_set_front_end(2)
             try:
                 try:
@@ -797,7 +802,9 @@ def train_shape_roofline(dev):
         fl = S.EulerIntegration()(mo, torch.tensor([t, t], device=dev)).contiguous()
         with torch.no_grad():
             fwd = _graph_call_us(lambda: S.softsplat._FunctionSoftsplat.apply(x, fl))
-            bwd = _graph_call_us(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), N, C, h, w, stream_of(x)), "backward"))
+            nb = int(L.slr_softsplat_backward_ws_bytes(N, C, h, w))          # (channel groups on small grids: what the autograd route uses)
+            bws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+            bwd = _graph_call_us(lambda: check(L.slr_softsplat_backward_ws(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), N, C, h, w, ptr(bws), nb, stream_of(x)), "backward"))
         # the autograd route end to end (eager, host launch pace included): what a training step pays
         xg, fg = x.clone().requires_grad_(True), fl.clone().requires_grad_(True)
 

@@ -257,6 +257,16 @@ int slr_softsplat_backward(const float *in, const float *flow, const float *grad
                            float *grad_in, float *grad_flow,
                            int N, int C, int H, int W, void *stream);
 
+/* The same with scratch for channel groups (round 6).  On grids smaller than the chip -- the reference TRAINS at 256 x 256, batch 2 per
+ * GPU (train_animating_scripts/train_baseline2_pconv.sh:14): 256 source tiles, one workgroup per CU walking all 65 channels -- the
+ * kernel's channels are dealt to 2-4 workgroups per tile; gradInput is per channel, the groups' partial gradFlow sums go to `ws` and
+ * a second small launch adds them up in group order (reproducible; the grouping of the channel sum differs from the one-group kernel
+ * by rounding).  slr_softsplat_backward_ws_bytes: bytes of `ws` this shape wants (0: no groups); a NULL / short `ws` = one group.
+ * slr_softsplat_backward is this call without scratch. */
+size_t slr_softsplat_backward_ws_bytes(int N, int C, int H, int W);
+int slr_softsplat_backward_ws(const float *in, const float *flow, const float *grad_out, float *grad_in,
+                              float *grad_flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------ maximum-splat family */
 
 /* _FunctionMaximumsplat.forward: out[corner] = max(init, max over sources of in*w).

@@ -21,7 +21,7 @@ SYMBOLS = (
     "slr_synth_group", "slr_global_max",
     "slr_clip_plan_bytes", "slr_clip_plan_totals", "slr_clip_plan_build", "slr_synth_group_clip",
     "slr_synth_group_clip_batch", "slr_synth_two_groups_clip_batch", "slr_pack_planes4",
-    "slr_softsplat_backward", "slr_maxsplat_forward", "slr_max_warp_norm",
+    "slr_softsplat_backward", "slr_softsplat_backward_ws_bytes", "slr_softsplat_backward_ws", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_wino_weight_bytes", "slr_conv3x3_wino_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_f32_weights", "slr_conv1x1_forward",
@@ -67,6 +67,8 @@ def lib():
         L.slr_splat_set_scan_shape.argtypes = [i, i, i, i]
         L.slr_splat_workspace_bytes.restype = sz
         L.slr_splat_workspace_bytes.argtypes = [i, i, i]
+        L.slr_softsplat_backward_ws_bytes.restype = sz
+        L.slr_softsplat_backward_ws_bytes.argtypes = [i, i, i, i]
         L.slr_clip_plan_bytes.restype = sz
         L.slr_clip_plan_bytes.argtypes = [i, i, i]
         L.slr_conv3x3_weight_bytes.restype = sz
@@ -96,6 +98,7 @@ def lib():
             "slr_pack_planes4": [fp, fp, i, i, i, i, vp],
             "slr_synth_two_groups_clip_batch": [fp, fp, fp, i, fp, fp, i, vp, vp, vp, vp, vp, i, i, i, f, vp, sz, i, vp, i, vp, vp],
             "slr_softsplat_backward": [fp, fp, fp, fp, fp, i, i, i, i, vp],
+            "slr_softsplat_backward_ws": [fp, fp, fp, fp, fp, i, i, i, i, vp, sz, vp],
             "slr_maxsplat_forward": [fp, fp, fp, f, i, i, i, i, vp, sz, i, vp],
             "slr_max_warp_norm": [fp, fp, fp, fp, i, i, i, i, vp, sz, i, vp],
             "slr_bn_relu_mask": [fp, fp, fp, fp, i, fp, i, i, i, i, vp],

@@ -21,7 +21,6 @@ namespace slr {
 // them over the gradInput stores by itself.  (Measured and not kept: the two corners of a row as ONE 4-byte-aligned
 // 8-byte load -- Euler flows -10 %, identity +20 %, tools/bwdbench.py.)
 #define SLR_GRAD_U 4
-#define SLR_GRAD_TILED 1       // 1: grad_tile_kernel (gathers through LDS where the block's destination box fits), 0: grad_kernel
 
 template <bool GIN, bool GFLOW>
 __global__ __launch_bounds__(256) void grad_kernel(const float *__restrict__ in, const float *__restrict__ flow,
@@ -114,6 +113,8 @@ constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
 #define SLR_GRAD_BENT 2                                // stage through LDS only where a wave's destinations spread over more rows than this
 #define SLR_GRAD_STRIPS 2                              // column strips of a block with a destination box each (1, 2, 4: power of two)
 #define SLR_GRAD_WAVES 4                               // __launch_bounds__ waves per SIMD of the tiled kernel
+#define SLR_GRAD_SLOTS 1024                            // small grids: channel groups while the launch stays within this many workgroups (two rounds of the 512 slots)
+#define SLR_GRAD_GROUPS_MAX 4
 #define SLR_GRAD_BUF_LD 0                              // 1: plane loads through buffer descriptors (plane offset in an SGPR, no 64-bit vector address sums).
                                 // Measured SLOWER for these gathers although the loop then has ~25 % fewer VALU instructions: both gradients
                                                        // identity / t=30 / t=59 169 / 204 / 310 us with global loads, 167 / 218 / 352 with buffer loads (box 2048)
@@ -125,8 +126,14 @@ constexpr int GT_BOX = SLR_GRAD_BOX;
 template <bool GIN, bool GFLOW>
 __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(const float *__restrict__ in, const float *__restrict__ flow,
                                                                const float *__restrict__ gout, float *__restrict__ gin,
-                                                               float *__restrict__ gflow, int C, int H, int W, int tiles_x) {
+                                                               float *__restrict__ gflow, int Ctot, int H, int W, int tiles_x, int cper,
+                                                               float *__restrict__ gpart) {
     constexpr int U = SLR_GRAD_TU;
+    // grid.z channel groups (small grids: 256 source tiles are one workgroup per CU, each walking all channels): group z takes channels
+    // [z * cper, ...) -- below, `C` is the group's channel count and every plane pointer starts at the group's first plane; its partial
+    // gradFlow sums go to gpart[z] and grad_flow_sum_kernel adds the groups up in order
+    const int cb = (int)blockIdx.z * cper;
+    const int C = min(cper, Ctot - cb);
     __shared__ float box[U][GT_BOX];
     __shared__ int red[TILE_H][SLR_GRAD_STRIPS][4];
     __shared__ int bentw[TILE_H];
@@ -203,12 +210,13 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     // The gradInput stores go through a buffer descriptor (plane offset in an SGPR, one 32-bit pixel offset; work-items outside the image
     // are dropped by its range check); the loads stay global loads (SLR_GRAD_BUF_LD above: the same gathers through a descriptor are slower).
     const uint32_t hw4 = (uint32_t)HW * 4u;
-    const rsrc_t rg = make_rsrc(gout + (size_t)n * C * HW, (uint32_t)C * hw4);
-    const rsrc_t ri = make_rsrc(GFLOW ? in + (size_t)n * C * HW : gout, (uint32_t)C * hw4);
-    const rsrc_t ro = make_rsrc(GIN ? gin + (size_t)n * C * HW : gflow, GIN ? (uint32_t)C * hw4 : 0u);
+    const size_t pbase = ((size_t)n * Ctot + cb) * HW;               // the group's first plane of this sample
+    const rsrc_t rg = make_rsrc(gout + pbase, (uint32_t)C * hw4);
+    const rsrc_t ri = make_rsrc(GFLOW ? in + pbase : gout, (uint32_t)C * hw4);
+    const rsrc_t ro = make_rsrc(GIN ? gin + pbase : gflow, GIN ? (uint32_t)C * hw4 : 0u);
     const uint32_t vi = (uint32_t)i * 4u, vst = live_px ? vi : BUF_OOB;
-    const float *gp = gout + (size_t)n * C * HW, *ip = in + (size_t)n * C * HW;
-    float *op = gin + (size_t)n * C * HW;
+    const float *gp = gout + pbase, *ip = in + pbase;
+    float *op = gin + pbase;
     auto ld_g = [&](int plane, uint32_t voff) { return SLR_GRAD_BUF_LD ? buf_ld(rg, voff, (uint32_t)plane * hw4) : gp[(size_t)plane * HW + (voff >> 2)]; };
     auto ld_i = [&](int plane, uint32_t voff) { return SLR_GRAD_BUF_LD ? buf_ld(ri, voff, (uint32_t)plane * hw4) : ip[(size_t)plane * HW + (voff >> 2)]; };
     auto st_o = [&](int plane, float g) {
@@ -320,9 +328,19 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
         }
     }
     if (GFLOW && live_px) {
-        gflow[(size_t)n * 2 * HW + i] = gx;
-        gflow[(size_t)n * 2 * HW + HW + i] = gy;
+        float *gf = gridDim.z > 1 ? gpart + ((size_t)blockIdx.z * gridDim.y + n) * 2 * HW : gflow + (size_t)n * 2 * HW;
+        gf[i] = gx;
+        gf[HW + i] = gy;
     }
+}
+
+// gradFlow = the channel groups' partial sums, added in group order
+__global__ __launch_bounds__(256) void grad_flow_sum_kernel(const float *__restrict__ gpart, float *__restrict__ gflow, size_t n, int groups) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = gpart[i];
+    for (int g = 1; g < groups; ++g) t += gpart[(size_t)g * n + i];
+    gflow[i] = t;
 }
 
 // out[src] = max(seed[src], max over in-bounds corners of maxwarp[corner])
@@ -358,28 +376,60 @@ __global__ __launch_bounds__(256) void inverse_max_kernel(const float *__restric
 
 using namespace slr;
 
-SLR_EXPORT int slr_softsplat_backward(const float *in, const float *flow, const float *grad_out, float *grad_in,
-                                      float *grad_flow, int N, int C, int H, int W, void *stream) {
+// Channel groups of the tiled kernel on grids smaller than the chip (its 64 KiB box: two workgroups per CU = 512 slots): as many groups as
+// keep the launch within ~2 rounds of the slots, each a multiple of the kernel's 4 channels per pass.
+static int grad_groups(int N, int C, int H, int W) {
+    const long long wgs = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    int g = (int)(SLR_GRAD_SLOTS / (wgs > 0 ? wgs : 1));
+    g = g > SLR_GRAD_GROUPS_MAX ? SLR_GRAD_GROUPS_MAX : g;
+    const int byc = C / 8;
+    g = g > byc ? byc : g;
+    return g < 1 ? 1 : g;
+}
+
+SLR_EXPORT size_t slr_softsplat_backward_ws_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const int g = grad_groups(N, C, H, W);
+    return g > 1 ? (size_t)g * N * 2 * H * W * 4 : 0;
+}
+
+SLR_EXPORT int slr_softsplat_backward_ws(const float *in, const float *flow, const float *grad_out, float *grad_in,
+                                         float *grad_flow, int N, int C, int H, int W, void *ws, size_t ws_bytes, void *stream) {
     SLR_CHECK_ARG(flow && grad_out, "null pointer");
     SLR_CHECK_ARG(!grad_flow || in, "input required for grad_flow");
     SLR_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && (long long)N * H * W < (1LL << 29), "sizes");
     hipStream_t st = (hipStream_t)stream;
     // the tiled kernel addresses one sample's C planes through a 32-bit buffer descriptor
-    const bool tiled = SLR_GRAD_TILED && (long long)C * H * W * 4 < (1LL << 31);
+    const bool tiled = (long long)C * H * W * 4 < (1LL << 31);
     if (tiled) {
-    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-    dim3 grid(tiles_x * tiles_y, N);
-    if (grad_in && grad_flow) hipLaunchKernelGGL((grad_tile_kernel<true, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
-    else if (grad_in) hipLaunchKernelGGL((grad_tile_kernel<true, false>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
-    else if (grad_flow) hipLaunchKernelGGL((grad_tile_kernel<false, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x);
+        const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+        // channel groups: only with scratch for the partial gradFlow sums (or when gradFlow is not asked for)
+        int groups = grad_groups(N, C, H, W);
+        if (grad_flow && groups > 1 && (!ws || ws_bytes < (size_t)groups * N * 2 * H * W * 4)) groups = 1;
+        const int cper = groups > 1 ? ((C + groups - 1) / groups + SLR_GRAD_TU - 1) / SLR_GRAD_TU * SLR_GRAD_TU : C;
+        groups = (C + cper - 1) / cper;
+        float *gpart = (float *)ws;
+        dim3 grid(tiles_x * tiles_y, N, groups);
+        if (grad_in && grad_flow) hipLaunchKernelGGL((grad_tile_kernel<true, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x, cper, gpart);
+        else if (grad_in) hipLaunchKernelGGL((grad_tile_kernel<true, false>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x, cper, gpart);
+        else if (grad_flow) hipLaunchKernelGGL((grad_tile_kernel<false, true>), grid, dim3(GT_THREADS), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W, tiles_x, cper, gpart);
+        if (grad_flow && groups > 1) {
+            const size_t n = (size_t)N * 2 * H * W;
+            hipLaunchKernelGGL(grad_flow_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)gpart, grad_flow, n, groups);
+        }
     } else {
-    dim3 grid((H * W + 255) / 256, N);
-    if (grad_in && grad_flow) hipLaunchKernelGGL((grad_kernel<true, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
-    else if (grad_in) hipLaunchKernelGGL((grad_kernel<true, false>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
-    else if (grad_flow) hipLaunchKernelGGL((grad_kernel<false, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
+        dim3 grid((H * W + 255) / 256, N);
+        if (grad_in && grad_flow) hipLaunchKernelGGL((grad_kernel<true, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
+        else if (grad_in) hipLaunchKernelGGL((grad_kernel<true, false>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
+        else if (grad_flow) hipLaunchKernelGGL((grad_kernel<false, true>), grid, dim3(256), 0, st, in, flow, grad_out, grad_in, grad_flow, C, H, W);
     }
     SLR_CHECK_LAUNCH();
     return 0;
+}
+
+SLR_EXPORT int slr_softsplat_backward(const float *in, const float *flow, const float *grad_out, float *grad_in,
+                                      float *grad_flow, int N, int C, int H, int W, void *stream) {
+    return slr_softsplat_backward_ws(in, flow, grad_out, grad_in, grad_flow, N, C, H, W, nullptr, 0, stream);
 }
 
 SLR_EXPORT int slr_max_warp_norm(const float *in, const float *flow, float *scratch, float *out, int N, int C,

@@ -16,7 +16,7 @@
 #define SLR_STORE_AUX 2         // cache policy of the output stores (buffer instruction aux bits on gfx950: 1 sc0, 2 nt, 16 sc1).  Round 5, fused clip kernel, us per
                                 // frame on one box: default policy 154.3 / 155.3, nt 150.5, sc1 154.8, sc0 + nt 150.2 (the kernel never reads its output: nt keeps it
                                 // out of the feature planes' way in L2)
-#define SLR_WAVES_SCAN 5        // scan tile kernel: 83 VGPRs, two workgroups per CU, no scratch (6: 80 VGPRs + 12 bytes of scratch, three per CU -- the same time on every small grid)
+#define SLR_WAVES_SCAN 4        // scan tile kernel: <= 128 VGPRs (it uses ~100) = two workgroups per CU, which is what its 63 KiB of LDS allow; 5 (<= 102): 8 bytes of scratch in the normalising variant
 #define SLR_KREG_TWO 6          // ... two flows
 #define SLR_LMAX 16             // records a work-item walks alone before the wave helps (8 / 16 / 32: within 1 %)
 #define SLR_HEAVY_SLACK 24      // a list this much longer than the wave's share is walked by the whole wave (8: t=59 +55 %; 64: +10 %)

@@ -762,8 +762,8 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
                         if (inside && c + u < nrow) __builtin_nontemporal_store(v[u] * inv, o + (size_t)(c + u) * hw);
                 }
             };
-            if (__popc(have) <= 4) add_up(std::integral_constant<uint32_t, 4>{}, std::integral_constant<uint32_t, 16>{});
-            else add_up(std::integral_constant<uint32_t, 8>{}, std::integral_constant<uint32_t, 8>{});
+            if (__popc(have) <= 4) add_up(std::integral_constant<uint32_t, 4>{}, std::integral_constant<uint32_t, 12>{});
+            else add_up(std::integral_constant<uint32_t, 8>{}, std::integral_constant<uint32_t, 6>{});
         }
         __syncthreads();
         SINK_STAMP(4, wall_clock64());

@@ -378,8 +378,8 @@ __device__ __forceinline__ void accum4(Acc4 &a, const float4 &v, const WRec &r, 
 // between(k), k = 0..3: called at four points of the gather -- the chunk pipeline issues the plane loads of a later chunk there, a
 // few at a time: the waves of a workgroup run in step, and a burst of loads per wave waits for the texture addresser (0.28 us per
 // chunk, measured) while the LDS pipe idles, then the LDS reads of the gather queue up while the addresser idles.
-// COOP4 (sink tasks: lists of ~1000 records on a pixel): the cooperative walks read 4 records per lane and trip.
-template <class Cfg, bool MAXOP, bool COOP4 = false, typename F>
+// COOPN > 1 (scan / sink kernels: lists of ~1000 records on a pixel): the cooperative walks read COOPN records per lane and trip.
+template <class Cfg, bool MAXOP, int COOPN = 1, typename F>
 __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelList<Cfg> &g, int lane, float init, float (&acc)[4], F &&between) {
     constexpr int RB = 4, KREG = Cfg::KREG;
     constexpr uint32_t NULL_B = Cfg::NULL_E * 16u;
@@ -410,16 +410,16 @@ __device__ __forceinline__ void gather_chunk(const TileLds<Cfg> &L, const PixelL
         const uint32_t hb = __shfl(g.rl, src), he = __shfl(g.r1, src);
         Acc4 part = acc4_init<MAXOP>(-INFINITY);
         uint32_t r = hb + (uint32_t)lane;
-        if constexpr (COOP4) {
-            for (; r + 192u < he; r += 256) {               // (all four inside the list)
-                WRec q[4];
-                float4 v[4];
+        if constexpr (COOPN > 1) {
+            for (; r + 64u * (COOPN - 1) < he; r += 64u * COOPN) {      // (all of them inside the list)
+                WRec q[COOPN];
+                float4 v[COOPN];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) q[k] = L.rec_get(r + 64u * (uint32_t)k);
+                for (int k = 0; k < COOPN; ++k) q[k] = L.rec_get(r + 64u * (uint32_t)k);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = L.staged(q[k]);
+                for (int k = 0; k < COOPN; ++k) v[k] = L.staged(q[k]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) accum4<MAXOP>(part, v[k], q[k], true);
+                for (int k = 0; k < COOPN; ++k) accum4<MAXOP>(part, v[k], q[k], true);
             }
         }
         for (; r < he; r += 64) {
@@ -608,7 +608,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
         if (G2) {
             // the special chunk (m | in2 * m2 | m2 per entry, staged in phase 1a): both normalisers and the second group's sum
             float a2[4];
-            gather_chunk<Cfg, false, false>(L, g, lane, 0.0f, a2, [](int) {});
+            gather_chunk<Cfg, false, 1>(L, g, lane, 0.0f, a2, [](int) {});
             sums.nrm += a2[0]; sums.g2_sum += a2[1]; sums.g2_nrm += a2[2];
             if (last && inside && cb == 0) f.out2[(size_t)p.n * hw + opix] = sums.g2_sum / norm_divisor(sums.g2_nrm, s.norm_mode, s.eps);
             __syncthreads();                          // val4 is overwritten by the first value chunk
@@ -668,7 +668,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
             }
             if (bal == 1) head = bal_walk<Cfg, false>(L, bl, tid, bal_s, later_loads);
         }
-        if (!CAN_BAL || bal != 1) gather_chunk<Cfg, MAXOP, ADAPT>(L, g, lane, s.init, acc, later_loads);
+        if (!CAN_BAL || bal != 1) gather_chunk<Cfg, MAXOP, !ADAPT ? 1 : (SLAB && NORM) ? 2 : 4>(L, g, lane, s.init, acc, later_loads);      // (the normalising sink kernel: 2 -- with 4 it spills)
         if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));
         __syncthreads();        // val4 is overwritten by the next chunk (the stores below do not hold the others up); balanced: every carry is in
         if constexpr (CAN_BAL) {

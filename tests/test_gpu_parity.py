@@ -220,6 +220,35 @@ def test_backward_one_launch_equals_separate_launches(S, oracle):
     np.testing.assert_allclose(host(gf1), ogf, rtol=1e-5, atol=1e-4)
 
 
+def test_backward_channel_groups_on_small_grids(S, oracle):
+    """slr_softsplat_backward_ws (round 6): on grids smaller than the chip -- the reference's training crops, [2,65,256,256] -- the
+    backward kernel's channels are dealt to 2-4 workgroups per tile; gradInput stays bit-identical (per channel), gradFlow is the groups'
+    partial sums added in order (rounding of the grouping only).  Through the C ABI with and without scratch, and through autograd."""
+    from slr_sfs_amd._lib import check, lib, ptr, stream_of
+    L = lib()
+    assert L.slr_softsplat_backward_ws_bytes(1, 65, 768, 1280) == 0                 # the chip is full: one group
+    for (N, C, H, W) in ((2, 65, 256, 256), (1, 64, 128, 240), (1, 13, 40, 100), (3, 9, 64, 64)):
+        nb = int(L.slr_softsplat_backward_ws_bytes(N, C, H, W))
+        assert (nb > 0) == (C >= 16), (N, C, H, W, nb)
+        rng = np.random.default_rng(N * 100 + C)
+        flow = np.concatenate([oracle.euler_integration(smooth_motion(H, W, n, amp=2.0), 20 + 9 * n)[0] for n in range(N)])
+        x, go = rng.standard_normal((N, C, H, W)).astype(np.float32), rng.standard_normal((N, C, H, W)).astype(np.float32)
+        X, F, G = dev(x), dev(flow), dev(go)
+        gi1, gf1, gi2, gf2 = torch.empty_like(X), torch.empty_like(F), torch.empty_like(X), torch.empty_like(F)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
+        st = stream_of(X)
+        check(L.slr_softsplat_backward_ws(ptr(X), ptr(F), ptr(G), ptr(gi1), ptr(gf1), N, C, H, W, ptr(ws), nb, st), "groups")
+        check(L.slr_softsplat_backward(ptr(X), ptr(F), ptr(G), ptr(gi2), ptr(gf2), N, C, H, W, st), "one group")
+        ogi, ogf = oracle.softsplat_backward(x, flow, go)
+        assert torch.equal(gi1, gi2) and np.array_equal(host(gi1), ogi)
+        scale = max(1.0, float(np.abs(ogf).max()))
+        np.testing.assert_allclose(host(gf1), ogf, rtol=2e-6, atol=2e-6 * scale)
+        np.testing.assert_allclose(host(gf2), ogf, rtol=1e-6, atol=1e-6 * scale)
+        a, b = X.clone().requires_grad_(True), F.clone().requires_grad_(True)
+        S.softsplat._FunctionSoftsplat.apply(a, b).backward(G)
+        assert torch.equal(a.grad, gi1) and torch.equal(b.grad, gf1)
+
+
 @pytest.mark.parametrize("shape", [(1, 65, 256, 480), (2, 7, 45, 131), (1, 16, 100, 64), (3, 1, 17, 70)])
 def test_splat_sum_vs_oracle_euler_flow(S, oracle, shape):
     """Euler-integrated fluid flow (piles sources up -> multi-segment tiles + combine path),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/rN_* is made from, in one run on the GPU box (from the repo root):
-#   tools/collect_profiles.sh gpurun_out/r5final
+#   tools/collect_profiles.sh gpurun_out/r6final
 # bench lines, rocprofv3 kernel traces (per-kernel summaries via tools/trace_csv_stats.py), PMC passes (SQ / TCC counters, FETCH_SIZE and
 # WRITE_SIZE in separate runs, kernel-trace only) for the fused clip kernel (C3 and C4), the one-flow operator (rows at 768x1280, scan at
 # config C2) and the backward kernel, stand-alone kernel benches.
@@ -23,6 +23,9 @@ trace bench_c3 python bench.py --no-extras --no-cpu-baseline
 trace splat_stage python tools/splat_stage.py 3
 trace splat_stage_v1 python tools/splat_stage.py 3 v1
 trace c2 python tools/c2_bench.py c2
+trace c2_smooth_t30 python tools/dev/fe_shape.py 1 64 256 480 softmax 30
+trace train_t30 python tools/dev/fe_shape.py 2 65 256 256 summation 30
+trace train_t59 python tools/dev/fe_shape.py 2 65 256 256 summation 59
 trace frontends python tools/dev/fe_one.py 2
 trace bwd python tools/bwdbench.py
 pmc() {     # name, kernel pattern, units of work per dispatch, command...
@@ -36,10 +39,12 @@ pmc clip_c3 "clip_tile_kernel<false, false, true>" 15 python tools/splat_stage.p
 pmc clip_c4 "clip_tile_kernel<true, false, true>" 15 python tools/splat_stage.py v1
 pmc op_rows_t30 "op_rows_kernel<false, false, false>" 1 python tools/dev/fe_one.py 2 t30
 pmc op_rows_t59 "op_rows_kernel<false, false, false>" 1 python tools/dev/fe_one.py 2 t59
-pmc op_scan_c2 "op_scan_kernel<true, false, false>" 1 python tools/dev/fe_one.py 1 c2
+pmc op_scan_c2 "op_scan_kernel<true, false>" 1 python tools/dev/fe_one.py 1 c2
 pmc grad_t30 "grad_tile_kernel<true, true>" 1 python tools/bwdbench.py t30
 python tools/kbench.py > $out/kbench.txt 2>&1
 python tools/frontend_bench.py > $out/frontend_bench.txt 2>&1
+python tools/small_grid_bench.py > $out/small_grid_bench.txt 2>&1
+python tools/dev/fuzz_frontends.py 3000 > $out/fuzz.txt 2>&1; python tools/dev/fuzz_clip.py >> $out/fuzz.txt 2>&1; python tools/dev/fuzz_backward.py >> $out/fuzz.txt 2>&1; python tools/dev/soak_frontends.py >> $out/fuzz.txt 2>&1
 python tools/bwdbench.py > $out/bwdbench.txt 2>&1
 python tools/dev/convbench_f32.py > $out/convbench_f32.txt 2>&1
 tail -3 $out/pytest.log; cat $out/smoke.log | tail -2; cut -c1-200 $out/bench_default.json

@@ -42,7 +42,9 @@ for (n, c, h, w, mode) in ((1, 64, 256, 480, "softmax"), (1, 64, 128, 240, "soft
         line = f"{n}x{c}x{h}x{w} {mode:9s} {kind:10s} fwd {us:7.1f} us ({alg / us / 1e3 / 8000:.3f})"
         if mode == "summation":
             go, gi, gf = torch.randn_like(x), torch.empty_like(x), torch.empty(n, 2, h, w, device=dev)
-            bus = _graph_call_us(lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), n, c, h, w, stream_of(x)), "bwd"))
+            nb = int(L.slr_softsplat_backward_ws_bytes(n, c, h, w))
+            bws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+            bus = _graph_call_us(lambda: check(L.slr_softsplat_backward_ws(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), n, c, h, w, ptr(bws), nb, stream_of(x)), "bwd"))
             line += f"  bwd {bus:6.1f} us ({(3 * c + 4) * n * h * w * 4 / bus / 1e3 / 8000:.3f})"
         if CHECK:
             ref = o.function_softsplat(x.cpu().numpy(), fl.cpu().numpy(), met.cpu().numpy(), mode) if mode != "summation" else \
