@@ -578,6 +578,7 @@ __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     __syncthreads();
     const uint32_t off = L.misc[10];
     if (off != 0xffffffffu) scan_collect<Cfg, 2, true>(s, f, L, p, tid, wb, a.sink_ent + off, ntask);
+    T_STAMP(s, 55);
 }
 
 // The SINK launch (grid: SINK_T task slots x channel groups x SINK_P pieces -- the slots of a piece on different XCDs; normally the deferred list is empty and every workgroup ends

@@ -463,7 +463,8 @@ struct BalLane {
     uint32_t valid, endm;          // bit k: position q0 + k holds a record; ... is the last position of its pixel's region
     uint32_t ua;                   // for a work-item that ends a region begun before its range: the work-item whose range the region starts in
     bool cont_in;                  // the first position continues a region begun before this range
-};
+    WRec rc[9];                    // the records of its positions (pads and positions past the end: the all-zero record) -- they do not change from
+};                                 // chunk to chunk: a chunk's walk is 9 independent LDS reads of staged values
 
 template <class Cfg>
 __device__ __forceinline__ BalLane bal_setup(const TileLds<Cfg> &L, int tid, uint32_t S, uint32_t ntot) {
@@ -488,6 +489,8 @@ __device__ __forceinline__ BalLane bal_setup(const TileLds<Cfg> &L, int tid, uin
         b.valid |= (q < roff + rcnt ? 1u : 0u) << k;
         b.endm |= (q + 1u == roff + (rcnt | 1u) ? 1u : 0u) << k;
     }
+#pragma unroll
+    for (uint32_t k = 0; k < 9; ++k) b.rc[k] = L.rec_get(((b.valid >> k) & 1u) ? b.q0 + k : Cfg::NULLREC);
     L.bflag[tid] = (b.endm != 0u || !b.cont_in) ? 1u : 0u;
     __syncthreads();
     b.ua = (uint32_t)tid;
@@ -499,18 +502,22 @@ __device__ __forceinline__ BalLane bal_setup(const TileLds<Cfg> &L, int tid, uin
     return b;
 }
 
-// one chunk (WEIGHTS: the record weights instead of weight x staged value, in .x): complete regions -> bsum, the open tail -> bcarry
-template <class Cfg, bool WEIGHTS, typename F>
-__device__ __forceinline__ Acc4 bal_walk(const TileLds<Cfg> &L, const BalLane &b, int tid, uint32_t S, F &&between) {
+// one chunk: complete regions -> bsum, the open tail -> bcarry; returns the head (the sum up to the first region end of a range that
+// continues a region begun before it)
+template <class Cfg, typename F>
+__device__ __forceinline__ Acc4 bal_walk(const TileLds<Cfg> &L, const BalLane &b, int tid, F &&between) {
     Acc4 a = acc4_init<false>(0.0f), head = acc4_init<false>(0.0f);
     uint32_t p = b.p0;
     bool first = b.cont_in;
-    for (uint32_t k = 0; k < S; ++k) {
-        if (k < 4u) between((int)k);
-        if ((b.valid >> k) & 1u) {
-            if (WEIGHTS) a.lo.x += L.rec_weight(b.q0 + k);
-            else { const WRec r = L.rec_get(b.q0 + k); accum4<false>(a, L.staged(r), r, true); }
-        }
+    float4 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k < 4) between(k);
+        v[k] = L.staged(b.rc[k]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 9; ++k) {
+        accum4<false>(a, v[k], b.rc[k], true);           // (the all-zero record adds 0 x 0)
         if ((b.endm >> k) & 1u) {
             if (first) head = a; else L.bsum[p] = make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y);
             first = false;
@@ -518,7 +525,6 @@ __device__ __forceinline__ Acc4 bal_walk(const TileLds<Cfg> &L, const BalLane &b
             ++p;
         }
     }
-    for (uint32_t k = S; k < 4u; ++k) between((int)k);
     L.bcarry[tid] = make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y);
     return head;
 }
@@ -584,7 +590,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
     // the decision is taken behind the first chunk's barrier (a barrier of its own cost ordinary tiles ~1 us per call).
     int bal = 0;                                       // 0 undecided, 1 balanced, 2 register path
     uint32_t bal_s = 0;
-    BalLane bl = {0u, 0u, 0u, 0u, 0u, false};
+    BalLane bl = {};
     constexpr bool CAN_BAL = Cfg::BAL && !MAXOP && !G2 && !SLAB;
     if constexpr (CAN_BAL) {
         if (g.g_log == 0) {                            // (uniform; pieces with lane groups keep their own rule)
@@ -666,7 +672,7 @@ __device__ __forceinline__ void stream_planes(const TileShared &s, const TileFra
                 bal = mx > bal_s + (uint32_t)SLR_BAL_SLACK ? 1 : 2;
                 if (bal == 1) bl = bal_setup<Cfg>(L, tid, bal_s, ntot);
             }
-            if (bal == 1) head = bal_walk<Cfg, false>(L, bl, tid, bal_s, later_loads);
+            if (bal == 1) head = bal_walk<Cfg>(L, bl, tid, later_loads);
         }
         if (!CAN_BAL || bal != 1) gather_chunk<Cfg, MAXOP, !ADAPT ? 1 : (SLAB && NORM) ? 2 : 4>(L, g, lane, s.init, acc, later_loads);      // (the normalising sink kernel: 2 -- with 4 it spills)
         if (c0 - cb < 32) T_STAMP(s, 11 + 6 * ((c0 - cb) / 4));

@@ -42,4 +42,4 @@ for i in order:
     print(f"  long: entries {r[60]} candidates {r[61]} | cand {(r[1]-r[0])/clk:.1f} walk {(r[2]-r[1])/clk:.1f} rec {(r[6]-r[2])/clk:.1f} lists {(r[7]-r[6])/clk:.1f} chunks {(r[59]-r[7])/clk:.1f} | life {(r[59]-r[0])/clk:.1f} start {(r[0]-t00)/clk:.1f} longest list {r[63]}")
 dfr = st[(st[:, 59] == 0) & (st[:, 2] > 0)]
 for r in dfr[np.argsort(-dfr[:, 60])][:6]:
-    print(f"  deferred: entries {r[60]} candidates {r[61]} | cand {(r[1]-r[0])/clk:.1f} first walk {(r[2]-r[1])/clk:.1f} start {(r[0]-t00)/clk:.1f}")
+    print(f"  deferred: entries {r[60]} candidates {r[61]} | cand {(r[1]-r[0])/clk:.1f} first walk {(r[2]-r[1])/clk:.1f} second walk + entries out {(r[55]-r[2])/clk:.1f} (0 stamp: a channel group that only returns) life {(r[55]-r[0])/clk:.1f}")
