@@ -375,13 +375,14 @@ def emit(line, extra, full=False):
     c = dict(line)
     c["dtype"] = "f32 (convs: fp32 in/out/accumulate, operands 2 x f16 splits = 22 bits; all-fp32: fps_fp32_convs)"
     c["config"] = {k: v for k, v in line["config"].items() if v is not None and k not in ("H", "W", "frames_per_step")}
-    c["config"]["workload"] = c["config"]["workload"].replace(", random-init weights of the reference architecture", ", random-init weights").replace(
+    c["config"]["workload"] = c["config"]["workload"].replace(", random-init weights of the reference architecture", ", random weights").replace(
         " encoder->Euler->softmax-splat->pconv2 decoder", "")
+    c["config"].pop("frames_rank0", None)
     r = line["roofline"]
     c["roofline"] = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "alg_bytes_per_launch",
-                          "launch_avg_us", "frac_min_bytes", "avg_us", "min_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
+                          "launch_avg_us", "frac_min_bytes", "avg_us", "stage_us", "stage_frac", "stage_prep_us_per_clip")
     src = r.get("traffic_source") or ""
-    c["roofline"]["traffic_source"] = "measured in this run" if src.startswith("measured in this run") else ("static (profiles/), not this run" if src else None)
+    c["roofline"]["traffic_source"] = "measured in this run" if src.startswith("measured in this run") else ("static file" if src else None)
     pe = line["parity_err"]
     if pe:
         c["parity_err"] = {"ok": pe.get("ok"), "tolerance": pe.get("tolerance"),
@@ -393,7 +394,8 @@ def emit(line, extra, full=False):
         c["parity_err"] = {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in c["parity_err"].items()}
     cb = line["cpu_baseline"]
     if cb:
-        c["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s (splat stage)", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+        c["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s (splat stage)", "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": cb["sample"].replace(" of the same 768x1280 N=60 clip", ""),
                              "one_thread": cb["one_thread"]["value"], "with_decoder": cb["with_decoder"]["value"]}
     f32 = extra.get("fps_fp32_convs")
     if f32:
@@ -407,7 +409,7 @@ def emit(line, extra, full=False):
     d = extra.get("roofline_dropin")
     if d:
         fl = d["flows"]
-        c["dropin"] = {"is": "one-flow operator, whole call: [us, frac of 8 TB/s]; frac = slower Euler flow", "frac": d.get("frac")}
+        c["dropin"] = {"is": "one-flow call: [us, frac of 8 TB/s]", "frac": d.get("frac")}
         for k in ("euler_t30", "euler_t59", "identity", "incoherent"):
             if k in fl:
                 c["dropin"][k] = [fl[k]["call_us"], fl[k]["call_frac"]]
@@ -418,7 +420,7 @@ def emit(line, extra, full=False):
             c["dropin"]["c2_batched_per_sample"] = [d["c2_batched"]["per_sample_us"], d["c2_batched"]["call_frac"]]
         if "train_shape" in d:
             c["train_shape"] = {k: [v["fwd_us"], v["bwd_us"], v["frac"]] for k, v in d["train_shape"]["flows"].items()}
-            c["train_shape"]["is"] = "_FunctionSoftsplat [2,65,256,256]: [fwd us, bwd us, frac]"
+            c["train_shape"]["is"] = "[2,65,256,256]: [fwd us, bwd us, frac]"
     b = extra.get("roofline_backward")
     if b:
         c["backward"] = {k: [v["avg_us"], v["frac"]] for k, v in b["flows"].items()}

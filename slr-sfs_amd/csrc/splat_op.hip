@@ -37,6 +37,7 @@ void set_error(const char *fmt, ...) {
 using OpCfg = TileCfg<1, SLR_EPT_ONE, true, SLR_KREG_ROWS>;       // one flow: 1024 entries per workgroup, 6-byte records, 46 KiB of LDS
 using OpPassCfg = TileCfg<1, SLR_EPT_DEFER, true, SLR_KREG_ROWS>; // the pass-by-pass launches: passes of 2048 entries, 86 KiB (most deferred pieces
                                                                   // are just over a segment and finish in one pass; these run on a near-empty chip)
+static_assert(SLR_SCAN_DEFER_AT <= SLR_EPT_ONE * 512, "a tile rendered in place fits one segment");
 using ScanCfg = TileCfg<1, SLR_EPT_ONE, true, SLR_KREG_ROWS, false, true>;     // the scan front end's kernels: + the balanced gather's sums (splat_tile.hpp: BalLane), 63 KiB (two workgroups per CU by their registers anyway)
 constexpr int OP_SEG = OpCfg::SEG;
 constexpr uint32_t OP_DEFER_WG = 64;               // workgroups of the pass-by-pass launch (x channel groups)
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     const uint32_t total = L.misc[0];
     T_STAMP(s, 2);
     T_NOTE(s, 60, total);
-    if (total <= (uint32_t)Cfg::SEG) {
+    if (total <= (uint32_t)SLR_SCAN_DEFER_AT) {
         const rsrc_t rin = sample_planes(s, p, k.hw4);
         PixelSums sums = {0.0f, 0.0f, 0.0f};
         EntryRegs<Cfg> e;
