@@ -381,8 +381,8 @@ __device__ __forceinline__ bool channel_group(int C, int &cb, int &ce) {
 struct OpArgs {
     TileShared s; TileFrame f;
     uint32_t *sink_cnt;            // scan front end: [items_cap][16] per deferred piece: arrivals of the sink launch per channel group [0..7], its tasks [8]
-    float *sink_pool;              // ... slabs: [sink_qcap][sink_t][rows][TILE_PIX], then the emergency slabs [SINK_P][rows][TILE_PIX]
-    uint32_t sink_qcap, sink_t;    // ... deferred pieces the pool holds slabs for; task slots per piece (rows = planes + channel groups of the sink launch)
+    float *sink_pool;              // ... slabs: [sink_cap][rows][TILE_PIX] handed out to the deferred pieces, then the emergency slabs [SINK_P][rows][TILE_PIX]
+    uint32_t sink_cap, sink_t;     // ... slabs of the pool; most task slots a piece gets (rows = planes + channel groups of the sink launch)
     float4 *sink_ent;              // ... [sink_ent_cap] the entries of the deferred pieces
     uint32_t sink_ent_cap;
 };
@@ -574,6 +574,11 @@ __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) hd[i] = 0u;
         hd[8] = ntask; hd[9] = all; hd[10] = room ? off : 0xffffffffu;
+        // its task slots: as many slabs of the pool as it has tasks (at most sink_t), or none (one workgroup per channel group, emergency slab)
+        const uint32_t tasks = room ? (all + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : ntask;
+        const uint32_t want = min(a.sink_t, max(tasks, 1u));
+        const uint32_t base = want ? atomicAdd(f.totals + 6, want) : a.sink_cap;
+        hd[11] = (want && base <= a.sink_cap && want <= a.sink_cap - base) ? base : 0xffffffffu;
         L.misc[10] = room ? off : 0xffffffffu;
     }
     __syncthreads();
@@ -593,7 +598,8 @@ __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
 // arrive adds the slabs up in slot order -- reproducible, no float atomics -- normalises and writes the piece's pixels.
 // (First built with agent-scope fp32 atomicAdds into the output instead of slabs: correct, and 375 us for the C2-sized smooth case --
 //  8 M memory-side atomics at ~22 G/s.)
-// Slabs: the pool holds sink_t slabs for the first sink_qcap deferred pieces; a piece beyond them is rendered by ONE workgroup per channel
+// Slabs: a deferred piece takes as many slabs of the pool as it has tasks (at most sink_t; one atomic when it is deferred); a piece that finds the
+// pool empty is rendered by ONE workgroup per channel
 // group (task slot 0) out of that workgroup's emergency slab -- correct for any flow, slow only for flows with hundreds of sinks.
 constexpr uint32_t SINK_P = SLR_SINK_PIECES, SINK_T = SLR_SINK_TASKS, SINK_MINE = 2048 / 2;
 #ifdef SLR_TRACE      // per-workgroup wall-clock stamps of the sink launch (tools/dev/trace_sink.py): 16 words per workgroup behind the tile kernels' area
@@ -624,15 +630,15 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     const uint32_t rows = (uint32_t)s.C + gridDim.y;      // slab rows of one task slot over all channel groups; this group's start at cb + its index
     const size_t slot_floats = (size_t)rows * TILE_PIX, my_rows = (size_t)(cb + (int)blockIdx.y) * TILE_PIX;
     for (uint32_t q = bpiece; q < ndef; q += npiece) {
-        const bool pooled = q < a.sink_qcap;
         const uint32_t *hd = a.sink_cnt + (size_t)q * 16u;
+        const uint32_t sbase = hd[11];
+        const bool pooled = sbase != 0xffffffffu;
         const uint32_t all = hd[9], eoff = hd[10];
         const bool listed = eoff != 0xffffffffu;           // the piece's entries were written out: tasks of exactly SEG entries, nothing to walk
         const uint32_t ntask_q = listed ? (all + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : hd[8];
         const uint32_t nslot = pooled ? min(a.sink_t, max(ntask_q, 1u)) : 1u;       // (no more slots than tasks)
         if (bslot >= nslot) continue;
-        float *slab0 = pooled ? a.sink_pool + (size_t)q * a.sink_t * slot_floats + my_rows
-                              : a.sink_pool + ((size_t)a.sink_qcap * a.sink_t + bpiece) * slot_floats + my_rows;
+        float *slab0 = a.sink_pool + (size_t)(pooled ? sbase : a.sink_cap + bpiece) * slot_floats + my_rows;
         float *slab = slab0 + (size_t)bslot * slot_floats;
         const uint32_t w = f.defer[q];
         ItemDesc it = {};
@@ -930,28 +936,28 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     if (int e = lds_opt_in((const void *)op_sink_kernel<NORM, MAXOP>, (int)ScanCfg::LDS_BYTES, attr_s)) return e;
     a.f.box = (const SrcBox *)w.box; a.f.totals = w.totals; a.f.defer = w.defer;
     a.sink_cnt = w.sink_cnt; a.sink_pool = w.sink_pool; a.sink_ent = w.sink_ent; a.sink_ent_cap = w.L.sink_ent_cap;
-    hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
-    const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
-    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
+    // the sink launch's shape: pieces x channel groups x task slots; slabs: rows x 2 KiB per task slot, the emergency slabs of the sink_x piece
+    // slots first out of the pool's budget, the rest handed out to the deferred pieces by their own workgroups (the tile kernel below)
     uint32_t pieces, groups;
     scan_shape(w.L.nt, a.s.C, pieces, groups);
-    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, groups, pieces), dim3(TT), ScanCfg::LDS_BYTES, st, a);
-    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
-    g_ev_start = g_ev_stop = nullptr;
-    // pieces of more than SEG entries (appended by their workgroups): the sink launch -- every piece by up to SINK_T x channel groups
-    // workgroups at once (an empty launch: every workgroup does one scalar load and ends -- 256 or 4096 of them cost the same 2 - 3 us)
     const int dwg = g_scan_defer_wg.load(), dgr = g_scan_defer_groups.load();
     const uint32_t gmax = dgr > 0 ? (uint32_t)dgr : (uint32_t)SLR_SINK_GROUPS;
     const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > gmax ? gmax : (uint32_t)a.s.C / 8u;
     const uint32_t dw = dwg > 0 ? (uint32_t)dwg : SINK_P;
     uint32_t sink_x = w.L.nt * pieces < dw ? w.L.nt * pieces : dw;
-    // slabs: rows x 2 KiB per task slot; the emergency slabs of the sink_x piece slots come first out of the pool's budget
     const size_t slot_bytes = (size_t)((uint32_t)a.s.C + wgroups) * TILE_PIX * 4, avail = w.L.sink_pool_bytes / slot_bytes;
     SLR_CHECK_ARG(avail >= 1, "plane count too large for the scan front end (use the rows front end: slr_splat_set_front_end(2))");
     if (avail < sink_x) sink_x = (uint32_t)avail;
-    a.sink_t = (uint32_t)((avail - sink_x) / sink_x < SINK_T ? (avail - sink_x) / sink_x : SINK_T);      // (at least every piece slot's own pieces get full slots)
-    a.sink_qcap = a.sink_t ? (uint32_t)((avail - sink_x) / a.sink_t) : 0u;
-    if (a.sink_qcap > w.L.items_cap) a.sink_qcap = w.L.items_cap;
+    a.sink_cap = (uint32_t)(avail - sink_x);
+    a.sink_t = a.sink_cap < SINK_T ? a.sink_cap : SINK_T;
+    hipLaunchKernelGGL(scan_box_kernel, dim3(w.L.nt), dim3(TILE_PIX), 0, st, a.f.flow[0], (SrcBox *)w.box, a.s.H, a.s.W, w.L.tiles_x, w.L.tiles, w.totals);
+    const uint32_t grid = ((w.L.nt + 8 * SLR_XCD_GROUP - 1) / (8 * SLR_XCD_GROUP)) * 8 * SLR_XCD_GROUP;
+    if (g_ev_start) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_start, st));
+    hipLaunchKernelGGL((op_scan_kernel<NORM, MAXOP>), dim3(grid, groups, pieces), dim3(TT), ScanCfg::LDS_BYTES, st, a);
+    if (g_ev_stop) SLR_CHECK_HIP(hipEventRecord((hipEvent_t)g_ev_stop, st));
+    g_ev_start = g_ev_stop = nullptr;
+    // pieces of more than SEG entries (appended by their workgroups): the sink launch -- every piece by up to SINK_T x channel groups
+    // workgroups at once (an empty launch: every workgroup does one scalar load and ends -- 256 or 4096 of them cost the same 2 - 3 us)
     hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_x, wgroups, SINK_T), dim3(TT), ScanCfg::LDS_BYTES, st, a);
     SLR_CHECK_LAUNCH();
     return 0;

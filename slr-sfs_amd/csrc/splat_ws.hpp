@@ -19,7 +19,7 @@ struct OpLayout {
     size_t off_box;       // SrcBox[nt]  scan front end: destination box of every source tile
     size_t off_ctl;       // uint32[64]  arrival counter (second level) of rowbin_kernel
     size_t off_arrive;    // uint32[ceil(nt / 64)][32]  first-level arrival counters, one per 128-byte line
-    size_t off_sink_cnt;  // uint32[items_cap][16]  scan front end, per deferred piece: [0..7] arrivals (| slabs written << 8) of the sink launch's workgroups per channel group, [8] its candidate-pair tasks, [9] its entries, [10] where they start in sink_ent (0xffffffff: not written out)
+    size_t off_sink_cnt;  // uint32[items_cap][16]  scan front end, per deferred piece: [0..7] arrivals (| slabs written << 8) of the sink launch's workgroups per channel group, [8] its candidate-pair tasks, [9] its entries, [10] where they start in sink_ent (0xffffffff: not written out), [11] its first slab of the pool (0xffffffff: none)
     size_t off_sink_pool; // float[sink_pool_bytes / 4]  scan front end: slabs of the sink launch (partial sums of a deferred piece per task slot)
     size_t sink_pool_bytes;
     size_t off_sink_ent;  // float4[sink_ent_cap]  scan front end: the entries of the deferred pieces, written out by their workgroups
