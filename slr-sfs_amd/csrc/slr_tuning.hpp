@@ -31,8 +31,9 @@
 // ---- small grids / scan front end
 #define SLR_CSPLIT_MAX 4        // channel groups per tile on grids smaller than the chip (256x480: 2 groups 37.5 -> 33.5 us; 128x240: 4 groups 34 -> 21 us)
 #define SLR_CSPLIT_SLOTS 512    // workgroup slots of the chip the groups may fill (256 CUs x 2).  1024 / 8 groups: config C2 39 -> 54 us
-#define SLR_SCAN_DEFER_AT 1024   // scan tile kernel: a tile of more entries than this goes to the sink launch (<= 1024 = one segment).  896 / 768 / 640, us: C2 grid t=30 80 / 84 / 109 (1024: 82),
-                                // training shape t=30 88 / 88 / 85 (91), t=59 124 / 123 / 122 (131), 384x640 t=30 135 / 165 / 165 (135), t=59 292 / 279 / 276 (282): more pieces than the slab pool holds
+#define SLR_SCAN_DEFER_AT 896    // scan tile kernel: a tile of more entries than this goes to the sink launch (<= 1024 = one segment; its near-full tiles are the
+                                // tile kernel's tail: 8 chunks at 3 us).  1024 / 896 / 768 / 640, us: C2 grid t=30 82 / 80 / 84 / 84, training shape t=30 91 / 89 / 87 / 86,
+                                // t=59 130 / 117 / 120 / 121, 384x640 t=30 106 / 106 / 119 / 126, t=59 135 / 139 / 131 / 133; incoherent flows: no tile above 640
 #define SLR_SINK_PIECES 33      // sink launch of the scan front end (splat_op.hip: op_sink_kernel): deferred pieces rendered at once (more: the list is looped) ...
 #define SLR_SINK_TASKS 16       // ... x task slots per piece (a task = 2 candidate source tiles = 16 row segments <= 1024 entries) ...
 #define SLR_SINK_POOL_MB 64     // ... bytes of slabs in the workspace (a slab = the partial sums of one task slot: (planes of its channel group + 1) x 2 KiB)
