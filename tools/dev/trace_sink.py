@@ -22,8 +22,8 @@ L.slr_debug_trace(buf.data_ptr())
 S.FunctionSoftsplat(x, fl, met, "softmax")
 torch.cuda.synchronize()
 L.slr_debug_trace(None)
-t = buf.cpu().numpy()[nb * 64:].reshape(-1, 16)
-t = t[t[:, 0] > 0]
+traw = buf.cpu().numpy()[nb * 64:].reshape(-1, 16)
+t = traw[traw[:, 0] > 0]
 us = 100.0          # wall clock: 100 MHz
 t0 = t[:, 0].min()
 fin = t[:, 4] > 0
@@ -54,3 +54,12 @@ for y in range(2):
     names = {3: "entries read", 4: "footprints+atomics", 5: "barrier", 6: "scan+scatter", 7: "pixel lists+norm", 8: "chunk0 staged", 9: "c0 barrier", 11: "c0 gathered", 13: "c0 barrier2", 14: "chunk1 staged", 59: "end"}
     ks = [k for k in sorted(names) if r[k] > 0]
     print(f"  tile-trace of sink block x=0 y={y} (shader clock, 2.2 cycles/ns; the LAST task that ran there):", " | ".join(f"{names[b]} +{(r[b] - r[a]) / 2200:.1f}" for a, b in zip(ks, ks[1:])), f"| list len note {r[63]}")
+# the tile-kernel stamps (shader clock) of the (x, y) block of the longest sink workgroup: grid = 33 (or fewer) pieces x groups x 16 slots
+idx = int(np.argmax(np.where(traw[:, 4] > 0, traw[:, 4] - traw[:, 0], 0)))
+gxy = None
+for gy in range(1, 9):
+    if (len(traw) and idx // (gx * gy) < 16): gxy = gy
+xy = idx % (gx * gxy) if gxy else 0
+r = tt[xy]
+ks = [k for k in sorted(names) if r[k] > 0]
+print(f"  tile-trace of the longest sink workgroup's block (index {idx}, x+gx*y = {xy}):", " | ".join(f"{names[b]} +{(r[b] - r[a]) / 2200:.1f}" for a, b in zip(ks, ks[1:])))
