@@ -12,8 +12,10 @@
 //         op_rows_kernel walks exactly the listed rows (splat_rows.hpp).  3 launches: rows + plan, tile kernel, a normally empty
 //         pass-by-pass launch for pieces that still hold more than SEG entries (the workspace arrives zeroed: see slr_splat_bin);
 //   scan  (small grids): scan_box_kernel writes the destination box of every 8x64 block of source pixels; every output tile's
-//         workgroup tests the boxes, lists the rows of the blocks that touch it in LDS and walks them with the same code.  2
-//         launches, nothing to zero, no plan: a tile of more than SEG entries is walked pass by pass by its own workgroup.
+//         workgroup tests the boxes, lists the rows of the blocks that touch it in LDS and walks them with the same code.  Nothing
+//         to zero, no plan.  A tile of more than SLR_SCAN_DEFER_AT entries -- a pile-up of a contracting flow -- writes its entries
+//         out once and is rendered by the SINK launch (op_sink_kernel: tasks of one segment on many workgroups, slabs added up in
+//         slot order; normally empty).  3 launches: boxes, tile kernel, sink launch.
 #include "splat_rows.hpp"
 #include "splat_ws.hpp"
 
