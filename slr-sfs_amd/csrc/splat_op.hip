@@ -701,8 +701,11 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
             if (total != 0u) {
                 EntryRegs<Cfg> e;
                 float preA[Cfg::EPT][4], preB[Cfg::EPT][4];
+                SINK_STAMP(5, wall_clock64());
                 build_records<Cfg, NORM, false>(s, L, p, tid, total, rin, k.hw4, cb, ce - 1, k.shift, k.sc0, k.sc1, e, preA, preB);
+                SINK_STAMP(6, wall_clock64());
                 stream_planes<Cfg, NORM, MAXOP, false, true, true>(s, f, L, p, tid, rin, k.hw4, cb, ce, e, preA, preB, sums, !wrote, false, slab);
+                SINK_STAMP(7, wall_clock64());
                 wrote = true;
             }
             __syncthreads();

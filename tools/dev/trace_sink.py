@@ -46,7 +46,7 @@ print("  active workgroups alive at t (us):", " ".join(f"{a}:{b}" for a, b in pr
 order = np.argsort(-(w_[:, 4] - w_[:, 0]))[:6]
 for i in order:
     r = w_[i]
-    print(f"  long: piece {r[11]} entries/candidates {r[8]} tasks {r[9]} last {r[10]} | setup {(r[1]-r[0])/us:.1f} tasks {(r[2]-r[1])/us:.1f} arrive {(r[3]-r[2])/us:.1f} finalise {(r[4]-r[3])/us:.1f} start {(r[0]-t0)/us:.1f}")
+    print(f"  long: piece {r[11]} entries/candidates {r[8]} tasks {r[9]} last {r[10]} | setup {(r[1]-r[0])/us:.1f} tasks {(r[2]-r[1])/us:.1f} (last task: entries in {(r[5]-r[1])/us:.1f}, records {(r[6]-r[5])/us:.1f}, planes {(r[7]-r[6])/us:.1f}) arrive {(r[3]-r[2])/us:.1f} finalise {(r[4]-r[3])/us:.1f} start {(r[0]-t0)/us:.1f}")
 tt = buf.cpu().numpy()[:nb * 64].reshape(nb, 64)
 gx = 32 if n * ((h + 7) // 8) * ((w + 63) // 64) >= 32 else n * ((h + 7) // 8) * ((w + 63) // 64)
 for y in range(2):
