@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SLR_ABI_VERSION 9
+#define SLR_ABI_VERSION 10
 
 #define SLR_E_BADARG   (-1)   /* null pointer / non-positive size / unknown enum  */
 #define SLR_E_WORKSPACE (-2)  /* workspace too small or misaligned                */
@@ -350,6 +350,7 @@ int slr_conv_saturation_record(unsigned *host_slot, void *stream);
  * domain is within a small factor of the direct fp32 convolution's (tests/test_gpu_conv_f32.py: both against fp64).  `wsplit` must then
  * come from slr_conv3x3_wino_weights (slr_conv3x3_wino_weight_bytes: 16 transformed values per weight instead of 9). */
 #define SLR_CONV_WINO   16
+#define SLR_CONV_SKIP_B8 32    /* slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip: `skip_in` is channel-blocked */
 /* Cout <= 4 (the 128 -> 3 end of the decoders): the 3x3 entry points run a kernel of their own on EITHER rung -- fp32 FMAs on the vector
  * ALUs (csrc/conv_few.hpp; the narrowest matrix-core tile would compute 32 channels for 3), i.e. the reference's arithmetic: both
  * weight-preparation calls then write plain fp32 weights into the buffer, wscale / xscale are accepted and unused, nothing saturates. */
@@ -388,6 +389,27 @@ int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pr
                          const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
                          const float *next_scale, const float *next_shift, float *out, float *um_out,
                          int N, int Cin, int Cout, int H, int W, int layout, void *stream);
+
+/* ABI 10.  The same two convolutions with the residual block's 1x1 skip branch INSIDE the kernel (models/layers/blocks.py:83-87 and
+ * :243-248: x_a + x_b with x_b = conv1x1(block input)):
+ *   out = [3x3 convolution with its whole epilogue, as above, without residual / next-BN] + conv1x1(skip_in) (+ skip_bias)
+ * The accumulators take the 3x3 epilogue, change to the skip operands' scale (a power of two: exact) and go on as the accumulators of
+ * the skip convolution over skip_cin more input channels (one tap): no separate 1x1 kernel, no write and re-read of its result.
+ * Against the two-kernel form (slr_conv1x1_forward -> residual) the result differs by the order of the last additions only (fp32
+ * rounding; tests/test_gpu_parity.py).  skip_wsplit: slr_conv1x1_split_weights(Cout, skip_cin, skip_wscale); the skip input shares
+ * `xscale`.  Split-f16 rung only (no SLR_CONV_F32 / _WINO), main input and skip input channel-blocked (SLR_CONV_IN_B8 and
+ * SLR_CONV_SKIP_B8 both set, skip_cin % 8 == 0), Cout > 4; anything else is SLR_E_BADARG -- callers keep the two-kernel form there
+ * (the networks' 3-channel first blocks and 65- / 3-channel ends). */
+int slr_conv3x3_forward_skip(const float *in, const void *wsplit, const float *bias, float *out,
+                             int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
+                             const float *pre_scale, const float *pre_shift,
+                             const float *skip_in, const void *skip_wsplit, const float *skip_bias /* [Cout] or NULL */, int skip_cin,
+                             float skip_wscale, int layout, void *stream);
+int slr_pconv3x3_forward_skip(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                              const void *wsplit, float wscale, float xscale, const float *bias, float *out, float *um_out,
+                              int N, int Cin, int Cout, int H, int W,
+                              const float *skip_in, const void *skip_wsplit, int skip_cin, float skip_wscale,
+                              int layout, void *stream);
 
 /* 1x1 convolution (skip branch of the residual blocks, models/layers/blocks.py:192-193,243-247) on the same
  * split-f16 arithmetic: out = conv1x1(in) + bias.  HBM-bound, no LDS.  Weights prepared once per layer with

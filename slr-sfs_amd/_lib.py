@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLR_SFS_AMD_LIB") or os.path.join(_HERE, "lib", "libslrsplat.so")   # env: dev only
-ABI_VERSION = 9
+ABI_VERSION = 10
 WS_PREBINNED, WS_CLEAN = 1, 2       # include/slr_splat.h: flags of the `prebinned` argument
 
 # every symbol include/slr_splat.h declares
@@ -24,6 +24,7 @@ SYMBOLS = (
     "slr_softsplat_backward", "slr_softsplat_backward_ws_bytes", "slr_softsplat_backward_ws", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_wino_weight_bytes", "slr_conv3x3_wino_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
+    "slr_conv3x3_forward_skip", "slr_pconv3x3_forward_skip",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_f32_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
 )
@@ -113,6 +114,8 @@ def lib():
             "slr_conv1x1_forward": [fp, vp, fp, fp, i, i, i, i, i, f, f, i, vp],
             "slr_conv3x3_forward": [fp, vp, fp, fp, fp, i, i, i, i, i, f, f, fp, fp, i, vp],
             "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp],
+            "slr_conv3x3_forward_skip": [fp, vp, fp, fp, i, i, i, i, i, f, f, fp, fp, fp, vp, fp, i, f, i, vp],
+            "slr_pconv3x3_forward_skip": [fp, fp, fp, fp, vp, f, f, fp, fp, fp, i, i, i, i, i, fp, vp, i, f, i, vp],
             "slr_avgpool3x3s2": [fp, fp, i, i, i, i, i, vp],
             "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, i, vp],
             "slr_conv1x1_small": [fp, fp, fp, fp, i, i, i, i, i, i, vp],

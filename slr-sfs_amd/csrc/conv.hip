@@ -78,6 +78,13 @@ struct ConvArgs {
     long long *trace;      // development builds: 16 time stamps per workgroup of the Winograd kernel (tools/dev/trace_wino.py)
 #endif
     int wino_groups;       // Winograd kernel (conv_wino.hpp): groups of 64 output channels (its grid.x carries blocks x groups)
+    // the block's 1x1 skip branch as extra K chunks of this convolution (SKIP instantiations; blocks.py:243-248, :83-87):
+    // out = epilogue(conv3x3(in)) + conv1x1(skip_in) (+ skip_bias)
+    const float *skip_in;  // [N,skip_cin,H,W] (skip_b8: channel-blocked), no prologue
+    const h8 *skip_w;      // split 1x1 weights in fragment order (taps = 1), scaled by the skip's own wscale
+    const float *skip_bias;
+    int skip_cin, skip_nchunk, skip_b8;
+    float skip_unscale;    // 1 / (xscale * skip wscale)
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -102,11 +109,15 @@ namespace slr {
 // ([co tile][chunk][tap][lane][k pair]: two 16-byte loads), and one tap is 8 x PT MFMAs with ONE ds_read_b32 each: the loop is
 // bound by the matrix pipe alone.
 constexpr int CV_FSTR = 352;                       // F32: floats per channel row of the staged block
-template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false>
+// SKIP: the residual block's 1x1 skip convolution rides in this kernel (see the skip phase behind the main loop): the separate 1x1 kernel,
+// the write of its result and the read of it as the residual are gone.
+template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false, bool SKIP = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
     static_assert(!F32 || CPW == 1, "the fp32 rung runs one 32-channel tile per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char xraw[F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16];
+    static_assert(!SKIP || (CPW == 1 && !F32 && INB8), "the skip phase: split rung, one tile per wave, channel-blocked main input");
+    constexpr int XRAW = F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16, XSKIP = SKIP ? SLR_CONV_SKIP_FILL * 2 * 2 * 256 * 16 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char xraw[XRAW > XSKIP ? XRAW : XSKIP];
     h8 (*xs)[2][2][CV_NPX] = reinterpret_cast<h8 (*)[2][2][CV_NPX]>(xraw);             // [buffer][hi|lo][8-channel group][halo pixel]
     float (*xf)[16][CV_FSTR] = reinterpret_cast<float (*)[16][CV_FSTR]>(xraw);          // F32: [buffer][channel][halo pixel]
     __shared__ float mpl[CV_NPX];                  // mask plane over the halo block (0 outside the image)
@@ -391,8 +402,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         __syncthreads();
     }
 
-    if (!F32 && a.sat && sat != 0ull && lane == 0) atomicAdd(a.sat, 1u);   // an activation left the f16 range (stage_value)
-
     if (pre == PRE_BN_NONZERO) {                       // mask plane = channel sum of (x != 0)  (architectures.py:369,
         mpl[tid] = cnt[0] + cnt[1];                    // partialconv2d.py:61 with a per-element mask)
         if (liveB) mplB[gB][pB - 256] = cnt[2];
@@ -401,13 +410,135 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     }
     __syncthreads();                                   // mpl complete (written before the main loop otherwise)
 
+    if constexpr (SKIP) {
+        // ---- skip phase.  The accumulators take the 3x3 convolution's epilogue NOW (the operations of the epilogue below, in its order) and
+        // go on, in the scale of the skip operands, as the accumulators of the block's 1x1 skip convolution:
+        //   out = ((raw*ratio + b)*um  |  raw + b)  +  conv1x1(skip_in)  (+ skip_bias)          blocks.py:243-248 / :83-87
+        // The change of scale is a multiplication by a power of two (exact).  A skip chunk (16 input channels) meets ONE tap -- 3 MFMAs per
+        // row -- so this phase is bound by the latency of its loads, not by the matrix pipe: the chunks are staged SK at a time (only the
+        // block's own 256 pixels, no halo: 16 KiB per chunk in the main loop's buffers), the loads of a fill are in flight under the
+        // epilogue arithmetic resp. the previous fill's MFMAs.  (First form, one chunk per barrier with the halo staging of the main loop:
+        // the four fused kernels of a decoder frame cost 18 % more than without their skips; HISTORY.md.)
+        constexpr int SK = SLR_CONV_SKIP_FILL;
+        static_assert(SK * 2 * 2 * 256 * 16 <= (int)sizeof(xraw), "skip fills live in the staging buffers");
+        h8 (*xk)[2][2][256] = reinterpret_cast<h8 (*)[2][2][256]>(xraw);      // [chunk of the fill][hi|lo][8-channel group][pixel of the block]
+        const int ns = a.skip_nchunk, sc8max = (a.skip_cin >> 3) - 1;
+        const int spr = tid >> 5, spc = tid & 31;
+        const bool sok = (y0 + spr < a.H) & (x0 + spc < a.W);
+        const float smk = sok ? a.xscale : 0.0f;                             // validity x the pre-scale of the split
+        const float4 *sq = reinterpret_cast<const float4 *>(a.skip_in + (size_t)n * a.skip_cin * HW) + (size_t)(sok ? (y0 + spr) * a.W + x0 + spc : 0) * 2;
+        float4 sv[SK][4];
+        auto sload = [&](int s0) {                     // chunks s0 .. s0 + SK - 1 (past the last: re-read it, unused -- every load unconditional)
+#pragma unroll
+            for (int k = 0; k < SK; ++k)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float4 *q = sq + (size_t)min(min(s0 + k, ns - 1) * 2 + g, sc8max) * HW * 2;      // (uniform plane base)
+                    sv[k][2 * g] = q[0];
+                    sv[k][2 * g + 1] = q[1];
+                }
+        };
+        auto sstore = [&]() {
+#pragma unroll
+            for (int k = 0; k < SK; ++k)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float x8[8] = {sv[k][2 * g].x, sv[k][2 * g].y, sv[k][2 * g].z, sv[k][2 * g].w,
+                                         sv[k][2 * g + 1].x, sv[k][2 * g + 1].y, sv[k][2 * g + 1].z, sv[k][2 * g + 1].w};
+                    h8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = __builtin_amdgcn_fmed3f(x8[j] * smk, -65472.0f, 65472.0f);         // (the range guard of stage_value)
+                        sat |= __ballot(fabsf(v) >= 65472.0f);
+                        const _Float16 h = (_Float16)v;
+                        hi[j] = h;
+                        lo[j] = (_Float16)(v - (float)h);
+                    }
+                    xk[k][0][g][tid] = hi;
+                    xk[k][1][g][tid] = lo;
+                }
+        };
+        sload(0);
+        {
+            const bool partial = a.partial != 0, has_bias = a.bias != nullptr;
+            const float unscale = a.unscale, rescale = 1.0f / a.skip_unscale;
+            const float mscale = a.mask_scale, winsize = a.winsize;
+            float eb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) eb[r] = has_bias ? a.bias[min(cot0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.Cout - 1)] : 0.0f;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                if (partial) {
+                    float box = 0.0f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) box += mpl[(wp * PT + pt + dy) * CV_HW + (lane & 31) + dx];
+                    const float u = box * mscale;
+                    const float um = fminf(fmaxf(u, 0.0f), 1.0f);
+                    const float ratio = (1.0f / (u + 1e-8f)) * winsize * um;
+                    const int oy = y0 + wp * PT + pt, ox = x0 + (lane & 31);
+                    if (ox < a.W && oy < a.H && a.um_out && blockIdx.y == 0 && wc == 0 && lane < 32)
+                        a.um_out[(size_t)n * HW + (size_t)oy * a.W + ox] = um;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][pt][r] = (((acc[0][pt][r] * unscale) * ratio + eb[r]) * um) * rescale;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][pt][r] = (acc[0][pt][r] * unscale + eb[r]) * rescale;
+                }
+            }
+        }
+        const h8 *swbase = a.skip_w + (size_t)cot0 * ((size_t)ns * 128);           // fragment (tile, chunk, half): 64 vectors
+        for (int s0 = 0; s0 < ns; s0 += SK) {
+            sstore();
+            h8 sa[SK][2];
+#pragma unroll
+            for (int k = 0; k < SK; ++k) {
+                const h8 *q = swbase + (size_t)min(s0 + k, ns - 1) * 128;
+                sa[k][0] = q[(unsigned)lane]; sa[k][1] = q[(unsigned)lane + 64u];
+            }
+            __syncthreads();
+            sload(s0 + SK);                            // the next fill, in flight under this one's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < SK; ++k) {
+                if (s0 + k >= ns) break;               // (uniform)
+                const h8 *xh = &xk[k][0][lane >> 5][0], *xl = &xk[k][1][lane >> 5][0];
+                constexpr int PB = PT > 4 ? 4 : PT, NB = PT / PB;
+#pragma unroll
+                for (int hb = 0; hb < NB; ++hb) {
+                    h8 bh[PB], bl[PB];
+#pragma unroll
+                    for (int kk = 0; kk < PB; ++kk) {
+                        const int p = (wp * PT + hb * PB + kk) * 32 + (lane & 31);
+                        bh[kk] = xh[p];
+                        bl[kk] = xl[p];
+                    }
+#pragma unroll
+                    for (int part = 0; part < 3; ++part)
+#pragma unroll
+                        for (int kk = 0; kk < PB; ++kk)
+                            acc[0][hb * PB + kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? sa[k][1] : sa[k][0], part == 1 ? bl[kk] : bh[kk],
+                                                                                          acc[0][hb * PB + kk], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (!F32 && a.sat && sat != 0ull && lane == 0) atomicAdd(a.sat, 1u);   // an activation left the f16 range (stage_value)
+
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel).
     // Work-items outside the image / channels past Cout are clamped for the loads and skipped for
     // the stores; all loads of a tile are issued before its first store.
     // The optional stages are uniform branches around whole 16-register blocks (never per element),
     // and every block issues all its loads before its arithmetic.
-    const bool partial = a.partial != 0, has_bias = a.bias != nullptr, has_res = a.residual != nullptr,
-               has_next = a.next_scale != nullptr;
+    // (SKIP: the 3x3 epilogue has been applied in front of the skip phase; what is left is the change of scale and the skip's bias)
+    const float *ebias = SKIP ? a.skip_bias : a.bias;
+    // (has_res stays a run-time test in the SKIP kernels although conv_set_skip admits no residual: with a constant there the
+    // compiler keeps the transposed tile of the vector store path in scratch memory)
+    const bool partial = !SKIP && a.partial != 0, has_bias = ebias != nullptr, has_res = a.residual != nullptr,
+               has_next = !SKIP && a.next_scale != nullptr;
     float *outp = a.out;
     // Vector path of the stores: the finished 32-channel x 32-pixel tile takes a round trip through the wave's own
     // LDS scratch (the staging buffers are free now) and comes back as [channel][4 consecutive pixels] per lane, so
@@ -421,7 +552,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     const int ox = x0 + bcol;
     const bool xin_img = ox < a.W;
     const int cout1 = a.Cout - 1;
-    const float mscale = a.mask_scale, winsize = a.winsize, unscale = a.unscale;
+    const float mscale = a.mask_scale, winsize = a.winsize, unscale = SKIP ? a.skip_unscale : a.unscale;
 #pragma unroll
     for (int ct = 0; ct < CPW; ++ct) {
         int co[16];
@@ -430,7 +561,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         float eb[16], esc[16], esh[16];
         if (has_bias) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) eb[r] = a.bias[min(co[r], cout1)];
+            for (int r = 0; r < 16; ++r) eb[r] = ebias[min(co[r], cout1)];
         }
         if (has_next) {
 #pragma unroll
@@ -974,6 +1105,19 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
     // channel-blocked activations).  The weight buffer is indexed by 32-channel tiles, so any row width reads it.
     if (ct == 128 && a.pre != PRE_NONE && !in_b8) ct = 64;
     const dim3 grid(tiles, conv_cout_pad(a.Cout) / ct, a.N);
+    if constexpr (!F32) {
+        if (a.skip_in) {                    // (conv_set_skip: split rung, channel-blocked main input, more than 4 output channels)
+#define CV_SKIP(WCO)                                                                                            \
+    do {                                                                                                       \
+        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, true, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);   \
+        else hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);                   \
+    } while (0)
+            if (ct == 128) CV_SKIP(4); else if (ct == 64) CV_SKIP(2); else CV_SKIP(1);
+#undef CV_SKIP
+            SLR_CHECK_LAUNCH();
+            return 0;
+        }
+    }
 #define CV_LAUNCH(CPW, WCO)                                                                                     \
     do {                                                                                                       \
         if (a.pre != PRE_NONE && in_b8) hipLaunchKernelGGL((conv3x3_split_kernel<CPW, WCO, true, true, F32>), grid, dim3(CV_THREADS), 0, st, a);    \
@@ -996,7 +1140,7 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
 
 static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
                              bool derived_mask) {
-    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO);
+    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO | SLR_CONV_SKIP_B8);      // (SLR_CONV_SKIP_B8: conv_set_skip)
     SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8 | SLR_CONV_RES_B8)) == 0, "layout flags");
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8) || ((layout & SLR_CONV_OUT_B8) && residual && !((uintptr_t)residual & 15)),
                   "a channel-blocked residual goes with a channel-blocked output");
@@ -1013,9 +1157,28 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
     return 0;
 }
 
-SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual,
+// The 1x1 skip branch riding in the 3x3 kernel (slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip)
+struct SkipOp { const float *in; const void *w; const float *bias; int cin; float wscale; };
+
+static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layout) {
+    const bool sb8 = (layout & SLR_CONV_SKIP_B8) != 0;
+    layout &= ~SLR_CONV_SKIP_B8;
+    if (!sk) { SLR_CHECK_ARG(!sb8, "layout flags"); return 0; }
+    SLR_CHECK_ARG(sk->in && sk->w, "null pointer");
+    SLR_CHECK_ARG(!(layout & (SLR_CONV_F32 | SLR_CONV_WINO)), "the fused skip branch runs on the split-f16 rung");
+    SLR_CHECK_ARG((layout & SLR_CONV_IN_B8) && a.Cout > CF_MAXCO, "the fused skip branch needs a channel-blocked main input and more than 4 output channels");
+    SLR_CHECK_ARG(sk->cin > 0 && (long long)sk->cin * a.H * a.W < (1LL << 31) && sk->wscale > 0.0f, "skip sizes");
+    SLR_CHECK_ARG(sb8 && sk->cin % 8 == 0 && !((uintptr_t)sk->in & 15), "the fused skip branch reads a channel-blocked skip input (SLR_CONV_SKIP_B8): skip_cin % 8 == 0, 16-byte aligned");
+    SLR_CHECK_ARG(!a.residual && !a.next_scale, "the fused skip branch replaces the residual; no next-BN fusion with it");
+    a.skip_in = sk->in; a.skip_w = (const h8 *)sk->w; a.skip_bias = sk->bias;
+    a.skip_cin = sk->cin; a.skip_nchunk = conv_cin_pad(sk->cin) / 16; a.skip_b8 = sb8;
+    a.skip_unscale = 1.0f / (xscale * sk->wscale);
+    return 0;
+}
+
+static int conv3x3_forward_impl(const float *in, const void *wsplit, const float *bias, const float *residual,
                                    float *out, int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
-                                   const float *pre_scale, const float *pre_shift, int layout, void *stream) {
+                                   const float *pre_scale, const float *pre_shift, const SkipOp *sk, int layout, void *stream) {
     SLR_CHECK_ARG(in && wsplit && out, "null pointer");
     if (int e = conv_check_layout(layout, in, out, Cin, Cout, residual, false)) return e;
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
@@ -1029,13 +1192,29 @@ SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const fl
     a.residual = residual;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
+    if (int e = conv_set_skip(a, sk, xscale, layout)) return e;
     return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream, (layout & SLR_CONV_WINO) != 0);
 }
 
-SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+SLR_EXPORT int slr_conv3x3_forward(const float *in, const void *wsplit, const float *bias, const float *residual,
+                                   float *out, int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
+                                   const float *pre_scale, const float *pre_shift, int layout, void *stream) {
+    return conv3x3_forward_impl(in, wsplit, bias, residual, out, N, Cin, Cout, H, W, wscale, xscale, pre_scale, pre_shift, nullptr, layout, stream);
+}
+
+SLR_EXPORT int slr_conv3x3_forward_skip(const float *in, const void *wsplit, const float *bias, float *out,
+                                        int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
+                                        const float *pre_scale, const float *pre_shift,
+                                        const float *skip_in, const void *skip_wsplit, const float *skip_bias, int skip_cin, float skip_wscale,
+                                        int layout, void *stream) {
+    const SkipOp sk = {skip_in, skip_wsplit, skip_bias, skip_cin, skip_wscale};
+    return conv3x3_forward_impl(in, wsplit, bias, nullptr, out, N, Cin, Cout, H, W, wscale, xscale, pre_scale, pre_shift, &sk, layout, stream);
+}
+
+static int pconv3x3_forward_impl(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
                                     const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
                                     const float *next_scale, const float *next_shift, float *out, float *um_out,
-                                    int N, int Cin, int Cout, int H, int W, int layout, void *stream) {
+                                    int N, int Cin, int Cout, int H, int W, const SkipOp *sk, int layout, void *stream) {
     SLR_CHECK_ARG(x && wsplit && bias && out, "null pointer");
     if (int e = conv_check_layout(layout, x, out, Cin, Cout, residual, mask == nullptr)) return e;
     SLR_CHECK_ARG(!pre_scale == !pre_shift, "pre_scale / pre_shift go together");
@@ -1055,5 +1234,24 @@ SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, cons
     a.residual = residual; a.next_scale = next_scale; a.next_shift = next_shift; a.um_out = um_out;
     a.out_b8 = (layout & SLR_CONV_OUT_B8) != 0;
     a.res_b8 = (layout & SLR_CONV_RES_B8) != 0;
+    if (int e = conv_set_skip(a, sk, xscale, layout)) return e;
     return conv_launch(a, wscale, xscale, (layout & SLR_CONV_IN_B8) != 0, (layout & SLR_CONV_F32) != 0, (hipStream_t)stream, (layout & SLR_CONV_WINO) != 0);
+}
+
+SLR_EXPORT int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                                    const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
+                                    const float *next_scale, const float *next_shift, float *out, float *um_out,
+                                    int N, int Cin, int Cout, int H, int W, int layout, void *stream) {
+    return pconv3x3_forward_impl(x, pre_scale, pre_shift, mask, wsplit, wscale, xscale, bias, residual, next_scale, next_shift, out, um_out,
+                                 N, Cin, Cout, H, W, nullptr, layout, stream);
+}
+
+SLR_EXPORT int slr_pconv3x3_forward_skip(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                                         const void *wsplit, float wscale, float xscale, const float *bias, float *out, float *um_out,
+                                         int N, int Cin, int Cout, int H, int W,
+                                         const float *skip_in, const void *skip_wsplit, int skip_cin, float skip_wscale,
+                                         int layout, void *stream) {
+    const SkipOp sk = {skip_in, skip_wsplit, nullptr, skip_cin, skip_wscale};
+    return pconv3x3_forward_impl(x, pre_scale, pre_shift, mask, wsplit, wscale, xscale, bias, nullptr, nullptr, nullptr, out, um_out,
+                                 N, Cin, Cout, H, W, &sk, layout, stream);
 }

@@ -62,6 +62,8 @@
 #define SLR_ROWS_GROUP 2        // narrow pieces: 0 one lane per output pixel; 1 groups of 8 / 4 lanes up to 16 columns; 2 also pairs up to 32 columns
 #define SLR_FRONT_END -1        // default of slr_splat_set_front_end: -1 = by grid size, 0 bins, 1 scan (boxes), 2 rows
 
+#define SLR_CONV_SKIP_FILL 3     // 3x3 kernels with the block's 1x1 skip inside (conv.hip, SKIP): skip chunks staged per barrier pair (16 KiB of LDS and 16 registers in flight each)
+
 // ---- development aids
 
 // ---- variant builds (csrc/Makefile: TUNE="NAME=value ...")

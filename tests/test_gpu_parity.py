@@ -1983,6 +1983,104 @@ def test_channel_blocked_resample_and_skip_kernels(S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pconv", "plain"])
+@pytest.mark.parametrize("cin,cout,h,w,resample", [(64, 128, 16, 64, "Down"), (128, 256, 9, 33, "Down"), (256, 128, 11, 40, "Up"),
+                                                   (128, 128, 8, 32, "Up"), (3, 32, 13, 70, None), (24, 72, 21, 37, None),
+                                                   (40, 64, 5, 96, None)])
+def test_skip_branch_inside_the_second_convolution(S, kind, cin, cout, h, w, resample):
+    """slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip (ABI 10): a residual block's 1x1 skip convolution as extra
+    K chunks of its second 3x3 kernel (models/layers/blocks.py:83-87, :237-248) against the two-kernel form (staged_skips(): 1x1 kernel ->
+    residual of the 3x3 epilogue).  Same products; only the order of the LAST additions differs (the skip's products join the finished
+    3x3 value one chunk at a time instead of as one sum), so the two agree to fp32 rounding: <= 2e-6 of the output scale (the split-f16
+    arithmetic itself is 2-5e-6 against fp64, test_conv3x3_matrix_core_kernel).  Update masks are bit-identical.  Down / Up blocks,
+    a 3-channel NCHW skip input (the encoders' first block), ragged sizes, padded channel counts; and against an fp64 definition."""
+    import torch.nn.functional as F
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin * 7 + w)
+    n = 2
+    with torch.no_grad():
+        if kind == "pconv":
+            blk = nets.PconvResBlock(cin, cout, resample).cuda()
+        else:
+            blk = nets.ResBlock(cin, cout, resample).cuda()
+        for m in blk.modules():
+            if isinstance(m, nets.AffineBN):
+                m.stored_mean.normal_(0, 0.3); m.stored_var.uniform_(0.5, 1.5)
+            if isinstance(m, nets.Conv) and m.bias is not None:
+                m.bias.normal_()
+        x = torch.randn(n, cin, h, w, device="cuda")
+        b8_in = cin % 8 == 0
+
+        def to_b8(t):
+            nn_, c, hh, ww = t.shape
+            return t.view(nn_, c // 8, 8, hh, ww).permute(0, 1, 3, 4, 2).contiguous().view(nn_, c, hh, ww)
+
+        def from_b8(t):
+            nn_, c, hh, ww = t.shape
+            return t.view(nn_, c // 8, hh, ww, 8).permute(0, 1, 4, 2, 3).contiguous().view(nn_, c, hh, ww)
+
+        xin = to_b8(x) if b8_in else x
+        mask = (torch.rand(n, 1, h, w, device="cuda") > 0.3).float()
+        L = nets._lib.lib()
+        name = "slr_pconv3x3_forward_skip" if kind == "pconv" else "slr_conv3x3_forward_skip"
+        entry, calls = getattr(L, name), []
+
+        def counted(*a):
+            calls.append(1)
+            return entry(*a)
+
+        def run():
+            if kind == "pconv":
+                y, m, b8 = blk(xin, mask, b8_in)
+            else:
+                (y, b8), m = blk(xin, b8_in), None
+            assert b8
+            return from_b8(y), m
+
+        setattr(L, name, counted)
+        try:
+            y1, m1 = run()
+            fused = 1 if b8_in else 0                  # (an NCHW block input keeps the two-kernel form)
+            assert len(calls) == fused, "the fused entry point was not called"
+            with nets.staged_skips():
+                y0, m0 = run()
+            assert len(calls) == fused
+        finally:
+            setattr(L, name, entry)
+        if m1 is not None:
+            assert torch.equal(m1, m0)
+        scale = y0.abs().max().item()
+        err = (y1 - y0).abs().max().item()
+        assert err <= 2e-6 * max(scale, 1.0), (kind, cin, cout, err, scale)
+        # fp64 definition of the block
+        xd = x.double()
+        def bn(t, b):
+            sc, sh = b.scale_shift()
+            return t * sc.double().view(1, -1, 1, 1) - sh.double().view(1, -1, 1, 1)
+        wa, wb_, ws_ = blk.conv_aa.weight.double(), blk.conv_ab.weight.double(), blk.conv_b.weight.double()
+        if kind == "plain":
+            a = F.conv2d(F.relu(bn(xd, blk.bn1)), wa, blk.conv_aa.bias.double(), padding=1)
+            a = F.conv2d(F.relu(bn(a, blk.bn2)), wb_, blk.conv_ab.bias.double(), padding=1)
+            a = a + F.conv2d(xd, ws_, blk.conv_b.bias.double())
+        else:
+            md = mask.double()
+            def pconv(t, msk, wt, bias, c_in):
+                box = F.avg_pool2d(msk, 3, stride=1, padding=1, divisor_override=1) * c_in
+                um = box.clamp(0, 1)
+                ratio = (c_in * 9) / (box + 1e-8) * um
+                return (F.conv2d(t, wt, None, padding=1) * ratio + bias.double().view(1, -1, 1, 1)) * um, um
+            a, um = pconv(F.relu(bn(xd, blk.bn1)) * md, md, wa, blk.conv_aa.bias, cin)
+            a, um = pconv(F.relu(bn(a, blk.bn2)) * um, um, wb_, blk.conv_ab.bias, cout)
+            a = a + F.conv2d(xd, ws_, None)
+        if resample == "Down":
+            a = F.avg_pool2d(a, 3, stride=2, padding=1)
+        elif resample == "Up":
+            a = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=False)
+        e64 = (y1.double() - a).abs().max().item()
+        assert e64 <= 3e-5 * max(a.abs().max().item(), 1.0), (kind, cin, cout, e64)
+
+
+@pytest.mark.gpu
 def test_clip_kernels_on_plane_blocked_values(S):
     """SLR_SYNTH_VALUES_B4 (ABI 8): slr_pack_planes4 writes [C/4][H][W][4]; the clip kernels then read a chunk's 4 planes of a source pixel
     with one 16-byte load.  Same arithmetic as on the planar tensor: the two agree to the run-to-run noise of the summation order
