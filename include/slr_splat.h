@@ -351,6 +351,7 @@ int slr_conv_saturation_record(unsigned *host_slot, void *stream);
  * come from slr_conv3x3_wino_weights (slr_conv3x3_wino_weight_bytes: 16 transformed values per weight instead of 9). */
 #define SLR_CONV_WINO   16
 #define SLR_CONV_SKIP_B8 32    /* slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip: `skip_in` is channel-blocked */
+#define SLR_CONV_POOL_OUT 64   /* ... and `out` is avgpool3x3s2 of the result, [N,Cout,(H-1)/2+1,(W-1)/2+1] channel-blocked (needs pool_ws) */
 /* Cout <= 4 (the 128 -> 3 end of the decoders): the 3x3 entry points run a kernel of their own on EITHER rung -- fp32 FMAs on the vector
  * ALUs (csrc/conv_few.hpp; the narrowest matrix-core tile would compute 32 channels for 3), i.e. the reference's arithmetic: both
  * weight-preparation calls then write plain fp32 weights into the buffer, wscale / xscale are accepted and unused, nothing saturates. */
@@ -399,17 +400,24 @@ int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pr
  * rounding; tests/test_gpu_parity.py).  skip_wsplit: slr_conv1x1_split_weights(Cout, skip_cin, skip_wscale); the skip input shares
  * `xscale`.  Split-f16 rung only (no SLR_CONV_F32 / _WINO), main input and skip input channel-blocked (SLR_CONV_IN_B8 and
  * SLR_CONV_SKIP_B8 both set, skip_cin % 8 == 0), Cout > 4; anything else is SLR_E_BADARG -- callers keep the two-kernel form there
- * (the networks' 3-channel first blocks and 65- / 3-channel ends). */
+ * (the networks' 3-channel first blocks and 65- / 3-channel ends).
+ * With SLR_CONV_POOL_OUT (and SLR_CONV_OUT_B8, Cout > 64) the "Down" block's nn.AvgPool2d(3, stride=2, padding=1) (blocks.py:196-199)
+ * happens in the epilogue: the full-resolution result -- whose only reader is the pool -- is never written; `out` is the pooled tensor,
+ * um_out stays full resolution.  A wave pools the 4 x 16 pixels of its tile in registers; the pooled pixels that need the row above /
+ * the column left of the tile are completed by a small second launch from side buffers in pool_ws (slr_conv_pool_ws_bytes: the last row
+ * of every tile row and the last column of every tile column, ~16 % of the full-resolution tensor).  Same 9 terms per pooled pixel as
+ * slr_avgpool3x3s2, summed rows first: equal to the two-kernel form to fp32 rounding.  pool_ws = NULL otherwise. */
+size_t slr_conv_pool_ws_bytes(int N, int Cout, int H, int W);
 int slr_conv3x3_forward_skip(const float *in, const void *wsplit, const float *bias, float *out,
                              int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
                              const float *pre_scale, const float *pre_shift,
                              const float *skip_in, const void *skip_wsplit, const float *skip_bias /* [Cout] or NULL */, int skip_cin,
-                             float skip_wscale, int layout, void *stream);
+                             float skip_wscale, void *pool_ws, size_t pool_ws_bytes, int layout, void *stream);
 int slr_pconv3x3_forward_skip(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
                               const void *wsplit, float wscale, float xscale, const float *bias, float *out, float *um_out,
                               int N, int Cin, int Cout, int H, int W,
                               const float *skip_in, const void *skip_wsplit, int skip_cin, float skip_wscale,
-                              int layout, void *stream);
+                              void *pool_ws, size_t pool_ws_bytes, int layout, void *stream);
 
 /* 1x1 convolution (skip branch of the residual blocks, models/layers/blocks.py:192-193,243-247) on the same
  * split-f16 arithmetic: out = conv1x1(in) + bias.  HBM-bound, no LDS.  Weights prepared once per layer with

@@ -85,6 +85,10 @@ struct ConvArgs {
     const float *skip_bias;
     int skip_cin, skip_nchunk, skip_b8;
     float skip_unscale;    // 1 / (xscale * skip wscale)
+    // POOL instantiations: `out` is the 3x3 / stride 2 / pad 1 average pool of the result ("Down" blocks, blocks.py:196-199), channel-blocked;
+    // the tile's last row / last column go to these side buffers for pool_fix_kernel: [N][tiles_y][Cout/8][W][8], [N][tiles_x][Cout/8][H][8]
+    float *pool_row, *pool_col;
+    int tiles_y;
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -111,9 +115,11 @@ namespace slr {
 constexpr int CV_FSTR = 352;                       // F32: floats per channel row of the staged block
 // SKIP: the residual block's 1x1 skip convolution rides in this kernel (see the skip phase behind the main loop): the separate 1x1 kernel,
 // the write of its result and the read of it as the residual are gone.
-template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false, bool SKIP = false>
+// POOL (with SKIP, 128-channel workgroup rows): the "Down" block's average pool in the epilogue -- see the end of the kernel.
+template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false, bool SKIP = false, bool POOL = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
+    static_assert(!POOL || (SKIP && WCO == 4), "the pooling epilogue: a wave holds all 8 rows of its channel tile");
     static_assert(!F32 || CPW == 1, "the fp32 rung runs one 32-channel tile per wave");
     static_assert(!SKIP || (CPW == 1 && !F32 && INB8), "the skip phase: split rung, one tile per wave, channel-blocked main input");
     constexpr int XRAW = F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16, XSKIP = SKIP ? SLR_CONV_SKIP_FILL * 2 * 2 * 256 * 16 : 0;
@@ -528,6 +534,66 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 
     if (!F32 && a.sat && sat != 0ull && lane == 0) atomicAdd(a.sat, 1u);   // an activation left the f16 range (stage_value)
 
+    if constexpr (POOL) {
+        // ---- pooling epilogue ("Down" blocks: the full-resolution result has one reader, nn.AvgPool2d(3, 2, 1) -- it is never written).
+        // A wave holds all 8 rows x 32 columns of its 32 channels: pooled pixel (i, j) of the tile = rows 2i-1 .. 2i+1 (register index) x
+        // columns 2j-1 .. 2j+1 (neighbouring lanes) -- 4 x 16 pooled pixels, of which the first row and the first column lack the row above /
+        // the column left of the tile.  Those get their partial sums here; the tile's last row and last column go to side buffers and
+        // pool_fix_kernel adds what is missing.  Sums are formed rows first, then columns (slr_avgpool3x3s2: columns first): same 9 terms, the
+        // result differs from the two-kernel form by fp32 rounding only.
+        const float unscale = a.skip_unscale;
+        const int ox = x0 + bcol;
+        const bool xin = ox < a.W;
+        const int OH = (a.H - 1) / 2 + 1, OW = (a.W - 1) / 2 + 1, C8 = a.Cout >> 3;
+        float sb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb[r] = a.skip_bias ? a.skip_bias[min(cot0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * bgrp, a.Cout - 1)] : 0.0f;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const bool ok = xin & (y0 + pt < a.H);                     // pixels outside the image are the pool's zero padding
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][pt][r] = ok ? acc[0][pt][r] * unscale + sb[r] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c8 = cot0 * 4 + q;
+            if (c8 * 8 + 4 * bgrp >= a.Cout) continue;
+            if (xin && y0 + 7 < a.H) {                                 // last row of the tile
+                float *rb = a.pool_row + ((((size_t)n * a.tiles_y + ty) * C8 + c8) * a.W + ox) * 8 + 4 * bgrp;
+                *reinterpret_cast<float4 *>(rb) = make_float4(acc[0][7][4 * q], acc[0][7][4 * q + 1], acc[0][7][4 * q + 2], acc[0][7][4 * q + 3]);
+            }
+            if (bcol == 31 && xin) {                                   // last column
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    if (y0 + pt < a.H) {
+                        float *cb = a.pool_col + ((((size_t)n * a.tiles_x + tx) * C8 + c8) * a.H + y0 + pt) * 8 + 4 * bgrp;
+                        *reinterpret_cast<float4 *>(cb) = make_float4(acc[0][pt][4 * q], acc[0][pt][4 * q + 1], acc[0][pt][4 * q + 2], acc[0][pt][4 * q + 3]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float hsum[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = i > 0 ? (acc[0][2 * i - 1][r] + acc[0][2 * i][r]) + acc[0][2 * i + 1][r] : acc[0][0][r] + acc[0][1][r];
+                const float left = __shfl_up(v, 1, 32), right = __shfl_down(v, 1, 32);
+                hsum[r] = (((bcol > 0 ? left : 0.0f) + v) + (bcol < 31 ? right : 0.0f)) * (1.0f / 9.0f);
+            }
+            const int py = (y0 >> 1) + i, px = (x0 + bcol) >> 1;
+            if ((bcol & 1) == 0 && xin && y0 + 2 * i < a.H) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c8 = cot0 * 4 + q;
+                    if (c8 * 8 + 4 * bgrp < a.Cout)
+                        *reinterpret_cast<float4 *>(&a.out[((((size_t)n * C8 + c8) * OH + py) * OW + px) * 8 + 4 * bgrp]) =
+                            make_float4(hsum[4 * q], hsum[4 * q + 1], hsum[4 * q + 2], hsum[4 * q + 3]);
+                }
+            }
+        }
+        return;
+    }
+
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel).
     // Work-items outside the image / channels past Cout are clamped for the loads and skipped for
     // the stores; all loads of a tile are issued before its first store.
@@ -810,6 +876,56 @@ __global__ __launch_bounds__(256) void conv1x1_split_kernel(const float *__restr
         }
     }
     if (!F32 && sat_count && __ballot(sat) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(sat_count, 1u);
+}
+
+// The pooled pixels the POOL epilogue left incomplete: first pooled row of every tile row but the top one (lacks the image row above the
+// tile: the last row of the tile above), first pooled column of every tile column but the left one (lacks the column left of the tile).
+// One work-item per such pixel and 8-channel group; lines = (tiles_y - 1) pooled rows of OW pixels, then (tiles_x - 1) pooled columns of OH.
+__global__ __launch_bounds__(256) void pool_fix_kernel(float *__restrict__ out, const float *__restrict__ prow, const float *__restrict__ pcol,
+                                                       int C8, int H, int W, int tiles_x, int tiles_y) {
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int nrow = (tiles_y - 1) * OW, ncol = (tiles_x - 1) * OH;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nrow + ncol) return;
+    int py, px;
+    if (idx < nrow) { py = (idx / OW + 1) * (CV_H / 2); px = idx % OW; }
+    else {
+        const int k = idx - nrow;
+        px = (k / OH + 1) * (CV_W / 2); py = k % OH;
+        if (py % (CV_H / 2) == 0 && py > 0) return;                 // a tile corner: done by its row line
+    }
+    if (py >= OH || px >= OW) return;
+    const int n = blockIdx.y / C8, c8 = blockIdx.y % C8;
+    const bool need_row = py % (CV_H / 2) == 0 && py > 0, need_col = px % (CV_W / 2) == 0 && px > 0;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto add = [&](const float *p) {
+        const float4 u = reinterpret_cast<const float4 *>(p)[0], v = reinterpret_cast<const float4 *>(p)[1];
+        s[0] += u.x; s[1] += u.y; s[2] += u.z; s[3] += u.w; s[4] += v.x; s[5] += v.y; s[6] += v.z; s[7] += v.w;
+    };
+    if (need_row) {
+        const int ty = py / (CV_H / 2);
+        const float *rb = prow + (((size_t)n * tiles_y + ty - 1) * C8 + c8) * (size_t)W * 8;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int x = 2 * px + dx;
+            if (x >= 0 && x < W) add(rb + (size_t)x * 8);
+        }
+    }
+    if (need_col) {
+        const int tx = px / (CV_W / 2);
+        const float *cb = pcol + (((size_t)n * tiles_x + tx - 1) * C8 + c8) * (size_t)H * 8;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = 2 * py + dy;
+            if (dy < 0 && need_row) continue;                        // (that corner came with the row above)
+            if (y >= 0 && y < H) add(cb + (size_t)y * 8);
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(out + ((((size_t)n * C8 + c8) * OH + py) * OW + px) * 8);
+    float4 u = o[0], v = o[1];
+    u.x += s[0] * (1.0f / 9.0f); u.y += s[1] * (1.0f / 9.0f); u.z += s[2] * (1.0f / 9.0f); u.w += s[3] * (1.0f / 9.0f);
+    v.x += s[4] * (1.0f / 9.0f); v.y += s[5] * (1.0f / 9.0f); v.z += s[6] * (1.0f / 9.0f); v.w += s[7] * (1.0f / 9.0f);
+    o[0] = u; o[1] = v;
 }
 
 // w [Cout,Cin,k,k] fp32 (taps = k*k = 9 or 1) -> split f16 weights in fragment order over the PADDED
@@ -1112,6 +1228,19 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
         if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, true, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);   \
         else hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);                   \
     } while (0)
+            if (a.pool_row) {               // (conv_set_skip: 128-channel workgroup rows)
+                if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, false, true, true>), grid, dim3(CV_THREADS), 0, st, a);
+                else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, false, true, true>), grid, dim3(CV_THREADS), 0, st, a);
+                SLR_CHECK_LAUNCH();
+                const int OH = (a.H - 1) / 2 + 1, OW = (a.W - 1) / 2 + 1;
+                const int items = (a.tiles_y - 1) * OW + (a.tiles_x - 1) * OH;
+                if (items > 0) {
+                    hipLaunchKernelGGL(pool_fix_kernel, dim3((items + 255) / 256, a.N * (a.Cout >> 3)), dim3(256), 0, st, a.out, (const float *)a.pool_row,
+                                       (const float *)a.pool_col, a.Cout >> 3, a.H, a.W, a.tiles_x, a.tiles_y);
+                    SLR_CHECK_LAUNCH();
+                }
+                return 0;
+            }
             if (ct == 128) CV_SKIP(4); else if (ct == 64) CV_SKIP(2); else CV_SKIP(1);
 #undef CV_SKIP
             SLR_CHECK_LAUNCH();
@@ -1140,7 +1269,7 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
 
 static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
                              bool derived_mask) {
-    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO | SLR_CONV_SKIP_B8);      // (SLR_CONV_SKIP_B8: conv_set_skip)
+    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO | SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT);      // (the last two: conv_set_skip)
     SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8 | SLR_CONV_RES_B8)) == 0, "layout flags");
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8) || ((layout & SLR_CONV_OUT_B8) && residual && !((uintptr_t)residual & 15)),
                   "a channel-blocked residual goes with a channel-blocked output");
@@ -1158,12 +1287,23 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
 }
 
 // The 1x1 skip branch riding in the 3x3 kernel (slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip)
-struct SkipOp { const float *in; const void *w; const float *bias; int cin; float wscale; };
+struct SkipOp { const float *in; const void *w; const float *bias; int cin; float wscale; void *pool_ws; size_t pool_ws_bytes; };
+
+// side buffers of the pooling epilogue: the last row of every tile row and the last column of every tile column of the result
+static size_t conv_pool_ws_bytes(int N, int Cout, int H, int W) {
+    const size_t tiles_x = (W + CV_W - 1) / CV_W, tiles_y = (H + CV_H - 1) / CV_H;
+    return (size_t)N * Cout * (tiles_y * W + tiles_x * H) * sizeof(float);
+}
+
+SLR_EXPORT size_t slr_conv_pool_ws_bytes(int N, int Cout, int H, int W) {
+    if (N <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    return conv_pool_ws_bytes(N, Cout, H, W);
+}
 
 static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layout) {
-    const bool sb8 = (layout & SLR_CONV_SKIP_B8) != 0;
-    layout &= ~SLR_CONV_SKIP_B8;
-    if (!sk) { SLR_CHECK_ARG(!sb8, "layout flags"); return 0; }
+    const bool sb8 = (layout & SLR_CONV_SKIP_B8) != 0, pool = (layout & SLR_CONV_POOL_OUT) != 0;
+    layout &= ~(SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT);
+    if (!sk) { SLR_CHECK_ARG(!sb8 && !pool, "layout flags"); return 0; }
     SLR_CHECK_ARG(sk->in && sk->w, "null pointer");
     SLR_CHECK_ARG(!(layout & (SLR_CONV_F32 | SLR_CONV_WINO)), "the fused skip branch runs on the split-f16 rung");
     SLR_CHECK_ARG((layout & SLR_CONV_IN_B8) && a.Cout > CF_MAXCO, "the fused skip branch needs a channel-blocked main input and more than 4 output channels");
@@ -1173,6 +1313,14 @@ static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layou
     a.skip_in = sk->in; a.skip_w = (const h8 *)sk->w; a.skip_bias = sk->bias;
     a.skip_cin = sk->cin; a.skip_nchunk = conv_cin_pad(sk->cin) / 16; a.skip_b8 = sb8;
     a.skip_unscale = 1.0f / (xscale * sk->wscale);
+    if (pool) {
+        SLR_CHECK_ARG(a.out_b8 && conv_cout_tile(a.Cout) == 128, "the pooling epilogue needs a channel-blocked output and more than 64 output channels");
+        SLR_CHECK_ARG(sk->pool_ws && !((uintptr_t)sk->pool_ws & 15) && sk->pool_ws_bytes >= conv_pool_ws_bytes(a.N, a.Cout, a.H, a.W),
+                      "pool_ws: slr_conv_pool_ws_bytes, 16-byte aligned");
+        a.tiles_y = (a.H + CV_H - 1) / CV_H;
+        a.pool_row = (float *)sk->pool_ws;
+        a.pool_col = a.pool_row + (size_t)a.N * a.Cout * a.tiles_y * a.W;
+    }
     return 0;
 }
 
@@ -1206,8 +1354,8 @@ SLR_EXPORT int slr_conv3x3_forward_skip(const float *in, const void *wsplit, con
                                         int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
                                         const float *pre_scale, const float *pre_shift,
                                         const float *skip_in, const void *skip_wsplit, const float *skip_bias, int skip_cin, float skip_wscale,
-                                        int layout, void *stream) {
-    const SkipOp sk = {skip_in, skip_wsplit, skip_bias, skip_cin, skip_wscale};
+                                        void *pool_ws, size_t pool_ws_bytes, int layout, void *stream) {
+    const SkipOp sk = {skip_in, skip_wsplit, skip_bias, skip_cin, skip_wscale, pool_ws, pool_ws_bytes};
     return conv3x3_forward_impl(in, wsplit, bias, nullptr, out, N, Cin, Cout, H, W, wscale, xscale, pre_scale, pre_shift, &sk, layout, stream);
 }
 
@@ -1250,8 +1398,8 @@ SLR_EXPORT int slr_pconv3x3_forward_skip(const float *x, const float *pre_scale,
                                          const void *wsplit, float wscale, float xscale, const float *bias, float *out, float *um_out,
                                          int N, int Cin, int Cout, int H, int W,
                                          const float *skip_in, const void *skip_wsplit, int skip_cin, float skip_wscale,
-                                         int layout, void *stream) {
-    const SkipOp sk = {skip_in, skip_wsplit, nullptr, skip_cin, skip_wscale};
+                                         void *pool_ws, size_t pool_ws_bytes, int layout, void *stream) {
+    const SkipOp sk = {skip_in, skip_wsplit, nullptr, skip_cin, skip_wscale, pool_ws, pool_ws_bytes};
     return pconv3x3_forward_impl(x, pre_scale, pre_shift, mask, wsplit, wscale, xscale, bias, nullptr, nullptr, nullptr, out, um_out,
                                  N, Cin, Cout, H, W, &sk, layout, stream);
 }

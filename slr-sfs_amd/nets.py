@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import _lib
 
 
-IN_B8, OUT_B8, RES_B8, CONV_F32, CONV_WINO, SKIP_B8 = 1, 2, 4, 8, 16, 32      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32 / SLR_CONV_WINO / SLR_CONV_SKIP_B8
+IN_B8, OUT_B8, RES_B8, CONV_F32, CONV_WINO, SKIP_B8, POOL_OUT = 1, 2, 4, 8, 16, 32, 64      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32 / _WINO / _SKIP_B8 / _POOL_OUT
 
 
 class _Route(threading.local):
@@ -44,6 +44,7 @@ class _Route(threading.local):
     f32_kernels = False                  # inside fp32_kernels(): the convolutions on the fp32 matrix instructions (the fp32 rung)
     winograd = False                     # ... its 3x3 convolutions as Winograd F(2x2, 3x3) (csrc/conv_wino.hpp); False (= FP32_WINOGRAD): direct
     fused_skips = True                   # a block's 1x1 skip convolution rides in its second 3x3 kernel (slr_*_forward_skip); staged_skips(): two kernels
+    fused_pools = True                   # ... and a "Down" block's average pool in that kernel's epilogue; staged_skips(pools_only=True): pool kernel
 
 
 _S = _Route()
@@ -128,12 +129,16 @@ class staged_skips:
     """VALIDATION AID: inside, a residual block's 1x1 skip convolution is a kernel of its own again (slr_conv1x1_forward, its result the
     residual of the second 3x3 kernel) -- the form the fused kernels are tested against (tests/test_gpu_parity.py)."""
 
+    def __init__(self, pools_only=False):
+        self.pools_only = pools_only                 # keep the fused skip, stage only the "Down" blocks' average pool
+
     def __enter__(self):
-        self._prev = _S.fused_skips
-        _S.fused_skips = False
+        self._prev = (_S.fused_skips, _S.fused_pools)
+        _S.fused_skips = self.pools_only
+        _S.fused_pools = False
 
     def __exit__(self, *exc):
-        _S.fused_skips = self._prev
+        _S.fused_skips, _S.fused_pools = self._prev
         return False
 
 
@@ -141,6 +146,16 @@ def _skip_rides(a, cout, b8, b8_in):
     """The skip branch can ride in the second 3x3 kernel: split-f16 rung, channel-blocked block input and intermediate, more than 4
     output channels (include/slr_splat.h: slr_conv3x3_forward_skip)."""
     return bool(_S.fused_skips and b8 and b8_in and cout > 4 and a.is_cuda and not _S.f32_kernels and not _S.torch_convs)
+
+
+def _pool_out(N, cout, H, W, like, pool):
+    """(output tensor, pooling scratch, its bytes, layout flag) of the *_forward_skip calls: with ``pool`` the output is the block's
+    avgpool3x3s2 result and the kernel needs side buffers (include/slr_splat.h: SLR_CONV_POOL_OUT)."""
+    if not pool:
+        return torch.empty(N, cout, H, W, device=like.device, dtype=like.dtype), None, 0, 0
+    nbytes = _lib.lib().slr_conv_pool_ws_bytes(N, cout, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+    return torch.empty(N, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=like.device, dtype=like.dtype), ws, nbytes, POOL_OUT
 
 
 class cpu_reference:
@@ -262,21 +277,22 @@ class Conv(nn.Module):
     def forward(self, x, pre_bn=None, residual=None, layout=0):
         return self.conv(x, self.bias, pre_bn, residual, layout)
 
-    def forward_skip(self, x, pre_bn, skip_x, skip_conv, layout=0, skip_b8=False):
-        """conv(relu(bn(x))) + bias + skip_conv(skip_x) in ONE kernel (slr_conv3x3_forward_skip; blocks.py:83-87)."""
+    def forward_skip(self, x, pre_bn, skip_x, skip_conv, layout=0, skip_b8=False, pool=False):
+        """conv(relu(bn(x))) + bias + skip_conv(skip_x) in ONE kernel (slr_conv3x3_forward_skip; blocks.py:83-87); ``pool``: and the
+        "Down" block's average pool (:196-199) in its epilogue."""
         assert self.k == 3 and skip_conv.k == 1 and _fused_ok(x, skip_x)
         cout, cin = self.weight.shape[:2]
         N, _, H, W = x.shape
         buf, wscale, xscale, arith = self._split_weights()
         sbuf, swscale, _, sarith = skip_conv._split_weights()
         assert arith == 0 and sarith == 0
-        out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+        out, ws, ws_bytes, pflag = _pool_out(N, cout, H, W, x, pool)
         sc, sh = pre_bn if pre_bn is not None else (None, None)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().slr_conv3x3_forward_skip(
                 _lib.ptr(x), _lib.ptr(buf), _lib.ptr(self.bias), _lib.ptr(out), N, cin, cout, H, W, wscale, xscale, _lib.ptr(sc), _lib.ptr(sh),
-                _lib.ptr(skip_x), _lib.ptr(sbuf), _lib.ptr(skip_conv.bias), skip_x.shape[1], swscale,
-                layout | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_conv3x3_forward_skip")
+                _lib.ptr(skip_x), _lib.ptr(sbuf), _lib.ptr(skip_conv.bias), skip_x.shape[1], swscale, _lib.ptr(ws), ws_bytes,
+                layout | pflag | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_conv3x3_forward_skip")
         return out
 
     def _split_weights(self):
@@ -372,7 +388,7 @@ class PartialConv(Conv):
     (slr_pconv3x3_forward, which also forms the box sum and the per-element mask from the staged
     input); on the CPU the torch composition that defines it."""
 
-    def forward_skip(self, x, mask, skip_x, skip_conv, layout=0, skip_b8=False):
+    def forward_skip(self, x, mask, skip_x, skip_conv, layout=0, skip_b8=False, pool=False):
         """The block's second partial convolution with the 1x1 skip branch inside (slr_pconv3x3_forward_skip; blocks.py:237-248):
         ``x`` is the activated, masked output of the first one.  Returns (out, update_mask)."""
         assert self.k == 3 and skip_conv.k == 1 and skip_conv.bias is None and _fused_ok(x, mask, skip_x)
@@ -382,13 +398,13 @@ class PartialConv(Conv):
         buf, wscale, xscale, arith = self._split_weights()
         sbuf, swscale, _, sarith = skip_conv._split_weights()
         assert arith == 0 and sarith == 0
-        out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+        out, ws, ws_bytes, pflag = _pool_out(N, cout, H, W, x, pool)
         um = torch.empty(N, 1, H, W, device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().slr_pconv3x3_forward_skip(
                 _lib.ptr(x), None, None, _lib.ptr(mask), _lib.ptr(buf), wscale, xscale, _lib.ptr(self.bias), _lib.ptr(out), _lib.ptr(um),
-                N, cin, cout, H, W, _lib.ptr(skip_x), _lib.ptr(sbuf), skip_x.shape[1], swscale,
-                layout | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_pconv3x3_forward_skip")
+                N, cin, cout, H, W, _lib.ptr(skip_x), _lib.ptr(sbuf), skip_x.shape[1], swscale, _lib.ptr(ws), ws_bytes,
+                layout | pflag | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_pconv3x3_forward_skip")
         return out, um
 
     def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None, layout=0):
@@ -468,6 +484,7 @@ class ResBlock(nn.Module):
         self.conv_aa, self.conv_ab = Conv(cin, cout, 3), Conv(cout, cout, 3)
         self.conv_b = Conv(cin, cout, 1) if (resample or cin != cout) else None
         self.resample = _resample(resample)
+        self.pools = bool(resample) and resample != "Up"
 
     def forward(self, x, b8_in=False):
         """-> (y, b8_out): ``b8_in`` / ``b8_out`` = x / y are channel-blocked in memory (see _b8)."""
@@ -476,8 +493,9 @@ class ResBlock(nn.Module):
         lin = IN_B8 if b8_in else 0
         a = self.conv_aa(x, self.bn1.scale_shift(), layout=lin | (OUT_B8 if b8 else 0))   # BN + ReLU ride in the prologue
         if self.conv_b is not None and _skip_rides(a, cout, b8, b8_in):                        # x_a + conv_b(x) (:83-87) in one kernel
-            a = self.conv_ab.forward_skip(a, self.bn2.scale_shift(), x, self.conv_b, layout=IN_B8 | OUT_B8, skip_b8=b8_in)
-            return self.resample(a, b8), b8
+            pool = self.pools and cout > 64 and _S.fused_pools
+            a = self.conv_ab.forward_skip(a, self.bn2.scale_shift(), x, self.conv_b, layout=IN_B8 | OUT_B8, skip_b8=b8_in, pool=pool)
+            return (a if pool else self.resample(a, b8)), b8
         if self.conv_b is not None:
             skip_b8 = b8 and cout > 4                       # (the <= 4-channel skip kernel writes NCHW)
             b = self.conv_b(x, layout=lin | (OUT_B8 if skip_b8 else 0))
@@ -498,6 +516,7 @@ class PconvResBlock(nn.Module):
         self.conv_b = Conv(cin, cout, 1, bias=False) if (resample or cin != cout) else None   # :192-193
         self.resample, self.resample_mask = _resample(resample), _resample_mask(resample)
         self.has_resample = bool(resample)
+        self.pools = bool(resample) and resample != "Up"
 
     def forward(self, x, mask, b8_in=False):
         """-> (y, update_mask, b8_out).  mask: None = (x != 0) per channel (architectures.py:369; x is NCHW then), else
@@ -511,8 +530,9 @@ class PconvResBlock(nn.Module):
         # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
         # rounding, lets the residual join the epilogue, and halves the resampling work.
         if self.conv_b is not None and _skip_rides(a, cout, b8, b8_in):                # :237-248 in one kernel
-            a, m = self.conv_ab.forward_skip(a, m, x, self.conv_b, layout=IN_B8 | OUT_B8, skip_b8=b8_in)
-            return self.resample(a, b8), self.resample_mask(m), b8
+            pool = self.pools and cout > 64 and _S.fused_pools
+            a, m = self.conv_ab.forward_skip(a, m, x, self.conv_b, layout=IN_B8 | OUT_B8, skip_b8=b8_in, pool=pool)
+            return (a if pool else self.resample(a, b8)), self.resample_mask(m), b8
         if self.conv_b is not None:                                                # :243-247
             skip_b8 = b8 and cout > 4
             skip = self.conv_b(x, layout=lin | (OUT_B8 if skip_b8 else 0))
