@@ -352,6 +352,7 @@ int slr_conv_saturation_record(unsigned *host_slot, void *stream);
 #define SLR_CONV_WINO   16
 #define SLR_CONV_SKIP_B8 32    /* slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip: `skip_in` is channel-blocked */
 #define SLR_CONV_POOL_OUT 64   /* ... and `out` is avgpool3x3s2 of the result, [N,Cout,(H-1)/2+1,(W-1)/2+1] channel-blocked (needs pool_ws) */
+#define SLR_CONV_UP_OUT 128    /* ... or `out` is the x2 bilinear up-sampling of the result, [N,Cout,2H,2W] channel-blocked (needs pool_ws) */
 /* Cout <= 4 (the 128 -> 3 end of the decoders): the 3x3 entry points run a kernel of their own on EITHER rung -- fp32 FMAs on the vector
  * ALUs (csrc/conv_few.hpp; the narrowest matrix-core tile would compute 32 channels for 3), i.e. the reference's arithmetic: both
  * weight-preparation calls then write plain fp32 weights into the buffer, wscale / xscale are accepted and unused, nothing saturates. */
@@ -408,6 +409,12 @@ int slr_pconv3x3_forward(const float *x, const float *pre_scale, const float *pr
  * of every tile row and the last column of every tile column, ~16 % of the full-resolution tensor).  Same 9 terms per pooled pixel as
  * slr_avgpool3x3s2, summed rows first: equal to the two-kernel form to fp32 rounding.  pool_ws = NULL otherwise. */
 size_t slr_conv_pool_ws_bytes(int N, int Cout, int H, int W);
+/* With SLR_CONV_UP_OUT (same conditions) the "Up" block's nn.Upsample(scale_factor=2, mode='bilinear') (blocks.py:200-203) happens in the
+ * epilogue: a tile's 8 x 32 pixels give the 16 x 64 output pixels below them; all but the first / last row and column of that block come
+ * from the wave's registers and neighbouring lanes, those borders are written by a second launch from side buffers (pool_ws of
+ * slr_conv_up_ws_bytes: first and last row / column of every tile).  Expression and order of slr_upsample_bilinear2x: bit-identical to
+ * the two-kernel form.  The low-resolution result is never written; um_out stays at the convolution's resolution. */
+size_t slr_conv_up_ws_bytes(int N, int Cout, int H, int W);
 int slr_conv3x3_forward_skip(const float *in, const void *wsplit, const float *bias, float *out,
                              int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
                              const float *pre_scale, const float *pre_shift,

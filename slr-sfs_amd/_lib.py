@@ -24,7 +24,7 @@ SYMBOLS = (
     "slr_softsplat_backward", "slr_softsplat_backward_ws_bytes", "slr_softsplat_backward_ws", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_wino_weight_bytes", "slr_conv3x3_wino_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
-    "slr_conv3x3_forward_skip", "slr_pconv3x3_forward_skip", "slr_conv_pool_ws_bytes",
+    "slr_conv3x3_forward_skip", "slr_pconv3x3_forward_skip", "slr_conv_pool_ws_bytes", "slr_conv_up_ws_bytes",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_f32_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
 )
@@ -80,6 +80,8 @@ def lib():
         L.slr_conv1x1_weight_bytes.argtypes = [i, i]
         L.slr_conv_pool_ws_bytes.restype = sz
         L.slr_conv_pool_ws_bytes.argtypes = [i, i, i, i]
+        L.slr_conv_up_ws_bytes.restype = sz
+        L.slr_conv_up_ws_bytes.argtypes = [i, i, i, i]
         sig = {
             "slr_euler_integrate": [fp, i, i, i, f, fp, fp, vp],
             "slr_euler_integrate_all": [fp, i, i, i, f, fp, fp, vp],

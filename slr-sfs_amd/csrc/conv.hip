@@ -87,8 +87,10 @@ struct ConvArgs {
     float skip_unscale;    // 1 / (xscale * skip wscale)
     // POOL instantiations: `out` is the 3x3 / stride 2 / pad 1 average pool of the result ("Down" blocks, blocks.py:196-199), channel-blocked;
     // the tile's last row / last column go to these side buffers for pool_fix_kernel: [N][tiles_y][Cout/8][W][8], [N][tiles_x][Cout/8][H][8]
+    // UPS instantiations: `out` is the x2 bilinear up-sampling of the result ("Up" blocks, blocks.py:200-203); side buffers: first / last row
+    // of every tile row, first / last column of every tile column: [N][tiles_y][2][Cout/8][W][8], [N][tiles_x][2][Cout/8][H][8]
     float *pool_row, *pool_col;
-    int tiles_y;
+    int tiles_y, resample;   // resample: 0 none, 1 POOL, 2 UPS
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -116,10 +118,11 @@ constexpr int CV_FSTR = 352;                       // F32: floats per channel ro
 // SKIP: the residual block's 1x1 skip convolution rides in this kernel (see the skip phase behind the main loop): the separate 1x1 kernel,
 // the write of its result and the read of it as the residual are gone.
 // POOL (with SKIP, 128-channel workgroup rows): the "Down" block's average pool in the epilogue -- see the end of the kernel.
-template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false, bool SKIP = false, bool POOL = false>
+// UPS (likewise): the "Up" block's x2 bilinear up-sampling in the epilogue.
+template <int CPW, int WCO, bool PRE, bool INB8, bool F32 = false, bool SKIP = false, bool POOL = false, bool UPS = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
-    static_assert(!POOL || (SKIP && WCO == 4), "the pooling epilogue: a wave holds all 8 rows of its channel tile");
+    static_assert(!(POOL || UPS) || (SKIP && WCO == 4 && !(POOL && UPS)), "the resampling epilogues: a wave holds all 8 rows of its channel tile");
     static_assert(!F32 || CPW == 1, "the fp32 rung runs one 32-channel tile per wave");
     static_assert(!SKIP || (CPW == 1 && !F32 && INB8), "the skip phase: split rung, one tile per wave, channel-blocked main input");
     constexpr int XRAW = F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16, XSKIP = SKIP ? SLR_CONV_SKIP_FILL * 2 * 2 * 256 * 16 : 0;
@@ -594,6 +597,83 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         return;
     }
 
+    if constexpr (UPS) {
+        // ---- up-sampling epilogue ("Up" blocks: nn.Upsample(scale_factor=2, mode='bilinear') of the result; the low-resolution result is never
+        // written).  The tile's 8 x 32 pixels give the 16 x 64 output pixels below them; all but the first / last row and column of those
+        // need values of this tile only: rows are registers, columns neighbouring lanes.  Expression and order of slr_upsample_bilinear2x
+        // (ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11), weights 0.25 / 0.75, clamped neighbours at the image border):
+        // bit-identical to the two-kernel form.  The border rows / columns of the 16 x 64 block are written by upsample_fix_kernel from the
+        // side buffers (first / last row and column of every tile).
+        const float unscale = a.skip_unscale;
+        const int ox = x0 + bcol;
+        const bool xin = ox < a.W, rclamp = ox + 1 >= a.W;
+        const int OH = 2 * a.H, OW = 2 * a.W, C8 = a.Cout >> 3;
+        float sb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb[r] = a.skip_bias ? a.skip_bias[min(cot0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * bgrp, a.Cout - 1)] : 0.0f;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][pt][r] = acc[0][pt][r] * unscale + sb[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c8 = cot0 * 4 + q;
+            if (c8 * 8 + 4 * bgrp >= a.Cout) continue;
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int pt = slot * 7;
+                if (xin && y0 + pt < a.H) {
+                    float *rb = a.pool_row + (((((size_t)n * a.tiles_y + ty) * 2 + slot) * C8 + c8) * a.W + ox) * 8 + 4 * bgrp;
+                    *reinterpret_cast<float4 *>(rb) = make_float4(acc[0][pt][4 * q], acc[0][pt][4 * q + 1], acc[0][pt][4 * q + 2], acc[0][pt][4 * q + 3]);
+                }
+            }
+            if ((bcol == 0 || bcol == 31) && xin) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    if (y0 + pt < a.H) {
+                        float *cb = a.pool_col + (((((size_t)n * a.tiles_x + tx) * 2 + (bcol ? 1 : 0)) * C8 + c8) * a.H + y0 + pt) * 8 + 4 * bgrp;
+                        *reinterpret_cast<float4 *>(cb) = make_float4(acc[0][pt][4 * q], acc[0][pt][4 * q + 1], acc[0][pt][4 * q + 2], acc[0][pt][4 * q + 3]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int pt = 1; pt < PT; ++pt)
+            if (y0 + pt >= a.H) {                                      // (uniform) rows below the image: the clamped neighbour = the last row
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][pt][r] = acc[0][pt - 1][r];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c8 = cot0 * 4 + q;
+            float hE[PT][4], hO[PT][4];                                // the rows' horizontal interpolations at output columns 2x, 2x + 1
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[0][pt][4 * q + e];
+                    const float left = __shfl_up(v, 1, 32), rgt = __shfl_down(v, 1, 32);
+                    hE[pt][e] = 0.25f * left + 0.75f * v;
+                    hO[pt][e] = 0.75f * v + 0.25f * (rclamp ? v : rgt);
+                }
+            if (!xin || c8 * 8 + 4 * bgrp >= a.Cout) continue;
+            float *ob = a.out + (((size_t)n * C8 + c8) * OH * OW + (size_t)(2 * y0) * OW + 2 * ox) * 8 + 4 * bgrp;
+#pragma unroll
+            for (int hr = 1; hr < 2 * PT - 1; ++hr) {
+                const int ra = (hr & 1) ? hr >> 1 : (hr >> 1) - 1, rb = ra + 1;
+                const float l0 = (hr & 1) ? 0.75f : 0.25f, l1 = (hr & 1) ? 0.25f : 0.75f;
+                if (y0 + (hr >> 1) >= a.H) continue;                   // (uniform)
+                float *orow = ob + (size_t)hr * OW * 8;
+                if (bcol > 0)
+                    *reinterpret_cast<float4 *>(orow) = make_float4(l0 * hE[ra][0] + l1 * hE[rb][0], l0 * hE[ra][1] + l1 * hE[rb][1],
+                                                                    l0 * hE[ra][2] + l1 * hE[rb][2], l0 * hE[ra][3] + l1 * hE[rb][3]);
+                if (bcol < 31)
+                    *reinterpret_cast<float4 *>(orow + 8) = make_float4(l0 * hO[ra][0] + l1 * hO[rb][0], l0 * hO[ra][1] + l1 * hO[rb][1],
+                                                                        l0 * hO[ra][2] + l1 * hO[rb][2], l0 * hO[ra][3] + l1 * hO[rb][3]);
+            }
+        }
+        return;
+    }
+
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel).
     // Work-items outside the image / channels past Cout are clamped for the loads and skipped for
     // the stores; all loads of a tile are issued before its first store.
@@ -928,6 +1008,47 @@ __global__ __launch_bounds__(256) void pool_fix_kernel(float *__restrict__ out, 
     o[0] = u; o[1] = v;
 }
 
+// The border rows / columns of every 16 x 64 output block of the UPS epilogue (output rows 16t, 16t + 15, columns 64t, 64t + 63), from the side
+// buffers alone: slr_upsample_bilinear2x's expression on the first / last rows and columns of the tiles.  Lines = 2 * tiles_y output rows of
+// OW pixels, then 2 * tiles_x output columns of OH pixels (minus the pixels of the border rows).
+__global__ __launch_bounds__(256) void upsample_fix_kernel(float *__restrict__ out, const float *__restrict__ prow, const float *__restrict__ pcol,
+                                                           int C8, int H, int W, int tiles_x, int tiles_y) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int nrow = 2 * tiles_y * OW, ncol = 2 * tiles_x * OH;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nrow + ncol) return;
+    int R, C;
+    bool rowline;
+    if (idx < nrow) { const int l = idx / OW; R = (l >> 1) * 2 * CV_H + ((l & 1) ? 2 * CV_H - 1 : 0); C = idx % OW; rowline = true; }
+    else {
+        const int k = idx - nrow, l = k / OH;
+        C = (l >> 1) * 2 * CV_W + ((l & 1) ? 2 * CV_W - 1 : 0); R = k % OH; rowline = false;
+        const int rm = R % (2 * CV_H);
+        if (rm == 0 || rm == 2 * CV_H - 1) return;                  // done by its row line
+    }
+    if (R >= OH || C >= OW) return;
+    const int n = blockIdx.y / C8, c8 = blockIdx.y % C8;
+    const float sy = fmaxf((R + 0.5f) * 0.5f - 0.5f, 0.0f), sx = fmaxf((C + 0.5f) * 0.5f - 0.5f, 0.0f);
+    const int ya = (int)sy, xa = (int)sx;
+    const float ly1 = sy - (float)ya, ly0 = 1.0f - ly1, lx1 = sx - (float)xa, lx0 = 1.0f - lx1;
+    // the second row / column meets weight 0 at the image's first row / column (the two-kernel form reads row / column 1 there): same row / column
+    const int yb = ly1 == 0.0f ? ya : min(ya + 1, H - 1), xb = lx1 == 0.0f ? xa : min(xa + 1, W - 1);
+    auto get = [&](int y, int x, float (&v)[8]) {
+        const float *p;
+        if (rowline) p = prow + (((((size_t)n * tiles_y + y / CV_H) * 2 + (y % CV_H ? 1 : 0)) * C8 + c8) * W + x) * 8;
+        else p = pcol + (((((size_t)n * tiles_x + x / CV_W) * 2 + (x % CV_W ? 1 : 0)) * C8 + c8) * H + y) * 8;
+        const float4 u = reinterpret_cast<const float4 *>(p)[0], w = reinterpret_cast<const float4 *>(p)[1];
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; v[4] = w.x; v[5] = w.y; v[6] = w.z; v[7] = w.w;
+    };
+    float a00[8], a01[8], a10[8], a11[8], r[8];
+    get(ya, xa, a00); get(ya, xb, a01); get(yb, xa, a10); get(yb, xb, a11);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = ly0 * (lx0 * a00[c] + lx1 * a01[c]) + ly1 * (lx0 * a10[c] + lx1 * a11[c]);
+    float4 *o = reinterpret_cast<float4 *>(out + ((((size_t)n * C8 + c8) * OH + R) * OW + C) * 8);
+    o[0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1] = make_float4(r[4], r[5], r[6], r[7]);
+}
+
 // w [Cout,Cin,k,k] fp32 (taps = k*k = 9 or 1) -> split f16 weights in fragment order over the PADDED
 // channel counts (zero weights for the padding), scaled by wscale (a power of two)
 __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ ws,
@@ -1228,7 +1349,17 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
         if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, true, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);   \
         else hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);                   \
     } while (0)
-            if (a.pool_row) {               // (conv_set_skip: 128-channel workgroup rows)
+            if (a.resample) {               // (conv_set_skip: 128-channel workgroup rows)
+                if (a.resample == 2) {
+                    if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);
+                    else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);
+                    SLR_CHECK_LAUNCH();
+                    const int items = 2 * a.tiles_y * 2 * a.W + 2 * a.tiles_x * 2 * a.H;
+                    hipLaunchKernelGGL(upsample_fix_kernel, dim3((items + 255) / 256, a.N * (a.Cout >> 3)), dim3(256), 0, st, a.out, (const float *)a.pool_row,
+                                       (const float *)a.pool_col, a.Cout >> 3, a.H, a.W, a.tiles_x, a.tiles_y);
+                    SLR_CHECK_LAUNCH();
+                    return 0;
+                }
                 if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, false, true, true>), grid, dim3(CV_THREADS), 0, st, a);
                 else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, false, true, true>), grid, dim3(CV_THREADS), 0, st, a);
                 SLR_CHECK_LAUNCH();
@@ -1269,7 +1400,7 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
 
 static int conv_check_layout(int layout, const void *in, const void *out, int Cin, int Cout, const void *residual,
                              bool derived_mask) {
-    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO | SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT);      // (the last two: conv_set_skip)
+    layout &= ~(SLR_CONV_F32 | SLR_CONV_WINO | SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT | SLR_CONV_UP_OUT);      // (the last three: conv_set_skip)
     SLR_CHECK_ARG((layout & ~(SLR_CONV_IN_B8 | SLR_CONV_OUT_B8 | SLR_CONV_RES_B8)) == 0, "layout flags");
     SLR_CHECK_ARG(!(layout & SLR_CONV_RES_B8) || ((layout & SLR_CONV_OUT_B8) && residual && !((uintptr_t)residual & 15)),
                   "a channel-blocked residual goes with a channel-blocked output");
@@ -1290,9 +1421,9 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
 struct SkipOp { const float *in; const void *w; const float *bias; int cin; float wscale; void *pool_ws; size_t pool_ws_bytes; };
 
 // side buffers of the pooling epilogue: the last row of every tile row and the last column of every tile column of the result
-static size_t conv_pool_ws_bytes(int N, int Cout, int H, int W) {
+static size_t conv_pool_ws_bytes(int N, int Cout, int H, int W, bool up = false) {
     const size_t tiles_x = (W + CV_W - 1) / CV_W, tiles_y = (H + CV_H - 1) / CV_H;
-    return (size_t)N * Cout * (tiles_y * W + tiles_x * H) * sizeof(float);
+    return (size_t)N * Cout * (tiles_y * W + tiles_x * H) * sizeof(float) * (up ? 2 : 1);       // (up-sampling: first AND last row / column)
 }
 
 SLR_EXPORT size_t slr_conv_pool_ws_bytes(int N, int Cout, int H, int W) {
@@ -1300,9 +1431,15 @@ SLR_EXPORT size_t slr_conv_pool_ws_bytes(int N, int Cout, int H, int W) {
     return conv_pool_ws_bytes(N, Cout, H, W);
 }
 
+SLR_EXPORT size_t slr_conv_up_ws_bytes(int N, int Cout, int H, int W) {
+    if (N <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    return conv_pool_ws_bytes(N, Cout, H, W, true);
+}
+
 static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layout) {
-    const bool sb8 = (layout & SLR_CONV_SKIP_B8) != 0, pool = (layout & SLR_CONV_POOL_OUT) != 0;
-    layout &= ~(SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT);
+    const int layout_in = layout;
+    const bool sb8 = (layout & SLR_CONV_SKIP_B8) != 0, up = (layout & SLR_CONV_UP_OUT) != 0, pool = (layout & SLR_CONV_POOL_OUT) != 0 || up;
+    layout &= ~(SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT | SLR_CONV_UP_OUT);
     if (!sk) { SLR_CHECK_ARG(!sb8 && !pool, "layout flags"); return 0; }
     SLR_CHECK_ARG(sk->in && sk->w, "null pointer");
     SLR_CHECK_ARG(!(layout & (SLR_CONV_F32 | SLR_CONV_WINO)), "the fused skip branch runs on the split-f16 rung");
@@ -1314,12 +1451,15 @@ static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layou
     a.skip_cin = sk->cin; a.skip_nchunk = conv_cin_pad(sk->cin) / 16; a.skip_b8 = sb8;
     a.skip_unscale = 1.0f / (xscale * sk->wscale);
     if (pool) {
-        SLR_CHECK_ARG(a.out_b8 && conv_cout_tile(a.Cout) == 128, "the pooling epilogue needs a channel-blocked output and more than 64 output channels");
-        SLR_CHECK_ARG(sk->pool_ws && !((uintptr_t)sk->pool_ws & 15) && sk->pool_ws_bytes >= conv_pool_ws_bytes(a.N, a.Cout, a.H, a.W),
-                      "pool_ws: slr_conv_pool_ws_bytes, 16-byte aligned");
+        SLR_CHECK_ARG(!(up && (layout_in & SLR_CONV_POOL_OUT)), "SLR_CONV_POOL_OUT and SLR_CONV_UP_OUT are exclusive");
+        SLR_CHECK_ARG(a.out_b8 && conv_cout_tile(a.Cout) == 128, "the resampling epilogues need a channel-blocked output and more than 64 output channels");
+        SLR_CHECK_ARG(!up || (long long)a.N * a.Cout * a.H * a.W < (1LL << 38), "sizes");
+        SLR_CHECK_ARG(sk->pool_ws && !((uintptr_t)sk->pool_ws & 15) && sk->pool_ws_bytes >= conv_pool_ws_bytes(a.N, a.Cout, a.H, a.W, up),
+                      "pool_ws: slr_conv_pool_ws_bytes / slr_conv_up_ws_bytes, 16-byte aligned");
         a.tiles_y = (a.H + CV_H - 1) / CV_H;
+        a.resample = up ? 2 : 1;
         a.pool_row = (float *)sk->pool_ws;
-        a.pool_col = a.pool_row + (size_t)a.N * a.Cout * a.tiles_y * a.W;
+        a.pool_col = a.pool_row + (size_t)a.N * a.Cout * a.tiles_y * a.W * (up ? 2 : 1);
     }
     return 0;
 }

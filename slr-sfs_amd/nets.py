@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import _lib
 
 
-IN_B8, OUT_B8, RES_B8, CONV_F32, CONV_WINO, SKIP_B8, POOL_OUT = 1, 2, 4, 8, 16, 32, 64      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32 / _WINO / _SKIP_B8 / _POOL_OUT
+IN_B8, OUT_B8, RES_B8, CONV_F32, CONV_WINO, SKIP_B8, POOL_OUT, UP_OUT = 1, 2, 4, 8, 16, 32, 64, 128      # include/slr_splat.h: SLR_CONV_IN_B8 / _OUT_B8 / _RES_B8 / SLR_CONV_F32 / _WINO / _SKIP_B8 / _POOL_OUT / _UP_OUT
 
 
 class _Route(threading.local):
@@ -153,6 +153,10 @@ def _pool_out(N, cout, H, W, like, pool):
     avgpool3x3s2 result and the kernel needs side buffers (include/slr_splat.h: SLR_CONV_POOL_OUT)."""
     if not pool:
         return torch.empty(N, cout, H, W, device=like.device, dtype=like.dtype), None, 0, 0
+    if pool == "Up":                                  # x2 bilinear up-sampling in the epilogue (SLR_CONV_UP_OUT)
+        nbytes = _lib.lib().slr_conv_up_ws_bytes(N, cout, H, W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+        return torch.empty(N, cout, 2 * H, 2 * W, device=like.device, dtype=like.dtype), ws, nbytes, UP_OUT
     nbytes = _lib.lib().slr_conv_pool_ws_bytes(N, cout, H, W)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
     return torch.empty(N, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=like.device, dtype=like.dtype), ws, nbytes, POOL_OUT
@@ -484,7 +488,7 @@ class ResBlock(nn.Module):
         self.conv_aa, self.conv_ab = Conv(cin, cout, 3), Conv(cout, cout, 3)
         self.conv_b = Conv(cin, cout, 1) if (resample or cin != cout) else None
         self.resample = _resample(resample)
-        self.pools = bool(resample) and resample != "Up"
+        self.pools = "Up" if resample == "Up" else bool(resample)        # the resampling the fused second convolution can take into its epilogue
 
     def forward(self, x, b8_in=False):
         """-> (y, b8_out): ``b8_in`` / ``b8_out`` = x / y are channel-blocked in memory (see _b8)."""
@@ -493,7 +497,7 @@ class ResBlock(nn.Module):
         lin = IN_B8 if b8_in else 0
         a = self.conv_aa(x, self.bn1.scale_shift(), layout=lin | (OUT_B8 if b8 else 0))   # BN + ReLU ride in the prologue
         if self.conv_b is not None and _skip_rides(a, cout, b8, b8_in):                        # x_a + conv_b(x) (:83-87) in one kernel
-            pool = self.pools and cout > 64 and _S.fused_pools
+            pool = self.pools if (cout > 64 and _S.fused_pools) else False
             a = self.conv_ab.forward_skip(a, self.bn2.scale_shift(), x, self.conv_b, layout=IN_B8 | OUT_B8, skip_b8=b8_in, pool=pool)
             return (a if pool else self.resample(a, b8)), b8
         if self.conv_b is not None:
@@ -516,7 +520,7 @@ class PconvResBlock(nn.Module):
         self.conv_b = Conv(cin, cout, 1, bias=False) if (resample or cin != cout) else None   # :192-193
         self.resample, self.resample_mask = _resample(resample), _resample_mask(resample)
         self.has_resample = bool(resample)
-        self.pools = bool(resample) and resample != "Up"
+        self.pools = "Up" if resample == "Up" else bool(resample)        # the resampling the fused second convolution can take into its epilogue
 
     def forward(self, x, mask, b8_in=False):
         """-> (y, update_mask, b8_out).  mask: None = (x != 0) per channel (architectures.py:369; x is NCHW then), else
@@ -530,7 +534,7 @@ class PconvResBlock(nn.Module):
         # and bilinear up-sampling are linear, so resample(x_a + x_b) is the same result up to fp32
         # rounding, lets the residual join the epilogue, and halves the resampling work.
         if self.conv_b is not None and _skip_rides(a, cout, b8, b8_in):                # :237-248 in one kernel
-            pool = self.pools and cout > 64 and _S.fused_pools
+            pool = self.pools if (cout > 64 and _S.fused_pools) else False
             a, m = self.conv_ab.forward_skip(a, m, x, self.conv_b, layout=IN_B8 | OUT_B8, skip_b8=b8_in, pool=pool)
             return (a if pool else self.resample(a, b8)), self.resample_mask(m), b8
         if self.conv_b is not None:                                                # :243-247

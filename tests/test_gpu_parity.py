@@ -1987,7 +1987,8 @@ def test_channel_blocked_resample_and_skip_kernels(S):
 @pytest.mark.parametrize("cin,cout,h,w,resample", [(64, 128, 16, 64, "Down"), (128, 256, 9, 33, "Down"), (256, 128, 11, 40, "Up"),
                                                    (128, 128, 8, 32, "Up"), (3, 32, 13, 70, None), (24, 72, 21, 37, None),
                                                    (40, 64, 5, 96, None), (64, 128, 21, 70, "Down"), (72, 136, 17, 33, "Down"),
-                                                   (32, 72, 40, 100, "Down"), (16, 64, 12, 40, "Down")])
+                                                   (32, 72, 40, 100, "Down"), (16, 64, 12, 40, "Down"), (128, 128, 13, 45, "Up"),
+                                                   (72, 136, 17, 33, "Up"), (256, 128, 9, 70, "Up"), (64, 72, 1, 5, "Up"), (64, 72, 3, 1, "Down")])
 def test_skip_branch_inside_the_second_convolution(S, kind, cin, cout, h, w, resample):
     """slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip (ABI 10): a residual block's 1x1 skip convolution as extra
     K chunks of its second 3x3 kernel (models/layers/blocks.py:83-87, :237-248) against the two-kernel form (staged_skips(): 1x1 kernel ->
@@ -1995,7 +1996,8 @@ def test_skip_branch_inside_the_second_convolution(S, kind, cin, cout, h, w, res
     3x3 value one chunk at a time instead of as one sum), so the two agree to fp32 rounding: <= 2e-6 of the output scale (the split-f16
     arithmetic itself is 2-5e-6 against fp64, test_conv3x3_matrix_core_kernel).  Update masks are bit-identical.  "Down" blocks with
     more than 64 output channels also pool in that kernel's epilogue (SLR_CONV_POOL_OUT: interior pooled pixels in registers, tile-border
-    ones completed by pool_fix_kernel) -- against the pool kernel on the fused convolution's output: <= 1e-6.  Down / Up blocks,
+    ones completed by pool_fix_kernel) -- against the pool kernel on the fused convolution's output: <= 1e-6; "Up" blocks up-sample there
+    (SLR_CONV_UP_OUT, borders by upsample_fix_kernel): bit-identical to the up-sampling kernel on the fused convolution's output.  Down / Up blocks,
     a 3-channel NCHW skip input (the encoders' first block), ragged sizes, padded channel counts; and against an fp64 definition."""
     import torch.nn.functional as F
     from slr_sfs_amd import nets
@@ -2040,32 +2042,37 @@ def test_skip_branch_inside_the_second_convolution(S, kind, cin, cout, h, w, res
             assert b8
             return from_b8(y), m
 
-        pool_entry, pool_calls = L.slr_avgpool3x3s2, []
+        rname = {"Down": "slr_avgpool3x3s2", "Up": "slr_upsample_bilinear2x"}.get(resample, "slr_avgpool3x3s2")
+        pool_entry, pool_calls = getattr(L, rname), []
 
         def counted_pool(*a):
             pool_calls.append(1)
             return pool_entry(*a)
 
         setattr(L, name, counted)
-        L.slr_avgpool3x3s2 = counted_pool
+        setattr(L, rname, counted_pool)
         try:
             y1, m1 = run()
             fused = 1 if b8_in else 0                  # (an NCHW block input keeps the two-kernel form)
             assert len(calls) == fused, "the fused entry point was not called"
-            # "Down" blocks with more than 64 output channels: the average pool happened in that kernel's epilogue (SLR_CONV_POOL_OUT)
-            assert len(pool_calls) == (1 if resample == "Down" and not (fused and cout > 64) else 0)
-            if resample == "Down" and fused and cout > 64:
-                with nets.staged_skips(pools_only=True):               # fused skip, pool kernel
+            # resampling blocks with more than 64 output channels: the average pool / the up-sampling happened in that kernel's epilogue
+            res_fused = bool(resample) and fused and cout > 64
+            assert len(pool_calls) == (1 if resample and not res_fused else 0)
+            if res_fused:
+                with nets.staged_skips(pools_only=True):               # fused skip, resampling kernel
                     y2, _ = run()
                 assert len(calls) == 2 and len(pool_calls) == 1
-                assert (y1 - y2).abs().max().item() <= 1e-6 * max(y2.abs().max().item(), 1.0)
+                if resample == "Up":
+                    assert torch.equal(y1, y2), (y1 - y2).abs().max().item()
+                else:
+                    assert (y1 - y2).abs().max().item() <= 1e-6 * max(y2.abs().max().item(), 1.0)
             calls.clear()
             with nets.staged_skips():
                 y0, m0 = run()
             assert len(calls) == 0
         finally:
             setattr(L, name, entry)
-            L.slr_avgpool3x3s2 = pool_entry
+            setattr(L, rname, pool_entry)
         if m1 is not None:
             assert torch.equal(m1, m0)
         scale = y0.abs().max().item()
