@@ -426,6 +426,21 @@ int slr_pconv3x3_forward_skip(const float *x, const float *pre_scale, const floa
                               const float *skip_in, const void *skip_wsplit, int skip_cin, float skip_wscale,
                               void *pool_ws, size_t pool_ws_bytes, int layout, void *stream);
 
+/* Cout <= 4 (the 128 -> 3 end of the decoders), channel-blocked input: the first convolution of the block as slr_conv3x3_forward /
+ * slr_pconv3x3_forward, and next to it skip_out [N,Cout,H,W] = conv1x1(in) + skip_bias -- the block's skip branch on the SAME (raw) input
+ * (blocks.py:192-193, 243-247), which the caller hands to the block's second convolution as its residual.  The 128 input planes are read
+ * from HBM once instead of twice.  skip_w4: plain fp32 weights [Cin][4] (row ci = w[0..3][ci], zero padded), 16-byte aligned.  Either rung
+ * (the <= 4-channel kernel is fp32 FMAs on both).  Bit-identical to slr_conv1x1_small on the same input. */
+int slr_conv3x3_forward_skipout(const float *in, const void *wsplit, const float *bias, const float *residual, float *out,
+                                int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
+                                const float *pre_scale, const float *pre_shift,
+                                const float *skip_w4, const float *skip_bias /* [Cout] or NULL */, float *skip_out, int layout, void *stream);
+int slr_pconv3x3_forward_skipout(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                                 const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
+                                 const float *next_scale, const float *next_shift, float *out, float *um_out,
+                                 int N, int Cin, int Cout, int H, int W,
+                                 const float *skip_w4, float *skip_out, int layout, void *stream);
+
 /* 1x1 convolution (skip branch of the residual blocks, models/layers/blocks.py:192-193,243-247) on the same
  * split-f16 arithmetic: out = conv1x1(in) + bias.  HBM-bound, no LDS.  Weights prepared once per layer with
  * slr_conv1x1_split_weights into slr_conv1x1_weight_bytes(Cout, Cin) bytes; wscale as for the 3x3 kernel. */

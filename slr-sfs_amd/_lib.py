@@ -24,7 +24,7 @@ SYMBOLS = (
     "slr_softsplat_backward", "slr_softsplat_backward_ws_bytes", "slr_softsplat_backward_ws", "slr_maxsplat_forward", "slr_max_warp_norm",
     "slr_bn_relu_mask", "slr_pconv_epilogue", "slr_conv_saturation_count", "slr_conv_saturation_record",
     "slr_conv3x3_weight_bytes", "slr_conv3x3_split_weights", "slr_conv3x3_f32_weights", "slr_conv3x3_wino_weight_bytes", "slr_conv3x3_wino_weights", "slr_conv3x3_forward", "slr_pconv3x3_forward",
-    "slr_conv3x3_forward_skip", "slr_pconv3x3_forward_skip", "slr_conv_pool_ws_bytes", "slr_conv_up_ws_bytes",
+    "slr_conv3x3_forward_skip", "slr_pconv3x3_forward_skip", "slr_conv_pool_ws_bytes", "slr_conv_up_ws_bytes", "slr_conv3x3_forward_skipout", "slr_pconv3x3_forward_skipout",
     "slr_conv1x1_weight_bytes", "slr_conv1x1_split_weights", "slr_conv1x1_f32_weights", "slr_conv1x1_forward",
     "slr_avgpool3x3s2", "slr_upsample_bilinear2x", "slr_conv1x1_small",
 )
@@ -120,6 +120,8 @@ def lib():
             "slr_pconv3x3_forward": [fp, fp, fp, fp, vp, f, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp],
             "slr_conv3x3_forward_skip": [fp, vp, fp, fp, i, i, i, i, i, f, f, fp, fp, fp, vp, fp, i, f, vp, sz, i, vp],
             "slr_pconv3x3_forward_skip": [fp, fp, fp, fp, vp, f, f, fp, fp, fp, i, i, i, i, i, fp, vp, i, f, vp, sz, i, vp],
+            "slr_conv3x3_forward_skipout": [fp, vp, fp, fp, fp, i, i, i, i, i, f, f, fp, fp, fp, fp, fp, i, vp],
+            "slr_pconv3x3_forward_skipout": [fp, fp, fp, fp, vp, f, f, fp, fp, fp, fp, fp, fp, i, i, i, i, i, fp, fp, i, vp],
             "slr_avgpool3x3s2": [fp, fp, i, i, i, i, i, vp],
             "slr_upsample_bilinear2x": [fp, fp, i, i, i, i, i, vp],
             "slr_conv1x1_small": [fp, fp, fp, fp, i, i, i, i, i, i, vp],

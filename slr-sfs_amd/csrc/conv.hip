@@ -91,6 +91,7 @@ struct ConvArgs {
     // of every tile row, first / last column of every tile column: [N][tiles_y][2][Cout/8][W][8], [N][tiles_x][2][Cout/8][H][8]
     float *pool_row, *pool_col;
     int tiles_y, resample;   // resample: 0 none, 1 POOL, 2 UPS
+    float *skip_out;       // conv3x3_few_kernel<.., SKP>: [N,Cout,H,W] = conv1x1(in) + skip_bias with skip_w = plain fp32 [Cin][4] weights
 };
 
 // padded channel counts of the weight buffer (shared by the split and the forward entry points)
@@ -1158,6 +1159,12 @@ static int conv_few_weights(const float *w, void *wbuf, int Cout, int Cin, hipSt
 template <int NCO>
 static int conv_few_launch(ConvArgs &a, bool in_b8, hipStream_t st) {
     const dim3 grid(((a.W + CF_BW - 1) / CF_BW) * ((a.H + CF_BH - 1) / CF_BH), 1, a.N);
+    if (a.skip_out) {                                   // (the *_skipout entry points: channel-blocked input)
+        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, true, true, true>), grid, dim3(CF_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_few_kernel<NCO, false, true, true>), grid, dim3(CF_THREADS), 0, st, a);
+        SLR_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.pre != PRE_NONE && in_b8) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, true, true>), grid, dim3(CF_THREADS), 0, st, a);
     else if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, true, false>), grid, dim3(CF_THREADS), 0, st, a);
     else if (in_b8) hipLaunchKernelGGL((conv3x3_few_kernel<NCO, false, true>), grid, dim3(CF_THREADS), 0, st, a);
@@ -1418,7 +1425,8 @@ static int conv_check_dims(int N, int Cin, int Cout, int H, int W) {
 }
 
 // The 1x1 skip branch riding in the 3x3 kernel (slr_conv3x3_forward_skip / slr_pconv3x3_forward_skip)
-struct SkipOp { const float *in; const void *w; const float *bias; int cin; float wscale; void *pool_ws; size_t pool_ws_bytes; };
+struct SkipOp { const float *in; const void *w; const float *bias; int cin; float wscale; void *pool_ws; size_t pool_ws_bytes;
+                float *skip_out; };        // skip_out: the *_skipout form (Cout <= 4: the skip of the SAME input written next to the result; w = [Cin][4] fp32)
 
 // side buffers of the pooling epilogue: the last row of every tile row and the last column of every tile column of the result
 static size_t conv_pool_ws_bytes(int N, int Cout, int H, int W, bool up = false) {
@@ -1441,6 +1449,14 @@ static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layou
     const bool sb8 = (layout & SLR_CONV_SKIP_B8) != 0, up = (layout & SLR_CONV_UP_OUT) != 0, pool = (layout & SLR_CONV_POOL_OUT) != 0 || up;
     layout &= ~(SLR_CONV_SKIP_B8 | SLR_CONV_POOL_OUT | SLR_CONV_UP_OUT);
     if (!sk) { SLR_CHECK_ARG(!sb8 && !pool, "layout flags"); return 0; }
+    if (sk->skip_out) {
+        SLR_CHECK_ARG(!sb8 && !pool, "layout flags");
+        SLR_CHECK_ARG(sk->w && a.Cout <= CF_MAXCO && (layout & SLR_CONV_IN_B8) && !((uintptr_t)sk->w & 15),
+                      "the skip output needs Cout <= 4, a channel-blocked input and 16-byte aligned [Cin][4] weights");
+        SLR_CHECK_ARG(a.pre != PRE_BN_NONZERO, "the skip output goes with an explicit mask");
+        a.skip_w = (const h8 *)sk->w; a.skip_bias = sk->bias; a.skip_out = sk->skip_out;
+        return 0;
+    }
     SLR_CHECK_ARG(sk->in && sk->w, "null pointer");
     SLR_CHECK_ARG(!(layout & (SLR_CONV_F32 | SLR_CONV_WINO)), "the fused skip branch runs on the split-f16 rung");
     SLR_CHECK_ARG((layout & SLR_CONV_IN_B8) && a.Cout > CF_MAXCO, "the fused skip branch needs a channel-blocked main input and more than 4 output channels");
@@ -1495,8 +1511,17 @@ SLR_EXPORT int slr_conv3x3_forward_skip(const float *in, const void *wsplit, con
                                         const float *pre_scale, const float *pre_shift,
                                         const float *skip_in, const void *skip_wsplit, const float *skip_bias, int skip_cin, float skip_wscale,
                                         void *pool_ws, size_t pool_ws_bytes, int layout, void *stream) {
-    const SkipOp sk = {skip_in, skip_wsplit, skip_bias, skip_cin, skip_wscale, pool_ws, pool_ws_bytes};
+    const SkipOp sk = {skip_in, skip_wsplit, skip_bias, skip_cin, skip_wscale, pool_ws, pool_ws_bytes, nullptr};
     return conv3x3_forward_impl(in, wsplit, bias, nullptr, out, N, Cin, Cout, H, W, wscale, xscale, pre_scale, pre_shift, &sk, layout, stream);
+}
+
+SLR_EXPORT int slr_conv3x3_forward_skipout(const float *in, const void *wsplit, const float *bias, const float *residual, float *out,
+                                           int N, int Cin, int Cout, int H, int W, float wscale, float xscale,
+                                           const float *pre_scale, const float *pre_shift,
+                                           const float *skip_w4, const float *skip_bias, float *skip_out, int layout, void *stream) {
+    SLR_CHECK_ARG(skip_w4 && skip_out, "null pointer");
+    const SkipOp sk = {nullptr, skip_w4, skip_bias, 0, 1.0f, nullptr, 0, skip_out};
+    return conv3x3_forward_impl(in, wsplit, bias, residual, out, N, Cin, Cout, H, W, wscale, xscale, pre_scale, pre_shift, &sk, layout, stream);
 }
 
 static int pconv3x3_forward_impl(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
@@ -1539,7 +1564,18 @@ SLR_EXPORT int slr_pconv3x3_forward_skip(const float *x, const float *pre_scale,
                                          int N, int Cin, int Cout, int H, int W,
                                          const float *skip_in, const void *skip_wsplit, int skip_cin, float skip_wscale,
                                          void *pool_ws, size_t pool_ws_bytes, int layout, void *stream) {
-    const SkipOp sk = {skip_in, skip_wsplit, nullptr, skip_cin, skip_wscale, pool_ws, pool_ws_bytes};
+    const SkipOp sk = {skip_in, skip_wsplit, nullptr, skip_cin, skip_wscale, pool_ws, pool_ws_bytes, nullptr};
     return pconv3x3_forward_impl(x, pre_scale, pre_shift, mask, wsplit, wscale, xscale, bias, nullptr, nullptr, nullptr, out, um_out,
+                                 N, Cin, Cout, H, W, &sk, layout, stream);
+}
+
+SLR_EXPORT int slr_pconv3x3_forward_skipout(const float *x, const float *pre_scale, const float *pre_shift, const float *mask,
+                                            const void *wsplit, float wscale, float xscale, const float *bias, const float *residual,
+                                            const float *next_scale, const float *next_shift, float *out, float *um_out,
+                                            int N, int Cin, int Cout, int H, int W,
+                                            const float *skip_w4, float *skip_out, int layout, void *stream) {
+    SLR_CHECK_ARG(skip_w4 && skip_out, "null pointer");
+    const SkipOp sk = {nullptr, skip_w4, nullptr, 0, 1.0f, nullptr, 0, skip_out};
+    return pconv3x3_forward_impl(x, pre_scale, pre_shift, mask, wsplit, wscale, xscale, bias, residual, next_scale, next_shift, out, um_out,
                                  N, Cin, Cout, H, W, &sk, layout, stream);
 }

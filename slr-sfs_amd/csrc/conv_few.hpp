@@ -36,10 +36,18 @@ __global__ __launch_bounds__(256) void conv_few_weights_kernel(const float *__re
 }
 
 // NCO: output channels computed (>= Cout)
-template <int NCO, bool PRE, bool INB8>
-__global__ __launch_bounds__(CF_THREADS, 2) void conv3x3_few_kernel(ConvArgs a) {
+// SKP: the block's 1x1 skip convolution of the SAME input (blocks.py:192-193, 243-247: conv_b(x) next to conv_aa(relu(bn(x)))) is computed
+// alongside and written to a.skip_out [N,Cout,H,W]: the input is read once instead of twice (the skip kernel's 128 planes were 1.6 % of a
+// frame).  The staged block holds the ACTIVATED input; the raw values pass through the registers of the STAGING work-item, so that one sums
+// the skip of its (up to 5) halo pixels, chunk by chunk, and writes those that lie inside the block at the end: no second read, no LDS.
+// (First form: every work-item read the raw values of its own 4 output pixels again, L2 hits, one chunk ahead -- the kernel is bound by its
+// loads and took exactly the time of the skip kernel it replaced longer: 635 -> 970 us per call of 4 frames.)  Bias first, then fused
+// multiply-adds in ascending channel order -- bit-identical to slr_conv1x1_small.
+template <int NCO, bool PRE, bool INB8, bool SKP = false>
+__global__ __launch_bounds__(CF_THREADS, SKP && NCO < 4 ? 3 : 2) void conv3x3_few_kernel(ConvArgs a) {      // (the plain kernel takes 121 registers: 3 workgroups per CU by its 53 KB of LDS; SKP must stay within 170 for the same -- 4 output channels do not)
+    static_assert(!SKP || INB8, "the skip output reads a channel-blocked input");
     __shared__ __attribute__((aligned(16))) float xs[8][CF_HH][CF_STR];
-    __shared__ float4 wl[72];                            // the chunk's weights: [8 ci][9 taps] x 4 output channels
+    __shared__ float4 wl[72 + (SKP ? 16 : 0)];           // the chunk's weights: [8 ci][9 taps] x 4 output channels (+ SKP: [2 buffers][8 ci] x 4 of the skip)
     __shared__ float mpl[CF_NPX];                        // mask plane over the halo block (0 outside the image)
     __shared__ __attribute__((aligned(16))) float pss[PRE ? 2 * CV_MAXCIN : 4];       // prologue scale / shift per input channel
     const int tid = threadIdx.x;
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void conv3x3_few_kernel(ConvArgs a) 
     const float *inb = a.in + (size_t)n * a.Cin * HW;
     const float *wf = reinterpret_cast<const float *>(a.w);
     const int pre = a.pre;
-    const bool nonzero_mask = pre == PRE_BN_NONZERO;
+    const bool nonzero_mask = !SKP && pre == PRE_BN_NONZERO;       // (SKP: explicit masks only -- the entry points check; frees the count registers)
 
     if (PRE) {
         for (int i = tid; i < nch * 8; i += CF_THREADS) {           // padded channels: scale = shift = 0 -> 0
@@ -82,8 +90,17 @@ __global__ __launch_bounds__(CF_THREADS, 2) void conv3x3_few_kernel(ConvArgs a) 
     const int c8max = (a.Cin >> 3) - 1;                   // INB8: last 8-channel group
     float st[CF_ITEMS][8];
     float4 wreg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int row = tid >> 4, xq = (tid & 15) * 4;        // this work-item's output pixels: (y0 + row, x0 + xq .. + 3)
+    float sacc[CF_ITEMS][NCO];                           // SKP: skip sums of this work-item's staging pixels
+    if (SKP) {
+#pragma unroll
+        for (int i = 0; i < CF_ITEMS; ++i)
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) sacc[i][co] = (a.skip_bias && co < a.Cout) ? a.skip_bias[co] : 0.0f;
+    }
     auto load_chunk = [&](int c) {
         if (tid < 72) wreg = reinterpret_cast<const float4 *>(wf)[c * 72 + tid];
+        if (SKP && tid >= 72 && tid < 80) wreg = reinterpret_cast<const float4 *>(a.skip_w)[min(c + 1, nch - 1) * 8 + tid - 72];   // (one chunk ahead: read before the barrier)
 #pragma unroll
         for (int i = 0; i < CF_ITEMS; ++i) {
             if (INB8) {
@@ -100,6 +117,19 @@ __global__ __launch_bounds__(CF_THREADS, 2) void conv3x3_few_kernel(ConvArgs a) 
     // prologue (normalization.py:231, ReLU, partialconv2d.py:69) + LDS store; the same expression as conv3x3_split_kernel's stage_value
     auto store_chunk = [&](int c) {
         if (tid < 72) wl[tid] = wreg;
+        if (SKP) {
+            // the skip's 8 channels of this chunk on the raw values in the staging registers; its weights were written a chunk ago
+            if (tid >= 72 && tid < 80) wl[72 + ((c + 1) & 1) * 8 + tid - 72] = wreg;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 w4 = wl[72 + (c & 1) * 8 + j];
+                const float wt[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int i = 0; i < CF_ITEMS; ++i)
+#pragma unroll
+                    for (int co = 0; co < NCO; ++co) sacc[i][co] = __builtin_fmaf(wt[co], st[i][j], sacc[i][co]);
+            }
+        }
         float sc[8], sh[8];                                // the chunk's scale / shift: four 16-byte broadcast reads, not two reads per value
         if (PRE) {
             const float4 s0 = *reinterpret_cast<const float4 *>(&pss[c * 8]), s1 = *reinterpret_cast<const float4 *>(&pss[c * 8 + 4]);
@@ -127,13 +157,13 @@ __global__ __launch_bounds__(CF_THREADS, 2) void conv3x3_few_kernel(ConvArgs a) 
         }
     };
 
-    const int row = tid >> 4, xq = (tid & 15) * 4;        // this work-item's output pixels: (y0 + row, x0 + xq .. + 3)
     float acc[NCO][4];
 #pragma unroll
     for (int co = 0; co < NCO; ++co)
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[co][p] = 0.0f;
 
+    if (SKP && tid >= 72 && tid < 80) wl[72 + tid - 72] = reinterpret_cast<const float4 *>(a.skip_w)[tid - 72];      // chunk 0's (visible behind the first barrier)
     load_chunk(0);
     for (int c = 0; c < nch; ++c) {
         __syncthreads();                                   // the previous chunk has been read (first round: pss / mpl written)
@@ -226,6 +256,18 @@ __global__ __launch_bounds__(CF_THREADS, 2) void conv3x3_few_kernel(ConvArgs a) 
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 if (rowok && ox0 + p < a.W) a.out[base + p] = o[p];
+    }
+    if (SKP) {                                             // the staging pixels inside the block (not its halo) and inside the image
+#pragma unroll
+        for (int i = 0; i < CF_ITEMS; ++i) {
+            const int p = tid + i * CF_THREADS;
+            const int pr = p / CF_HW, pc = p - pr * CF_HW;
+            const bool inside = p < CF_NPX && pr >= 1 && pr <= CF_BH && pc >= 1 && pc <= CF_BW && y0 - 1 + pr < a.H && x0 - 1 + pc < a.W;
+            if (!inside) continue;
+#pragma unroll
+            for (int co = 0; co < NCO; ++co)
+                if (co < a.Cout) a.skip_out[((size_t)n * a.Cout + co) * HW + off[i]] = sacc[i][co];
+        }
     }
 }
 

@@ -281,6 +281,33 @@ class Conv(nn.Module):
     def forward(self, x, pre_bn=None, residual=None, layout=0):
         return self.conv(x, self.bias, pre_bn, residual, layout)
 
+    def _w4(self):
+        """This 1x1 convolution's weights as plain fp32 [Cin][4] (row ci = w[0..3][ci], zero padded): the skip operand of the <= 4-channel
+        3x3 kernel (slr_*_forward_skipout); prepared once per device / weight version."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        c = self.__dict__.get("_w4c")
+        if c is None or c[0] != key:
+            w4 = torch.zeros(w.shape[1], 4, device=w.device, dtype=torch.float32)
+            w4[:, :w.shape[0]] = w.view(w.shape[0], w.shape[1]).t()
+            c = self.__dict__["_w4c"] = (key, w4.contiguous())
+        return c[1]
+
+    def forward_skipout(self, x, pre_bn, skip_conv, layout=0):
+        """(conv(relu(bn(x))) + bias, skip_conv(x)) from ONE pass over x: Cout <= 4, channel-blocked x (slr_conv3x3_forward_skipout)."""
+        assert self.k == 3 and skip_conv.k == 1 and _fused_ok(x)
+        cout, cin = self.weight.shape[:2]
+        N, _, H, W = x.shape
+        buf, wscale, xscale, arith = self._split_weights()
+        out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+        skip = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+        sc, sh = pre_bn if pre_bn is not None else (None, None)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().slr_conv3x3_forward_skipout(
+                _lib.ptr(x), _lib.ptr(buf), _lib.ptr(self.bias), None, _lib.ptr(out), N, cin, cout, H, W, wscale, xscale, _lib.ptr(sc), _lib.ptr(sh),
+                _lib.ptr(skip_conv._w4()), _lib.ptr(skip_conv.bias), _lib.ptr(skip), layout | arith, _lib.stream_of(x)), "slr_conv3x3_forward_skipout")
+        return out, skip
+
     def forward_skip(self, x, pre_bn, skip_x, skip_conv, layout=0, skip_b8=False, pool=False):
         """conv(relu(bn(x))) + bias + skip_conv(skip_x) in ONE kernel (slr_conv3x3_forward_skip; blocks.py:83-87); ``pool``: and the
         "Down" block's average pool (:196-199) in its epilogue."""
@@ -392,6 +419,26 @@ class PartialConv(Conv):
     (slr_pconv3x3_forward, which also forms the box sum and the per-element mask from the staged
     input); on the CPU the torch composition that defines it."""
 
+    def forward_skipout(self, x, mask, skip_conv, next_bn, pre_bn, layout=0):
+        """The block's first partial convolution and, from the same pass over x, the block's 1x1 skip convolution of the raw x: Cout <= 4,
+        channel-blocked x (slr_pconv3x3_forward_skipout; blocks.py:229-236, 243-247).  Returns (out, update_mask, skip)."""
+        assert self.k == 3 and skip_conv.k == 1 and skip_conv.bias is None and _fused_ok(x, *([] if mask is None else [mask]))
+        cin = x.shape[1]
+        N, _, H, W = x.shape
+        cout = self.weight.shape[0]
+        buf, wscale, xscale, arith = self._split_weights()
+        out = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+        skip = torch.empty(N, cout, H, W, device=x.device, dtype=x.dtype)
+        um = torch.empty(N, 1, H, W, device=x.device, dtype=x.dtype)
+        psc, psh = pre_bn if pre_bn is not None else (None, None)
+        nsc, nsh = next_bn if next_bn is not None else (None, None)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().slr_pconv3x3_forward_skipout(
+                _lib.ptr(x), _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(mask), _lib.ptr(buf), wscale, xscale, _lib.ptr(self.bias), None,
+                _lib.ptr(nsc), _lib.ptr(nsh), _lib.ptr(out), _lib.ptr(um), N, cin, cout, H, W,
+                _lib.ptr(skip_conv._w4()), _lib.ptr(skip), layout | arith, _lib.stream_of(x)), "slr_pconv3x3_forward_skipout")
+        return out, um, skip
+
     def forward_skip(self, x, mask, skip_x, skip_conv, layout=0, skip_b8=False, pool=False):
         """The block's second partial convolution with the 1x1 skip branch inside (slr_pconv3x3_forward_skip; blocks.py:237-248):
         ``x`` is the activated, masked output of the first one.  Returns (out, update_mask)."""
@@ -495,6 +542,11 @@ class ResBlock(nn.Module):
         cout = self.conv_aa.weight.shape[0]
         b8 = _b8(x, cout)                                   # layout of everything this block produces
         lin = IN_B8 if b8_in else 0
+        if self.conv_b is not None and cout <= 4 and b8_in and _S.fused_skips and x.is_cuda and not _S.torch_convs:
+            # the narrow end (128 -> 3): conv_aa and the skip conv_b(x) from one pass over x
+            a, b = self.conv_aa.forward_skipout(x, self.bn1.scale_shift(), self.conv_b, layout=lin)
+            a = self.conv_ab(a, self.bn2.scale_shift(), residual=b)
+            return self.resample(a, b8), b8
         a = self.conv_aa(x, self.bn1.scale_shift(), layout=lin | (OUT_B8 if b8 else 0))   # BN + ReLU ride in the prologue
         if self.conv_b is not None and _skip_rides(a, cout, b8, b8_in):                        # x_a + conv_b(x) (:83-87) in one kernel
             pool = self.pools if (cout > 64 and _S.fused_pools) else False
@@ -528,6 +580,11 @@ class PconvResBlock(nn.Module):
         cout = self.conv_aa.weight.shape[0]
         b8 = _b8(x, cout)
         lin = IN_B8 if b8_in else 0
+        if self.conv_b is not None and cout <= 4 and b8_in and mask is not None and _S.fused_skips and x.is_cuda and not _S.torch_convs:
+            # the narrow end (128 -> 3): conv_aa and the skip conv_b(x) from one pass over x
+            a, m, skip = self.conv_aa.forward_skipout(x, mask, self.conv_b, self.bn2.scale_shift(), self.bn1.scale_shift(), layout=lin)
+            a, m = self.conv_ab(a, m, residual=skip)
+            return self.resample(a, b8), self.resample_mask(m), b8
         a, m = self.conv_aa(x, mask, next_bn=self.bn2.scale_shift(), pre_bn=self.bn1.scale_shift(),
                             layout=lin | (OUT_B8 if b8 else 0))                      # :229-236
         # x_a + x_b (:248).  The reference resamples the two branches separately and adds; avg-pool

@@ -2107,6 +2107,56 @@ def test_skip_branch_inside_the_second_convolution(S, kind, cin, cout, h, w, res
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pconv", "plain"])
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 21, 70), (64, 3, 16, 64), (24, 2, 9, 33), (8, 4, 40, 131), (16, 1, 1, 3)])
+def test_narrow_end_skip_from_the_same_pass(S, kind, cin, cout, h, w):
+    """slr_conv3x3_forward_skipout / slr_pconv3x3_forward_skipout (ABI 10): the decoders' 128 -> 3 end -- the block's first convolution and the
+    block's 1x1 skip convolution of the same input from ONE pass over it (models/layers/blocks.py:192-193, 229-248).  Against the
+    two-kernel form (staged_skips(): slr_conv1x1_small): bit-identical block output and update mask."""
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin + 3 * w)
+    n = 2
+    with torch.no_grad():
+        blk = (nets.PconvResBlock if kind == "pconv" else nets.ResBlock)(cin, cout).cuda()
+        for m in blk.modules():
+            if isinstance(m, nets.AffineBN):
+                m.stored_mean.normal_(0, 0.3); m.stored_var.uniform_(0.5, 1.5)
+            if isinstance(m, nets.Conv) and m.bias is not None:
+                m.bias.normal_()
+        x = torch.randn(n, cin, h, w, device="cuda")
+        xin = x.view(n, cin // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous().view(n, cin, h, w)
+        mask = (torch.rand(n, 1, h, w, device="cuda") > 0.3).float()
+        L = nets._lib.lib()
+        name = "slr_pconv3x3_forward_skipout" if kind == "pconv" else "slr_conv3x3_forward_skipout"
+        entry, calls = getattr(L, name), []
+
+        def counted(*a):
+            calls.append(1)
+            return entry(*a)
+
+        def run():
+            if kind == "pconv":
+                y, m, b8 = blk(xin, mask, True)
+            else:
+                (y, b8), m = blk(xin, True), None
+            assert not b8
+            return y, m
+
+        setattr(L, name, counted)
+        try:
+            y1, m1 = run()
+            assert len(calls) == 1, "the skip-out entry point was not called"
+            with nets.staged_skips():
+                y0, m0 = run()
+            assert len(calls) == 1
+        finally:
+            setattr(L, name, entry)
+        assert torch.equal(y1, y0), (y1 - y0).abs().max().item()
+        if m1 is not None:
+            assert torch.equal(m1, m0)
+
+
+@pytest.mark.gpu
 def test_clip_kernels_on_plane_blocked_values(S):
     """SLR_SYNTH_VALUES_B4 (ABI 8): slr_pack_planes4 writes [C/4][H][W][4]; the clip kernels then read a chunk's 4 planes of a source pixel
     with one 16-byte load.  Same arithmetic as on the planar tensor: the two agree to the run-to-run noise of the summation order
