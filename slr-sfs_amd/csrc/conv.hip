@@ -116,6 +116,7 @@ namespace slr {
 // ([co tile][chunk][tap][lane][k pair]: two 16-byte loads), and one tap is 8 x PT MFMAs with ONE ds_read_b32 each: the loop is
 // bound by the matrix pipe alone.
 constexpr int CV_FSTR = 352;                       // F32: floats per channel row of the staged block
+constexpr int CV_KSTR = 260;                       // F32, skip fills: floats per channel row (256 pixels; channels k and k + 8 -- lanes 0-31 / 32-63 of a fragment -- on disjoint banks)
 // SKIP: the residual block's 1x1 skip convolution rides in this kernel (see the skip phase behind the main loop): the separate 1x1 kernel,
 // the write of its result and the read of it as the residual are gone.
 // POOL (with SKIP, 128-channel workgroup rows): the "Down" block's average pool in the epilogue -- see the end of the kernel.
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     constexpr int WPX = 4 / WCO, PT = CV_H / WPX;
     static_assert(!(POOL || UPS) || (SKIP && WCO == 4 && !(POOL && UPS)), "the resampling epilogues: a wave holds all 8 rows of its channel tile");
     static_assert(!F32 || CPW == 1, "the fp32 rung runs one 32-channel tile per wave");
-    static_assert(!SKIP || (CPW == 1 && !F32 && INB8), "the skip phase: split rung, one tile per wave, channel-blocked main input");
-    constexpr int XRAW = F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16, XSKIP = SKIP ? SLR_CONV_SKIP_FILL * 2 * 2 * 256 * 16 : 0;
+    static_assert(!SKIP || (CPW == 1 && INB8), "the skip phase: one tile per wave, channel-blocked main input");
+    constexpr int XRAW = F32 ? 2 * 16 * CV_FSTR * 4 : 2 * 2 * 2 * CV_NPX * 16, XSKIP = !SKIP ? 0 : SLR_CONV_SKIP_FILL * (F32 ? 16 * CV_KSTR * 4 : 2 * 2 * 256 * 16);
     __shared__ __attribute__((aligned(16))) unsigned char xraw[XRAW > XSKIP ? XRAW : XSKIP];
     h8 (*xs)[2][2][CV_NPX] = reinterpret_cast<h8 (*)[2][2][CV_NPX]>(xraw);             // [buffer][hi|lo][8-channel group][halo pixel]
     float (*xf)[16][CV_FSTR] = reinterpret_cast<float (*)[16][CV_FSTR]>(xraw);          // F32: [buffer][channel][halo pixel]
@@ -430,8 +431,9 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         // epilogue arithmetic resp. the previous fill's MFMAs.  (First form, one chunk per barrier with the halo staging of the main loop:
         // the four fused kernels of a decoder frame cost 18 % more than without their skips; HISTORY.md.)
         constexpr int SK = SLR_CONV_SKIP_FILL;
-        static_assert(SK * 2 * 2 * 256 * 16 <= (int)sizeof(xraw), "skip fills live in the staging buffers");
+        static_assert(SK * (F32 ? 16 * CV_KSTR * 4 : 2 * 2 * 256 * 16) <= (int)sizeof(xraw), "skip fills live in the staging buffers");
         h8 (*xk)[2][2][256] = reinterpret_cast<h8 (*)[2][2][256]>(xraw);      // [chunk of the fill][hi|lo][8-channel group][pixel of the block]
+        float (*xkf)[16][CV_KSTR] = reinterpret_cast<float (*)[16][CV_KSTR]>(xraw);   // F32
         const int ns = a.skip_nchunk, sc8max = (a.skip_cin >> 3) - 1;
         const int spr = tid >> 5, spc = tid & 31;
         const bool sok = (y0 + spr < a.H) & (x0 + spc < a.W);
@@ -455,6 +457,11 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                 for (int g = 0; g < 2; ++g) {
                     const float x8[8] = {sv[k][2 * g].x, sv[k][2 * g].y, sv[k][2 * g].z, sv[k][2 * g].w,
                                          sv[k][2 * g + 1].x, sv[k][2 * g + 1].y, sv[k][2 * g + 1].z, sv[k][2 * g + 1].w};
+                    if constexpr (F32) {               // fp32 rung: the values as they are, [chunk of the fill][channel][pixel of the block]
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xkf[k][8 * g + j][tid] = x8[j] * smk;
+                        continue;
+                    }
                     h8 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -505,6 +512,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
             for (int k = 0; k < SK; ++k) {
                 const h8 *q = swbase + (size_t)min(s0 + k, ns - 1) * 128;
+                if (F32) { sa[k][0] = q[2u * (unsigned)lane]; sa[k][1] = q[2u * (unsigned)lane + 1u]; continue; }     // the lane's 8 fp32 weights
                 sa[k][0] = q[(unsigned)lane]; sa[k][1] = q[(unsigned)lane + 64u];
             }
             __syncthreads();
@@ -513,6 +521,22 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
 #pragma unroll
             for (int k = 0; k < SK; ++k) {
                 if (s0 + k >= ns) break;               // (uniform)
+                if constexpr (F32) {
+                    // MFMA kp: the weights of input channels kp (lanes 0-31) and 8 + kp (lanes 32-63) -- slr_conv1x1_f32_weights' pairing --
+                    // with the row's 32 pixels of those channels
+                    typedef float f8v __attribute__((ext_vector_type(8)));
+                    union AW { h8 h[2]; f8v f; } aw;
+                    aw.h[0] = sa[k][0]; aw.h[1] = sa[k][1];
+#pragma unroll
+                    for (int kp = 0; kp < 8; ++kp) {
+                        float bv[PT];
+#pragma unroll
+                        for (int kk = 0; kk < PT; ++kk) bv[kk] = xkf[k][kp + 8 * (lane >> 5)][(wp * PT + kk) * 32 + (lane & 31)];
+#pragma unroll
+                        for (int kk = 0; kk < PT; ++kk) acc[0][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.f[kp], bv[kk], acc[0][kk], 0, 0, 0);
+                    }
+                    continue;
+                }
                 const h8 *xh = &xk[k][0][lane >> 5][0], *xl = &xk[k][1][lane >> 5][0];
                 constexpr int PB = PT > 4 ? 4 : PT, NB = PT / PB;
 #pragma unroll
@@ -1349,17 +1373,17 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
     // channel-blocked activations).  The weight buffer is indexed by 32-channel tiles, so any row width reads it.
     if (ct == 128 && a.pre != PRE_NONE && !in_b8) ct = 64;
     const dim3 grid(tiles, conv_cout_pad(a.Cout) / ct, a.N);
-    if constexpr (!F32) {
-        if (a.skip_in) {                    // (conv_set_skip: split rung, channel-blocked main input, more than 4 output channels)
+    {
+        if (a.skip_in) {                    // (conv_set_skip: channel-blocked main input, more than 4 output channels; fp32 rung: more than 64)
 #define CV_SKIP(WCO)                                                                                            \
     do {                                                                                                       \
-        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, true, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);   \
-        else hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);                   \
+        if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, true, true, F32, true>), grid, dim3(CV_THREADS), 0, st, a);   \
+        else hipLaunchKernelGGL((conv3x3_split_kernel<1, WCO, false, true, F32, true>), grid, dim3(CV_THREADS), 0, st, a);                   \
     } while (0)
             if (a.resample) {               // (conv_set_skip: 128-channel workgroup rows)
                 if (a.resample == 2) {
-                    if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);
-                    else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, false, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);
+                    if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, F32, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);
+                    else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, F32, true, false, true>), grid, dim3(CV_THREADS), 0, st, a);
                     SLR_CHECK_LAUNCH();
                     const int items = 2 * a.tiles_y * 2 * a.W + 2 * a.tiles_x * 2 * a.H;
                     hipLaunchKernelGGL(upsample_fix_kernel, dim3((items + 255) / 256, a.N * (a.Cout >> 3)), dim3(256), 0, st, a.out, (const float *)a.pool_row,
@@ -1367,8 +1391,8 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
                     SLR_CHECK_LAUNCH();
                     return 0;
                 }
-                if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, false, true, true>), grid, dim3(CV_THREADS), 0, st, a);
-                else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, false, true, true>), grid, dim3(CV_THREADS), 0, st, a);
+                if (a.pre != PRE_NONE) hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, true, true, F32, true, true>), grid, dim3(CV_THREADS), 0, st, a);
+                else hipLaunchKernelGGL((conv3x3_split_kernel<1, 4, false, true, F32, true, true>), grid, dim3(CV_THREADS), 0, st, a);
                 SLR_CHECK_LAUNCH();
                 const int OH = (a.H - 1) / 2 + 1, OW = (a.W - 1) / 2 + 1;
                 const int items = (a.tiles_y - 1) * OW + (a.tiles_x - 1) * OH;
@@ -1379,7 +1403,8 @@ static int conv_launch_t(ConvArgs &a, bool in_b8, hipStream_t st) {
                 }
                 return 0;
             }
-            if (ct == 128) CV_SKIP(4); else if (ct == 64) CV_SKIP(2); else CV_SKIP(1);
+            if (ct == 128) CV_SKIP(4);
+            else if constexpr (!F32) { if (ct == 64) CV_SKIP(2); else CV_SKIP(1); }
 #undef CV_SKIP
             SLR_CHECK_LAUNCH();
             return 0;
@@ -1458,7 +1483,9 @@ static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layou
         return 0;
     }
     SLR_CHECK_ARG(sk->in && sk->w, "null pointer");
-    SLR_CHECK_ARG(!(layout & (SLR_CONV_F32 | SLR_CONV_WINO)), "the fused skip branch runs on the split-f16 rung");
+    SLR_CHECK_ARG(!(layout & SLR_CONV_WINO), "no fused skip branch in the Winograd kernel");
+    SLR_CHECK_ARG(!(layout & SLR_CONV_F32) || (conv_cout_tile(a.Cout) == 128 && sk->wscale == 1.0f),
+                  "the fused skip branch on the fp32 rung: more than 64 output channels, skip_wscale = 1");
     SLR_CHECK_ARG((layout & SLR_CONV_IN_B8) && a.Cout > CF_MAXCO, "the fused skip branch needs a channel-blocked main input and more than 4 output channels");
     SLR_CHECK_ARG(sk->cin > 0 && (long long)sk->cin * a.H * a.W < (1LL << 31) && sk->wscale > 0.0f, "skip sizes");
     SLR_CHECK_ARG(sb8 && sk->cin % 8 == 0 && !((uintptr_t)sk->in & 15), "the fused skip branch reads a channel-blocked skip input (SLR_CONV_SKIP_B8): skip_cin % 8 == 0, 16-byte aligned");

@@ -145,7 +145,9 @@ class staged_skips:
 def _skip_rides(a, cout, b8, b8_in):
     """The skip branch can ride in the second 3x3 kernel: split-f16 rung, channel-blocked block input and intermediate, more than 4
     output channels (include/slr_splat.h: slr_conv3x3_forward_skip)."""
-    return bool(_S.fused_skips and b8 and b8_in and cout > 4 and a.is_cuda and not _S.f32_kernels and not _S.torch_convs)
+    if _S.f32_kernels and (_S.winograd or cout <= 64):         # fp32 rung: the 128-channel kernels only; none in the Winograd kernel
+        return False
+    return bool(_S.fused_skips and b8 and b8_in and cout > 4 and a.is_cuda and not _S.torch_convs)
 
 
 def _pool_out(N, cout, H, W, like, pool):
@@ -316,14 +318,14 @@ class Conv(nn.Module):
         N, _, H, W = x.shape
         buf, wscale, xscale, arith = self._split_weights()
         sbuf, swscale, _, sarith = skip_conv._split_weights()
-        assert arith == 0 and sarith == 0
+        assert arith == sarith and not (arith & CONV_WINO)
         out, ws, ws_bytes, pflag = _pool_out(N, cout, H, W, x, pool)
         sc, sh = pre_bn if pre_bn is not None else (None, None)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().slr_conv3x3_forward_skip(
                 _lib.ptr(x), _lib.ptr(buf), _lib.ptr(self.bias), _lib.ptr(out), N, cin, cout, H, W, wscale, xscale, _lib.ptr(sc), _lib.ptr(sh),
                 _lib.ptr(skip_x), _lib.ptr(sbuf), _lib.ptr(skip_conv.bias), skip_x.shape[1], swscale, _lib.ptr(ws), ws_bytes,
-                layout | pflag | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_conv3x3_forward_skip")
+                layout | arith | pflag | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_conv3x3_forward_skip")
         return out
 
     def _split_weights(self):
@@ -448,14 +450,14 @@ class PartialConv(Conv):
         cout = self.weight.shape[0]
         buf, wscale, xscale, arith = self._split_weights()
         sbuf, swscale, _, sarith = skip_conv._split_weights()
-        assert arith == 0 and sarith == 0
+        assert arith == sarith and not (arith & CONV_WINO)
         out, ws, ws_bytes, pflag = _pool_out(N, cout, H, W, x, pool)
         um = torch.empty(N, 1, H, W, device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().slr_pconv3x3_forward_skip(
                 _lib.ptr(x), None, None, _lib.ptr(mask), _lib.ptr(buf), wscale, xscale, _lib.ptr(self.bias), _lib.ptr(out), _lib.ptr(um),
                 N, cin, cout, H, W, _lib.ptr(skip_x), _lib.ptr(sbuf), skip_x.shape[1], swscale, _lib.ptr(ws), ws_bytes,
-                layout | pflag | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_pconv3x3_forward_skip")
+                layout | arith | pflag | (SKIP_B8 if skip_b8 else 0), _lib.stream_of(x)), "slr_pconv3x3_forward_skip")
         return out, um
 
     def forward(self, x, mask, residual=None, next_bn=None, pre_bn=None, layout=0):

@@ -2108,6 +2108,61 @@ def test_skip_branch_inside_the_second_convolution(S, kind, cin, cout, h, w, res
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["pconv", "plain"])
+@pytest.mark.parametrize("cin,cout,h,w,resample", [(64, 128, 21, 70, "Down"), (256, 128, 9, 70, "Up"), (128, 136, 17, 33, None), (72, 256, 8, 32, "Down")])
+def test_skip_branch_inside_the_second_convolution_fp32_rung(S, kind, cin, cout, h, w, resample):
+    """The fused residual-block kernels on the fp32 rung (SLR_CONV_F32: v_mfma_f32_32x32x2_f32, more than 64 output channels): against the
+    two-kernel forms inside the same rung -- skip <= 2e-6 of the output scale, pooled <= 1e-6, up-sampled bit-identical, masks bit-identical."""
+    from slr_sfs_amd import nets
+    torch.manual_seed(cin + w)
+    n = 2
+    with torch.no_grad(), nets.fp32_kernels(winograd=False):
+        blk = (nets.PconvResBlock if kind == "pconv" else nets.ResBlock)(cin, cout, resample).cuda()
+        for m in blk.modules():
+            if isinstance(m, nets.AffineBN):
+                m.stored_mean.normal_(0, 0.3); m.stored_var.uniform_(0.5, 1.5)
+            if isinstance(m, nets.Conv) and m.bias is not None:
+                m.bias.normal_()
+        x = torch.randn(n, cin, h, w, device="cuda")
+        xin = x.view(n, cin // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous().view(n, cin, h, w)
+        mask = (torch.rand(n, 1, h, w, device="cuda") > 0.3).float()
+        L = nets._lib.lib()
+        name = "slr_pconv3x3_forward_skip" if kind == "pconv" else "slr_conv3x3_forward_skip"
+        entry, calls = getattr(L, name), []
+
+        def counted(*a):
+            calls.append(1)
+            return entry(*a)
+
+        def run():
+            if kind == "pconv":
+                y, m, b8 = blk(xin, mask, True)
+            else:
+                (y, b8), m = blk(xin, True), None
+            return y, m
+
+        setattr(L, name, counted)
+        try:
+            y1, m1 = run()
+            assert len(calls) == 1
+            with nets.staged_skips(pools_only=True):
+                y2, _ = run()
+            with nets.staged_skips():
+                y0, m0 = run()
+            assert len(calls) == 2
+        finally:
+            setattr(L, name, entry)
+        if m1 is not None:
+            assert torch.equal(m1, m0)
+        scale = max(y0.abs().max().item(), 1.0)
+        assert (y1 - y0).abs().max().item() <= 2e-6 * scale
+        if resample == "Up":
+            assert torch.equal(y1, y2)
+        else:
+            assert (y1 - y2).abs().max().item() <= 1e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pconv", "plain"])
 @pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 21, 70), (64, 3, 16, 64), (24, 2, 9, 33), (8, 4, 40, 131), (16, 1, 1, 3)])
 def test_narrow_end_skip_from_the_same_pass(S, kind, cin, cout, h, w):
     """slr_conv3x3_forward_skipout / slr_pconv3x3_forward_skipout (ABI 10): the decoders' 128 -> 3 end -- the block's first convolution and the
