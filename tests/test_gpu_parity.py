@@ -2162,6 +2162,54 @@ def test_skip_branch_inside_the_second_convolution_fp32_rung(S, kind, cin, cout,
 
 
 @pytest.mark.gpu
+def test_fused_residual_blocks_randomised_sweep(S):
+    """48 random residual blocks (channel counts in steps of 8 up to 160, sizes 1 .. 70 x 1 .. 150, Down / Up / none, plain / partial, both
+    rungs): the fused kernels (skip, pool, up-sampling in the second convolution; narrow-end skip in the first) against the two-kernel forms
+    -- tile borders, images smaller than a tile, cut tiles, padded channel tiles."""
+    from slr_sfs_amd import nets
+    rng = np.random.default_rng(20260929)
+    torch.manual_seed(5)
+    for case in range(48):
+        cin = int(rng.integers(1, 21)) * 8
+        cout = int(rng.choice([1, 2, 3, 4])) if case % 6 == 5 else int(rng.integers(1, 21)) * 8
+        h, w = int(rng.integers(1, 71)), int(rng.integers(1, 151))
+        resample = None if cout <= 4 else [None, "Down", "Up"][int(rng.integers(0, 3))]
+        kind = "pconv" if rng.integers(0, 2) else "plain"
+        f32 = case % 4 == 3
+        n = int(rng.integers(1, 3))
+        with torch.no_grad():
+            blk = (nets.PconvResBlock if kind == "pconv" else nets.ResBlock)(cin, cout, resample).cuda()
+            for m in blk.modules():
+                if isinstance(m, nets.AffineBN):
+                    m.stored_mean.normal_(0, 0.3); m.stored_var.uniform_(0.5, 1.5)
+                if isinstance(m, nets.Conv) and m.bias is not None:
+                    m.bias.normal_()
+            x = torch.randn(n, cin, h, w, device="cuda")
+            xin = x.view(n, cin // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous().view(n, cin, h, w)
+            mask = (torch.rand(n, 1, h, w, device="cuda") > 0.3).float()
+
+            def run():
+                if kind == "pconv":
+                    y, m, _ = blk(xin, mask, True)
+                    return y, m
+                return blk(xin, True)[0], None
+
+            import contextlib
+            with (nets.fp32_kernels(winograd=False) if f32 else contextlib.nullcontext()):
+                y1, m1 = run()
+                with nets.staged_skips():
+                    y0, m0 = run()
+            what = (case, kind, cin, cout, h, w, resample, f32)
+            if m1 is not None:
+                assert torch.equal(m1, m0), what
+            if blk.conv_b is None:
+                assert torch.equal(y1, y0), what
+            else:
+                err, scale = (y1 - y0).abs().max().item(), max(y0.abs().max().item(), 1.0)
+                assert err <= 3e-6 * scale, what + (err, scale)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["pconv", "plain"])
 @pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 21, 70), (64, 3, 16, 64), (24, 2, 9, 33), (8, 4, 40, 131), (16, 1, 1, 3)])
 def test_narrow_end_skip_from_the_same_pass(S, kind, cin, cout, h, w):
