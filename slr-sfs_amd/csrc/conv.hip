@@ -80,10 +80,10 @@ struct ConvArgs {
     int wino_groups;       // Winograd kernel (conv_wino.hpp): groups of 64 output channels (its grid.x carries blocks x groups)
     // the block's 1x1 skip branch as extra K chunks of this convolution (SKIP instantiations; blocks.py:243-248, :83-87):
     // out = epilogue(conv3x3(in)) + conv1x1(skip_in) (+ skip_bias)
-    const float *skip_in;  // [N,skip_cin,H,W] (skip_b8: channel-blocked), no prologue
+    const float *skip_in;  // [N,skip_cin,H,W] channel-blocked, no prologue
     const h8 *skip_w;      // split 1x1 weights in fragment order (taps = 1), scaled by the skip's own wscale
     const float *skip_bias;
-    int skip_cin, skip_nchunk, skip_b8;
+    int skip_cin, skip_nchunk;
     float skip_unscale;    // 1 / (xscale * skip wscale)
     // POOL instantiations: `out` is the 3x3 / stride 2 / pad 1 average pool of the result ("Down" blocks, blocks.py:196-199), channel-blocked;
     // the tile's last row / last column go to these side buffers for pool_fix_kernel: [N][tiles_y][Cout/8][W][8], [N][tiles_x][Cout/8][H][8]
@@ -1491,7 +1491,7 @@ static int conv_set_skip(ConvArgs &a, const SkipOp *sk, float xscale, int &layou
     SLR_CHECK_ARG(sb8 && sk->cin % 8 == 0 && !((uintptr_t)sk->in & 15), "the fused skip branch reads a channel-blocked skip input (SLR_CONV_SKIP_B8): skip_cin % 8 == 0, 16-byte aligned");
     SLR_CHECK_ARG(!a.residual && !a.next_scale, "the fused skip branch replaces the residual; no next-BN fusion with it");
     a.skip_in = sk->in; a.skip_w = (const h8 *)sk->w; a.skip_bias = sk->bias;
-    a.skip_cin = sk->cin; a.skip_nchunk = conv_cin_pad(sk->cin) / 16; a.skip_b8 = sb8;
+    a.skip_cin = sk->cin; a.skip_nchunk = conv_cin_pad(sk->cin) / 16;
     a.skip_unscale = 1.0f / (xscale * sk->wscale);
     if (pool) {
         SLR_CHECK_ARG(!(up && (layout_in & SLR_CONV_POOL_OUT)), "SLR_CONV_POOL_OUT and SLR_CONV_UP_OUT are exclusive");
