@@ -291,7 +291,13 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
         store_round(R2{}, 0, 0, s2);
     }
     __syncthreads();
-    float st[8];
+    // DEEP (kernels with registers to spare: fewer than 8 rows per wave): a staging round's loads are issued five taps before the round is consumed
+    // instead of two -- round 0 already in the previous chunk iteration -- in a register set per round.  A tap of these kernels is 6 / 12 MFMAs per wave:
+    // two taps are less than the memory latency under load (the same kernels with every staging load redirected to a cached 4 KB ran 13 % faster).
+    constexpr bool DEEP = SLR_CONV_DEEP_STAGE && WCO < 4 && !F32;
+    float stx[DEEP ? 3 : 1][8];
+    float (&st)[8] = stx[0];
+    if (DEEP) load_round(R0{}, min(1, nchunk - 1), stx[0]);
 
     const int bcol = lane & 31, bgrp = lane >> 5;
     // A fragments (weights) come straight from global memory / L2, one tap ahead of their use.
@@ -310,6 +316,10 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
     };
     load_a(a_cur, 0);
     const int glast = nchunk * 9 - 1;
+    // DEEP: the weight fragments run TWO taps ahead.  Memory returns in order: a fragment load issued behind a staging round's loads comes back with
+    // them (memory latency, not L2 latency), and one tap of these kernels is shorter than that
+    h8 a_nx2[DEEP ? CPW : 1][2];
+    if (DEEP) { load_a(a_nxt, min(1, glast)); }
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         const int cn = min(c + 1, nchunk - 1);         // the chunk staged under this one's MFMAs (the last
@@ -326,12 +336,19 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
             // A round's loads are issued at the top of taps 0 / 3 / 6 (behind the weight loads) and consumed
             // (prologue, split, LDS store) in taps 2 / 5 / 8, where that VALU work is interleaved with
             // the tap's MFMAs (below).
-            load_a(a_nxt, min(c * 9 + tap + 1, glast));
+            if (DEEP) load_a(a_nx2, min(c * 9 + tap + 2, glast));
+            else load_a(a_nxt, min(c * 9 + tap + 1, glast));
             // AFTER the weight loads: memory returns in order, so a staging load (HBM latency) issued in
             // front of an A load (L2 latency) would make the next tap wait for HBM
-            if (tap == 0) load_round(R0{}, cn, st);
-            if (tap == 3) load_round(R1{}, cn, st);
-            if (tap == 6) load_round(R2{}, cn, st);
+            if (DEEP) {
+                if (tap == 0) load_round(R1{}, cn, stx[DEEP ? 1 : 0]);
+                if (tap == 3) load_round(R2{}, cn, stx[DEEP ? 2 : 0]);
+                if (tap == 6) load_round(R0{}, min(c + 2, nchunk - 1), stx[0]);
+            } else {
+                if (tap == 0) load_round(R0{}, cn, st);
+                if (tap == 3) load_round(R1{}, cn, st);
+                if (tap == 6) load_round(R2{}, cn, st);
+            }
             __builtin_amdgcn_sched_barrier(0);         // loads are issued HERE, a whole tap ahead of their use
             const bool stage_tap = tap == 2 || tap == 5 || tap == 8;
             Stage sg;
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                             const int j0 = i * 8 / NMF, j1 = (i + 1) * 8 / NMF;
                             if (j1 > j0) {
 #pragma unroll
-                                for (int j = j0; j < j1; ++j) stage_value(j, sg, st);
+                                for (int j = j0; j < j1; ++j) stage_value(j, sg, stx[DEEP ? tap / 3 : 0]);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                         const int j0 = i * 8 / NM, j1 = (i + 1) * 8 / NM;
                         if (j1 > j0) {
 #pragma unroll
-                            for (int j = j0; j < j1; ++j) stage_value(j, sg, st);
+                            for (int j = j0; j < j1; ++j) stage_value(j, sg, stx[DEEP ? tap / 3 : 0]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -408,7 +425,10 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv3x3_split_kernel(ConvArgs a
                 if (tap == 8) stage_finish(R2{}, buf ^ 1, sg);
             }
 #pragma unroll
-            for (int ct = 0; ct < CPW; ++ct) { a_cur[ct][0] = a_nxt[ct][0]; a_cur[ct][1] = a_nxt[ct][1]; }
+            for (int ct = 0; ct < CPW; ++ct) {
+                a_cur[ct][0] = a_nxt[ct][0]; a_cur[ct][1] = a_nxt[ct][1];
+                if (DEEP) { a_nxt[ct][0] = a_nx2[ct][0]; a_nxt[ct][1] = a_nx2[ct][1]; }
+            }
         }
         __syncthreads();
     }

@@ -64,6 +64,8 @@
 
 #define SLR_CONV_SKIP_FILL 3     // 3x3 kernels with the block's 1x1 skip inside (conv.hip, SKIP): skip chunks staged per barrier pair (16 KiB of LDS and 16 registers in flight each)
 
+#define SLR_CONV_DEEP_STAGE 1    // 3x3 split kernels with fewer than 8 rows per wave: staging loads five taps ahead of their use (three register sets) instead of two
+
 // ---- development aids
 
 // ---- variant builds (csrc/Makefile: TUNE="NAME=value ...")
