@@ -120,8 +120,12 @@ constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
                                                        // identity / t=30 / t=59 169 / 204 / 310 us with global loads, 167 / 218 / 352 with buffer loads (box 2048)
 #define SLR_GRAD_BUF_ST 1                              // gradInput stores through a buffer descriptor (out-of-image work-items dropped by the range check, no
                                 // exec-mask juggling around the stores): gradInput alone t=30 192 -> 176 us, t=59 295 -> 264; both: 204 -> 208 / 310 -> 297
-#define SLR_GRAD_ENTRY_ST 0                            // U dropped stores before the staged loop (the loop header then merges two equal wait states): no change
+#define SLR_GRAD_NSE_VARIANTS 1                        // the staged loop once per count of box cells a work-item carries (1, 2, 3, 4, 6, 8) instead of always 8
+                                // loads per channel: both gradients t=30 201 -> 187 us, t=59 253 -> 246, gradFlow alone t=30 166 -> 144 (round 6)
+#define SLR_GRAD_PAIRS 1                               // bent blocks whose boxes do not fit: the two corners of a destination row as one 8-byte load
+                                // (round 6: both gradients t=59 246 -> 227-236 us, gradFlow alone 228 -> 187; t=30 / identity have no such block)
 constexpr int GT_BOX = SLR_GRAD_BOX;
+struct __attribute__((packed, aligned(4))) float2u { float x, y; };   // two floats at a 4-byte-aligned address (global_load_dwordx2)
 
 template <bool GIN, bool GFLOW>
 __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(const float *__restrict__ in, const float *__restrict__ flow,
@@ -238,15 +242,6 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
         const int r = (int)(((float)rel + 0.5f) / (float)qbw);     // rel / qbw, exact for rel < 2^22
         soff[k] = (staged && idx < nbox) ? (uint32_t)((qy0 + r) * W + qx0 + (rel - r * qbw)) * 4u : 0u;
     }
-    float sv[NS][U];
-    auto issue = [&](int ch) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int pl = min(ch + u, C - 1);
-#pragma unroll
-            for (int k = 0; k < NS; ++k) sv[k][u] = ld_g(pl, soff[k]);
-        }
-    };
     // one pass of U channels: the reference's terms in the reference's order (bit-identical on either path).  FULL: all U channels
     // exist -- every store of the pass is unconditional (counted waits in the loop); the last pass of a channel count that is not a
     // multiple of U branches around the missing ones.
@@ -274,33 +269,94 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
     };
     if (staged) {                                                  // (workgroup-uniform: each path is a loop of its own)
         const uint32_t b0 = (uint32_t)l0, b1 = (uint32_t)l1, b2 = (uint32_t)l2, b3 = (uint32_t)l3;
-        auto pass = [&](auto full_tag, int ch) {
-            float a0[U], a1[U], a2[U], a3[U], v[U];
-            __syncthreads();                                       // the previous pass has been gathered
+        // The staged loop exists once per number of box cells a work-item carries (NSE = ceil(nbox / GT_THREADS), rounded up to 1, 2, 3, 4, 6, NS):
+        // a typical Euler block's boxes hold 900-1100 cells, and a loop that always issued NS loads per channel spent three quarters of its
+        // vector-memory instructions on cells that do not exist.
+        auto run = [&](auto nse_tag) {
+            constexpr int NSE = decltype(nse_tag)::value;
+            float sv[NSE][U];
+            auto issue = [&](int ch) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int idx = tid + k * GT_THREADS;
-                if (idx < nbox)
+                for (int u = 0; u < U; ++u) {
+                    const int pl = min(ch + u, C - 1);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) box[u][idx] = sv[k][u];
-            }
+                    for (int k = 0; k < NSE; ++k) sv[k][u] = ld_g(pl, soff[k]);
+                }
+            };
+            auto pass = [&](auto full_tag, int ch) {
+                float a0[U], a1[U], a2[U], a3[U], v[U];
+                __syncthreads();                                   // the previous pass has been gathered
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (GFLOW) v[u] = ld_i(min(ch + u, C - 1), vi);
-            __syncthreads();
-            issue(ch + U);                                         // in flight under this pass's gathers, sums and stores (past the last
+                for (int k = 0; k < NSE; ++k) {
+                    const int idx = tid + k * GT_THREADS;
+                    if (idx < nbox)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) box[u][idx] = sv[k][u];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (GFLOW) v[u] = ld_i(min(ch + u, C - 1), vi);
+                __syncthreads();
+                issue(ch + U);                                     // in flight under this pass's gathers, sums and stores (past the last
                                                                    // channel: re-reads channel C - 1, unused)
 #pragma unroll
-            for (int u = 0; u < U; ++u) { a0[u] = box[u][b0]; a1[u] = box[u][b1]; a2[u] = box[u][b2]; a3[u] = box[u][b3]; }
+                for (int u = 0; u < U; ++u) { a0[u] = box[u][b0]; a1[u] = box[u][b1]; a2[u] = box[u][b2]; a3[u] = box[u][b3]; }
+                finish(full_tag, ch, a0, a1, a2, a3, v);
+            };
+            issue(0);
+            int ch = 0;
+            for (; ch + U <= C; ch += U) pass(std::true_type{}, ch);
+            if (ch < C) pass(std::false_type{}, ch);
+        };
+        const int need = (nbox + GT_THREADS - 1) / GT_THREADS;    // (workgroup-uniform)
+        if (SLR_GRAD_NSE_VARIANTS == 0 || need > 6) run(std::integral_constant<int, NS>{});
+        else if (need <= 1) run(std::integral_constant<int, 1>{});
+        else if (need == 2) run(std::integral_constant<int, 2>{});
+        else if (need == 3) run(std::integral_constant<int, 3>{});
+        else if (need == 4) run(std::integral_constant<int, 4>{});
+        else run(std::integral_constant<int, 6>{});
+    } else if (SLR_GRAD_PAIRS && bent > SLR_GRAD_BENT) {
+        // Direct gathers of a block whose rows bend but whose boxes do not fit (a flow that rotates and stretches the block: boxes of 4400-7600
+        // cells at Euler t=59; incoherent flows): every lane of a gather instruction sits on a cache line of its own, the block is bound by the
+        // line requests its CU's L1 takes (36 of 1920 blocks ran 115-150 us each and were a fifth of the launch).  The two corners of a
+        // destination ROW come as one 4-byte-aligned 8-byte load: half the requests.  Same values, same terms: bit-identical.
+        const bool kT = k0 | k1, kB = k2 | k3;
+        const int safe = min(i, HW - 2);                           // (bent > 2 implies H >= 3)
+        const int pT = kT ? min(max(o, 0), HW - 2) : safe, pB = kB ? min(max(o + W, 0), HW - 2) : safe;
+        const int dT = o - pT, dB = o + W - pB;                    // -1 (x0 = -1 at the plane's first pixel), 0, +1 (x0 + 1 past its last)
+        float2u p0[U], p1[U], q0[U], q1[U];
+        float pv[U], qv[U];
+        auto load = [&](int ch, float2u (&t)[U], float2u (&b)[U], float (&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pl = min(ch + u, C - 1);
+                t[u] = *reinterpret_cast<const float2u *>(gp + (size_t)pl * HW + pT);
+                b[u] = *reinterpret_cast<const float2u *>(gp + (size_t)pl * HW + pB);
+                if (GFLOW) v[u] = ld_i(pl, vi);
+            }
+        };
+        auto fin = [&](auto full_tag, int ch, const float2u (&t)[U], const float2u (&b)[U], const float (&v)[U]) {
+            float a0[U], a1[U], a2[U], a3[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a0[u] = dT == 1 ? t[u].y : t[u].x; a1[u] = dT == -1 ? t[u].x : t[u].y;
+                a2[u] = dB == 1 ? b[u].y : b[u].x; a3[u] = dB == -1 ? b[u].x : b[u].y;
+            }
             finish(full_tag, ch, a0, a1, a2, a3, v);
         };
-        issue(0);
-        if (SLR_GRAD_ENTRY_ST && GIN)
-#pragma unroll
-            for (int u = 0; u < U; ++u) buf_st(ro, BUF_OOB, 0u, 0.0f);
+        load(0, p0, p1, pv);
         int ch = 0;
-        for (; ch + U <= C; ch += U) pass(std::true_type{}, ch);
-        if (ch < C) pass(std::false_type{}, ch);
+        for (; ch + 2 * U <= C; ch += 2 * U) {
+            load(ch + U, q0, q1, qv);
+            fin(std::true_type{}, ch, p0, p1, pv);
+            load(ch + 2 * U, p0, p1, pv);
+            fin(std::true_type{}, ch + U, q0, q1, qv);
+        }
+        if (ch < C) {
+            load(ch + U, q0, q1, qv);
+            fin(std::false_type{}, ch, p0, p1, pv);
+            if (ch + U < C) fin(std::false_type{}, ch + U, q0, q1, qv);
+        }
     } else {
         // direct gathers, two register sets: the loads of the NEXT pass are issued before this pass's sums and stores
         const uint32_t v0 = (uint32_t)g0 * 4u, v1 = (uint32_t)g1 * 4u, v2 = (uint32_t)g2 * 4u, v3 = (uint32_t)g3 * 4u;

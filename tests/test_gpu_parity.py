@@ -220,6 +220,53 @@ def test_backward_one_launch_equals_separate_launches(S, oracle):
     np.testing.assert_allclose(host(gf1), ogf, rtol=1e-5, atol=1e-4)
 
 
+def test_backward_blocks_whose_boxes_do_not_fit(S, oracle):
+    """grad_tile_kernel, third path (round 6): a flow that rotates and stretches every 8 x 64 block (destination boxes far above the
+    4096 LDS cells, rows bent) takes the direct gathers with the two corners of a destination row as ONE 4-byte-aligned 8-byte load.
+    gradInput bit-identical to the oracle, both-gradient launch = the separate launches; the pair's edge cases are planted: the
+    plane's first pixel reached from x0 = -1 (pair shifted right), its last pixel reached with x0 + 1 past the row (pair shifted left),
+    the same one row up for the bottom pair, and destinations outside the image."""
+    from slr_sfs_amd._lib import check, lib, ptr, stream_of
+    N, C, H, W = 2, 65, 160, 264
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flows = []
+    for n, (deg, sc) in enumerate(((55.0, 2.2), (-60.0, 2.4))):
+        a = np.deg2rad(deg)
+        cx, cy = W / 2 + 3.3 * n, H / 2 - 1.7
+        X = cx + sc * (np.cos(a) * (xx - cx) - np.sin(a) * (yy - cy)) + 0.37
+        Y = cy + sc * (np.sin(a) * (xx - cx) + np.cos(a) * (yy - cy)) + 0.21
+        flows.append(np.stack([X - xx, Y - yy]))
+    flow = np.stack(flows).astype(np.float32)
+    # the kernel's rule on the host: blocks of the image centre have two strip boxes of more than 4096 cells together (third path)
+    x0, y0 = np.floor(xx + flow[0, 0]).astype(int), np.floor(yy + flow[0, 1]).astype(int)
+    cells = sum((x0[48:56, q:q + 32].max() - x0[48:56, q:q + 32].min() + 2) * (y0[48:56, q:q + 32].max() - y0[48:56, q:q + 32].min() + 2) for q in (128, 160))
+    assert cells > 4096 and x0[48:56, 128:192].min() > 0 and x0[48:56, 128:192].max() < W - 2, cells
+
+    def plant(n, y, x, tx, ty):
+        flow[n, 0, y, x] = tx - x
+        flow[n, 1, y, x] = ty - y
+    plant(0, 50, 140, -0.5, 0.25)                # x0 = -1, y0 = 0: only NE / SE corners, top pair starts before the plane
+    plant(0, 51, 150, W - 0.5, H - 0.75)         # x0 = W-1, y0 = H-1: only NW, top pair ends past the plane
+    plant(0, 52, 160, W - 0.25, H - 1.5)         # x0 = W-1, y0 = H-2: bottom pair ends past the plane
+    plant(1, 60, 130, -0.75, -0.5)               # x0 = -1, y0 = -1: only SE = the plane's first pixel (bottom pair before the plane)
+    plant(1, 61, 131, -7.0, 3.0)                 # outside
+    plant(1, 62, 132, 12.0, H + 4.0)             # outside
+    rng = np.random.default_rng(77)
+    x, go = rng.standard_normal((N, C, H, W)).astype(np.float32), rng.standard_normal((N, C, H, W)).astype(np.float32)
+    Xd, F, G = dev(x), dev(flow), dev(go)
+    gi1, gf1, gi2, gf2 = torch.empty_like(Xd), torch.empty_like(F), torch.empty_like(Xd), torch.empty_like(F)
+    L, st = lib(), stream_of(Xd)
+    check(L.slr_softsplat_backward(ptr(Xd), ptr(F), ptr(G), ptr(gi1), ptr(gf1), N, C, H, W, st), "both")
+    check(L.slr_softsplat_backward(ptr(Xd), ptr(F), ptr(G), ptr(gi2), None, N, C, H, W, st), "input")
+    check(L.slr_softsplat_backward(ptr(Xd), ptr(F), ptr(G), None, ptr(gf2), N, C, H, W, st), "flow")
+    assert torch.equal(gi1, gi2) and torch.equal(gf1, gf2)
+    ogi, ogf = oracle.softsplat_backward(x, flow, go)
+    assert np.array_equal(host(gi1), ogi)
+    assert np.abs(ogi[0, :, 50, 140]).max() > 0 and np.abs(ogi[0, :, 51, 150]).max() > 0 and np.abs(ogi[1, :, 60, 130]).max() > 0
+    scale = max(1.0, float(np.abs(ogf).max()))
+    np.testing.assert_allclose(host(gf1), ogf, rtol=2e-6, atol=2e-6 * scale)
+
+
 def test_backward_channel_groups_on_small_grids(S, oracle):
     """slr_softsplat_backward_ws (round 6): on grids smaller than the chip -- the reference's training crops, [2,65,256,256] -- the
     backward kernel's channels are dealt to 2-4 workgroups per tile; gradInput stays bit-identical (per channel), gradFlow is the groups'
