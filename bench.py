@@ -825,7 +825,7 @@ def train_shape_roofline(dev):
 def backward_roofline(dev, motion):
     """The reference's backward kernels (softsplat.py:204-326) as ONE gather kernel, 65 planes at 768x1280 on Euler-integrated flows:
     gradInput + gradFlow in one launch; algorithmic bytes = gradOutput + input read, gradInput written = 3*C*H*W*4 (+ flow, gradFlow).
-    avg_us: the one launch of a call, 20 calls captured into a HIP graph and replayed (event pair around the replay); eager_us: event pair
+    avg_us: the launches of a call (slr_softsplat_backward_ws: the gather kernel + the 8 MB sum of the second group's partial gradFlow), 20 calls captured into a HIP graph and replayed (event pair around the replay); eager_us: event pair
     around each Python call."""
     import slr_sfs_amd as S
     from slr_sfs_amd._lib import check, lib, ptr, stream_of
@@ -833,13 +833,15 @@ def backward_roofline(dev, motion):
     C = 65
     x, go = torch.randn(1, C, H, W, device=dev), torch.randn(1, C, H, W, device=dev)
     gi, gf = torch.empty_like(x), torch.empty(1, 2, H, W, device=dev)
+    nb = int(L.slr_softsplat_backward_ws_bytes(1, C, H, W))              # (two channel groups: what the autograd route uses)
+    bws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     alg = (3 * C + 4) * H * W * 4
-    res = {"bound": "hbm", "kernel": "slr::grad_tile_kernel<true,true> (gradInput + gradFlow, one launch)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    res = {"bound": "hbm", "kernel": "slr::grad_tile_kernel<true,true> (gradInput + gradFlow, two channel groups) + grad_flow_sum_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "alg_bytes_per_launch": alg, "flows": {}}
     for name, t in (("euler_t30", 30), ("euler_t59", 59), ("identity", 0)):
         fl = S.euler_integration(motion, t)[0] if t else torch.zeros(1, 2, H, W, device=dev)
         # (the library launches on the stream it is handed: inside _graph_call_us that is the capturing stream)
-        call = lambda: check(L.slr_softsplat_backward(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), 1, C, H, W, stream_of(x)), "backward")
+        call = lambda: check(L.slr_softsplat_backward_ws(ptr(x), ptr(fl), ptr(go), ptr(gi), ptr(gf), 1, C, H, W, ptr(bws), nb, stream_of(x)), "backward")
         eager, _ = _time_calls(call, 20)
         avg = _graph_call_us(call)
         r = {"avg_us": round(avg, 1), "eager_us": round(eager, 1), "achieved": round(alg / avg / 1e3, 1), "frac": round(alg / avg / 1e3 / HBM_PEAK_GBS, 4)}

@@ -257,11 +257,13 @@ int slr_softsplat_backward(const float *in, const float *flow, const float *grad
                            float *grad_in, float *grad_flow,
                            int N, int C, int H, int W, void *stream);
 
-/* The same with scratch for channel groups (round 6).  On grids smaller than the chip -- the reference TRAINS at 256 x 256, batch 2 per
- * GPU (train_animating_scripts/train_baseline2_pconv.sh:14): 256 source tiles, one workgroup per CU walking all 65 channels -- the
- * kernel's channels are dealt to 2-4 workgroups per tile; gradInput is per channel, the groups' partial gradFlow sums go to `ws` and
- * a second small launch adds them up in group order (reproducible; the grouping of the channel sum differs from the one-group kernel
- * by rounding).  slr_softsplat_backward_ws_bytes: bytes of `ws` this shape wants (0: no groups); a NULL / short `ws` = one group.
+/* The same with scratch for channel groups (round 6).  The kernel's channels are dealt to 2-4 workgroups per tile: 2-4 on grids
+ * smaller than the chip -- the reference TRAINS at 256 x 256, batch 2 per GPU (train_animating_scripts/train_baseline2_pconv.sh:14):
+ * 256 source tiles, one workgroup per CU walking all 65 channels --, 2 on larger ones (halves the life of the blocks a flow's sinks
+ * make slow: 65 x 768 x 1280 at Euler t=59 230 -> 210 us).  gradInput is per channel (bit-identical); group 0 writes gradFlow itself,
+ * the other groups' partial sums go to `ws` and a second small launch adds them on in group order (reproducible; the grouping of the
+ * channel sum differs from the one-group kernel by rounding).  slr_softsplat_backward_ws_bytes: bytes of `ws` this shape wants
+ * ((groups - 1) * N * 2 * H * W * 4; 0: fewer than 16 channels); a NULL / short `ws` = one group when grad_flow is asked for.
  * slr_softsplat_backward is this call without scratch. */
 size_t slr_softsplat_backward_ws_bytes(int N, int C, int H, int W);
 int slr_softsplat_backward_ws(const float *in, const float *flow, const float *grad_out, float *grad_in,

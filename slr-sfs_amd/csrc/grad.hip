@@ -115,6 +115,10 @@ constexpr int GT_THREADS = TILE_PIX;                  // 8 x 64 source pixels
 #define SLR_GRAD_WAVES 4                               // __launch_bounds__ waves per SIMD of the tiled kernel
 #define SLR_GRAD_SLOTS 1024                            // small grids: channel groups while the launch stays within this many workgroups (two rounds of the 512 slots)
 #define SLR_GRAD_GROUPS_MAX 4
+#define SLR_GRAD_GROUPS_MIN 2                          // grids larger than the chip: two groups (group-major launch order) halve the life of the blocks a
+                                // flow's sinks make slow (their tail was a seventh of the launch at Euler t=59); round 6, 65 x 768 x 1280, both gradients,
+                                                       // identity / t=30 / t=59: 1 group 176 / 187 / 230 us, 2 groups 167 / 186 / 210, 4 groups 189 / 203 / 215;
+                                                       // the two groups of a tile next to each other in launch order: 174 / 191 / 215
 #define SLR_GRAD_BUF_LD 0                              // 1: plane loads through buffer descriptors (plane offset in an SGPR, no 64-bit vector address sums).
                                 // Measured SLOWER for these gathers although the loop then has ~25 % fewer VALU instructions: both gradients
                                                        // identity / t=30 / t=59 169 / 204 / 310 us with global loads, 167 / 218 / 352 with buffer loads (box 2048)
@@ -133,10 +137,11 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
                                                                float *__restrict__ gflow, int Ctot, int H, int W, int tiles_x, int cper,
                                                                float *__restrict__ gpart) {
     constexpr int U = SLR_GRAD_TU;
-    // grid.z channel groups (small grids: 256 source tiles are one workgroup per CU, each walking all channels): group z takes channels
+    // grid.z channel groups (small grids: 256 source tiles are one workgroup per CU, each walking all channels; large ones: two): group z takes channels
     // [z * cper, ...) -- below, `C` is the group's channel count and every plane pointer starts at the group's first plane; its partial
-    // gradFlow sums go to gpart[z] and grad_flow_sum_kernel adds the groups up in order
-    const int cb = (int)blockIdx.z * cper;
+    // gradFlow sums go to gflow (group 0) / gpart[z - 1] and grad_flow_sum_kernel adds the groups up in order
+    const int gz = (int)blockIdx.z;
+    const int cb = gz * cper;
     const int C = min(cper, Ctot - cb);
     __shared__ float box[U][GT_BOX];
     __shared__ int red[TILE_H][SLR_GRAD_STRIPS][4];
@@ -384,18 +389,19 @@ __global__ __launch_bounds__(GT_THREADS, SLR_GRAD_WAVES) void grad_tile_kernel(c
         }
     }
     if (GFLOW && live_px) {
-        float *gf = gridDim.z > 1 ? gpart + ((size_t)blockIdx.z * gridDim.y + n) * 2 * HW : gflow + (size_t)n * 2 * HW;
+        // group 0 writes gradFlow itself, group g > 0 its partial sums to gpart[g - 1]
+        float *gf = gz > 0 ? gpart + ((size_t)(gz - 1) * gridDim.y + n) * 2 * HW : gflow + (size_t)n * 2 * HW;
         gf[i] = gx;
         gf[HW + i] = gy;
     }
 }
 
-// gradFlow = the channel groups' partial sums, added in group order
+// gradFlow = the channel groups' partial sums, added in group order (group 0 wrote gflow itself, group g > 0 gpart[g - 1])
 __global__ __launch_bounds__(256) void grad_flow_sum_kernel(const float *__restrict__ gpart, float *__restrict__ gflow, size_t n, int groups) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float t = gpart[i];
-    for (int g = 1; g < groups; ++g) t += gpart[(size_t)g * n + i];
+    float t = gflow[i];
+    for (int g = 1; g < groups; ++g) t += gpart[(size_t)(g - 1) * n + i];
     gflow[i] = t;
 }
 
@@ -432,12 +438,13 @@ __global__ __launch_bounds__(256) void inverse_max_kernel(const float *__restric
 
 using namespace slr;
 
-// Channel groups of the tiled kernel on grids smaller than the chip (its 64 KiB box: two workgroups per CU = 512 slots): as many groups as
-// keep the launch within ~2 rounds of the slots, each a multiple of the kernel's 4 channels per pass.
+// Channel groups of the tiled kernel (its 64 KiB box: two workgroups per CU = 512 slots): on grids smaller than the chip as many groups as
+// keep the launch within ~2 rounds of the slots, on larger ones two; each a multiple of the kernel's 4 channels per pass.
 static int grad_groups(int N, int C, int H, int W) {
     const long long wgs = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     int g = (int)(SLR_GRAD_SLOTS / (wgs > 0 ? wgs : 1));
     g = g > SLR_GRAD_GROUPS_MAX ? SLR_GRAD_GROUPS_MAX : g;
+    g = g < SLR_GRAD_GROUPS_MIN ? SLR_GRAD_GROUPS_MIN : g;
     const int byc = C / 8;
     g = g > byc ? byc : g;
     return g < 1 ? 1 : g;
@@ -446,7 +453,7 @@ static int grad_groups(int N, int C, int H, int W) {
 SLR_EXPORT size_t slr_softsplat_backward_ws_bytes(int N, int C, int H, int W) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     const int g = grad_groups(N, C, H, W);
-    return g > 1 ? (size_t)g * N * 2 * H * W * 4 : 0;
+    return g > 1 ? (size_t)(g - 1) * N * 2 * H * W * 4 : 0;
 }
 
 SLR_EXPORT int slr_softsplat_backward_ws(const float *in, const float *flow, const float *grad_out, float *grad_in,
@@ -461,7 +468,7 @@ SLR_EXPORT int slr_softsplat_backward_ws(const float *in, const float *flow, con
         const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
         // channel groups: only with scratch for the partial gradFlow sums (or when gradFlow is not asked for)
         int groups = grad_groups(N, C, H, W);
-        if (grad_flow && groups > 1 && (!ws || ws_bytes < (size_t)groups * N * 2 * H * W * 4)) groups = 1;
+        if (grad_flow && groups > 1 && (!ws || ws_bytes < (size_t)(groups - 1) * N * 2 * H * W * 4)) groups = 1;
         const int cper = groups > 1 ? ((C + groups - 1) / groups + SLR_GRAD_TU - 1) / SLR_GRAD_TU * SLR_GRAD_TU : C;
         groups = (C + cper - 1) / cper;
         float *gpart = (float *)ws;

@@ -53,7 +53,7 @@ class _FunctionSoftsplat(torch.autograd.Function):
         gradFlow = torch.empty_like(flow) if self.needs_input_grad[1] == True else None
         if gradInput is not None or gradFlow is not None:
             with torch.cuda.device(input.device):
-                # (small grids -- the training crops: channel groups, their partial gradFlow sums in a scratch tensor of torch's allocator)
+                # (channel groups -- 2-4 on the training crops, 2 on grids larger than the chip: partial gradFlow sums in a scratch tensor of torch's allocator)
                 nb = int(lib().slr_softsplat_backward_ws_bytes(N, C, H, W)) if gradFlow is not None else 0
                 ws = torch.empty(nb, dtype=torch.uint8, device=input.device) if nb else None
                 check(lib().slr_softsplat_backward_ws(ptr(input), ptr(flow), ptr(gradOutput), ptr(gradInput),

@@ -273,7 +273,8 @@ def test_backward_channel_groups_on_small_grids(S, oracle):
     partial sums added in order (rounding of the grouping only).  Through the C ABI with and without scratch, and through autograd."""
     from slr_sfs_amd._lib import check, lib, ptr, stream_of
     L = lib()
-    assert L.slr_softsplat_backward_ws_bytes(1, 65, 768, 1280) == 0                 # the chip is full: one group
+    assert L.slr_softsplat_backward_ws_bytes(1, 65, 768, 1280) == 2 * 768 * 1280 * 4   # larger than the chip: two groups, group 0 writes gradFlow itself
+    assert L.slr_softsplat_backward_ws_bytes(2, 65, 256, 256) == 3 * 2 * 2 * 256 * 256 * 4   # four groups
     for (N, C, H, W) in ((2, 65, 256, 256), (1, 64, 128, 240), (1, 13, 40, 100), (3, 9, 64, 64)):
         nb = int(L.slr_softsplat_backward_ws_bytes(N, C, H, W))
         assert (nb > 0) == (C >= 16), (N, C, H, W, nb)
