@@ -9,7 +9,7 @@ torch.manual_seed(0)
 image = torch.rand(1, 3, H, W, device=dev) * 2 - 1
 motion = torch.from_numpy(smooth_motion(H, W)).to(dev)
 m = pipeline.BaselineAnimator(convs="fp32").to(dev).eval()
-for wino in ((True,) if "--wino" in sys.argv else (True, False)):
+for wino in ((True,) if "--wino" in sys.argv else ((False,) if "--direct" in sys.argv else (True, False))):
     m.convs = "fp32-winograd" if wino else "fp32"
     m.synthesize(image, motion, NFRAMES)
     torch.cuda.synchronize()
