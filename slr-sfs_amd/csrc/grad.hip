@@ -452,6 +452,7 @@ static int grad_groups(int N, int C, int H, int W) {
 
 SLR_EXPORT size_t slr_softsplat_backward_ws_bytes(int N, int C, int H, int W) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    if ((long long)C * H * W * 4 >= (1LL << 31)) return 0;      // (plane stacks of 2 GiB and more per sample: grad_kernel, no groups)
     const int g = grad_groups(N, C, H, W);
     return g > 1 ? (size_t)(g - 1) * N * 2 * H * W * 4 : 0;
 }

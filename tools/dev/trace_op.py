@@ -4,7 +4,7 @@ import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["SLR_SFS_AMD_LIB"] = os.path.join(ROOT, "slr-sfs_amd/lib/var_trace.so")
+os.environ.setdefault("SLR_SFS_AMD_LIB", os.path.join(ROOT, "slr-sfs_amd/lib/var_trace.so"))
 import slr_sfs_amd as S
 from bench import smooth_motion, H, W
 L = S._lib.lib()
