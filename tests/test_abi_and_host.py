@@ -38,6 +38,12 @@ def test_workspace_size_and_argument_errors(L):
     assert 3 * 1920 * 256 * 8 < L.slr_splat_workspace_bytes(1, 768, 1280) < 32 << 20
     assert L.slr_splat_workspace_bytes(0, 768, 1280) == 0
     assert L.slr_splat_workspace_bytes(1, 16, 16) > 0
+    # scratch of the backward's channel groups (host arithmetic only): (groups - 1) partial gradFlow planes pairs -- two groups on grids larger
+    # than the chip, up to four on the training crops, none below 16 channels or where the tiled kernel does not take the plane stack (>= 2 GiB)
+    assert L.slr_softsplat_backward_ws_bytes(1, 65, 768, 1280) == 1 * 2 * 768 * 1280 * 4
+    assert L.slr_softsplat_backward_ws_bytes(2, 65, 256, 256) == 3 * 2 * 2 * 256 * 256 * 4
+    assert L.slr_softsplat_backward_ws_bytes(1, 8, 768, 1280) == 0 and L.slr_softsplat_backward_ws_bytes(1, 65, 0, 1280) == 0
+    assert L.slr_softsplat_backward_ws_bytes(1, 600, 768, 1280) == 0
     # argument validation happens before anything touches the device
     rc = L.slr_softsplat_forward(None, None, None, 1, 1, 8, 8, None, 0, 0, None)
     assert rc == -1 and b"null" in L.slr_last_error()
