@@ -39,6 +39,7 @@
 #define SLR_SINK_POOL_MB 64     // ... bytes of slabs in the workspace (a slab = the partial sums of one task slot: (planes of its channel group + 1) x 2 KiB)
 #define SLR_SINK_ENT_MB 16      // ... bytes of entries (16 each) the deferred pieces of a call may write out; pieces beyond that are cut by candidate pairs
 #define SLR_SINK_GROUPS 8       // ... x channel groups
+#define SLR_SINK_GRID 512       // ... workgroups of the sink launch: what the chip holds of them at once (256 CUs x 2, a multiple of 8); each takes the tasks lin, lin + grid, ... of the call's ordered task list
 #define SLR_SCAN_MAX_TILES 1024 // default of slr_splat_set_scan_max_tiles: one-flow calls on grids of at most this many tiles take the scan front end,
                                 // larger ones the rows front end (config C2, 240 tiles: bins 56 / scan 39 / rows 56 us; 384x640, 960 tiles: incoherent
                                 // 80 / 61 / 77, Euler t=30 124 / 116 / 112; 768x1280, 1920 tiles: identity 175 / 142 / 146, t=30 202 / 207 / 165, t=59 245 / 278 / 216)

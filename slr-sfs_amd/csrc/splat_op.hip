@@ -341,7 +341,7 @@ __global__ __launch_bounds__(TILE_PIX) void scan_box_kernel(const float *__restr
                                                             int tiles_x, int tiles, uint32_t *__restrict__ totals) {
     const int t = blockIdx.x, n = t / tiles, tl = t - n * tiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (t == 0 && tid < 8) totals[tid] = 0u;          // the deferred list of the tile kernel that follows (a kernel boundary makes the zeros visible)
+    if (t == 0 && tid < 8) { totals[tid] = 0u; totals[16 + tid] = 0u; }   // the deferred list of the tile kernel that follows, the sink launch's task counters (a kernel boundary makes the zeros visible)
     const int y = (tl / tiles_x) * TILE_H + wid, x = (tl % tiles_x) * TILE_W + lane;
     int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
     if (y < H && x < W) {
@@ -379,6 +379,18 @@ __device__ __forceinline__ bool channel_group(int C, int &cb, int &ce) {
     ce = min(C, cb + cper);
     return cb < C;
 }
+// The sink launch's rule (8 groups): the planes in units of 8, dealt as evenly as whole units go; the LAST groups take the odd units, so
+// that the partial unit at the end (C = 65: one plane) rides along with a full one -- 65 planes are 7 x 8 + 9.  (The rule above makes
+// them 4 x 16 + 1 and three groups without planes: a task streamed 16 planes where 8 - 9 do; training shape t=59, sink launch 58.7 ->
+// 51.4 us.  In the tile kernels the even split measured SLOWER -- C = 65 over 2 groups, 32 + 33 against 40 + 25 planes: 54.6 against
+// 50.8 us at the training shape -- they keep the rule above.)
+__device__ __forceinline__ bool channel_range(int C, int G, int g, int &cb, int &ce) {
+    const int U = (C + 7) >> 3, base = U / G, first_big = G - (U - base * G);
+    const int ub = g * base + max(0, g - first_big), un = base + (g >= first_big ? 1 : 0);
+    cb = ub * 8;
+    ce = min(C, cb + un * 8);
+    return cb < ce;
+}
 
 struct OpArgs {
     TileShared s; TileFrame f;
@@ -387,6 +399,7 @@ struct OpArgs {
     uint32_t sink_cap, sink_t;     // ... slabs of the pool; most task slots a piece gets (rows = planes + channel groups of the sink launch)
     float4 *sink_ent;              // ... [sink_ent_cap] the entries of the deferred pieces
     uint32_t sink_ent_cap;
+    uint32_t sink_x, sink_groups;  // ... the sink launch's piece slots and channel groups (its grid: sink_x * sink_groups * SINK_T workgroups, one dimension)
 };
 
 // rows front end.  grid.x: a multiple of 8 * SLR_XCD_GROUP blocks covering the plan's items (surplus workgroups exit at once).
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
 // group (task slot 0) out of that workgroup's emergency slab -- correct for any flow, slow only for flows with hundreds of sinks.
 constexpr uint32_t SINK_P = SLR_SINK_PIECES, SINK_T = SLR_SINK_TASKS, SINK_MINE = 2048 / 2;
 #ifdef SLR_TRACE      // per-workgroup wall-clock stamps of the sink launch (tools/dev/trace_sink.py): 16 words per workgroup behind the tile kernels' area
-#define SINK_STAMP(slot, v) do { if (s.trace && threadIdx.x == 0) s.trace[(size_t)16384 * 64 + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (slot)] = (long long)(v); } while (0)
+#define SINK_STAMP(slot, v) do { if (s.trace && threadIdx.x == 0) s.trace[(size_t)16384 * 64 + (size_t)blockIdx.x * 16 + (slot)] = (long long)(v); } while (0)
 #else
 #define SINK_STAMP(slot, v) do { } while (0)
 #endif
@@ -615,23 +628,96 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     using Cfg = ScanCfg;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t mine[2 * SINK_MINE];              // this workgroup's tasks of a candidate block (build_records overwrites the list)
-    __shared__ uint32_t arrived;
+    __shared__ uint32_t arrived, next_j;
     const TileLds<Cfg> L(smem);
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
-    const int tid = threadIdx.x;
-    const uint32_t bslot = blockIdx.z, bpiece = blockIdx.x, npiece = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t ndef = f.totals[4];
     if (ndef == 0u) return;                                // the normal case: an empty launch whose workgroups do one scalar load
-    int cb, ce;
-    if (!channel_group(s.C, cb, ce)) return;              // (arrivals are counted per channel group)
     SINK_STAMP(0, wall_clock64());
     const TileScalars k = tile_scalars(s, f);
     const uint32_t *clist = L.rl + 4 * ROW_CAP;
     const size_t hw = (size_t)s.H * s.W;
-    const uint32_t rows = (uint32_t)s.C + gridDim.y;      // slab rows of one task slot over all channel groups; this group's start at cb + its index
-    const size_t slot_floats = (size_t)rows * TILE_PIX, my_rows = (size_t)(cb + (int)blockIdx.y) * TILE_PIX;
-    for (uint32_t q = bpiece; q < ndef; q += npiece) {
+    const uint32_t G = a.sink_groups, NP = a.sink_x, lin = blockIdx.x;
+    const uint32_t rows = (uint32_t)s.C + G;               // slab rows of one task slot over all channel groups; a group's start at cb + its index
+    const size_t slot_floats = (size_t)rows * TILE_PIX;
+    // Which (piece, task slot, channel group) a workgroup renders.  The tasks that exist come FIRST in dispatch order: a slot of the
+    // chip changes hands in microseconds, and behind a grid of pieces x groups x SINK_T slots of which a few hundred have work (most
+    // pieces are one task) the later slots' workgroups waited for thousands of empty ones to pass (traced: half of the working
+    // workgroups of a C2-sized call started 5 - 19 us late, 35 us at the training shape).  Rounds of R pieces of the deferred list; in
+    // a round every workgroup derives the same ordered list of (slot z, piece) pairs whose piece has more than z task slots from the
+    // pieces' headers (one lane each, SINK_T ballots) and takes the entry its index names.  With 8 channel groups the list is kept
+    // per XCD (workgroup lin runs on XCD lin % 8): entry j = lin / 8 of XCD c = lin % 8 is (z, piece p) with group (c - p) mod 8 --
+    // all task slots of a (piece, group) on ONE XCD, whose L2 then holds that group's source planes once (slots spread over the XCDs:
+    // C2-sized smooth case 139 against 91 us).  Pieces without slabs of their own (the pool ran out: one workgroup per channel group
+    // out of an emergency slab) keep the static assignment: piece slot lin % NP, group lin / NP, pieces q = slot, slot + NP, ...
+    // The grid is as large as the chip holds workgroups of this kernel (launch_scan) and the workgroups DRAW their entries: one counter
+    // per list (totals[16 + XCD]; zeroed by scan_box_kernel), so a launch with little work is a few hundred short-lived workgroups, not
+    // thousands queueing for the slots behind the tasks, a second task starts on its workgroup's slot without a hand-over, and the
+    // workgroups whose task was short (a piece's last one) take what is left.  (Static shares lin, lin + grid, ...: C2-sized smooth case
+    // 84 against 79 us before -- 40 workgroups ran two full tasks one after the other.)
+    const uint32_t R = min(32u, NP), nrA = (ndef + R - 1u) / R, gsz = gridDim.x;
+    const bool xcd_lists = G == 8u && (gsz & 7u) == 0u;
+    uint32_t *draw = f.totals + 16 + (xcd_lists ? lin & 7u : 0u);
+    const uint32_t share = xcd_lists ? gsz >> 3 : gsz;     // workgroups per list: entry lin (>> 3) is mine without a draw, the draws hand out entries share, share + 1, ...
+    uint32_t step = 0, jbase = 0, v = lin, kB = 0, ns = 0, ns_step = 0xffffffffu, jd = xcd_lists ? lin >> 3 : lin;
+    bool phase_b = false, have_j = true;
+    for (;;) {
+        uint32_t q, bslot, g, eslot = 0;
+        if (!phase_b) {
+            if (step >= nrA) { phase_b = true; continue; }
+            if (!have_j) {
+                __syncthreads();
+                if (tid == 0) next_j = share + atomicAdd(draw, 1u);
+                __syncthreads();
+                jd = next_j; have_j = true;
+            }
+            const uint32_t qb = step * R, ql = qb + (uint32_t)lane;
+            if (ns_step != step) {                         // task slots of the round's pieces, one lane each (0: no slabs of its own)
+                ns = 0; ns_step = step;
+                if ((uint32_t)lane < R && ql < ndef) {
+                    const uint32_t *h = a.sink_cnt + (size_t)ql * 16u;
+                    if (h[11] != 0xffffffffu) {
+                        const uint32_t nt_ = h[10] != 0xffffffffu ? (h[9] + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : h[8];
+                        ns = min(a.sink_t, max(nt_, 1u));
+                    }
+                }
+            }
+            uint32_t j = jd - jbase;                       // (draws only grow: the rounds before this one stay behind)
+            uint32_t found = 0xffffffffu, fz = 0, fg = 0, len = 0;
+            for (uint32_t z = 0; z < SINK_T; ++z) {
+                const uint32_t m = (uint32_t)__ballot(ns > z);
+                const uint32_t n = (uint32_t)__popc(m);
+                if (n == 0u) break;                        // (the masks are nested: nothing above either)
+                const uint32_t per = xcd_lists ? n : n * G;
+                len += per;
+                if (found == 0xffffffffu && j < per) {
+                    const uint32_t r = xcd_lists ? j : j % n;
+                    const uint32_t rank = (uint32_t)__popc(m & ((1u << (lane & 31)) - 1u));
+                    const unsigned long long hit = __ballot((uint32_t)lane < 32u && ((m >> (lane & 31)) & 1u) && rank == r);
+                    found = (uint32_t)__ffsll((long long)hit) - 1u;
+                    fz = z; fg = xcd_lists ? ((lin & 7u) - found) & 7u : j / n;
+                }
+                j -= min(j, per);
+            }
+            if (found == 0xffffffffu) { ++step; jbase += len; continue; }    // (past this round's list: on to the next round with the same entry index)
+            q = qb + found; bslot = fz; g = fg;
+            have_j = false;
+            // the usual launch -- one round of pieces, fewer entries than workgroups: nothing to draw after this one
+            if (step + 1u == nrA && jbase + len <= share) step = nrA;
+        } else {
+            if (v >= NP * G) break;
+            eslot = v % NP; g = v / NP; bslot = 0;
+            q = eslot + kB * NP;
+            if (q >= ndef) { v += gsz; kB = 0; continue; }
+            ++kB;
+            if (a.sink_cnt[(size_t)q * 16u + 11u] != 0xffffffffu) continue;     // (has slabs of its own: rendered above)
+        }
+        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q); bslot = (uint32_t)__builtin_amdgcn_readfirstlane((int)bslot); g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        int cb, ce;
+        if (!channel_range((int)s.C, (int)G, (int)g, cb, ce)) continue;    // (arrivals are counted per channel group)
+        const size_t my_rows = (size_t)(cb + (int)g) * TILE_PIX;
         const uint32_t *hd = a.sink_cnt + (size_t)q * 16u;
         const uint32_t sbase = hd[11];
         const bool pooled = sbase != 0xffffffffu;
@@ -639,8 +725,7 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
         const bool listed = eoff != 0xffffffffu;           // the piece's entries were written out: tasks of exactly SEG entries, nothing to walk
         const uint32_t ntask_q = listed ? (all + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : hd[8];
         const uint32_t nslot = pooled ? min(a.sink_t, max(ntask_q, 1u)) : 1u;       // (no more slots than tasks)
-        if (bslot >= nslot) continue;
-        float *slab0 = a.sink_pool + (size_t)(pooled ? sbase : a.sink_cap + bpiece) * slot_floats + my_rows;
+        float *slab0 = a.sink_pool + (size_t)(pooled ? sbase : a.sink_cap + eslot) * slot_floats + my_rows;
         float *slab = slab0 + (size_t)bslot * slot_floats;
         const uint32_t w = f.defer[q];
         ItemDesc it = {};
@@ -718,7 +803,7 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
         __syncthreads();
         if (tid == 0) {
             const uint32_t mineb = wrote ? 1u << (8u + bslot) : 0u;
-            arrived = atomicAdd(a.sink_cnt + (size_t)q * 16u + blockIdx.y, 1u | mineb) | mineb;
+            arrived = atomicAdd(a.sink_cnt + (size_t)q * 16u + g, 1u | mineb) | mineb;
         }
         __syncthreads();
         const uint32_t aw = arrived;
@@ -963,7 +1048,9 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     g_ev_start = g_ev_stop = nullptr;
     // pieces of more than SEG entries (appended by their workgroups): the sink launch -- every piece by up to SINK_T x channel groups
     // workgroups at once (an empty launch: every workgroup does one scalar load and ends -- 256 or 4096 of them cost the same 2 - 3 us)
-    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_x, wgroups, SINK_T), dim3(TT), ScanCfg::LDS_BYTES, st, a);
+    a.sink_x = sink_x; a.sink_groups = wgroups;
+    const uint32_t sink_all = sink_x * wgroups * SINK_T;
+    hipLaunchKernelGGL((op_sink_kernel<NORM, MAXOP>), dim3(sink_all < (uint32_t)SLR_SINK_GRID ? sink_all : (uint32_t)SLR_SINK_GRID), dim3(TT), ScanCfg::LDS_BYTES, st, a);
     SLR_CHECK_LAUNCH();
     return 0;
 }
