@@ -142,7 +142,8 @@ int slr_splat_bin_pair(const float *flow_a, const float *flow_b, int N, int H, i
 int slr_splat_set_scan_max_tiles(int max_tiles);
 int slr_splat_set_front_end(int front_end);
 /* Tuning of the scan front end (process-wide, 0 = the built-in choice by grid size): column pieces per output tile in the first launch
- * (1, 2, 4 or 8) x channel groups per piece; deferred pieces rendered at once (default 33) x channel groups (default 8) of the sink launch. */
+ * (1, 2, 4 or 8) x channel groups per piece; piece slots (default 33: the emergency slabs of pieces that find the slab pool empty; the sink
+ * launch's task list takes min(32, slots) pieces per round) x channel groups (default 8) of the sink launch. */
 void slr_splat_set_scan_shape(int pieces, int groups, int defer_wg, int defer_groups);
 
 /* ------------------------------------------------------------------ splat: forward */

@@ -632,16 +632,16 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     const TileLds<Cfg> L(smem);
     const TileShared &s = a.s;
     const TileFrame &f = a.f;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const uint32_t ndef = f.totals[4];
     if (ndef == 0u) return;                                // the normal case: an empty launch whose workgroups do one scalar load
     SINK_STAMP(0, wall_clock64());
     const TileScalars k = tile_scalars(s, f);
     const uint32_t *clist = L.rl + 4 * ROW_CAP;
     const size_t hw = (size_t)s.H * s.W;
-    const uint32_t G = a.sink_groups, NP = a.sink_x, lin = blockIdx.x;
-    const uint32_t rows = (uint32_t)s.C + G;               // slab rows of one task slot over all channel groups; a group's start at cb + its index
-    const size_t slot_floats = (size_t)rows * TILE_PIX;
+    const uint32_t lin = blockIdx.x;
+#define G a.sink_groups
+#define NP a.sink_x
     // Which (piece, task slot, channel group) a workgroup renders.  The tasks that exist come FIRST in dispatch order: a slot of the
     // chip changes hands in microseconds, and behind a grid of pieces x groups x SINK_T slots of which a few hundred have work (most
     // pieces are one task) the later slots' workgroups waited for thousands of empty ones to pass (traced: half of the working
@@ -657,31 +657,31 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     // thousands queueing for the slots behind the tasks, a second task starts on its workgroup's slot without a hand-over, and the
     // workgroups whose task was short (a piece's last one) take what is left.  (Static shares lin, lin + grid, ...: C2-sized smooth case
     // 84 against 79 us before -- 40 workgroups ran two full tasks one after the other.)
-    const uint32_t R = min(32u, NP), nrA = (ndef + R - 1u) / R, gsz = gridDim.x;
-    const bool xcd_lists = G == 8u && (gsz & 7u) == 0u;
-    uint32_t *draw = f.totals + 16 + (xcd_lists ? lin & 7u : 0u);
-    const uint32_t share = xcd_lists ? gsz >> 3 : gsz;     // workgroups per list: entry lin (>> 3) is mine without a draw, the draws hand out entries share, share + 1, ...
-    uint32_t step = 0, jbase = 0, v = lin, kB = 0, ns = 0, ns_step = 0xffffffffu, jd = xcd_lists ? lin >> 3 : lin;
-    bool phase_b = false, have_j = true;
+    // (State kept across a task: the round, the entries of the rounds before it, my entry index -- the kernel sits at its register
+    //  limit: the pieces' task slots are read again for every entry (kept in a register across the task, or in LDS behind a round
+    //  marker, the kernel spilled to scratch), R, the list shares etc. are recomputed where they are used.)
+    constexpr uint32_t PHASE_B = 0xffffffffu, DRAW = 0xffffffffu;      // step == PHASE_B: the static part; jd == DRAW: no entry index in hand
+    uint32_t step = 0, jbase = 0, jd = (G == 8u && (gridDim.x & 7u) == 0u) ? lin >> 3 : lin;
     for (;;) {
         uint32_t q, bslot, g, eslot = 0;
-        if (!phase_b) {
-            if (step >= nrA) { phase_b = true; continue; }
-            if (!have_j) {
+        const uint32_t R = min(32u, NP);
+        if (step != PHASE_B) {
+            const bool xcd_lists = G == 8u && (gridDim.x & 7u) == 0u;
+            if (step >= (ndef + R - 1u) / R) { step = PHASE_B; jd = lin; jbase = 0; continue; }     // (below: jd = the static index, jbase = its pieces done)
+            if (jd == DRAW) {
+                // entry lin (>> 3) was mine without a draw; the draws hand out entries share, share + 1, ... of my list
                 __syncthreads();
-                if (tid == 0) next_j = share + atomicAdd(draw, 1u);
+                if (tid == 0) next_j = (xcd_lists ? gridDim.x >> 3 : gridDim.x) + atomicAdd(f.totals + 16 + (xcd_lists ? lin & 7u : 0u), 1u);
                 __syncthreads();
-                jd = next_j; have_j = true;
+                jd = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_j);
             }
-            const uint32_t qb = step * R, ql = qb + (uint32_t)lane;
-            if (ns_step != step) {                         // task slots of the round's pieces, one lane each (0: no slabs of its own)
-                ns = 0; ns_step = step;
-                if ((uint32_t)lane < R && ql < ndef) {
-                    const uint32_t *h = a.sink_cnt + (size_t)ql * 16u;
-                    if (h[11] != 0xffffffffu) {
-                        const uint32_t nt_ = h[10] != 0xffffffffu ? (h[9] + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : h[8];
-                        ns = min(a.sink_t, max(nt_, 1u));
-                    }
+            const uint32_t lane = (uint32_t)tid & 63u, qb = step * R, ql = qb + lane;
+            uint32_t ns = 0;                               // task slots of the round's pieces, one lane each (0: no slabs of its own)
+            if (lane < R && ql < ndef) {
+                const uint32_t *h = a.sink_cnt + (size_t)ql * 16u;
+                if (h[11] != 0xffffffffu) {
+                    const uint32_t nt_ = h[10] != 0xffffffffu ? (h[9] + (uint32_t)Cfg::SEG - 1u) / (uint32_t)Cfg::SEG : h[8];
+                    ns = min(a.sink_t, max(nt_, 1u));
                 }
             }
             uint32_t j = jd - jbase;                       // (draws only grow: the rounds before this one stay behind)
@@ -694,8 +694,8 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
                 len += per;
                 if (found == 0xffffffffu && j < per) {
                     const uint32_t r = xcd_lists ? j : j % n;
-                    const uint32_t rank = (uint32_t)__popc(m & ((1u << (lane & 31)) - 1u));
-                    const unsigned long long hit = __ballot((uint32_t)lane < 32u && ((m >> (lane & 31)) & 1u) && rank == r);
+                    const uint32_t rank = (uint32_t)__popc(m & ((1u << (lane & 31u)) - 1u));
+                    const unsigned long long hit = __ballot(lane < 32u && ((m >> (lane & 31u)) & 1u) && rank == r);
                     found = (uint32_t)__ffsll((long long)hit) - 1u;
                     fz = z; fg = xcd_lists ? ((lin & 7u) - found) & 7u : j / n;
                 }
@@ -703,21 +703,21 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
             }
             if (found == 0xffffffffu) { ++step; jbase += len; continue; }    // (past this round's list: on to the next round with the same entry index)
             q = qb + found; bslot = fz; g = fg;
-            have_j = false;
+            jd = DRAW;
             // the usual launch -- one round of pieces, fewer entries than workgroups: nothing to draw after this one
-            if (step + 1u == nrA && jbase + len <= share) step = nrA;
+            if (step + 1u == (ndef + R - 1u) / R && jbase + len <= (xcd_lists ? gridDim.x >> 3 : gridDim.x)) step = 0xfffffff0u;
         } else {
-            if (v >= NP * G) break;
-            eslot = v % NP; g = v / NP; bslot = 0;
-            q = eslot + kB * NP;
-            if (q >= ndef) { v += gsz; kB = 0; continue; }
-            ++kB;
+            if (jd >= NP * G) break;
+            eslot = jd % NP; g = jd / NP; bslot = 0;
+            q = eslot + jbase * NP;
+            if (q >= ndef) { jd += gridDim.x; jbase = 0; continue; }
+            ++jbase;
             if (a.sink_cnt[(size_t)q * 16u + 11u] != 0xffffffffu) continue;     // (has slabs of its own: rendered above)
         }
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q); bslot = (uint32_t)__builtin_amdgcn_readfirstlane((int)bslot); g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         int cb, ce;
         if (!channel_range((int)s.C, (int)G, (int)g, cb, ce)) continue;    // (arrivals are counted per channel group)
-        const size_t my_rows = (size_t)(cb + (int)g) * TILE_PIX;
+        const size_t slot_floats = (size_t)((uint32_t)s.C + G) * TILE_PIX, my_rows = (size_t)(cb + (int)g) * TILE_PIX;   // slab rows of one task slot over all channel groups; a group's start at cb + its index
         const uint32_t *hd = a.sink_cnt + (size_t)q * 16u;
         const uint32_t sbase = hd[11];
         const bool pooled = sbase != 0xffffffffu;
@@ -868,6 +868,8 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     }
     // (the deferred list is emptied by the next call's scan_box_kernel: the scan front end has no prebinned form)
 }
+#undef G
+#undef NP
 
 // =========================================================================== small kernels
 

@@ -249,6 +249,36 @@ def test_many_deferred_pieces(S, oracle, frontend):
         assert float(np.abs(out - ref).max()) < 2e-4 * scale, (seed, N, float(np.abs(out - ref).max()), scale)
 
 
+@pytest.mark.parametrize("case", ["overflow_c64", "rounds_c65", "one_list_c33", "groups_c72"])
+def test_sink_launch_task_list(S, oracle, case):
+    """The scan front end's sink launch takes its (piece, task slot, channel group) from an ordered task list (csrc/splat_op.hip:
+    op_sink_kernel): `overflow_c64` -- more tasks than the launch has workgroups (the C2 grid under an Euler t=30 flow: the early
+    finishers draw the rest); `rounds_c65` -- more than 32 deferred pieces (two rounds of the list) with 65 planes (groups of 8 + one
+    of 9); `one_list_c33` -- 4 channel groups (one list instead of one per XCD); `groups_c72` -- 9 units of 8 planes over 8 groups.
+    Against the oracle, three calls each: the result must not depend on who drew which task."""
+    L = S._lib.lib()
+    prev = L.slr_splat_set_front_end(1)
+    try:
+        rng = np.random.default_rng(5)
+        if case == "overflow_c64":
+            N, C, H, W = 1, 64, 256, 480
+            flow = oracle.euler_integration(smooth_motion(H, W), 30)[0]
+        else:
+            N, C, H, W = {"rounds_c65": (3, 65, 200, 480), "one_list_c33": (2, 33, 200, 300), "groups_c72": (1, 72, 128, 256)}[case]
+            yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+            flow = np.stack([np.stack([(W * rng.uniform(0.2, 0.8) - xx) * rng.uniform(0.5, 0.9), (H * rng.uniform(0.2, 0.8) - yy) * rng.uniform(0.5, 0.9)])
+                             for _ in range(N)]).astype(np.float32)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        xd, fd = dev(x), dev(flow)
+        ref = oracle.softsplat_forward(x, flow)
+        bound = 4e-6 * oracle.softsplat_forward(np.abs(x), flow) + 1e-6
+        for _ in range(3):                                  # (who draws which task differs from call to call; entry slots are handed out by atomics: agreement to rounding)
+            out = host(S.FunctionSoftsplat(xd, fd, None, "summation"))
+            assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
+    finally:
+        L.slr_splat_set_front_end(prev)
+
+
 def test_differential_fuzz_of_the_front_ends(S):
     """tools/dev/fuzz_frontends.py, a short run with a fixed seed: random shapes (ragged edges, one-pixel images, batches, a
     768x1280 case), ten flow families (incoherent, collapsing onto points / lines, far outside, non-finite sprinkles, ...) and
