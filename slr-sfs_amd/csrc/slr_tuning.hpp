@@ -34,7 +34,7 @@
 #define SLR_SCAN_DEFER_AT 896    // scan tile kernel: a tile of more entries than this goes to the sink launch (<= 1024 = one segment; its near-full tiles are the
                                 // tile kernel's tail: 8 chunks at 3 us).  1024 / 896 / 768 / 640, us: C2 grid t=30 82 / 80 / 84 / 84, training shape t=30 91 / 89 / 87 / 86,
                                 // t=59 130 / 117 / 120 / 121, 384x640 t=30 106 / 106 / 119 / 126, t=59 135 / 139 / 131 / 133; incoherent flows: no tile above 640
-#define SLR_SINK_PIECES 33      // sink launch of the scan front end (splat_op.hip: op_sink_kernel): deferred pieces rendered at once (more: the list is looped) ...
+#define SLR_SINK_PIECES 33      // sink launch of the scan front end (splat_op.hip: op_sink_kernel): piece slots = emergency slabs of pieces that find the pool empty; the task list takes min(32, this) pieces per round ...
 #define SLR_SINK_TASKS 16       // ... x task slots per piece (a task = 2 candidate source tiles = 16 row segments <= 1024 entries) ...
 #define SLR_SINK_POOL_MB 64     // ... bytes of slabs in the workspace (a slab = the partial sums of one task slot: (planes of its channel group + 1) x 2 KiB)
 #define SLR_SINK_ENT_MB 16      // ... bytes of entries (16 each) the deferred pieces of a call may write out; pieces beyond that are cut by candidate pairs

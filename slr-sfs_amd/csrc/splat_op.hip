@@ -602,8 +602,8 @@ __global__ __launch_bounds__(TT, SLR_WAVES_SCAN) void op_scan_kernel(OpArgs a) {
     T_STAMP(s, 55);
 }
 
-// The SINK launch (grid: SINK_T task slots x channel groups x SINK_P pieces -- the slots of a piece on different XCDs; normally the deferred list is empty and every workgroup ends
-// after one scalar load).  A deferred piece holds thousands of entries -- Euler-integrated flows pile hundreds of source pixels onto a few
+// The SINK launch (grid: SLR_SINK_GRID workgroups that take their (piece, task slot, channel group) from an ordered task list -- below; normally the
+// deferred list is empty and every workgroup ends after one scalar load).  A deferred piece holds thousands of entries -- Euler-integrated flows pile hundreds of source pixels onto a few
 // output pixels; on a 256 x 256 training crop at t = 59 two tiles receive 12 000 entries each and one pixel 4 000 -- and walking them pass by
 // pass in ONE workgroup (rounds 1-5) left the chip idle behind it: 116 us for a C2-sized call whose other tiles take 29, 670 us at the
 // training shape.  Here the piece is cut by SOURCE: task k = candidate source tiles 2k, 2k + 1 of the piece's ordered candidate list
