@@ -640,8 +640,6 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     const uint32_t *clist = L.rl + 4 * ROW_CAP;
     const size_t hw = (size_t)s.H * s.W;
     const uint32_t lin = blockIdx.x;
-#define G a.sink_groups
-#define NP a.sink_x
     // Which (piece, task slot, channel group) a workgroup renders.  The tasks that exist come FIRST in dispatch order: a slot of the
     // chip changes hands in microseconds, and behind a grid of pieces x groups x SINK_T slots of which a few hundred have work (most
     // pieces are one task) the later slots' workgroups waited for thousands of empty ones to pass (traced: half of the working
@@ -651,7 +649,7 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     // per XCD (workgroup lin runs on XCD lin % 8): entry j = lin / 8 of XCD c = lin % 8 is (z, piece p) with group (c - p) mod 8 --
     // all task slots of a (piece, group) on ONE XCD, whose L2 then holds that group's source planes once (slots spread over the XCDs:
     // C2-sized smooth case 139 against 91 us).  Pieces without slabs of their own (the pool ran out: one workgroup per channel group
-    // out of an emergency slab) keep the static assignment: piece slot lin % NP, group lin / NP, pieces q = slot, slot + NP, ...
+    // out of an emergency slab) keep the static assignment: piece slot lin % sink_x, group lin / sink_x, pieces q = slot, slot + sink_x, ...
     // The grid is as large as the chip holds workgroups of this kernel (launch_scan) and the workgroups DRAW their entries: one counter
     // per list (totals[16 + XCD]; zeroed by scan_box_kernel), so a launch with little work is a few hundred short-lived workgroups, not
     // thousands queueing for the slots behind the tasks, a second task starts on its workgroup's slot without a hand-over, and the
@@ -661,12 +659,12 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     //  limit: the pieces' task slots are read again for every entry (kept in a register across the task, or in LDS behind a round
     //  marker, the kernel spilled to scratch), R, the list shares etc. are recomputed where they are used.)
     constexpr uint32_t PHASE_B = 0xffffffffu, DRAW = 0xffffffffu;      // step == PHASE_B: the static part; jd == DRAW: no entry index in hand
-    uint32_t step = 0, jbase = 0, jd = (G == 8u && (gridDim.x & 7u) == 0u) ? lin >> 3 : lin;
+    uint32_t step = 0, jbase = 0, jd = (a.sink_groups == 8u && (gridDim.x & 7u) == 0u) ? lin >> 3 : lin;
     for (;;) {
         uint32_t q, bslot, g, eslot = 0;
-        const uint32_t R = min(32u, NP);
+        const uint32_t R = min(32u, a.sink_x);
         if (step != PHASE_B) {
-            const bool xcd_lists = G == 8u && (gridDim.x & 7u) == 0u;
+            const bool xcd_lists = a.sink_groups == 8u && (gridDim.x & 7u) == 0u;
             if (step >= (ndef + R - 1u) / R) { step = PHASE_B; jd = lin; jbase = 0; continue; }     // (below: jd = the static index, jbase = its pieces done)
             if (jd == DRAW) {
                 // entry lin (>> 3) was mine without a draw; the draws hand out entries share, share + 1, ... of my list
@@ -690,7 +688,7 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
                 const uint32_t m = (uint32_t)__ballot(ns > z);
                 const uint32_t n = (uint32_t)__popc(m);
                 if (n == 0u) break;                        // (the masks are nested: nothing above either)
-                const uint32_t per = xcd_lists ? n : n * G;
+                const uint32_t per = xcd_lists ? n : n * a.sink_groups;
                 len += per;
                 if (found == 0xffffffffu && j < per) {
                     const uint32_t r = xcd_lists ? j : j % n;
@@ -707,17 +705,17 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
             // the usual launch -- one round of pieces, fewer entries than workgroups: nothing to draw after this one
             if (step + 1u == (ndef + R - 1u) / R && jbase + len <= (xcd_lists ? gridDim.x >> 3 : gridDim.x)) step = 0xfffffff0u;
         } else {
-            if (jd >= NP * G) break;
-            eslot = jd % NP; g = jd / NP; bslot = 0;
-            q = eslot + jbase * NP;
+            if (jd >= a.sink_x * a.sink_groups) break;
+            eslot = jd % a.sink_x; g = jd / a.sink_x; bslot = 0;
+            q = eslot + jbase * a.sink_x;
             if (q >= ndef) { jd += gridDim.x; jbase = 0; continue; }
             ++jbase;
             if (a.sink_cnt[(size_t)q * 16u + 11u] != 0xffffffffu) continue;     // (has slabs of its own: rendered above)
         }
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q); bslot = (uint32_t)__builtin_amdgcn_readfirstlane((int)bslot); g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         int cb, ce;
-        if (!channel_range((int)s.C, (int)G, (int)g, cb, ce)) continue;    // (arrivals are counted per channel group)
-        const size_t slot_floats = (size_t)((uint32_t)s.C + G) * TILE_PIX, my_rows = (size_t)(cb + (int)g) * TILE_PIX;   // slab rows of one task slot over all channel groups; a group's start at cb + its index
+        if (!channel_range((int)s.C, (int)a.sink_groups, (int)g, cb, ce)) continue;    // (arrivals are counted per channel group)
+        const size_t slot_floats = (size_t)((uint32_t)s.C + a.sink_groups) * TILE_PIX, my_rows = (size_t)(cb + (int)g) * TILE_PIX;   // slab rows of one task slot over all channel groups; a group's start at cb + its index
         const uint32_t *hd = a.sink_cnt + (size_t)q * 16u;
         const uint32_t sbase = hd[11];
         const bool pooled = sbase != 0xffffffffu;
@@ -868,8 +866,6 @@ __global__ __launch_bounds__(TT, 4) void op_sink_kernel(OpArgs a) {
     }
     // (the deferred list is emptied by the next call's scan_box_kernel: the scan front end has no prebinned form)
 }
-#undef G
-#undef NP
 
 // =========================================================================== small kernels
 
@@ -1033,7 +1029,7 @@ static int launch_scan(OpArgs &a, OpWs &w, hipStream_t st) {
     uint32_t pieces, groups;
     scan_shape(w.L.nt, a.s.C, pieces, groups);
     const int dwg = g_scan_defer_wg.load(), dgr = g_scan_defer_groups.load();
-    const uint32_t gmax = dgr > 0 ? (uint32_t)dgr : (uint32_t)SLR_SINK_GROUPS;
+    const uint32_t gmax = dgr > 0 && dgr <= 8 ? (uint32_t)dgr : (uint32_t)SLR_SINK_GROUPS;      // (a deferred piece's header counts the arrivals of at most 8 channel groups)
     const uint32_t wgroups = (uint32_t)a.s.C / 8u < 1u ? 1u : (uint32_t)a.s.C / 8u > gmax ? gmax : (uint32_t)a.s.C / 8u;
     const uint32_t dw = dwg > 0 ? (uint32_t)dwg : SINK_P;
     uint32_t sink_x = w.L.nt * pieces < dw ? w.L.nt * pieces : dw;
