@@ -249,17 +249,22 @@ def test_many_deferred_pieces(S, oracle, frontend):
         assert float(np.abs(out - ref).max()) < 2e-4 * scale, (seed, N, float(np.abs(out - ref).max()), scale)
 
 
-@pytest.mark.parametrize("case", ["overflow_c64", "rounds_c65", "one_list_c33", "groups_c72"])
+@pytest.mark.parametrize("case", ["overflow_c64", "rounds_c65", "one_list_c33", "groups_c72", "shape_7x4", "shape_2x16"])
 def test_sink_launch_task_list(S, oracle, case):
     """The scan front end's sink launch takes its (piece, task slot, channel group) from an ordered task list (csrc/splat_op.hip:
     op_sink_kernel): `overflow_c64` -- more tasks than the launch has workgroups (the C2 grid under an Euler t=30 flow: the early
     finishers draw the rest); `rounds_c65` -- more than 32 deferred pieces (two rounds of the list) with 65 planes (groups of 8 + one
-    of 9); `one_list_c33` -- 4 channel groups (one list instead of one per XCD); `groups_c72` -- 9 units of 8 planes over 8 groups.
+    of 9); `one_list_c33` -- 4 channel groups (one list instead of one per XCD); `groups_c72` -- 9 units of 8 planes over 8 groups;
+    `shape_7x4` / `shape_2x16` -- slr_splat_set_scan_shape: 7 piece slots (rounds of 7 pieces) x 4 groups; 2 piece slots and a group
+    count the piece headers cannot hold (16: the library falls back to 8).
     Against the oracle, three calls each: the result must not depend on who drew which task."""
     L = S._lib.lib()
     prev = L.slr_splat_set_front_end(1)
     try:
         rng = np.random.default_rng(5)
+        if case.startswith("shape_"):
+            L.slr_splat_set_scan_shape(0, 0, *{"shape_7x4": (7, 4), "shape_2x16": (2, 16)}[case])
+            case = "rounds_c65"
         if case == "overflow_c64":
             N, C, H, W = 1, 64, 256, 480
             flow = oracle.euler_integration(smooth_motion(H, W), 30)[0]
@@ -276,6 +281,7 @@ def test_sink_launch_task_list(S, oracle, case):
             out = host(S.FunctionSoftsplat(xd, fd, None, "summation"))
             assert (np.abs(out - ref) <= bound).all(), float((np.abs(out - ref) - bound).max())
     finally:
+        L.slr_splat_set_scan_shape(0, 0, 0, 0)
         L.slr_splat_set_front_end(prev)
 
 
